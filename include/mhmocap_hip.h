@@ -1,0 +1,155 @@
+/*
+ * mhmocap_hip.h -- C ABI of the MI355X-native (gfx950) scene-constrained SMPL optimisation path.
+ *
+ * The reference (dluvizon/scene-aware-3d-multi-human) has no FFI of its own: its boundary for
+ * this path is the Python API of mhmocap/smpl.py and mhmocap/optimizer.py.  This header is the
+ * thin C ABI underneath the build's Python mirror of that API
+ * (scene-aware-3d-multi-human_amd/mhmocap/{smpl,optimizer,losses,...}.py binds it with ctypes;
+ * INTEGRATION.md shows the binding).  Every entry point cites the reference code it replaces.
+ *
+ * Conventions
+ *   - all functions return 0 on success, a negative mh_status otherwise; mh_last_error() gives
+ *     the message of the last failure on the calling thread;
+ *   - every pointer that is not marked HOST is a device pointer owned by the caller (PyTorch-ROCm
+ *     allocations, tensor.data_ptr()); the library never frees or keeps caller memory and
+ *     allocates nothing except the immutable model constants inside mh_model;
+ *   - all floating point data is fp32 like the reference (smpl.py:134); indices are int32;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); calls only enqueue work;
+ *   - a body is one (frame, person) pair; bodies are stored frame-major: b = t*N + n;
+ *     a "person table" of NB rows is addressed as row (b % NB), so NB == N shares shape/scale
+ *     across frames (optimizer.py:297,691) and NB == B gives per-body values (smpl.py:357).
+ */
+#ifndef MHMOCAP_HIP_H
+#define MHMOCAP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MH_NUM_JOINTS 24
+#define MH_NUM_BETAS 10
+#define MH_NUM_POSE_BASIS 207
+#define MH_NUM_KP 17          /* sparse key-points of the 2D term (optimizer.py:75) */
+#define MH_FEAT_STRIDE 224    /* [beta(10) | R_1..R_23 - I (207) | 0 pad] */
+
+typedef enum mh_status {
+  MH_OK = 0,
+  MH_ERR_INVALID = -1,   /* bad argument */
+  MH_ERR_HIP = -2,       /* a HIP runtime call failed */
+  MH_ERR_NO_DEVICE = -3, /* no usable gfx950 device */
+  MH_ERR_UNSUPPORTED = -4
+} mh_status;
+
+typedef struct mh_model mh_model; /* opaque: immutable SMPL constants resident in HBM */
+
+/* HOST arrays describing an SMPL-shaped model: the fields smpl.py:201-275 reads from the pickle
+ * plus the optional joint regressors of smpl.py:234-261 (NULL = absent). */
+typedef struct mh_model_host {
+  int32_t num_verts;            /* V (6890) */
+  int32_t num_faces;            /* F (13776) */
+  const float* v_template;      /* (V,3)            smpl.py:211 */
+  const float* shapedirs;       /* (V,3,10)         smpl.py:227 */
+  const float* posedirs;        /* (V,3,207) as in the pickle; smpl.py:264-267 reshapes it */
+  const float* J_regressor;     /* (24,V) dense     smpl.py:231 */
+  const float* lbs_weights;     /* (V,24)           smpl.py:274 */
+  const int32_t* parents;       /* (24), parents[0] = -1   smpl.py:270-272 */
+  const int32_t* faces;         /* (F,3)            smpl.py:205 */
+  const float* reg_alphapose;   /* (17,V) or NULL   smpl.py:250 (already transposed)  */
+  const float* reg_h36m17;      /* (17,V) or NULL   smpl.py:243 (already re-ordered)  */
+  const float* reg_mupots;      /* (17,V) or NULL   smpl.py:257 */
+  const float* reg_extra9;      /* (9,V)  or NULL   smpl.py:235 */
+} mh_model_host;
+
+/* joint sets of mh_joints_regress */
+enum { MH_REG_ALPHAPOSE = 0, MH_REG_H36M17 = 1, MH_REG_MUPOTS = 2, MH_REG_EXTRA9 = 3 };
+
+const char* mh_last_error(void);
+int mh_version(void);
+/* number of visible HIP devices (0 on a CPU-only host; never fails) */
+int mh_device_count(void);
+
+/* replaces SMPL.__init__ (smpl.py:124-275): uploads and re-lays the constants once. */
+int mh_model_create(mh_model** out, const mh_model_host* host);
+int mh_model_destroy(mh_model* m);
+/* device pointer to the (F,3) int32 face table (optimizer.py:73-74) */
+const int32_t* mh_model_faces(const mh_model* m);
+
+/* ---- a2-a6: batched LBS forward (smpl.py:490-576 + optimizer.py:702-703) -------------------
+ * verts[b] = s * LBS(beta[b%NB], pose[b]) + transl[b],  s = 1.1^xscale[b%NB]
+ * xscale == NULL -> s = 1; transl == NULL -> 0.
+ * vposed (B,V,3) (rest-pose vertices after the blend shapes, kept for the backward) may be NULL.
+ * posed_joints (B,24,3) = joints_smpl24 (smpl.py:362) without scale/translation, may be NULL.
+ * ws: workspace of mh_lbs_workspace_bytes(B) bytes (keeps per-body joint transforms).       */
+size_t mh_lbs_workspace_bytes(int B);
+int mh_lbs_forward(const mh_model* m, int B, int NB, const float* betas /*(NB,10)*/,
+                   const float* poses /*(B,72)*/, const float* xscale /*(NB) or NULL*/,
+                   const float* transl /*(B,3) or NULL*/, float* verts /*(B,V,3)*/,
+                   float* vposed /*(B,V,3) or NULL*/, float* posed_joints /*(B,24,3) or NULL*/,
+                   void* ws, void* stream);
+
+/* sparse joint regression from vertices (smpl.py:603-620, 367-386):
+ * joints[b][j] = sum_v R[j][v] * verts[b][v]  (+ (1 - rowsum_j) * corr[b] when corr != NULL,
+ * which turns regression of translated/scaled vertices into s*R*x + t exactly).
+ * root_relative_to >= 0 subtracts that joint (h36m17: 14, smpl.py:371-372).                 */
+int mh_joints_regress(const mh_model* m, int which, int B, const float* verts /*(B,V,3)*/,
+                      const float* corr /*(B,3) or NULL*/, int root_relative_to,
+                      float* joints /*(B,J,3)*/, void* stream);
+
+/* ---- LBS backward (hand-written adjoint of the above) ---------------------------------------
+ * In : gverts (B,V,3) = dL/dverts, gjoints (B,17,3) = dL/d(alphapose joints of the translated,
+ *      scaled body) or NULL, vposed from the forward, the same parameters, ws from the forward.
+ * Out: gposes (B,72) [+=], gtransl (B,3) [+=], gbetas (NB,10) [+=], gxscale (NB) [+=].
+ * Accumulates (+=) so that several loss terms / the priors can share one gradient buffer, like
+ * autograd accumulation across the reference's per-batch backward() calls (optimizer.py:544).
+ * ws2: workspace of mh_lbs_backward_workspace_bytes(B) bytes.                               */
+size_t mh_lbs_backward_workspace_bytes(int B);
+int mh_lbs_backward(const mh_model* m, int B, int NB, const float* betas, const float* poses,
+                    const float* xscale, const float* transl, const float* vposed,
+                    const float* gverts, const float* gjoints, float* gposes, float* gtransl,
+                    float* gbetas, float* gxscale, void* ws, void* ws2, void* stream);
+
+/* ---- a11/a12: pinhole projection of the 17 key-points + masked 2D residual ------------------
+ * (transforms.py:74-95, optimizer.py:364-368, 404-405, 414-420).
+ * K: HOST 3x3 row-major intrinsics; Kd: HOST 5 distortion coefficients or NULL.
+ * pose2d (B,17,3) = (x, y, confidence).  mode 0 ("fit"): residual sum((c*(uv-gt)/[W,H])^2),
+ * c = conf >= thr; mode 1 ("warm-up", optimizer.py:735,754-756): mean over all B*17*2 elements
+ * of (c*(uv-gt))^2 in pixels, c = conf > thr.  Writes uv (B,17,2) (may be NULL), the gradient
+ * gjoints (B,17,3) scaled by `coef` (overwritten) and per-body loss partials loss (B).      */
+int mh_project_joints_loss(int B, const float* joints /*(B,17,3)*/, const float* K_host,
+                           const float* Kd_host, const float* pose2d, float thr, int mode,
+                           float img_w, float img_h, float coef, float* uv, float* gjoints,
+                           float* loss, void* stream);
+
+/* ---- a20: optimiser updates (optimizer.py:355-356, 586-587, 738-739, 764-765) --------------- */
+int mh_rmsprop_step(float* params, const float* grads, float* square_avg, float* momentum_buf,
+                    size_t n, float lr, float alpha, float momentum, float eps, void* stream);
+int mh_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n,
+                 int step, float lr, float beta1, float beta2, float eps, void* stream);
+
+/* ---- a19: one-euro filter over the leading (time) axis (optimizer.py:664-675,
+ * one_euro_filter.py:32-53 with d_cutoff = 1): x (T,E) -> y (T,E), E independent channels.  */
+int mh_one_euro_scan(const float* x, float* y, int T, size_t E, float min_cutoff, float beta,
+                     float frame_rate, void* stream);
+
+/* ---- a18: temporal terms (optimizer.py:560-575) ---------------------------------------------
+ * velocity: loss = sum_t ||pT[t]-pT[t-1]||^2 over t=1..T-1; gpT += coef * d loss.
+ * prev_halo / next_halo (N,3): poses_T of the frame before the first / after the last local
+ * frame when the sequence is sharded over GPUs (NULL at the sequence ends).  The pair
+ * (t-1,t) is owned by the rank that owns frame t.  loss_out: 1 float (overwritten).         */
+int mh_velocity_term(int T, int N, const float* pT /*(T,N,3)*/, const float* prev_halo,
+                     const float* next_halo, float coef, float* gpT, float* loss_out, void* stream);
+/* filtered-vertex smoothness: loss = sum ||(v[t]-v[t-1]) - (vf[t]-vf[t-1])||^2,
+ * gverts += coef * d loss / d v.  E = N*V*3 floats per frame.  prev_* / next_* (E): the
+ * neighbouring ranks' boundary frames (NULL at the sequence ends).                          */
+int mh_filtered_verts_term(int T, size_t E, const float* verts, const float* verts_filt,
+                           const float* prev_v, const float* prev_vf, const float* next_v,
+                           const float* next_vf, float coef, float* gverts, float* loss_out,
+                           void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MHMOCAP_HIP_H */

@@ -1,0 +1,110 @@
+// Internal helpers shared by the HIP translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mhmocap_hip.h"
+
+#define MH_KD 220       // rows of the k-major basis planes: 10 shape + 207 pose + 3 zero
+#define MH_FS 224       // MH_FEAT_STRIDE
+#define MH_NJ 24
+#define MH_NKP 17
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+void mh_set_error(const char* fmt, ...);
+
+#define MH_HIP(call)                                                                   \
+  do {                                                                                 \
+    hipError_t e__ = (call);                                                           \
+    if (e__ != hipSuccess) {                                                           \
+      mh_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+      return MH_ERR_HIP;                                                               \
+    }                                                                                  \
+  } while (0)
+
+#define MH_CHECK(cond, msg)                          \
+  do {                                               \
+    if (!(cond)) {                                   \
+      mh_set_error("invalid argument: %s", msg);     \
+      return MH_ERR_INVALID;                         \
+    }                                                \
+  } while (0)
+
+#define MH_LAUNCH_CHECK()                                        \
+  do {                                                           \
+    hipError_t e__ = hipGetLastError();                          \
+    if (e__ != hipSuccess) {                                     \
+      mh_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e__), __FILE__, __LINE__); \
+      return MH_ERR_HIP;                                         \
+    }                                                            \
+  } while (0)
+
+struct mh_tree {
+  int parent[MH_NJ];
+  int level[MH_NJ];
+  int maxlevel;
+};
+
+// CSR of a sparse joint regressor, rows = joints
+struct mh_regressor {
+  int J;           // 0 = absent
+  int nnz;
+  int* ptr;        // [J+1]
+  int* vidx;       // [nnz]
+  float* w;        // [nnz]
+  float* rowsum;   // [J]
+};
+
+struct mh_model {
+  int V, VP, F, nw;
+  float* vt;       // [VP][3]   template, zero padded
+  float* D;        // [3][MH_KD][VP] basis planes (x,y,z), k-major: rows 0..9 shape, 10..216 pose
+  float* Dt;       // [3][VP][MH_FS] the same, vertex-major (backward operand)
+  int* skidx;      // [VP][nw] bones of the <= nw non-zero skinning weights per vertex
+  float* skw;      // [VP][nw]
+  float* Jt;       // [24][3]     J_regressor . v_template
+  float* JS;       // [24][3][10] J_regressor . shapedirs
+  int* faces;      // [F][3]
+  mh_tree tree;
+  mh_regressor reg[4];
+  // alphapose regressor by vertex (CSR over vertices) for the backward scatter
+  int* kpv_ptr;    // [VP+1]
+  int* kpv_j;      // [nnz]
+  float* kpv_w;    // [nnz]
+};
+
+static inline int mh_groups(int B) { return (B + 31) / 32; }
+
+// ---- fp32 helpers used by several kernels --------------------------------------------------
+__device__ __forceinline__ void mh_rodrigues(const float r[3], float R[9]) {
+  // smpl.py:647-678 -- angle from the eps-shifted vector, axis from the plain one
+  const float e = 1e-8f;
+  float a0 = r[0] + e, a1 = r[1] + e, a2 = r[2] + e;
+  float ang = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+  float x = r[0] / ang, y = r[1] / ang, z = r[2] / ang;
+  float s = sinf(ang), c = cosf(ang);
+  float omc = 1.0f - c;
+  // K = [[0,-z,y],[z,0,-x],[-y,x,0]];  K.K written out as the explicit 3x3 product
+  float k2_00 = -z * z - y * y, k2_01 = x * y, k2_02 = x * z;
+  float k2_10 = x * y, k2_11 = -z * z - x * x, k2_12 = y * z;
+  float k2_20 = x * z, k2_21 = y * z, k2_22 = -y * y - x * x;
+  R[0] = 1.0f + omc * k2_00;
+  R[1] = s * (-z) + omc * k2_01;
+  R[2] = s * y + omc * k2_02;
+  R[3] = s * z + omc * k2_10;
+  R[4] = 1.0f + omc * k2_11;
+  R[5] = s * (-x) + omc * k2_12;
+  R[6] = s * (-y) + omc * k2_20;
+  R[7] = s * x + omc * k2_21;
+  R[8] = 1.0f + omc * k2_22;
+}
+
+__device__ __forceinline__ float mh_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

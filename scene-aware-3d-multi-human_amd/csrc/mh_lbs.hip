@@ -1,0 +1,815 @@
+// Batched SMPL linear-blend skinning for gfx950: forward and hand-written backward.
+// Replaces smpl.py:490-576 (lbs), :647-678 (rodrigues), :692-746 (kinematic chain) and the
+// scale/translate of optimizer.py:702-703, plus everything autograd did for them.
+//
+// Data flow (B bodies in groups of 32; V vertices in tiles of 32):
+//   k_pose_fwd   per body, 32 lanes = joints: rodrigues, shape-dependent joints, level-parallel
+//                kinematic chain  ->  featT[g][k][32] (beta | R-I, transposed for the MFMA A
+//                operand), A[b][24][3x4], scale[b]
+//   k_skin_fwd   per (vertex tile, 4 body groups): v_posed = v_template + [S;P]^T.feat as a
+//                K=217 f32 MFMA (32x32x2) contraction, then sparse skinning in the epilogue
+//                (lane = vertex, 16 accumulator rows = bodies) -> coalesced 384-B row stores
+//   k_skin_bwd   per (body group, vertex chunk): lane = (body, vertex) so the element-wise
+//                adjoints ARE the MFMA A operands: gfeat += g_vposed x Dt, gA += gT x W
+//   k_pose_bwd   per body: adjoint of the chain and of rodrigues, priors-free
+#include "mh_common.h"
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// =============================================================================================
+// forward
+// =============================================================================================
+struct PoseFwdP {
+  int B, NB, G;
+  const float* betas;
+  const float* poses;
+  const float* xscale;
+  const float* Jt;
+  const float* JS;
+  float* featT;   // [G][224][32]
+  float* A;       // [G*32][24][12]
+  float* scale;   // [G*32]
+  float* posed;   // [B][24][3] or null
+  mh_tree tree;
+};
+
+__device__ __forceinline__ void mh_joint_rest(const float* Jt, const float* JS, const float* beta, int j, float J[3]) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float a = Jt[j * 3 + c];
+#pragma unroll
+    for (int l = 0; l < MH_NUM_BETAS; ++l) a = fmaf(JS[(j * 3 + c) * MH_NUM_BETAS + l], beta[l], a);
+    J[c] = a;
+  }
+}
+
+// G = Gp o [R | rel]   (row-major 3x4)
+__device__ __forceinline__ void mh_compose(const float* Gp, const float R[9], const float rel[3], float G[12]) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      G[r * 4 + c] = fmaf(Gp[r * 4 + 2], R[6 + c], fmaf(Gp[r * 4 + 1], R[3 + c], Gp[r * 4 + 0] * R[c]));
+    G[r * 4 + 3] = fmaf(Gp[r * 4 + 2], rel[2], fmaf(Gp[r * 4 + 1], rel[1], Gp[r * 4 + 0] * rel[0])) + Gp[r * 4 + 3];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_pose_fwd(PoseFwdP p) {
+  __shared__ float sG[8][MH_NJ][12];
+  __shared__ float sJ[8][MH_NJ][3];
+  const int bl = threadIdx.x >> 5, j = threadIdx.x & 31;
+  const int b = blockIdx.x * 8 + bl;
+  const bool valid = b < p.B, act = j < MH_NJ;
+  float beta[MH_NUM_BETAS];
+#pragma unroll
+  for (int l = 0; l < MH_NUM_BETAS; ++l) beta[l] = valid ? p.betas[(size_t)(b % p.NB) * MH_NUM_BETAS + l] : 0.f;
+  float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, J[3] = {0, 0, 0};
+  if (valid && act) {
+    mh_joint_rest(p.Jt, p.JS, beta, j, J);
+    if (j < 22) {   // hands (22,23) stay identity: smpl.py:542-546
+      float r[3] = {p.poses[(size_t)b * 72 + 3 * j], p.poses[(size_t)b * 72 + 3 * j + 1], p.poses[(size_t)b * 72 + 3 * j + 2]};
+      mh_rodrigues(r, R);
+    }
+    sJ[bl][j][0] = J[0];
+    sJ[bl][j][1] = J[1];
+    sJ[bl][j][2] = J[2];
+  }
+  __syncthreads();
+  float Gm[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  const int par = act ? p.tree.parent[j] : -1;
+  const int lev = act ? p.tree.level[j] : -1;
+  float rel[3] = {J[0], J[1], J[2]};
+  if (valid && act && j > 0) {
+    rel[0] -= sJ[bl][par][0];
+    rel[1] -= sJ[bl][par][1];
+    rel[2] -= sJ[bl][par][2];
+  }
+  for (int l = 0; l <= p.tree.maxlevel; ++l) {
+    if (valid && act && lev == l) {
+      if (l == 0) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          Gm[r * 4 + 0] = R[r * 3 + 0];
+          Gm[r * 4 + 1] = R[r * 3 + 1];
+          Gm[r * 4 + 2] = R[r * 3 + 2];
+          Gm[r * 4 + 3] = J[r];
+        }
+      } else {
+        float Gp[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) Gp[e] = sG[bl][par][e];
+        mh_compose(Gp, R, rel, Gm);
+      }
+#pragma unroll
+      for (int e = 0; e < 12; ++e) sG[bl][j][e] = Gm[e];
+    }
+    __syncthreads();
+  }
+  const int g = b >> 5, bi = b & 31;
+  if (b < p.G * 32 && act) {
+    float* Ao = p.A + ((size_t)b * MH_NJ + j) * 12;
+    if (valid) {
+      // A = [G.R | G.t - G.R.J]  (rest pose removed, smpl.py:743-744)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        Ao[r * 4 + 0] = Gm[r * 4 + 0];
+        Ao[r * 4 + 1] = Gm[r * 4 + 1];
+        Ao[r * 4 + 2] = Gm[r * 4 + 2];
+        float gj = fmaf(Gm[r * 4 + 2], J[2], fmaf(Gm[r * 4 + 1], J[1], Gm[r * 4 + 0] * J[0]));
+        Ao[r * 4 + 3] = Gm[r * 4 + 3] - gj;
+      }
+      if (p.posed) {
+        p.posed[((size_t)b * MH_NJ + j) * 3 + 0] = Gm[3];
+        p.posed[((size_t)b * MH_NJ + j) * 3 + 1] = Gm[7];
+        p.posed[((size_t)b * MH_NJ + j) * 3 + 2] = Gm[11];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 12; ++e) Ao[e] = 0.f;
+    }
+  }
+  if (b < p.G * 32) {
+    float* fT = p.featT + (size_t)g * MH_FS * 32 + bi;
+    if (j < MH_NUM_BETAS) fT[j * 32] = beta[j];
+    if (act && j >= 1) {
+#pragma unroll
+      for (int e = 0; e < 9; ++e) {
+        float id = (e == 0 || e == 4 || e == 8) ? 1.f : 0.f;
+        fT[(10 + (j - 1) * 9 + e) * 32] = valid ? (R[e] - id) : 0.f;   // smpl.py:547
+      }
+    }
+    if (j >= 24 && j < 31) fT[(217 + (j - 24)) * 32] = 0.f;
+    if (j == 0) p.scale[b] = (valid && p.xscale) ? powf(1.1f, p.xscale[b % p.NB]) : 1.f;   // optimizer.py:681
+  }
+}
+
+struct SkinFwdP {
+  int B, G, V, VP, nw;
+  const float* featT;
+  const float* A;
+  const float* scale;
+  const float* transl;   // [B][3] or null
+  const float* D;
+  const float* vt;
+  const int* skidx;
+  const float* skw;
+  float* verts;          // [B][V][3]
+  float* vposed;         // [B][V][3] or null
+};
+
+__global__ __launch_bounds__(256) void k_skin_fwd(SkinFwdP p) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int g = blockIdx.y * 4 + wave;
+  if (g >= p.G) return;
+  const int v = blockIdx.x * 32 + li;
+  const float* fT = p.featT + (size_t)g * MH_FS * 32 + li;
+  const float* Dx = p.D + (size_t)v;
+  const size_t plane = (size_t)MH_KD * p.VP;
+  f32x16 ax = {0}, ay = {0}, az = {0};
+#pragma unroll 4
+  for (int s = 0; s < 109; ++s) {     // K = 218 (217 used)
+    const int k = 2 * s + lh;
+    const float a = fT[k * 32];
+    const float* d = Dx + (size_t)k * p.VP;
+    const float bx = d[0], by = d[plane], bz = d[2 * plane];
+    ax = MFMA32(a, bx, ax);
+    ay = MFMA32(a, by, ay);
+    az = MFMA32(a, bz, az);
+  }
+  if (v >= p.V) return;
+  const float t0 = p.vt[(size_t)v * 3], t1 = p.vt[(size_t)v * 3 + 1], t2 = p.vt[(size_t)v * 3 + 2];
+  int sj[4];
+  float sw[4];
+  const int nwl = p.nw < 4 ? p.nw : 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    sj[k] = k < nwl ? p.skidx[(size_t)v * p.nw + k] : 0;
+    sw[k] = k < nwl ? p.skw[(size_t)v * p.nw + k] : 0.f;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+    const int b = g * 32 + row;
+    if (b >= p.B) continue;
+    const float vp0 = t0 + ax[r], vp1 = t1 + ay[r], vp2 = t2 + az[r];
+    float T[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) T[e] = 0.f;
+    const float* Ab = p.A + (size_t)b * MH_NJ * 12;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f32x4* Aj = (const f32x4*)(Ab + sj[k] * 12);
+      const f32x4 q0 = Aj[0], q1 = Aj[1], q2 = Aj[2];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        T[e] = fmaf(sw[k], q0[e], T[e]);
+        T[4 + e] = fmaf(sw[k], q1[e], T[4 + e]);
+        T[8 + e] = fmaf(sw[k], q2[e], T[8 + e]);
+      }
+    }
+    for (int k = 4; k < p.nw; ++k) {   // models with more than 4 bones per vertex
+      const float w = p.skw[(size_t)v * p.nw + k];
+      const float* Aj = Ab + p.skidx[(size_t)v * p.nw + k] * 12;
+#pragma unroll
+      for (int e = 0; e < 12; ++e) T[e] = fmaf(w, Aj[e], T[e]);
+    }
+    const float x0 = fmaf(T[2], vp2, fmaf(T[1], vp1, T[0] * vp0)) + T[3];
+    const float x1 = fmaf(T[6], vp2, fmaf(T[5], vp1, T[4] * vp0)) + T[7];
+    const float x2 = fmaf(T[10], vp2, fmaf(T[9], vp1, T[8] * vp0)) + T[11];
+    const float s = p.scale[b];
+    float o0 = s * x0, o1 = s * x1, o2 = s * x2;
+    if (p.transl) {
+      o0 += p.transl[(size_t)b * 3];
+      o1 += p.transl[(size_t)b * 3 + 1];
+      o2 += p.transl[(size_t)b * 3 + 2];
+    }
+    float* o = p.verts + ((size_t)b * p.V + v) * 3;
+    o[0] = o0;
+    o[1] = o1;
+    o[2] = o2;
+    if (p.vposed) {
+      float* q = p.vposed + ((size_t)b * p.V + v) * 3;
+      q[0] = vp0;
+      q[1] = vp1;
+      q[2] = vp2;
+    }
+  }
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct FwdWs {
+  float* featT;
+  float* A;
+  float* scale;
+};
+static FwdWs carve_fwd(void* ws, int G) {
+  char* p = (char*)ws;
+  FwdWs w;
+  w.featT = (float*)p;
+  p += align256((size_t)G * MH_FS * 32 * 4);
+  w.A = (float*)p;
+  p += align256((size_t)G * 32 * MH_NJ * 12 * 4);
+  w.scale = (float*)p;
+  return w;
+}
+
+extern "C" size_t mh_lbs_workspace_bytes(int B) {
+  int G = mh_groups(B < 1 ? 1 : B);
+  return align256((size_t)G * MH_FS * 32 * 4) + align256((size_t)G * 32 * MH_NJ * 12 * 4) + align256((size_t)G * 32 * 4);
+}
+
+extern "C" int mh_lbs_forward(const mh_model* m, int B, int NB, const float* betas, const float* poses,
+                              const float* xscale, const float* transl, float* verts, float* vposed,
+                              float* posed_joints, void* ws, void* stream) {
+  MH_CHECK(m && betas && poses && verts && ws, "null argument");
+  MH_CHECK(B > 0 && NB > 0, "B and NB must be positive");
+  hipStream_t st = (hipStream_t)stream;
+  const int G = mh_groups(B);
+  FwdWs w = carve_fwd(ws, G);
+  PoseFwdP pp;
+  pp.B = B; pp.NB = NB; pp.G = G;
+  pp.betas = betas; pp.poses = poses; pp.xscale = xscale;
+  pp.Jt = m->Jt; pp.JS = m->JS;
+  pp.featT = w.featT; pp.A = w.A; pp.scale = w.scale; pp.posed = posed_joints;
+  pp.tree = m->tree;
+  hipLaunchKernelGGL(k_pose_fwd, dim3(G * 4), dim3(256), 0, st, pp);
+  MH_LAUNCH_CHECK();
+  SkinFwdP sp;
+  sp.B = B; sp.G = G; sp.V = m->V; sp.VP = m->VP; sp.nw = m->nw;
+  sp.featT = w.featT; sp.A = w.A; sp.scale = w.scale; sp.transl = transl;
+  sp.D = m->D; sp.vt = m->vt; sp.skidx = m->skidx; sp.skw = m->skw;
+  sp.verts = verts; sp.vposed = vposed;
+  hipLaunchKernelGGL(k_skin_fwd, dim3(m->VP / 32, (G + 3) / 4), dim3(256), 0, st, sp);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+// =============================================================================================
+// sparse joint regression
+// =============================================================================================
+__global__ __launch_bounds__(64) void k_joints_regress(int B, int V, int J, const int* ptr, const int* vidx,
+                                                       const float* w, const float* rowsum, const float* verts,
+                                                       const float* corr, int root, float* joints) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float* vb = verts + (size_t)b * V * 3;
+  float rx = 0, ry = 0, rz = 0;
+  for (int pass = (root >= 0 ? 0 : 1); pass < 2; ++pass) {
+    for (int jj = 0; jj < J; ++jj) {
+      const int j = (pass == 0) ? root : jj;
+      float a0 = 0, a1 = 0, a2 = 0;
+      for (int e = ptr[j] + lane; e < ptr[j + 1]; e += 64) {
+        const float ww = w[e];
+        const float* q = vb + (size_t)vidx[e] * 3;
+        a0 = fmaf(ww, q[0], a0);
+        a1 = fmaf(ww, q[1], a1);
+        a2 = fmaf(ww, q[2], a2);
+      }
+      a0 = mh_wave_sum(a0);
+      a1 = mh_wave_sum(a1);
+      a2 = mh_wave_sum(a2);
+      if (corr) {
+        const float c = 1.f - rowsum[j];
+        a0 = fmaf(c, corr[(size_t)b * 3], a0);
+        a1 = fmaf(c, corr[(size_t)b * 3 + 1], a1);
+        a2 = fmaf(c, corr[(size_t)b * 3 + 2], a2);
+      }
+      if (pass == 0) {
+        rx = a0; ry = a1; rz = a2;
+        break;
+      }
+      if (lane == 0) {
+        float* o = joints + ((size_t)b * J + j) * 3;
+        o[0] = a0 - rx;
+        o[1] = a1 - ry;
+        o[2] = a2 - rz;
+      }
+    }
+  }
+}
+
+extern "C" int mh_joints_regress(const mh_model* m, int which, int B, const float* verts, const float* corr,
+                                 int root_relative_to, float* joints, void* stream) {
+  MH_CHECK(m && verts && joints, "null argument");
+  MH_CHECK(which >= 0 && which < 4, "unknown joint set");
+  const mh_regressor& r = m->reg[which];
+  MH_CHECK(r.J > 0, "this joint regressor was not given to mh_model_create");
+  MH_CHECK(root_relative_to < r.J, "root joint out of range");
+  MH_CHECK(B > 0, "B must be positive");
+  hipLaunchKernelGGL(k_joints_regress, dim3(B), dim3(64), 0, (hipStream_t)stream, B, m->V, r.J, r.ptr, r.vidx, r.w,
+                     r.rowsum, verts, corr, root_relative_to, joints);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+// =============================================================================================
+// backward
+// =============================================================================================
+#define BWD_AS 292   // LDS row stride (floats) of one body's 24x12 transforms: conflict-free b128 reads
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define BWD_NACC (14 + 24)   // f32x4 accumulators per lane: 14 feature tiles + 12 x 2 joint tiles
+
+struct SkinBwdP {
+  int B, G16, GB, V, VP, nw, CH, PQ;   // G16 = groups of 16 bodies, GB = padded body count, PQ = vertex quads per chunk
+  const float* A;
+  const float* scale;
+  const float* vposed;
+  const float* gverts;
+  const float* gjoints;   // [B][17][3] or null
+  const float* Dt;
+  const int* skidx;
+  const float* skw;
+  const int* kpv_ptr;
+  const int* kpv_j;
+  const float* kpv_w;
+  float* pF;   // [CH][GB][224]
+  float* pA;   // [CH][GB][12][24]
+  float* pS;   // [CH][GB][4]  (gT.xyz, gscale)
+};
+
+// lane = (body li = lane&15, vertex lq = lane>>4): the element-wise adjoints of one (body, vertex)
+// pair are exactly the A operand of v_mfma_f32_16x16x4_f32 (A[i=body][k=vertex]); the B operands
+// are rows of the constant tables (B[k=vertex][j=column]).
+__global__ __launch_bounds__(256, 2) void k_skin_bwd(SkinBwdP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sA = smem;                       // [16][BWD_AS]
+  float* sGj = sA + 16 * BWD_AS;          // [16][52]
+  float* sRed = sGj + 16 * 52;            // [BWD_NACC*4][64] accumulators + [16][4] scalars
+  const int g = blockIdx.x, ch = blockIdx.y;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
+  for (int i = tid; i < 16 * MH_NJ * 12; i += 256) {
+    const int bb = i / (MH_NJ * 12), e = i % (MH_NJ * 12);
+    sA[bb * BWD_AS + e] = p.A[(size_t)(g * 16 + bb) * MH_NJ * 12 + e];
+  }
+  for (int i = tid; i < 16 * 51; i += 256) {
+    const int bb = i / 51, e = i % 51;
+    const int b = g * 16 + bb;
+    sGj[bb * 52 + e] = (p.gjoints && b < p.B) ? p.gjoints[(size_t)b * 51 + e] : 0.f;
+  }
+  __syncthreads();
+  const int b = g * 16 + li;
+  const bool bvalid = b < p.B;
+  const float sb = bvalid ? p.scale[b] : 0.f;
+  f32x4 accF[14], accA[24];
+#pragma unroll
+  for (int i = 0; i < 14; ++i) accF[i] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 24; ++i) accA[i] = (f32x4){0, 0, 0, 0};
+  float sT0 = 0, sT1 = 0, sT2 = 0, sS = 0;
+  const int qend = min((ch + 1) * p.PQ, p.VP / 4);
+  const float* sAb = sA + li * BWD_AS;
+  const size_t plane = (size_t)p.VP * MH_FS;
+  for (int qd = ch * p.PQ + wave; qd < qend; qd += 4) {
+    const int v = 4 * qd + lq;
+    float g0 = 0, g1 = 0, g2 = 0, q0 = 0, q1 = 0, q2 = 0;
+    if (bvalid && v < p.V) {
+      const size_t o = ((size_t)b * p.V + v) * 3;
+      g0 = p.gverts[o]; g1 = p.gverts[o + 1]; g2 = p.gverts[o + 2];
+      q0 = p.vposed[o]; q1 = p.vposed[o + 1]; q2 = p.vposed[o + 2];
+    }
+    // key-point regressor adjoint: dL/dverts += R^T dL/djoints
+    for (int e = p.kpv_ptr[v]; e < p.kpv_ptr[v + 1]; ++e) {
+      const float w = p.kpv_w[e];
+      const float* gj = sGj + li * 52 + p.kpv_j[e] * 3;
+      g0 = fmaf(w, gj[0], g0);
+      g1 = fmaf(w, gj[1], g1);
+      g2 = fmaf(w, gj[2], g2);
+    }
+    // blended transform of this (body, vertex)
+    float T[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) T[e] = 0.f;
+    float wd0 = 0.f, wd1 = 0.f;   // dense skinning weights W[v][li], W[v][16+li] (MFMA B operands)
+    for (int k = 0; k < p.nw; ++k) {
+      const int j = p.skidx[(size_t)v * p.nw + k];
+      const float w = p.skw[(size_t)v * p.nw + k];
+      const f32x4* Aj = (const f32x4*)(sAb + j * 12);
+      const f32x4 a0 = Aj[0], a1 = Aj[1], a2 = Aj[2];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        T[e] = fmaf(w, a0[e], T[e]);
+        T[4 + e] = fmaf(w, a1[e], T[4 + e]);
+        T[8 + e] = fmaf(w, a2[e], T[8 + e]);
+      }
+      wd0 += (j == li) ? w : 0.f;
+      wd1 += (j == li + 16) ? w : 0.f;
+    }
+    const float x0 = fmaf(T[2], q2, fmaf(T[1], q1, T[0] * q0)) + T[3];
+    const float x1 = fmaf(T[6], q2, fmaf(T[5], q1, T[4] * q0)) + T[7];
+    const float x2 = fmaf(T[10], q2, fmaf(T[9], q1, T[8] * q0)) + T[11];
+    sT0 += g0; sT1 += g1; sT2 += g2;
+    sS += g0 * x0 + g1 * x1 + g2 * x2;
+    const float gx0 = sb * g0, gx1 = sb * g1, gx2 = sb * g2;
+    // d/d v_posed = T.R^T gx  -> rows of the [shape | pose] basis
+    const float gv[3] = {fmaf(T[8], gx2, fmaf(T[4], gx1, T[0] * gx0)), fmaf(T[9], gx2, fmaf(T[5], gx1, T[1] * gx0)),
+                         fmaf(T[10], gx2, fmaf(T[6], gx1, T[2] * gx0))};
+    const float* dt = p.Dt + (size_t)v * MH_FS + li;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+      for (int t = 0; t < 14; ++t) accF[t] = MFMA16(gv[c], dt[c * plane + t * 16], accF[t]);
+    }
+    // d/dA_j = sum_v w_vj gx (x) [v_posed;1]
+    const float gxs[3] = {gx0, gx1, gx2};
+    const float qh[4] = {q0, q1, q2, 1.f};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float a = gxs[r] * qh[c];
+        accA[(r * 4 + c) * 2] = MFMA16(a, wd0, accA[(r * 4 + c) * 2]);
+        accA[(r * 4 + c) * 2 + 1] = MFMA16(a, wd1, accA[(r * 4 + c) * 2 + 1]);
+      }
+    }
+  }
+  // ---- reduce the 4 waves through LDS (fixed order -> deterministic) ----
+  sT0 += __shfl_xor(sT0, 16, 64); sT0 += __shfl_xor(sT0, 32, 64);
+  sT1 += __shfl_xor(sT1, 16, 64); sT1 += __shfl_xor(sT1, 32, 64);
+  sT2 += __shfl_xor(sT2, 16, 64); sT2 += __shfl_xor(sT2, 32, 64);
+  sS += __shfl_xor(sS, 16, 64); sS += __shfl_xor(sS, 32, 64);
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < 14; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float* q = sRed + (t * 4 + r) * 64 + lane;
+          *q = (w == 0) ? accF[t][r] : (*q + accF[t][r]);
+        }
+#pragma unroll
+      for (int t = 0; t < 24; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float* q = sRed + ((14 + t) * 4 + r) * 64 + lane;
+          *q = (w == 0) ? accA[t][r] : (*q + accA[t][r]);
+        }
+      if (lq == 0) {
+        float* q = sRed + BWD_NACC * 4 * 64 + li * 4;
+        if (w == 0) { q[0] = sT0; q[1] = sT1; q[2] = sT2; q[3] = sS; }
+        else { q[0] += sT0; q[1] += sT1; q[2] += sT2; q[3] += sS; }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- write this chunk's partials; accumulator (t, r) of lane l is C[row = (l>>4)*4 + r][col = l&15] ----
+  const size_t base = (size_t)ch * p.GB + (size_t)g * 16;
+  float* oF = p.pF + base * MH_FS;
+  for (int i = tid; i < 14 * 4 * 64; i += 256) {
+    const int t = i >> 8, r = (i >> 6) & 3, l = i & 63;
+    const int row = (l >> 4) * 4 + r;
+    oF[(size_t)row * MH_FS + t * 16 + (l & 15)] = sRed[i];
+  }
+  float* oA = p.pA + base * 288;
+  for (int i = tid; i < 24 * 4 * 64; i += 256) {
+    const int t = i >> 8, r = (i >> 6) & 3, l = i & 63;
+    const int row = (l >> 4) * 4 + r;
+    const int joint = (t & 1) * 16 + (l & 15);
+    if (joint < MH_NJ) oA[(size_t)row * 288 + (t >> 1) * MH_NJ + joint] = sRed[14 * 256 + i];
+  }
+  float* oS = p.pS + base * 4;
+  for (int i = tid; i < 64; i += 256) oS[i] = sRed[BWD_NACC * 4 * 64 + i];
+}
+
+struct PoseBwdP {
+  int B, NB, G, CH;
+  const float* betas;
+  const float* poses;
+  const float* gjoints;     // null ok
+  const float* kp_rowsum;   // [17] (null when no key-point regressor)
+  const float* scale;
+  const float* Jt;
+  const float* JS;
+  const float* pF;
+  const float* pA;
+  const float* pS;
+  float* gposes;    // [B][72] +=
+  float* gtransl;   // [B][3] += (null ok)
+  float* gbeta_b;   // [G*32][10]
+  float* gxs_b;     // [G*32]
+  mh_tree tree;
+};
+
+__global__ __launch_bounds__(256) void k_pose_bwd(PoseBwdP p) {
+  __shared__ float sGA[8][12 * MH_NJ];   // summed dL/dA  [e][j]
+  __shared__ float sGF[8][MH_FS];        // summed dL/dfeat
+  __shared__ float sG[8][MH_NJ][12];
+  __shared__ float sgG[8][MH_NJ][12];
+  __shared__ float sJ[8][MH_NJ][3];
+  __shared__ float sgJ[8][MH_NJ][3];
+  __shared__ float sS[8][4];
+  const int bl = threadIdx.x >> 5, j = threadIdx.x & 31;
+  const int b = blockIdx.x * 8 + bl;
+  const bool valid = b < p.B, act = j < MH_NJ;
+  const size_t GB = (size_t)p.G * 32;
+  // 1. sum the chunk partials (fixed order)
+  for (int e = j; e < 288; e += 32) {
+    float a = 0;
+    for (int c = 0; c < p.CH; ++c) a += p.pA[((size_t)c * GB + b) * 288 + e];
+    sGA[bl][e] = a;
+  }
+  for (int e = j; e < MH_FS; e += 32) {
+    float a = 0;
+    for (int c = 0; c < p.CH; ++c) a += p.pF[((size_t)c * GB + b) * MH_FS + e];
+    sGF[bl][e] = a;
+  }
+  if (j < 4) {
+    float a = 0;
+    for (int c = 0; c < p.CH; ++c) a += p.pS[((size_t)c * GB + b) * 4 + j];
+    sS[bl][j] = a;
+  }
+  // 2. recompute the forward chain
+  float beta[MH_NUM_BETAS];
+#pragma unroll
+  for (int l = 0; l < MH_NUM_BETAS; ++l) beta[l] = valid ? p.betas[(size_t)(b % p.NB) * MH_NUM_BETAS + l] : 0.f;
+  float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, J[3] = {0, 0, 0}, th[3] = {0, 0, 0};
+  if (valid && act) {
+    mh_joint_rest(p.Jt, p.JS, beta, j, J);
+    if (j < 22) {
+      th[0] = p.poses[(size_t)b * 72 + 3 * j];
+      th[1] = p.poses[(size_t)b * 72 + 3 * j + 1];
+      th[2] = p.poses[(size_t)b * 72 + 3 * j + 2];
+      mh_rodrigues(th, R);
+    }
+  }
+  if (act) {
+    sJ[bl][j][0] = J[0]; sJ[bl][j][1] = J[1]; sJ[bl][j][2] = J[2];
+  }
+  __syncthreads();
+  const int par = act ? p.tree.parent[j] : -1;
+  const int lev = act ? p.tree.level[j] : -1;
+  float rel[3] = {J[0], J[1], J[2]};
+  if (act && j > 0) {
+    rel[0] -= sJ[bl][par][0]; rel[1] -= sJ[bl][par][1]; rel[2] -= sJ[bl][par][2];
+  }
+  float Gm[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  for (int l = 0; l <= p.tree.maxlevel; ++l) {
+    if (act && lev == l) {
+      if (l == 0) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          Gm[r * 4 + 0] = R[r * 3]; Gm[r * 4 + 1] = R[r * 3 + 1]; Gm[r * 4 + 2] = R[r * 3 + 2]; Gm[r * 4 + 3] = J[r];
+        }
+      } else {
+        float Gp[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) Gp[e] = sG[bl][par][e];
+        mh_compose(Gp, R, rel, Gm);
+      }
+#pragma unroll
+      for (int e = 0; e < 12; ++e) sG[bl][j][e] = Gm[e];
+    }
+    __syncthreads();
+  }
+  // 3. adjoint of A = [G.R | G.t - G.R.J]
+  float gA[12];
+  if (act) {
+#pragma unroll
+    for (int e = 0; e < 12; ++e) gA[e] = sGA[bl][e * MH_NJ + j];
+    float gJ[3] = {0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float gt = gA[r * 4 + 3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        sgG[bl][j][r * 4 + c] = gA[r * 4 + c] - gt * J[c];
+        gJ[c] -= Gm[r * 4 + c] * gt;
+      }
+      sgG[bl][j][r * 4 + 3] = gt;
+    }
+    sgJ[bl][j][0] = gJ[0]; sgJ[bl][j][1] = gJ[1]; sgJ[bl][j][2] = gJ[2];
+  }
+  __syncthreads();
+  // 4. adjoint of the chain, deepest level first
+  float gR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int l = p.tree.maxlevel; l >= 1; --l) {
+    if (act && lev == l) {
+      float gG[12], Gp[12];
+#pragma unroll
+      for (int e = 0; e < 12; ++e) { gG[e] = sgG[bl][j][e]; Gp[e] = sG[bl][par][e]; }
+      float grel[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        grel[c] = Gp[0 * 4 + c] * gG[3] + Gp[1 * 4 + c] * gG[7] + Gp[2 * 4 + c] * gG[11];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)   // gR = Gp.R^T gG.R
+          gR[c * 3 + d] = Gp[0 * 4 + c] * gG[0 * 4 + d] + Gp[1 * 4 + c] * gG[1 * 4 + d] + Gp[2 * 4 + c] * gG[2 * 4 + d];
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {   // gGp.R += gG.R R^T + gG.t (x) rel
+          const float a = gG[r * 4 + 0] * R[c * 3 + 0] + gG[r * 4 + 1] * R[c * 3 + 1] + gG[r * 4 + 2] * R[c * 3 + 2] + gG[r * 4 + 3] * rel[c];
+          atomicAdd(&sgG[bl][par][r * 4 + c], a);
+        }
+        atomicAdd(&sgG[bl][par][r * 4 + 3], gG[r * 4 + 3]);
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        atomicAdd(&sgJ[bl][j][c], grel[c]);
+        atomicAdd(&sgJ[bl][par][c], -grel[c]);
+      }
+    }
+    __syncthreads();
+  }
+  if (act && j == 0) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      gR[r * 3] = sgG[bl][0][r * 4]; gR[r * 3 + 1] = sgG[bl][0][r * 4 + 1]; gR[r * 3 + 2] = sgG[bl][0][r * 4 + 2];
+      sgJ[bl][0][r] += sgG[bl][0][r * 4 + 3];
+    }
+  }
+  __syncthreads();
+  // 5. pose-blend features are R_j - I for j >= 1
+  if (act && j >= 1) {
+#pragma unroll
+    for (int e = 0; e < 9; ++e) gR[e] += sGF[bl][10 + (j - 1) * 9 + e];
+  }
+  // 6. adjoint of rodrigues (joints 0..21)
+  if (valid && act && j < 22) {
+    const float e = 1e-8f;
+    const float a0 = th[0] + e, a1 = th[1] + e, a2 = th[2] + e;
+    const float ang = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+    const float x = th[0] / ang, y = th[1] / ang, z = th[2] / ang;
+    const float s = sinf(ang), c = cosf(ang), omc = 1.f - c;
+    const float K[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+    const float K2[9] = {-z * z - y * y, x * y, x * z, x * y, -z * z - x * x, y * z, x * z, y * z, -y * y - x * x};
+    float ga = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) ga += gR[i] * (c * K[i] + s * K2[i]);
+    // gK = s gR + (1-c)(gR K^T + K^T gR)
+    float gK[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+        float t = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t += gR[r * 3 + k] * K[cc * 3 + k] + K[k * 3 + r] * gR[k * 3 + cc];
+        gK[r * 3 + cc] = s * gR[r * 3 + cc] + omc * t;
+      }
+    const float gd0 = gK[7] - gK[5], gd1 = gK[2] - gK[6], gd2 = gK[3] - gK[1];
+    const float gat = ga - (gd0 * th[0] + gd1 * th[1] + gd2 * th[2]) / (ang * ang);
+    float* o = p.gposes + (size_t)b * 72 + 3 * j;
+    o[0] += gd0 / ang + gat * a0 / ang;
+    o[1] += gd1 / ang + gat * a1 / ang;
+    o[2] += gd2 / ang + gat * a2 / ang;
+  }
+  // 7. shape: direct rows of the basis + the joint-location path
+  if (b < p.G * 32 && j < MH_NUM_BETAS) {
+    float a = 0;
+    if (valid) {
+      a = sGF[bl][j];
+      for (int q = 0; q < MH_NJ * 3; ++q) a = fmaf(p.JS[q * MH_NUM_BETAS + j], sgJ[bl][q / 3][q % 3], a);
+    }
+    p.gbeta_b[(size_t)b * MH_NUM_BETAS + j] = a;
+  }
+  // 8. translation and scale
+  if (b < p.G * 32 && j == 31) p.gxs_b[b] = valid ? sS[bl][3] * p.scale[b] * 0.0953101798043249f /* ln 1.1 */ : 0.f;
+  if (valid && j >= 24 && j < 27 && p.gtransl) {
+    const int c = j - 24;
+    float a = sS[bl][c];
+    if (p.gjoints && p.kp_rowsum)
+      for (int q = 0; q < MH_NKP; ++q) a = fmaf(1.f - p.kp_rowsum[q], p.gjoints[((size_t)b * MH_NKP + q) * 3 + c], a);
+    p.gtransl[(size_t)b * 3 + c] += a;
+  }
+}
+
+// per-person reduction over frames of the per-body shape/scale gradients (fixed order)
+__global__ __launch_bounds__(256) void k_person_reduce(int B, int NB, const float* gbeta_b, const float* gxs_b,
+                                                       float* gbetas, float* gxscale) {
+  __shared__ float s[256];
+  const int n = blockIdx.x, q = blockIdx.y;   // q < 10: beta component, q == 10: scale
+  float a = 0;
+  for (int b = n + threadIdx.x * NB; b < B; b += 256 * NB) a += (q < 10) ? gbeta_b[(size_t)b * MH_NUM_BETAS + q] : gxs_b[b];
+  s[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (q < 10) {
+      if (gbetas) gbetas[(size_t)n * MH_NUM_BETAS + q] += s[0];
+    } else if (gxscale) {
+      gxscale[n] += s[0];
+    }
+  }
+}
+
+static int bwd_chunks(int G16) {
+  int ch = (512 + G16 / 2) / G16;
+  if (ch < 1) ch = 1;
+  if (ch > 27) ch = 27;
+  return ch;
+}
+
+struct BwdWs {
+  float* pF;
+  float* pA;
+  float* pS;
+  float* gbeta_b;
+  float* gxs_b;
+};
+static BwdWs carve_bwd(void* ws, int G, int CH) {
+  char* p = (char*)ws;
+  BwdWs w;
+  const size_t GB = (size_t)G * 32;
+  w.pF = (float*)p; p += align256((size_t)CH * GB * MH_FS * 4);
+  w.pA = (float*)p; p += align256((size_t)CH * GB * 288 * 4);
+  w.pS = (float*)p; p += align256((size_t)CH * GB * 4 * 4);
+  w.gbeta_b = (float*)p; p += align256(GB * MH_NUM_BETAS * 4);
+  w.gxs_b = (float*)p;
+  return w;
+}
+
+extern "C" size_t mh_lbs_backward_workspace_bytes(int B) {
+  const int G = mh_groups(B < 1 ? 1 : B), CH = bwd_chunks(2 * G);
+  const size_t GB = (size_t)G * 32;
+  return align256((size_t)CH * GB * MH_FS * 4) + align256((size_t)CH * GB * 288 * 4) + align256((size_t)CH * GB * 16) +
+         align256(GB * MH_NUM_BETAS * 4) + align256(GB * 4);
+}
+
+extern "C" int mh_lbs_backward(const mh_model* m, int B, int NB, const float* betas, const float* poses,
+                               const float* xscale, const float* transl, const float* vposed, const float* gverts,
+                               const float* gjoints, float* gposes, float* gtransl, float* gbetas, float* gxscale,
+                               void* ws, void* ws2, void* stream) {
+  (void)xscale; (void)transl;
+  MH_CHECK(m && betas && poses && vposed && gverts && gposes && ws && ws2, "null argument");
+  MH_CHECK(B > 0 && NB > 0, "B and NB must be positive");
+  MH_CHECK(!gjoints || m->reg[MH_REG_ALPHAPOSE].J == MH_NKP, "gjoints needs the key-point regressor");
+  hipStream_t st = (hipStream_t)stream;
+  const int G = mh_groups(B), G16 = 2 * G, CH = bwd_chunks(G16);
+  FwdWs fw = carve_fwd(ws, G);
+  BwdWs bw = carve_bwd(ws2, G, CH);
+  static bool attr_set = false;
+  const size_t lds = (size_t)(16 * BWD_AS + 16 * 52 + BWD_NACC * 4 * 64 + 64) * 4;
+  if (!attr_set) {
+    MH_HIP(hipFuncSetAttribute((const void*)k_skin_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  SkinBwdP sp;
+  sp.B = B; sp.G16 = G16; sp.GB = G * 32; sp.V = m->V; sp.VP = m->VP; sp.nw = m->nw; sp.CH = CH;
+  sp.PQ = (m->VP / 4 + CH - 1) / CH;
+  sp.A = fw.A; sp.scale = fw.scale; sp.vposed = vposed; sp.gverts = gverts; sp.gjoints = gjoints;
+  sp.Dt = m->Dt; sp.skidx = m->skidx; sp.skw = m->skw;
+  sp.kpv_ptr = m->kpv_ptr; sp.kpv_j = m->kpv_j; sp.kpv_w = m->kpv_w;
+  sp.pF = bw.pF; sp.pA = bw.pA; sp.pS = bw.pS;
+  hipLaunchKernelGGL(k_skin_bwd, dim3(G16, CH), dim3(256), lds, st, sp);
+  MH_LAUNCH_CHECK();
+  PoseBwdP pp;
+  pp.B = B; pp.NB = NB; pp.G = G; pp.CH = CH;
+  pp.betas = betas; pp.poses = poses; pp.gjoints = gjoints;
+  pp.kp_rowsum = m->reg[MH_REG_ALPHAPOSE].rowsum;
+  pp.scale = fw.scale; pp.Jt = m->Jt; pp.JS = m->JS;
+  pp.pF = bw.pF; pp.pA = bw.pA; pp.pS = bw.pS;
+  pp.gposes = gposes; pp.gtransl = gtransl; pp.gbeta_b = bw.gbeta_b; pp.gxs_b = bw.gxs_b;
+  pp.tree = m->tree;
+  hipLaunchKernelGGL(k_pose_bwd, dim3(G * 4), dim3(256), 0, st, pp);
+  MH_LAUNCH_CHECK();
+  if (gbetas || gxscale) {
+    hipLaunchKernelGGL(k_person_reduce, dim3(NB, 11), dim3(256), 0, st, B, NB, bw.gbeta_b, bw.gxs_b, gbetas, gxscale);
+    MH_LAUNCH_CHECK();
+  }
+  return MH_OK;
+}

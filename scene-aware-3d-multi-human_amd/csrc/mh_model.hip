@@ -1,0 +1,221 @@
+// mh_model: immutable SMPL constants, re-laid for the gfx950 kernels and uploaded once.
+// Replaces SMPL.__init__ (reference smpl.py:124-275).
+#include <algorithm>
+#include <vector>
+
+#include "mh_common.h"
+
+static thread_local char g_err[512] = "";
+
+void mh_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* mh_last_error(void) { return g_err; }
+extern "C" int mh_version(void) { return 1; }
+extern "C" int mh_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+template <typename T>
+static int upload(T** dst, const std::vector<T>& src) {
+  *dst = nullptr;
+  size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+  MH_HIP(hipMalloc((void**)dst, bytes));
+  if (!src.empty()) MH_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  return MH_OK;
+}
+
+static int build_regressor(mh_regressor* r, const float* dense, int J, int V) {
+  r->J = 0;
+  r->nnz = 0;
+  r->ptr = nullptr;
+  r->vidx = nullptr;
+  r->w = nullptr;
+  r->rowsum = nullptr;
+  if (!dense) return MH_OK;
+  std::vector<int> ptr(J + 1, 0), vidx;
+  std::vector<float> w, rs(J, 0.f);
+  for (int j = 0; j < J; ++j) {
+    double s = 0;
+    for (int v = 0; v < V; ++v) {
+      float x = dense[(size_t)j * V + v];
+      if (x != 0.f) {
+        vidx.push_back(v);
+        w.push_back(x);
+        s += x;
+      }
+    }
+    ptr[j + 1] = (int)vidx.size();
+    rs[j] = (float)s;
+  }
+  r->J = J;
+  r->nnz = (int)vidx.size();
+  int rc;
+  if ((rc = upload(&r->ptr, ptr))) return rc;
+  if ((rc = upload(&r->vidx, vidx))) return rc;
+  if ((rc = upload(&r->w, w))) return rc;
+  if ((rc = upload(&r->rowsum, rs))) return rc;
+  return MH_OK;
+}
+
+extern "C" int mh_model_create(mh_model** out, const mh_model_host* h) {
+  MH_CHECK(out && h, "null argument");
+  MH_CHECK(h->num_verts > 0 && h->num_faces > 0, "empty model");
+  MH_CHECK(h->v_template && h->shapedirs && h->posedirs && h->J_regressor && h->lbs_weights && h->parents && h->faces,
+           "missing model array");
+  if (mh_device_count() <= 0) {
+    mh_set_error("no HIP device visible: the MI355X path cannot run here");
+    return MH_ERR_NO_DEVICE;
+  }
+  const int V = h->num_verts, F = h->num_faces;
+  const int VP = ((V + 31) / 32) * 32;
+  mh_model* m = new mh_model();
+  memset(m, 0, sizeof(*m));
+  m->V = V;
+  m->VP = VP;
+  m->F = F;
+
+  // kinematic tree (smpl.py:270-272): parents must precede children
+  for (int j = 0; j < MH_NJ; ++j) {
+    int p = h->parents[j];
+    if (j == 0) p = -1;
+    if (j > 0 && (p < 0 || p >= j)) {
+      delete m;
+      mh_set_error("parents[%d]=%d: parents must precede children", j, p);
+      return MH_ERR_INVALID;
+    }
+    m->tree.parent[j] = p;
+    m->tree.level[j] = (j == 0) ? 0 : m->tree.level[p] + 1;
+    m->tree.maxlevel = std::max(m->tree.maxlevel, m->tree.level[j]);
+  }
+
+  int rc = MH_OK;
+  {
+    std::vector<float> vt((size_t)VP * 3, 0.f);
+    memcpy(vt.data(), h->v_template, (size_t)V * 3 * sizeof(float));
+    if ((rc = upload(&m->vt, vt))) return rc;
+  }
+  {
+    // basis planes: D[c][k][v]; k<10: shapedirs[v][c][k]; 10<=k<217: posedirs[v][c][k-10]
+    std::vector<float> D((size_t)3 * MH_KD * VP, 0.f), Dt((size_t)3 * VP * MH_FS, 0.f);
+    for (int v = 0; v < V; ++v)
+      for (int c = 0; c < 3; ++c) {
+        for (int k = 0; k < MH_NUM_BETAS; ++k) {
+          float x = h->shapedirs[((size_t)v * 3 + c) * MH_NUM_BETAS + k];
+          D[((size_t)c * MH_KD + k) * VP + v] = x;
+          Dt[((size_t)c * VP + v) * MH_FS + k] = x;
+        }
+        for (int k = 0; k < MH_NUM_POSE_BASIS; ++k) {
+          float x = h->posedirs[((size_t)v * 3 + c) * MH_NUM_POSE_BASIS + k];
+          D[((size_t)c * MH_KD + 10 + k) * VP + v] = x;
+          Dt[((size_t)c * VP + v) * MH_FS + 10 + k] = x;
+        }
+      }
+    if ((rc = upload(&m->D, D))) return rc;
+    if ((rc = upload(&m->Dt, Dt))) return rc;
+  }
+  {
+    // skinning weights: keep the non-zeros per vertex (<= 4 in SMPL); nw = max count
+    int nw = 1;
+    for (int v = 0; v < V; ++v) {
+      int c = 0;
+      for (int j = 0; j < MH_NJ; ++j) c += h->lbs_weights[(size_t)v * MH_NJ + j] != 0.f;
+      nw = std::max(nw, c);
+    }
+    if (nw > 4 && nw < 8) nw = 8;
+    if (nw > 8) nw = MH_NJ;
+    m->nw = nw;
+    std::vector<int> idx((size_t)VP * nw, 0);
+    std::vector<float> w((size_t)VP * nw, 0.f);
+    for (int v = 0; v < V; ++v) {
+      int c = 0;
+      for (int j = 0; j < MH_NJ; ++j) {
+        float x = h->lbs_weights[(size_t)v * MH_NJ + j];
+        if (x != 0.f) {
+          idx[(size_t)v * nw + c] = j;
+          w[(size_t)v * nw + c] = x;
+          ++c;
+        }
+      }
+    }
+    if ((rc = upload(&m->skidx, idx))) return rc;
+    if ((rc = upload(&m->skw, w))) return rc;
+  }
+  {
+    // J = Jt + JS.beta  ==  J_regressor.(v_template + shapedirs.beta)  (smpl.py:532-535), hoisted
+    std::vector<float> Jt(MH_NJ * 3), JS(MH_NJ * 3 * MH_NUM_BETAS);
+    for (int j = 0; j < MH_NJ; ++j)
+      for (int c = 0; c < 3; ++c) {
+        double a = 0;
+        std::vector<double> s(MH_NUM_BETAS, 0.0);
+        for (int v = 0; v < V; ++v) {
+          double r = h->J_regressor[(size_t)j * V + v];
+          if (r == 0.0) continue;
+          a += r * h->v_template[(size_t)v * 3 + c];
+          for (int l = 0; l < MH_NUM_BETAS; ++l) s[l] += r * h->shapedirs[((size_t)v * 3 + c) * MH_NUM_BETAS + l];
+        }
+        Jt[j * 3 + c] = (float)a;
+        for (int l = 0; l < MH_NUM_BETAS; ++l) JS[(j * 3 + c) * MH_NUM_BETAS + l] = (float)s[l];
+      }
+    if ((rc = upload(&m->Jt, Jt))) return rc;
+    if ((rc = upload(&m->JS, JS))) return rc;
+  }
+  {
+    std::vector<int> f(h->faces, h->faces + (size_t)F * 3);
+    for (int x : f)
+      if (x < 0 || x >= V) {
+        mh_set_error("face index out of range");
+        return MH_ERR_INVALID;
+      }
+    if ((rc = upload(&m->faces, f))) return rc;
+  }
+  if ((rc = build_regressor(&m->reg[MH_REG_ALPHAPOSE], h->reg_alphapose, MH_NKP, V))) return rc;
+  if ((rc = build_regressor(&m->reg[MH_REG_H36M17], h->reg_h36m17, 17, V))) return rc;
+  if ((rc = build_regressor(&m->reg[MH_REG_MUPOTS], h->reg_mupots, 17, V))) return rc;
+  if ((rc = build_regressor(&m->reg[MH_REG_EXTRA9], h->reg_extra9, 9, V))) return rc;
+  {
+    std::vector<int> ptr(VP + 1, 0), js;
+    std::vector<float> ws;
+    for (int v = 0; v < VP; ++v) {
+      if (h->reg_alphapose && v < V)
+        for (int j = 0; j < MH_NKP; ++j) {
+          float x = h->reg_alphapose[(size_t)j * V + v];
+          if (x != 0.f) {
+            js.push_back(j);
+            ws.push_back(x);
+          }
+        }
+      ptr[v + 1] = (int)js.size();
+    }
+    if ((rc = upload(&m->kpv_ptr, ptr))) return rc;
+    if ((rc = upload(&m->kpv_j, js))) return rc;
+    if ((rc = upload(&m->kpv_w, ws))) return rc;
+  }
+  *out = m;
+  return MH_OK;
+}
+
+extern "C" int mh_model_destroy(mh_model* m) {
+  if (!m) return MH_OK;
+  void* ptrs[] = {m->vt, m->D, m->Dt, m->skidx, m->skw, m->Jt, m->JS, m->faces, m->kpv_ptr, m->kpv_j, m->kpv_w};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  for (int i = 0; i < 4; ++i) {
+    void* q[] = {m->reg[i].ptr, m->reg[i].vidx, m->reg[i].w, m->reg[i].rowsum};
+    for (void* p : q)
+      if (p) (void)hipFree(p);
+  }
+  delete m;
+  return MH_OK;
+}
+
+extern "C" const int32_t* mh_model_faces(const mh_model* m) { return m ? m->faces : nullptr; }

@@ -1,0 +1,288 @@
+// Streaming (HBM-bound) kernels of the optimisation loop: key-point projection + 2D residual,
+// RMSprop / Adam updates, one-euro scan, temporal terms.
+#include "mh_common.h"
+
+// =============================================================================================
+// a11/a12: projection of the 17 key-points + masked 2D residual and its gradient
+// =============================================================================================
+struct ProjP {
+  int B, mode, has_kd;
+  float K[9];
+  float Kd[5];
+  float thr, w, h, coef;
+  const float* joints;
+  const float* pose2d;
+  float* uv;
+  float* gj;
+  float* loss;
+};
+
+__global__ __launch_bounds__(64) void k_project_loss(ProjP p) {
+  const int b = blockIdx.x, j = threadIdx.x;
+  float l = 0.f;
+  if (j < MH_NKP) {
+    const size_t o = (size_t)b * MH_NKP + j;
+    const float X = p.joints[o * 3], Y = p.joints[o * 3 + 1], Z = p.joints[o * 3 + 2];
+    const float x = X / Z, y = Y / Z;                        // transforms.py:75-76
+    float xx = x, yy = y, dxx_dx = 1, dxx_dy = 0, dyy_dx = 0, dyy_dy = 1;
+    if (p.has_kd) {                                          // transforms.py:78-90
+      const float k1 = p.Kd[0], k2 = p.Kd[1], p1 = p.Kd[2], p2 = p.Kd[3], k3 = p.Kd[4];
+      const float r = x * x + y * y;
+      const float rad = 1 + k1 * r + k2 * r * r + k3 * r * r * r;
+      const float drad = k1 + 2 * k2 * r + 3 * k3 * r * r;
+      xx = x * rad + 2 * p1 * x * y + p2 * (r + 2 * x * x);
+      yy = y * rad + 2 * p2 * y * y + p1 * (r + 2 * y * y);  // (sic) the reference's second tangential term
+      dxx_dx = rad + x * drad * 2 * x + 2 * p1 * y + p2 * (2 * x + 4 * x);
+      dxx_dy = x * drad * 2 * y + 2 * p1 * x + p2 * (2 * y);
+      dyy_dx = y * drad * 2 * x + p1 * (2 * x);
+      dyy_dy = rad + y * drad * 2 * y + 4 * p2 * y + p1 * (2 * y + 4 * y);
+    }
+    const float u = xx * p.K[0] + yy * p.K[1] + p.K[2];      // transforms.py:92
+    const float v = xx * p.K[3] + yy * p.K[4] + p.K[5];
+    if (p.uv) {
+      p.uv[o * 2] = u;
+      p.uv[o * 2 + 1] = v;
+    }
+    const float conf = p.pose2d[o * 3 + 2];
+    float gu, gvv;
+    if (p.mode == 0) {   // optimizer.py:364-368, 404, 419-420
+      const float c = conf >= p.thr ? 1.f : 0.f;
+      const float du = c * u / p.w - c * p.pose2d[o * 3] / p.w;
+      const float dv = c * v / p.h - c * p.pose2d[o * 3 + 1] / p.h;
+      l = du * du + dv * dv;
+      gu = 2 * du * c / p.w;
+      gvv = 2 * dv * c / p.h;
+    } else {             // optimizer.py:735, 754-756 (mean over B*17*2 elements, pixels)
+      const float c = conf > p.thr ? 1.f : 0.f;
+      const float du = c * u - c * p.pose2d[o * 3];
+      const float dv = c * v - c * p.pose2d[o * 3 + 1];
+      const float inv = 1.f / ((float)p.B * MH_NKP * 2);
+      l = (du * du + dv * dv) * inv;
+      gu = 2 * du * c * inv;
+      gvv = 2 * dv * c * inv;
+    }
+    gu *= p.coef;
+    gvv *= p.coef;
+    const float gxx = gu * p.K[0] + gvv * p.K[3], gyy = gu * p.K[1] + gvv * p.K[4];
+    const float gx = gxx * dxx_dx + gyy * dyy_dx, gy = gxx * dxx_dy + gyy * dyy_dy;
+    p.gj[o * 3] = gx / Z;
+    p.gj[o * 3 + 1] = gy / Z;
+    p.gj[o * 3 + 2] = -(gx * x + gy * y) / Z;
+  }
+  l = mh_wave_sum(l);
+  if (j == 0) p.loss[b] = l;
+}
+
+extern "C" int mh_project_joints_loss(int B, const float* joints, const float* K_host, const float* Kd_host,
+                                      const float* pose2d, float thr, int mode, float img_w, float img_h, float coef,
+                                      float* uv, float* gjoints, float* loss, void* stream) {
+  MH_CHECK(joints && K_host && pose2d && gjoints && loss, "null argument");
+  MH_CHECK(B > 0, "B must be positive");
+  ProjP p;
+  p.B = B; p.mode = mode; p.has_kd = Kd_host != nullptr;
+  for (int i = 0; i < 9; ++i) p.K[i] = K_host[i];
+  for (int i = 0; i < 5; ++i) p.Kd[i] = Kd_host ? Kd_host[i] : 0.f;
+  p.thr = thr; p.w = img_w; p.h = img_h; p.coef = coef;
+  p.joints = joints; p.pose2d = pose2d; p.uv = uv; p.gj = gjoints; p.loss = loss;
+  hipLaunchKernelGGL(k_project_loss, dim3(B), dim3(64), 0, (hipStream_t)stream, p);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+// =============================================================================================
+// a20: optimiser updates
+// =============================================================================================
+__global__ void k_rmsprop(float* p, const float* g, float* sq, float* buf, size_t n, float lr, float alpha,
+                          float mom, float eps) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float s = alpha * sq[i] + (1.f - alpha) * gi * gi;   // square_avg.mul_(alpha).addcmul_(g, g, 1-alpha)
+    sq[i] = s;
+    const float b = mom * buf[i] + gi / (sqrtf(s) + eps);      // buf.mul_(momentum).addcdiv_(g, avg)
+    buf[i] = b;
+    p[i] = p[i] - lr * b;
+  }
+}
+
+extern "C" int mh_rmsprop_step(float* params, const float* grads, float* square_avg, float* momentum_buf, size_t n,
+                               float lr, float alpha, float momentum, float eps, void* stream) {
+  MH_CHECK(params && grads && square_avg && momentum_buf, "null argument");
+  if (n == 0) return MH_OK;
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(k_rmsprop, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, square_avg,
+                     momentum_buf, n, lr, alpha, momentum, eps);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+__global__ void k_adam(float* p, const float* g, float* m, float* v, size_t n, float step_size, float b1, float b2,
+                       float inv_sqrt_bc2, float eps) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+  }
+}
+
+extern "C" int mh_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, int step,
+                            float lr, float beta1, float beta2, float eps, void* stream) {
+  MH_CHECK(params && grads && exp_avg && exp_avg_sq, "null argument");
+  MH_CHECK(step >= 1, "step counts from 1");
+  if (n == 0) return MH_OK;
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n,
+                     (float)(lr / bc1), beta1, beta2, (float)(1.0 / sqrt(bc2)), eps);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+// =============================================================================================
+// a19: one-euro filter, sequential in t, parallel over channels
+// =============================================================================================
+__global__ void k_one_euro(const float* x, float* y, int T, size_t E, float min_cutoff, float beta, float frame_rate) {
+  const float two_pi = 6.283185307179586f;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < E; e += (size_t)gridDim.x * blockDim.x) {
+    float xp = x[e], dxp = 0.f, tp = 0.f, ti = 0.f;
+    y[e] = xp;
+    for (int i = 1; i < T; ++i) {
+      ti = __fadd_rn(ti, (float)((double)i / (double)frame_rate));     // optimizer.py:671 (float32 running sum)
+      const float xi = x[(size_t)i * E + e];
+      // numpy evaluates every product/sum separately in float32: no FMA contraction here
+      const float te = __fsub_rn(ti, tp);
+      float r = __fmul_rn(two_pi, te);                        // d_cutoff = 1
+      const float ad = __fdiv_rn(r, __fadd_rn(r, 1.f));
+      const float dx = __fdiv_rn(__fsub_rn(xi, xp), te);
+      const float dxh = __fadd_rn(__fmul_rn(ad, dx), __fmul_rn(__fsub_rn(1.f, ad), dxp));
+      const float cutoff = __fadd_rn(min_cutoff, __fmul_rn(beta, fabsf(dxh)));
+      r = __fmul_rn(__fmul_rn(two_pi, cutoff), te);
+      const float a = __fdiv_rn(r, __fadd_rn(r, 1.f));
+      const float xh = __fadd_rn(__fmul_rn(a, xi), __fmul_rn(__fsub_rn(1.f, a), xp));
+      y[(size_t)i * E + e] = xh;
+      xp = xh;
+      dxp = dxh;
+      tp = ti;
+    }
+  }
+}
+
+extern "C" int mh_one_euro_scan(const float* x, float* y, int T, size_t E, float min_cutoff, float beta,
+                                float frame_rate, void* stream) {
+  MH_CHECK(x && y, "null argument");
+  MH_CHECK(T >= 1 && E >= 1, "empty input");
+  const size_t nb = (E + 255) / 256;
+  hipLaunchKernelGGL(k_one_euro, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, (hipStream_t)stream, x, y, T, E,
+                     min_cutoff, beta, frame_rate);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+// =============================================================================================
+// a18: temporal terms
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_velocity(int T, int N, const float* pT, const float* prev, const float* next,
+                                                  float coef, float* gpT, float* loss_out) {
+  // single block: the problem is T*N*3 floats
+  __shared__ float s[256];
+  const size_t E = (size_t)N * 3, n = (size_t)T * E;
+  float acc = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += 256) {
+    const size_t t = i / E, e = i % E;
+    const float c = pT[i];
+    float g = 0.f;
+    if (t > 0 || prev) {
+      const float d = c - (t > 0 ? pT[i - E] : prev[e]);
+      acc += d * d;          // the pair (t-1, t) belongs to the owner of t
+      g += 2.f * d;
+    }
+    if (t + 1 < (size_t)T || next) {
+      const float d = (t + 1 < (size_t)T ? pT[i + E] : next[e]) - c;
+      g -= 2.f * d;
+    }
+    gpT[i] += coef * g;
+  }
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss_out[0] = s[0];
+}
+
+extern "C" int mh_velocity_term(int T, int N, const float* pT, const float* prev_halo, const float* next_halo,
+                                float coef, float* gpT, float* loss_out, void* stream) {
+  MH_CHECK(pT && gpT && loss_out, "null argument");
+  MH_CHECK(T >= 1 && N >= 1, "empty input");
+  hipLaunchKernelGGL(k_velocity, dim3(1), dim3(256), 0, (hipStream_t)stream, T, N, pT, prev_halo, next_halo, coef, gpT,
+                     loss_out);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+__global__ __launch_bounds__(256) void k_filtered_verts(int T, size_t E, const float* v, const float* vf,
+                                                        const float* pv, const float* pvf, const float* nv,
+                                                        const float* nvf, float coef, float* gv, float* partial) {
+  __shared__ float s[256];
+  float acc = 0.f;
+  const size_t n = (size_t)T * E;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t t = i / E, e = i - t * E;
+    const float c = v[i], cf = vf[i];
+    float g = 0.f;
+    if (t > 0 || pv) {
+      const float d = (c - (t > 0 ? v[i - E] : pv[e])) - (cf - (t > 0 ? vf[i - E] : pvf[e]));
+      acc += d * d;
+      g += 2.f * d;
+    }
+    if (t + 1 < (size_t)T || nv) {
+      const float d = ((t + 1 < (size_t)T ? v[i + E] : nv[e]) - c) - ((t + 1 < (size_t)T ? vf[i + E] : nvf[e]) - cf);
+      g -= 2.f * d;
+    }
+    gv[i] += coef * g;
+  }
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = s[0];
+}
+
+__global__ __launch_bounds__(256) void k_sum_partials(const float* partial, int n, float* out) {
+  __shared__ float s[256];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) a += partial[i];
+  s[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = s[0];
+}
+
+#define FV_BLOCKS 1024
+static float* g_fv_partial = nullptr;   // FV_BLOCKS floats of scratch, allocated once per process
+
+extern "C" int mh_filtered_verts_term(int T, size_t E, const float* verts, const float* verts_filt,
+                                      const float* prev_v, const float* prev_vf, const float* next_v,
+                                      const float* next_vf, float coef, float* gverts, float* loss_out, void* stream) {
+  MH_CHECK(verts && verts_filt && gverts && loss_out, "null argument");
+  MH_CHECK(T >= 1 && E >= 1, "empty input");
+  MH_CHECK((prev_v == nullptr) == (prev_vf == nullptr) && (next_v == nullptr) == (next_vf == nullptr),
+           "halo vertices and filtered halo vertices come in pairs");
+  if (!g_fv_partial) MH_HIP(hipMalloc((void**)&g_fv_partial, FV_BLOCKS * sizeof(float)));
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_filtered_verts, dim3(FV_BLOCKS), dim3(256), 0, st, T, E, verts, verts_filt, prev_v, prev_vf,
+                     next_v, next_vf, coef, gverts, g_fv_partial);
+  MH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, (const float*)g_fv_partial, FV_BLOCKS, loss_out);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}

@@ -1,0 +1,90 @@
+"""ctypes binding of include/mhmocap_hip.h.  Fails loudly when the HIP library is missing:
+there is no CPU fallback anywhere in the product path."""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libmhmocap_hip.so')
+HEADER = os.path.join(os.path.dirname(os.path.dirname(HERE)), 'include', 'mhmocap_hip.h')
+
+c_float_p = ctypes.POINTER(ctypes.c_float)
+c_int_p = ctypes.POINTER(ctypes.c_int32)
+vp = ctypes.c_void_p
+
+
+class MhError(RuntimeError):
+    pass
+
+
+class ModelHost(ctypes.Structure):
+    _fields_ = [('num_verts', ctypes.c_int32), ('num_faces', ctypes.c_int32),
+                ('v_template', c_float_p), ('shapedirs', c_float_p), ('posedirs', c_float_p),
+                ('J_regressor', c_float_p), ('lbs_weights', c_float_p), ('parents', c_int_p),
+                ('faces', c_int_p), ('reg_alphapose', c_float_p), ('reg_h36m17', c_float_p),
+                ('reg_mupots', c_float_p), ('reg_extra9', c_float_p)]
+
+
+_lib = None
+
+
+def declared_symbols():
+    """Every function the public header declares (used by the load/export test)."""
+    txt = open(HEADER).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(mh_[a-z0-9_]+)\s*\(', txt)))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MhError('%s is missing: build it with `python -m mhhip.build` (hipcc, gfx950). '
+                          'There is no CPU fallback.' % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.mh_last_error.restype = ctypes.c_char_p
+        L.mh_model_faces.restype = vp
+        L.mh_lbs_workspace_bytes.restype = ctypes.c_size_t
+        L.mh_lbs_backward_workspace_bytes.restype = ctypes.c_size_t
+        L.mh_lbs_workspace_bytes.argtypes = [ctypes.c_int]
+        L.mh_lbs_backward_workspace_bytes.argtypes = [ctypes.c_int]
+        L.mh_model_create.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(ModelHost)]
+        L.mh_model_destroy.argtypes = [vp]
+        L.mh_model_faces.argtypes = [vp]
+        L.mh_lbs_forward.argtypes = [vp, ctypes.c_int, ctypes.c_int] + [vp] * 9
+        L.mh_joints_regress.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int, vp, vp]
+        L.mh_lbs_backward.argtypes = [vp, ctypes.c_int, ctypes.c_int] + [vp] * 14
+        L.mh_project_joints_loss.argtypes = [ctypes.c_int, vp, c_float_p, c_float_p, vp, ctypes.c_float, ctypes.c_int,
+                                             ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp]
+        L.mh_rmsprop_step.argtypes = [vp, vp, vp, vp, ctypes.c_size_t] + [ctypes.c_float] * 4 + [vp]
+        L.mh_adam_step.argtypes = [vp, vp, vp, vp, ctypes.c_size_t, ctypes.c_int] + [ctypes.c_float] * 4 + [vp]
+        L.mh_one_euro_scan.argtypes = [vp, vp, ctypes.c_int, ctypes.c_size_t] + [ctypes.c_float] * 3 + [vp]
+        L.mh_velocity_term.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_float, vp, vp, vp]
+        L.mh_filtered_verts_term.argtypes = [ctypes.c_int, ctypes.c_size_t] + [vp] * 6 + [ctypes.c_float, vp, vp, vp]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise MhError('mhmocap_hip error %d: %s' % (rc, lib().mh_last_error().decode()))
+
+
+def ptr(t):
+    """Device (or host) pointer of a torch tensor / None."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), 'tensor must be contiguous'
+    return t.data_ptr()
+
+
+def stream_ptr(device=None):
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def host_f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(c_float_p)

@@ -1,0 +1,203 @@
+"""Torch-facing wrappers over the C ABI: device memory, streams and shapes only -- every
+floating-point operation of the path happens in the HIP library."""
+import ctypes
+import pickle
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, ptr
+
+H36M_ROW_ORDER = [6, 5, 4, 1, 2, 3, 16, 15, 14, 11, 12, 13, 8, 10, 0, 7, 9]   # reference smpl.py:242
+REG_ALPHAPOSE, REG_H36M17, REG_MUPOTS, REG_EXTRA9 = 0, 1, 2, 3
+NUM_REG_JOINTS = {0: 17, 1: 17, 2: 17, 3: 9}
+
+
+class _ChStub(object):
+    """Stand-in for chumpy.Ch objects inside the official SMPL pickle (chumpy is not needed)."""
+
+    def __setstate__(self, state):
+        self.__dict__.update(state if isinstance(state, dict) else {'x': state})
+
+    def __array__(self, dtype=None):
+        x = self.__dict__.get('x', None)
+        if x is None:
+            raise ValueError('unsupported chumpy object in the SMPL pickle')
+        return np.asarray(x, dtype=dtype)
+
+
+class _SmplUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if module.startswith('chumpy'):
+            return _ChStub
+        return super().find_class(module, name)
+
+
+def load_smpl_pickle(path):
+    """The fields the reference reads from SMPL_{GENDER}.pkl (smpl.py:187-188) without chumpy."""
+    with open(path, 'rb') as f:
+        d = _SmplUnpickler(f, encoding='latin1').load()
+    return d
+
+
+def _dense(a, dtype=np.float32):
+    if 'scipy.sparse' in str(type(a)):
+        a = a.todense()
+    return np.ascontiguousarray(np.array(a, dtype=dtype))
+
+
+class BodyModel(object):
+    """Device-resident SMPL constants (an ``mh_model``)."""
+
+    def __init__(self, struct, regs=None, device='cuda:0'):
+        if not torch.cuda.is_available():
+            raise _lib.MhError('no HIP device: the MI355X path cannot run (there is no CPU fallback)')
+        self.device = torch.device(device)
+        get = (lambda k: struct[k]) if isinstance(struct, dict) else (lambda k: getattr(struct, k))
+        self.v_template = _dense(get('v_template'))
+        V = self.v_template.shape[0]
+        shapedirs = _dense(get('shapedirs'))[:, :, :10].copy()
+        posedirs = _dense(get('posedirs'))
+        assert posedirs.shape == (V, 3, 207), posedirs.shape
+        J_regressor = _dense(get('J_regressor'))
+        weights = _dense(get('weights'))
+        parents = np.asarray(get('kintree_table'))[0].astype(np.int64)
+        parents[0] = -1
+        parents = parents.astype(np.int32)
+        self.faces = np.asarray(get('f')).astype(np.int64)
+        faces32 = np.ascontiguousarray(self.faces.astype(np.int32))
+        regs = regs or {}
+        self.has_reg = {}
+        keep = [self.v_template, shapedirs, posedirs, J_regressor, weights, parents, faces32]
+        h = _lib.ModelHost()
+        h.num_verts, h.num_faces = V, faces32.shape[0]
+        fp = lambda a: a.ctypes.data_as(_lib.c_float_p)
+        h.v_template, h.shapedirs, h.posedirs = fp(self.v_template), fp(shapedirs), fp(posedirs)
+        h.J_regressor, h.lbs_weights = fp(J_regressor), fp(weights)
+        h.parents = parents.ctypes.data_as(_lib.c_int_p)
+        h.faces = faces32.ctypes.data_as(_lib.c_int_p)
+        for key, field, which in [('alphapose', 'reg_alphapose', REG_ALPHAPOSE), ('h36m', 'reg_h36m17', REG_H36M17),
+                                  ('mupots', 'reg_mupots', REG_MUPOTS), ('extra9', 'reg_extra9', REG_EXTRA9)]:
+            a = regs.get(key)
+            self.has_reg[which] = a is not None
+            if a is None:
+                continue
+            a = _dense(a)
+            if key in ('alphapose', 'mupots'):
+                a = np.ascontiguousarray(a.T)            # files are (V,17): smpl.py:250,257
+            if key == 'h36m':
+                a = np.ascontiguousarray(a[H36M_ROW_ORDER])   # smpl.py:243
+            assert a.shape == (NUM_REG_JOINTS[which], V), (key, a.shape)
+            keep.append(a)
+            setattr(h, field, fp(a))
+        self.V, self.F = V, faces32.shape[0]
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mh_model_create(ctypes.byref(handle), ctypes.byref(h)))
+        self.handle = handle
+        del keep
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                _lib.lib().mh_model_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # -- raw calls ------------------------------------------------------------------------------
+    def workspace(self, B):
+        n = _lib.lib().mh_lbs_workspace_bytes(B)
+        return torch.empty(n, dtype=torch.uint8, device=self.device)
+
+    def backward_workspace(self, B):
+        n = _lib.lib().mh_lbs_backward_workspace_bytes(B)
+        return torch.empty(n, dtype=torch.uint8, device=self.device)
+
+    def lbs_forward(self, betas, poses, xscale=None, transl=None, ws=None, want_vposed=True, want_posed=False):
+        B, NB = poses.shape[0], betas.shape[0]
+        f = lambda t: None if t is None else t.contiguous().float()
+        betas, poses, xscale, transl = f(betas), f(poses), f(xscale), f(transl)
+        verts = torch.empty(B, self.V, 3, dtype=torch.float32, device=self.device)
+        vposed = torch.empty_like(verts) if want_vposed else None
+        posed = torch.empty(B, 24, 3, dtype=torch.float32, device=self.device) if want_posed else None
+        ws = ws if ws is not None else self.workspace(B)
+        check(_lib.lib().mh_lbs_forward(self.handle, B, NB, ptr(betas), ptr(poses), ptr(xscale), ptr(transl),
+                                        ptr(verts), ptr(vposed), ptr(posed), ptr(ws), _lib.stream_ptr(self.device)))
+        return verts, vposed, posed, ws
+
+    def joints_regress(self, which, verts, corr=None, root=-1):
+        B = verts.shape[0]
+        out = torch.empty(B, NUM_REG_JOINTS[which], 3, dtype=torch.float32, device=self.device)
+        check(_lib.lib().mh_joints_regress(self.handle, which, B, ptr(verts), ptr(corr), root, ptr(out),
+                                           _lib.stream_ptr(self.device)))
+        return out
+
+    def lbs_backward(self, betas, poses, xscale, transl, vposed, gverts, gjoints, ws, gposes=None, gtransl=None,
+                     gbetas=None, gxscale=None, ws2=None):
+        B, NB = poses.shape[0], betas.shape[0]
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=self.device)
+        gposes = gposes if gposes is not None else z(B, 72)
+        gtransl = gtransl if gtransl is not None else z(B, 3)
+        gbetas = gbetas if gbetas is not None else z(NB, 10)
+        gxscale = gxscale if gxscale is not None else z(NB)
+        ws2 = ws2 if ws2 is not None else self.backward_workspace(B)
+        check(_lib.lib().mh_lbs_backward(self.handle, B, NB, ptr(betas), ptr(poses), ptr(xscale), ptr(transl),
+                                         ptr(vposed), ptr(gverts), ptr(gjoints), ptr(gposes), ptr(gtransl),
+                                         ptr(gbetas), ptr(gxscale), ptr(ws), ptr(ws2), _lib.stream_ptr(self.device)))
+        return gposes, gtransl, gbetas, gxscale
+
+
+def project_joints_loss(joints, K, Kd, pose2d, thr, mode, img_w, img_h, coef=1.0, want_uv=True):
+    B = joints.shape[0]
+    dev = joints.device
+    _, Kp = _lib.host_f32(np.asarray(K, np.float32).reshape(3, 3))
+    Kk = np.ascontiguousarray(np.asarray(K, np.float32).reshape(9))
+    Kdd = None if Kd is None else np.ascontiguousarray(np.asarray(Kd, np.float32).reshape(5))
+    uv = torch.empty(B, 17, 2, dtype=torch.float32, device=dev) if want_uv else None
+    gj = torch.empty(B, 17, 3, dtype=torch.float32, device=dev)
+    loss = torch.empty(B, dtype=torch.float32, device=dev)
+    check(_lib.lib().mh_project_joints_loss(
+        B, ptr(joints), Kk.ctypes.data_as(_lib.c_float_p),
+        None if Kdd is None else Kdd.ctypes.data_as(_lib.c_float_p), ptr(pose2d), float(thr), int(mode),
+        float(img_w), float(img_h), float(coef), ptr(uv), ptr(gj), ptr(loss), _lib.stream_ptr(dev)))
+    return uv, gj, loss
+
+
+def rmsprop_step(params, grads, sq, buf, lr, alpha=0.5, momentum=0.9, eps=1e-8):
+    check(_lib.lib().mh_rmsprop_step(ptr(params), ptr(grads), ptr(sq), ptr(buf), params.numel(), lr, alpha, momentum,
+                                     eps, _lib.stream_ptr(params.device)))
+
+
+def adam_step(params, grads, m, v, step, lr, b1=0.5, b2=0.5, eps=1e-6):
+    check(_lib.lib().mh_adam_step(ptr(params), ptr(grads), ptr(m), ptr(v), params.numel(), int(step), lr, b1, b2, eps,
+                                  _lib.stream_ptr(params.device)))
+
+
+def one_euro_scan(x, min_cutoff, beta, frame_rate=25.0):
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    T = x.shape[0]
+    check(_lib.lib().mh_one_euro_scan(ptr(x), ptr(y), T, x.numel() // T, float(min_cutoff), float(beta),
+                                      float(frame_rate), _lib.stream_ptr(x.device)))
+    return y
+
+
+def velocity_term(pT, coef, gpT, prev_halo=None, next_halo=None):
+    T, N = pT.shape[0], pT.shape[1]
+    loss = torch.empty(1, dtype=torch.float32, device=pT.device)
+    check(_lib.lib().mh_velocity_term(T, N, ptr(pT), ptr(prev_halo), ptr(next_halo), float(coef), ptr(gpT), ptr(loss),
+                                      _lib.stream_ptr(pT.device)))
+    return loss
+
+
+def filtered_verts_term(verts, verts_filt, coef, gverts, prev=None, nxt=None):
+    T = verts.shape[0]
+    loss = torch.empty(1, dtype=torch.float32, device=verts.device)
+    pv, pvf = prev if prev is not None else (None, None)
+    nv, nvf = nxt if nxt is not None else (None, None)
+    check(_lib.lib().mh_filtered_verts_term(T, verts.numel() // T, ptr(verts), ptr(verts_filt), ptr(pv), ptr(pvf),
+                                            ptr(nv), ptr(nvf), float(coef), ptr(gverts), ptr(loss),
+                                            _lib.stream_ptr(verts.device)))
+    return loss

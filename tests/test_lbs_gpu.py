@@ -1,0 +1,200 @@
+"""GPU parity of the HIP LBS path (forward + hand-written backward) through the C ABI, against
+the oracle (autograd on torch-CPU) and against the reference-generated golden fixtures."""
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+from oracle import fit_oracle as fo
+from oracle import lbs_oracle as lo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def hip_model(smpl_struct, smpl_regs):
+    from mhhip import engine
+    return engine.BodyModel(smpl_struct, smpl_regs)
+
+
+def dev(a):
+    return torch.tensor(np.asarray(a, np.float32), device='cuda:0')
+
+
+def test_forward_matches_golden_and_oracle(golden, oracle_model, hip_model):
+    from mhhip import engine
+    betas, poses = gi.lbs_inputs()
+    verts, vposed, posed, _ = hip_model.lbs_forward(dev(betas), dev(poses), want_posed=True)
+    torch.cuda.synchronize()
+    # fp32 tolerance stated by the path: 1e-5 m on vertices / joints
+    np.testing.assert_allclose(verts.cpu().numpy()[:, ::53], golden['smpl_verts'], atol=1e-5)
+    np.testing.assert_allclose(posed.cpu().numpy(), golden['smpl_joints_smpl24'], atol=1e-5)
+    ref = lo.smpl_forward(oracle_model, torch.tensor(betas), torch.tensor(poses))
+    np.testing.assert_allclose(verts.cpu().numpy(), ref['verts'].numpy(), atol=1e-5)
+    for which, key, root in [(engine.REG_ALPHAPOSE, 'joints_alphapose', -1), (engine.REG_H36M17, 'joints_h36m17', 14),
+                             (engine.REG_MUPOTS, 'joints_mupots', -1)]:
+        j = hip_model.joints_regress(which, verts, root=root)
+        np.testing.assert_allclose(j.cpu().numpy(), golden['smpl_' + key], atol=1e-5)
+    e9 = hip_model.joints_regress(engine.REG_EXTRA9, verts)
+    np.testing.assert_allclose(e9.cpu().numpy(), golden['smpl_j3d'][:, 45:], atol=1e-5)
+
+
+@pytest.mark.parametrize('B,NB', [(1, 1), (7, 7), (40, 4), (70, 2), (33, 33)])
+def test_forward_shared_shape_scale_translation(oracle_model, hip_model, B, NB):
+    rng = np.random.RandomState(B)
+    betas = rng.normal(0, 0.7, (NB, 10)).astype(np.float32)
+    poses = rng.normal(0, 0.3, (B, 72)).astype(np.float32)
+    xs = rng.normal(0, 1.0, (NB,)).astype(np.float32)
+    tr = rng.normal(0, 2.0, (B, 3)).astype(np.float32)
+    verts, _, _, _ = hip_model.lbs_forward(dev(betas), dev(poses), dev(xs), dev(tr))
+    bidx = np.arange(B) % NB
+    ref = lo.smpl_forward(oracle_model, torch.tensor(betas[bidx]), torch.tensor(poses))
+    s = torch.pow(torch.tensor(1.1), torch.tensor(xs[bidx]))[:, None, None]
+    want = s * ref['verts'] + torch.tensor(tr)[:, None]
+    np.testing.assert_allclose(verts.cpu().numpy(), want.numpy(), atol=2e-5)
+    kp = hip_model.joints_regress(0, verts, corr=dev(tr))
+    want_kp = s * ref['joints_alphapose'] + torch.tensor(tr)[:, None]
+    np.testing.assert_allclose(kp.cpu().numpy(), want_kp.numpy(), atol=2e-5)
+
+
+def _oracle_grads(oracle_model, betas, poses, xs, tr, wv, wj, NB, dtype):
+    B = poses.shape[0]
+    bidx = torch.tensor(np.arange(B) % NB)
+    tb = torch.tensor(betas, dtype=dtype, requires_grad=True)
+    tp = torch.tensor(poses, dtype=dtype, requires_grad=True)
+    tx = torch.tensor(xs, dtype=dtype, requires_grad=True)
+    tt = torch.tensor(tr, dtype=dtype, requires_grad=True)
+    out = lo.smpl_forward(oracle_model, tb[bidx], tp)
+    s = torch.pow(torch.tensor(1.1, dtype=dtype), tx[bidx])[:, None, None]
+    v = s * out['verts'] + tt[:, None]
+    j = s * out['joints_alphapose'] + tt[:, None]
+    ((v * torch.tensor(wv, dtype=dtype)).sum() + (j * torch.tensor(wj, dtype=dtype)).sum()).backward()
+    return [x.grad.numpy() for x in (tp, tt, tb, tx)]
+
+
+@pytest.mark.parametrize('B,NB', [(6, 6), (40, 4), (50, 2)])
+def test_backward_matches_autograd(smpl_struct, smpl_regs, hip_model, B, NB):
+    model64 = lo.BodyModel(smpl_struct, smpl_regs, dtype=torch.float64)
+    rng = np.random.RandomState(100 + B)
+    betas = rng.normal(0, 0.7, (NB, 10)).astype(np.float32)
+    poses = rng.normal(0, 0.3, (B, 72)).astype(np.float32)
+    poses[:, 66:] = 0
+    xs = rng.normal(0, 1.0, (NB,)).astype(np.float32)
+    tr = rng.normal(0, 2.0, (B, 3)).astype(np.float32)
+    wv = rng.normal(0, 1, (B, 6890, 3)).astype(np.float32)
+    wj = rng.normal(0, 5, (B, 17, 3)).astype(np.float32)
+    want = _oracle_grads(model64, betas, poses, xs, tr, wv, wj, NB, torch.float64)
+    dbetas, dposes, dxs, dtr = dev(betas), dev(poses), dev(xs), dev(tr)
+    verts, vposed, _, ws = hip_model.lbs_forward(dbetas, dposes, dxs, dtr)
+    got = hip_model.lbs_backward(dbetas, dposes, dxs, dtr, vposed, dev(wv), dev(wj), ws)
+    torch.cuda.synchronize()
+    for name, g, w in zip(['poses', 'transl', 'betas', 'xscale'], got, want):
+        g = g.cpu().numpy().reshape(w.shape)
+        scale = np.abs(w).max()
+        np.testing.assert_allclose(g, w, atol=2e-4 * scale, err_msg=name)
+    assert np.all(got[0].cpu().numpy()[:, 66:] == 0)
+    # accumulation semantics (+=): calling twice doubles
+    again = hip_model.lbs_backward(dbetas, dposes, dxs, dtr, vposed, dev(wv), dev(wj), ws, *[g.clone() for g in got])
+    np.testing.assert_allclose(again[0].cpu().numpy(), 2 * got[0].cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_backward_matches_golden_reference_grads(golden, hip_model):
+    """The same weighted-sum loss the fixtures were generated with (make_golden.py (i))."""
+    betas, poses = gi.lbs_inputs()
+    B = poses.shape[0]
+    rng = np.random.RandomState(3)
+    wv = rng.normal(0, 1, (B, 6890, 3)).astype(np.float32)
+    wj = rng.normal(0, 1, (B, 17, 3)).astype(np.float32)
+    db, dp = dev(betas), dev(poses)
+    verts, vposed, _, ws = hip_model.lbs_forward(db, dp)
+    gp, gt, gb, gx = hip_model.lbs_backward(db, dp, None, None, vposed, dev(wv), dev(wj), ws)
+    g = golden['smpl_grad_betas']
+    np.testing.assert_allclose(gb.cpu().numpy(), g, atol=3e-4 * np.abs(g).max())
+    g = golden['smpl_grad_poses']
+    np.testing.assert_allclose(gp.cpu().numpy()[1:], g[1:], atol=3e-4 * np.abs(g[1:]).max())
+
+
+def test_project_joints_loss(golden):
+    from mhhip import engine
+    pts, K, Kd = gi.projection_inputs()
+    rng = np.random.RandomState(5)
+    p2d = np.concatenate([rng.uniform(0, 200, (5, 17, 2)), rng.uniform(0, 1, (5, 17, 1))], -1).astype(np.float32)
+    for kd, key in [(None, 'proj_plain'), (Kd, 'proj_dist')]:
+        for mode, thr in [(0, 0.5), (1, 0.15)]:
+            uv, gj, loss = engine.project_joints_loss(dev(pts), K[0], kd, dev(p2d), thr, mode, 240, 135, coef=0.7)
+            np.testing.assert_allclose(uv.cpu().numpy(), golden[key], atol=2e-4)
+            tp = torch.tensor(pts, requires_grad=True)
+            puv = fo.project_points(tp, torch.tensor(K), kd)
+            if mode == 0:
+                c = torch.tensor((p2d[..., 2:] >= thr).astype(np.float32))
+                nrm = torch.tensor([240.0, 135.0])
+                l = ((c * puv / nrm - c * torch.tensor(p2d[..., :2]) / nrm) ** 2).sum()
+            else:
+                c = torch.tensor((p2d[..., 2:] > thr).astype(np.float32))
+                l = torch.mean((c * puv - c * torch.tensor(p2d[..., :2])) ** 2)
+            (0.7 * l).backward()
+            np.testing.assert_allclose(float(loss.sum().cpu()), float(l), rtol=1e-4)
+            g = tp.grad.numpy()
+            np.testing.assert_allclose(gj.cpu().numpy(), g, atol=2e-4 * np.abs(g).max())
+
+
+def test_optimizer_steps_and_one_euro(golden):
+    from mhhip import engine
+    rng = np.random.RandomState(9)
+    n = 10007
+    p = rng.normal(0, 1, n).astype(np.float32)
+    tp, sq, buf = torch.tensor(p), torch.zeros(n), torch.zeros(n)
+    dp, dsq, dbuf = dev(p), dev(np.zeros(n)), dev(np.zeros(n))
+    lr = 0.01
+    for it in range(5):
+        g = rng.normal(0, 1, n).astype(np.float32) * (it != 3)
+        fo.rmsprop_step(tp, torch.tensor(g), sq, buf, lr)
+        engine.rmsprop_step(dp, dev(g), dsq, dbuf, lr)
+        lr *= 0.99
+    np.testing.assert_allclose(dp.cpu().numpy(), tp.numpy(), atol=2e-6)
+    tp, m, v = torch.tensor(p), torch.zeros(n), torch.zeros(n)
+    dp, dm, dv = dev(p), dev(np.zeros(n)), dev(np.zeros(n))
+    lr = 0.5
+    for it in range(5):
+        g = rng.normal(0, 1, n).astype(np.float32)
+        fo.adam_step(tp, torch.tensor(g), m, v, it + 1, lr)
+        engine.adam_step(dp, dev(g), dm, dv, it + 1, lr)
+        lr *= 0.95
+    np.testing.assert_allclose(dp.cpu().numpy(), tp.numpy(), atol=1e-5)
+    x = gi.one_euro_inputs()
+    np.testing.assert_allclose(engine.one_euro_scan(dev(x), 0.01, 0.02).cpu().numpy(), golden['one_euro_a'], atol=1e-6)
+    np.testing.assert_allclose(engine.one_euro_scan(dev(x), 0.001, 0.5).cpu().numpy(), golden['one_euro_b'], atol=1e-6)
+
+
+def test_temporal_terms():
+    from mhhip import engine
+    rng = np.random.RandomState(17)
+    T, N, E = 9, 3, 3 * 50 * 3
+    pT = rng.normal(0, 1, (T, N, 1, 3)).astype(np.float32)
+    t = torch.tensor(pT, requires_grad=True)
+    l = ((t[1:] - t[:-1]) ** 2).sum()
+    (0.05 * l).backward()
+    g = dev(np.zeros_like(pT))
+    loss = engine.velocity_term(dev(pT), 0.05, g)
+    np.testing.assert_allclose(float(loss.cpu()), float(l), rtol=1e-5)
+    np.testing.assert_allclose(g.cpu().numpy(), t.grad.numpy(), atol=1e-6)
+    # sharded: two halves with halos reproduce the same gradient and the same total
+    h = 4
+    g1, g2 = dev(np.zeros_like(pT[:h])), dev(np.zeros_like(pT[h:]))
+    l1 = engine.velocity_term(dev(pT[:h]), 0.05, g1, next_halo=dev(pT[h]))
+    l2 = engine.velocity_term(dev(pT[h:]), 0.05, g2, prev_halo=dev(pT[h - 1]))
+    np.testing.assert_allclose(torch.cat([g1, g2]).cpu().numpy(), t.grad.numpy(), atol=1e-6)
+    np.testing.assert_allclose(float(l1.cpu() + l2.cpu()), float(l), rtol=1e-5)
+    v = rng.normal(0, 1, (T, E)).astype(np.float32)
+    vf = rng.normal(0, 1, (T, E)).astype(np.float32)
+    tv = torch.tensor(v, requires_grad=True)
+    l = (((tv[1:] - tv[:-1]) - (torch.tensor(vf)[1:] - torch.tensor(vf)[:-1])) ** 2).sum()
+    (0.002 * l).backward()
+    gv = dev(np.zeros_like(v))
+    loss = engine.filtered_verts_term(dev(v), dev(vf), 0.002, gv)
+    np.testing.assert_allclose(float(loss.cpu()), float(l), rtol=1e-5)
+    np.testing.assert_allclose(gv.cpu().numpy(), tv.grad.numpy(), atol=1e-6)
+    g1, g2 = dev(np.zeros_like(v[:h])), dev(np.zeros_like(v[h:]))
+    engine.filtered_verts_term(dev(v[:h]), dev(vf[:h]), 0.002, g1, nxt=(dev(v[h]), dev(vf[h])))
+    engine.filtered_verts_term(dev(v[h:]), dev(vf[h:]), 0.002, g2, prev=(dev(v[h - 1]), dev(vf[h - 1])))
+    np.testing.assert_allclose(torch.cat([g1, g2]).cpu().numpy(), tv.grad.numpy(), atol=1e-6)

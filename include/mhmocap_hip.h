@@ -123,6 +123,15 @@ int mh_project_joints_loss(int B, const float* joints /*(B,17,3)*/, const float*
                            float img_w, float img_h, float coef, float* uv, float* gjoints,
                            float* loss, void* stream);
 
+/* a9 warm-up (optimizer.py:710-770): only poses_T is a leaf there, so the 17 key-points of every
+ * body are computed ONCE (mh_lbs_forward + mh_joints_regress) and each Adam iteration is
+ * joints = 1.1^xscale[b%NB] * local + transl -> projection -> mean-reduced pixel residual
+ * (optimizer.py:754-756) -> gtransl (B,3) = coef * d loss / d transl (overwritten), loss (B).  */
+int mh_warmup_project(int B, int NB, const float* local_joints /*(B,17,3)*/, const float* xscale,
+                      const float* transl /*(B,3)*/, const float* K_host, const float* Kd_host,
+                      const float* pose2d, float thr, float coef, float* gtransl, float* loss,
+                      void* stream);
+
 /* ---- a20: optimiser updates (optimizer.py:355-356, 586-587, 738-739, 764-765) --------------- */
 int mh_rmsprop_step(float* params, const float* grads, float* square_avg, float* momentum_buf,
                     size_t n, float lr, float alpha, float momentum, float eps, void* stream);
@@ -148,6 +157,58 @@ int mh_filtered_verts_term(int T, size_t E, const float* verts, const float* ver
                            const float* prev_v, const float* prev_vf, const float* next_v,
                            const float* next_vf, float coef, float* gverts, float* loss_out,
                            void* stream);
+
+/* ---- staging of the constant per-frame inputs (once per sequence; optimizer.py:396-409, 434) --
+ * The N float {0,1} instance masks of a frame become ONE 32-bit word per pixel (bit n = person n,
+ * N <= 32): 4 B/pixel instead of 4N, and the erosion of morphology.py:6-41 runs once instead of
+ * once per batch per cycle.                                                                  */
+int mh_pack_masks(const float* seg /*(T,N,H,W)*/, int T, int N, int H, int W,
+                  uint32_t* bits /*(T,H,W)*/, float* area /*(T,N) pixel counts*/, void* stream);
+int mh_erode_bits(const uint32_t* in, uint32_t* out /*must not alias*/, int T, int H, int W, void* stream);
+/* pose2d_valid = (#joints with conf >= thr) >= 2, mask_valid = area >= min_area (optimizer.py:404-409) */
+int mh_stage_gates(const float* pose2d /*(B,17,3)*/, const float* area /*(B)*/, int B, float thr,
+                   float min_area, float* pose2d_valid /*(B)*/, float* mask_valid /*(B)*/, void* stream);
+
+/* ---- a14 (mask part): occlusion ordering of the silhouette term (optimizer.py:450-477) -------
+ * front[t][n] = bit set of the people closer than n (poses_T z, ties by index); apply[t][n] =
+ * gate of the term (indexed by RANK like the reference, :472); D = sum_px (1-acc);
+ * S = sum_px (1-acc)*seg_n over the full image.                                              */
+int mh_sil_mask_stats(const uint32_t* bits, int T, int N, int H, int W, const float* pT /*(T,N,3)*/,
+                      const float* pose2d_valid, const float* mask_valid, uint32_t* front /*(T,N)*/,
+                      float* apply /*(T,N)*/, float* D /*(T,N)*/, float* S /*(T,N)*/, void* stream);
+
+/* ---- a17: priors (optimizer.py:523-532, 535-542) ---------------------------------------------
+ * pose prior L1(valid*ref, valid*pose) per body -> body_loss (B), gposes +=;
+ * shape prior T*L1(beta, beta_ref) (the reference adds batch_size*L1 per batch), gbetas +=;
+ * scale regularisers, added once per batch (nbatches), gxscale +=.
+ * loss3 = { T*L1(beta), (sum(s-1))^2, mean((s-1)^2) }.                                       */
+int mh_prior_terms(int T, int N, int nbatches, const float* poses, const float* poses_ref,
+                   const float* valid /*(T*N)*/, const float* betas, const float* betas_ref,
+                   const float* xscale /*(N) or NULL*/, float coef_poses, float coef_scales,
+                   float* gposes, float* gbetas, float* gxscale, float* body_loss /*(T*N)*/,
+                   float* loss3, void* stream);
+/* out[0] = scale * sum(x[0..n)) in a fixed order (loss logging, optimizer.py:546-554, 588-593) */
+int mh_reduce_sum(const float* x, size_t n, float scale, float* out, void* stream);
+
+/* ---- a15/a16: scene contact and foot sliding (optimizer.py:485-518) --------------------------- */
+/* argmax over vertices of y (first index on ties) and that vertex                           */
+int mh_lowest_vertex(const float* verts /*(B,V,3)*/, int B, int V, int32_t* low_idx /*(B)*/,
+                     float* low_xyz /*(B,3)*/, void* stream);
+/* dy[b] = (mean of the k nearest scene points).y - low_xyz[b].y; k <= 32 (reference: 32, by a
+ * full argsort over M, optimizer.py:494-502); if M < k all M points are used.              */
+int mh_contact_knn(const float* points /*(M,3)*/, int M, const float* low_xyz, int B, int k,
+                   float* dy /*(B)*/, void* stream);
+/* contact: sum |dy+0.02| per batch, gpT.y += coef * (-sign(dy+0.02)); foot sliding between
+ * IN-BATCH consecutive frames (batch = frames per batch, optimizer.py:512-518), gverts +=
+ * (atomic).  batch_contact / batch_foot: one value per batch (nbatches = ceil(T/batch)).     */
+int mh_contact_foot_terms(int T, int N, int V, int batch, const float* verts, const int32_t* low_idx,
+                          const float* low_xyz, const float* dy, float coef_contact, float coef_foot,
+                          float* gpT, float* gverts, float* batch_contact, float* batch_foot,
+                          void* stream);
+/* a21: pixel centres + depth -> camera-space points (H*W,3) (optimizer.py:605-612,
+ * transforms.py:114-130).  K_host: HOST 3x3 intrinsics.                                       */
+int mh_scene_unproject(const float* depth /*(H,W)*/, int H, int W, const float* K_host,
+                       float* points /*(H*W,3)*/, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,281 @@
+// Image-space staging and mask statistics: instance masks as one bit-plane word per pixel,
+// binary erosion, validity gates, occlusion ordering of the silhouette term, priors.
+#include "mh_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// staging: (T,N,H,W) float {0,1} masks -> bits[t][p] (bit n = person n), area[t][n]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_masks(const float* seg, int N, size_t P, uint32_t* bits, float* area) {
+  const int t = blockIdx.y;
+  __shared__ float s[32][4];
+  float cnt[32];
+  for (int n = 0; n < 32; ++n) cnt[n] = 0.f;
+  for (size_t p = blockIdx.x * (size_t)256 + threadIdx.x; p < P; p += (size_t)gridDim.x * 256) {
+    uint32_t w = 0;
+    for (int n = 0; n < N; ++n) {
+      const float v = seg[((size_t)t * N + n) * P + p];
+      if (v >= 0.5f) {
+        w |= 1u << n;
+        cnt[n] += 1.f;
+      }
+    }
+    bits[(size_t)t * P + p] = w;
+  }
+  const int wave = threadIdx.x >> 6;
+  for (int n = 0; n < N; ++n) {
+    const float c = mh_wave_sum(cnt[n]);
+    if ((threadIdx.x & 63) == 0) s[n][wave] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x < N) atomicAdd(&area[(size_t)t * N + threadIdx.x], s[threadIdx.x][0] + s[threadIdx.x][1] + s[threadIdx.x][2] + s[threadIdx.x][3]);
+}
+
+extern "C" int mh_pack_masks(const float* seg, int T, int N, int H, int W, uint32_t* bits, float* area, void* stream) {
+  MH_CHECK(seg && bits && area, "null argument");
+  MH_CHECK(T > 0 && N > 0 && N <= 32 && H > 0 && W > 0, "need 1..32 people per frame");
+  hipStream_t st = (hipStream_t)stream;
+  MH_HIP(hipMemsetAsync(area, 0, (size_t)T * N * sizeof(float), st));   // pixel counts are integers: order-free
+  const size_t P = (size_t)H * W;
+  int bx = (int)((P + 255) / 256);
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(k_pack_masks, dim3(bx, T), dim3(256), 0, st, seg, N, P, bits, area);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+// one Erode2D(kernel_size=3) on every bit plane (morphology.py:29-31): a pixel survives when none
+// of its in-image 3x3 neighbours is background
+__global__ __launch_bounds__(256) void k_erode_bits(const uint32_t* in, uint32_t* out, int H, int W) {
+  const int t = blockIdx.y;
+  const uint32_t* src = in + (size_t)t * H * W;
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < H * W; p += gridDim.x * 256) {
+    const int y = p / W, x = p % W;
+    uint32_t w = 0xffffffffu;
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int yy = y + dy, xx = x + dx;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) w &= src[yy * W + xx];
+      }
+    out[(size_t)t * H * W + p] = w;
+  }
+}
+
+extern "C" int mh_erode_bits(const uint32_t* in, uint32_t* out, int T, int H, int W, void* stream) {
+  MH_CHECK(in && out && in != out, "null or aliased argument");
+  MH_CHECK(T > 0 && H > 0 && W > 0, "empty input");
+  int bx = (H * W + 255) / 256;
+  if (bx > 128) bx = 128;
+  hipLaunchKernelGGL(k_erode_bits, dim3(bx, T), dim3(256), 0, (hipStream_t)stream, in, out, H, W);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+// validity gates (optimizer.py:404-409)
+__global__ void k_gates(const float* pose2d, const float* area, int B, float thr, float min_area, float* p2d_valid,
+                        float* mask_valid) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int c = 0;
+  for (int j = 0; j < MH_NKP; ++j) c += pose2d[((size_t)b * MH_NKP + j) * 3 + 2] >= thr;
+  p2d_valid[b] = c >= 2 ? 1.f : 0.f;
+  mask_valid[b] = area[b] >= min_area ? 1.f : 0.f;
+}
+
+extern "C" int mh_stage_gates(const float* pose2d, const float* area, int B, float thr, float min_area,
+                              float* pose2d_valid, float* mask_valid, void* stream) {
+  MH_CHECK(pose2d && area && pose2d_valid && mask_valid, "null argument");
+  MH_CHECK(B > 0, "B must be positive");
+  hipLaunchKernelGGL(k_gates, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, pose2d, area, B, thr, min_area,
+                     pose2d_valid, mask_valid);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// silhouette term, mask-only part (optimizer.py:450-477): near->far ordering by poses_T.z,
+// front[t][n] = bit set of the people in front of n, apply[t][n] (gate indexed by RANK, as the
+// reference does), D = sum(1-acc), S = sum((1-acc)*seg_n) over the whole image.
+// ---------------------------------------------------------------------------------------------
+template <int NMAX>
+__global__ __launch_bounds__(256) void k_sil_stats(const uint32_t* bits, int N, int P, const float* pT,
+                                                   const float* p2d_valid, const float* mask_valid, uint32_t* front,
+                                                   float* apply, float* D, float* S) {
+  const int t = blockIdx.x;
+  __shared__ uint32_t sfront[32];
+  __shared__ float sred[2][32][4];
+  if (threadIdx.x < N) {
+    const int n = threadIdx.x;
+    const float z = pT[((size_t)t * N + n) * 3 + 2];
+    uint32_t f = 0;
+    int rank = 0;
+    for (int m = 0; m < N; ++m) {
+      const float zm = pT[((size_t)t * N + m) * 3 + 2];
+      if (zm < z || (zm == z && m < n)) {
+        f |= 1u << m;
+        ++rank;
+      }
+    }
+    sfront[n] = f;
+    front[(size_t)t * N + n] = f;
+    apply[(size_t)t * N + n] = mask_valid[(size_t)t * N + rank] * p2d_valid[(size_t)t * N + rank];   // optimizer.py:472 (sic)
+  }
+  __syncthreads();
+  float d[NMAX], s[NMAX];
+  uint32_t fr[NMAX];
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n) {
+    d[n] = s[n] = 0.f;
+    fr[n] = n < N ? sfront[n] : 0xffffffffu;
+  }
+  for (int p = threadIdx.x; p < P; p += 256) {
+    const uint32_t w = bits[(size_t)t * P + p];
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) {
+      const bool free_px = (w & fr[n]) == 0;
+      d[n] += free_px ? 1.f : 0.f;
+      s[n] += (free_px && ((w >> n) & 1u)) ? 1.f : 0.f;
+    }
+  }
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n) {
+    const float a = mh_wave_sum(d[n]), b = mh_wave_sum(s[n]);
+    if ((threadIdx.x & 63) == 0 && n < N) {
+      sred[0][n][wave] = a;
+      sred[1][n][wave] = b;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < N) {
+    const int n = threadIdx.x;
+    D[(size_t)t * N + n] = sred[0][n][0] + sred[0][n][1] + sred[0][n][2] + sred[0][n][3];
+    S[(size_t)t * N + n] = sred[1][n][0] + sred[1][n][1] + sred[1][n][2] + sred[1][n][3];
+  }
+}
+
+extern "C" int mh_sil_mask_stats(const uint32_t* bits, int T, int N, int H, int W, const float* pT,
+                                 const float* pose2d_valid, const float* mask_valid, uint32_t* front, float* apply,
+                                 float* D, float* S, void* stream) {
+  MH_CHECK(bits && pT && pose2d_valid && mask_valid && front && apply && D && S, "null argument");
+  MH_CHECK(T > 0 && N > 0 && N <= 32, "need 1..32 people per frame");
+#define SIL_LAUNCH(NM) hipLaunchKernelGGL(k_sil_stats<NM>, dim3(T), dim3(256), 0, (hipStream_t)stream, bits, N, \
+                                          H * W, pT, pose2d_valid, mask_valid, front, apply, D, S)
+  if (N <= 4) SIL_LAUNCH(4);
+  else if (N <= 8) SIL_LAUNCH(8);
+  else if (N <= 16) SIL_LAUNCH(16);
+  else SIL_LAUNCH(32);
+#undef SIL_LAUNCH
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// priors (optimizer.py:523-532, 535-542)
+// ---------------------------------------------------------------------------------------------
+struct PriorP {
+  int T, N, nbatches;
+  const float* poses;
+  const float* ref;
+  const float* valid;
+  const float* betas;
+  const float* betas_ref;
+  const float* xscale;
+  float cp, cs;
+  float* gposes;
+  float* gbetas;
+  float* gxscale;
+  float* body_loss;   // [B] per-body pose-prior partial
+  float* loss3;       // [3]: T*L1(beta), scale_avg, scale_person
+};
+
+__global__ __launch_bounds__(128) void k_priors(PriorP p) {
+  const int B = p.T * p.N;
+  if ((int)blockIdx.x < B) {
+    const int b = blockIdx.x;
+    const float v = p.valid[b];
+    float l = 0.f;
+    if (threadIdx.x < 72) {
+      const size_t o = (size_t)b * 72 + threadIdx.x;
+      const float d = v * p.ref[o] - v * p.poses[o];             // L1(valid*ref, valid*pose), :523-525
+      l = fabsf(d);
+      const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+      p.gposes[o] += p.cp * (-v * sg);
+    }
+    l = mh_wave_sum(l);
+    __shared__ float s2[2];
+    if ((threadIdx.x & 63) == 0) s2[threadIdx.x >> 6] = l;
+    __syncthreads();
+    if (threadIdx.x == 0) p.body_loss[b] = s2[0] + s2[1];
+    return;
+  }
+  // last block: shape and scale priors (shared leaves)
+  __shared__ float sb[128];
+  float l = 0.f;
+  for (int i = threadIdx.x; i < p.N * MH_NUM_BETAS; i += 128) {
+    const float d = p.betas[i] - p.betas_ref[i];
+    l += fabsf(d);
+    const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    if (p.gbetas) p.gbetas[i] += p.cp * (float)p.T * sg;           // sum over batches of batch_size = T (:526)
+  }
+  sb[threadIdx.x] = l;
+  __syncthreads();
+  for (int o = 64; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sb[threadIdx.x] += sb[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float sum = 0.f, sq = 0.f;
+    for (int n = 0; n < p.N; ++n) {
+      const float s = powf(1.1f, p.xscale ? p.xscale[n] : 0.f) - 1.f;
+      sum += s;
+      sq += s * s;
+    }
+    p.loss3[0] = (float)p.T * sb[0];
+    p.loss3[1] = sum * sum;            // reg_scale_avg   (:531)
+    p.loss3[2] = sq / (float)p.N;      // reg_scale_person (:532)
+    if (p.gxscale && p.xscale)
+      for (int n = 0; n < p.N; ++n) {
+        const float s = powf(1.1f, p.xscale[n]);
+        const float ds = s * 0.0953101798043249f;
+        const float g = p.cs * 2.f * (s - 1.f) / (float)p.N + (p.cs > 0.f ? 1.f : 0.f) * 2.f * sum;   // :539
+        p.gxscale[n] += (float)p.nbatches * g * ds;
+      }
+  }
+}
+
+extern "C" int mh_prior_terms(int T, int N, int nbatches, const float* poses, const float* poses_ref,
+                              const float* valid, const float* betas, const float* betas_ref, const float* xscale,
+                              float coef_poses, float coef_scales, float* gposes, float* gbetas, float* gxscale,
+                              float* body_loss, float* loss3, void* stream) {
+  MH_CHECK(poses && poses_ref && valid && betas && betas_ref && gposes && body_loss && loss3, "null argument");
+  MH_CHECK(T > 0 && N > 0 && nbatches > 0, "empty input");
+  PriorP p;
+  p.T = T; p.N = N; p.nbatches = nbatches;
+  p.poses = poses; p.ref = poses_ref; p.valid = valid; p.betas = betas; p.betas_ref = betas_ref; p.xscale = xscale;
+  p.cp = coef_poses; p.cs = coef_scales;
+  p.gposes = gposes; p.gbetas = gbetas; p.gxscale = gxscale; p.body_loss = body_loss; p.loss3 = loss3;
+  hipLaunchKernelGGL(k_priors, dim3(T * N + 1), dim3(128), 0, (hipStream_t)stream, p);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+// deterministic sum of n floats, scaled: out[0] = scale * sum(x)
+__global__ __launch_bounds__(256) void k_reduce_sum(const float* x, size_t n, float scale, float* out) {
+  __shared__ float s[256];
+  float a = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += 256) a += x[i];
+  s[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = scale * s[0];
+}
+
+extern "C" int mh_reduce_sum(const float* x, size_t n, float scale, float* out, void* stream) {
+  MH_CHECK(x && out, "null argument");
+  hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, (hipStream_t)stream, x, n, scale, out);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}

@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void k_skin_bwd(SkinBwdP p) {
     float g0 = 0, g1 = 0, g2 = 0, q0 = 0, q1 = 0, q2 = 0;
     if (bvalid && v < p.V) {
       const size_t o = ((size_t)b * p.V + v) * 3;
-      g0 = p.gverts[o]; g1 = p.gverts[o + 1]; g2 = p.gverts[o + 2];
+      if (p.gverts) { g0 = p.gverts[o]; g1 = p.gverts[o + 1]; g2 = p.gverts[o + 2]; }
       q0 = p.vposed[o]; q1 = p.vposed[o + 1]; q2 = p.vposed[o + 2];
     }
     // key-point regressor adjoint: dL/dverts += R^T dL/djoints
@@ -775,7 +775,8 @@ extern "C" int mh_lbs_backward(const mh_model* m, int B, int NB, const float* be
                                const float* gjoints, float* gposes, float* gtransl, float* gbetas, float* gxscale,
                                void* ws, void* ws2, void* stream) {
   (void)xscale; (void)transl;
-  MH_CHECK(m && betas && poses && vposed && gverts && gposes && ws && ws2, "null argument");
+  MH_CHECK(m && betas && poses && vposed && gposes && ws && ws2, "null argument");
+  MH_CHECK(gverts || gjoints, "need gverts and/or gjoints");
   MH_CHECK(B > 0 && NB > 0, "B and NB must be positive");
   MH_CHECK(!gjoints || m->reg[MH_REG_ALPHAPOSE].J == MH_NKP, "gjoints needs the key-point regressor");
   hipStream_t st = (hipStream_t)stream;

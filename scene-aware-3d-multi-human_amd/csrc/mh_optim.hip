@@ -15,14 +15,29 @@ struct ProjP {
   float* uv;
   float* gj;
   float* loss;
+  // warm-up form: joints = 1.1^xscale[b%NB] * local + transl, gtransl = sum_j gj
+  int NB;
+  const float* local;
+  const float* xscale;
+  const float* transl;
+  float* gtransl;
 };
 
 __global__ __launch_bounds__(64) void k_project_loss(ProjP p) {
   const int b = blockIdx.x, j = threadIdx.x;
   float l = 0.f;
+  float g3[3] = {0.f, 0.f, 0.f};
   if (j < MH_NKP) {
     const size_t o = (size_t)b * MH_NKP + j;
-    const float X = p.joints[o * 3], Y = p.joints[o * 3 + 1], Z = p.joints[o * 3 + 2];
+    float X, Y, Z;
+    if (p.local) {                                           // optimizer.py:749-750
+      const float sc = p.xscale ? powf(1.1f, p.xscale[b % p.NB]) : 1.f;
+      X = sc * p.local[o * 3] + p.transl[(size_t)b * 3];
+      Y = sc * p.local[o * 3 + 1] + p.transl[(size_t)b * 3 + 1];
+      Z = sc * p.local[o * 3 + 2] + p.transl[(size_t)b * 3 + 2];
+    } else {
+      X = p.joints[o * 3]; Y = p.joints[o * 3 + 1]; Z = p.joints[o * 3 + 2];
+    }
     const float x = X / Z, y = Y / Z;                        // transforms.py:75-76
     float xx = x, yy = y, dxx_dx = 1, dxx_dy = 0, dyy_dx = 0, dyy_dy = 1;
     if (p.has_kd) {                                          // transforms.py:78-90
@@ -65,12 +80,25 @@ __global__ __launch_bounds__(64) void k_project_loss(ProjP p) {
     gvv *= p.coef;
     const float gxx = gu * p.K[0] + gvv * p.K[3], gyy = gu * p.K[1] + gvv * p.K[4];
     const float gx = gxx * dxx_dx + gyy * dyy_dx, gy = gxx * dxx_dy + gyy * dyy_dy;
-    p.gj[o * 3] = gx / Z;
-    p.gj[o * 3 + 1] = gy / Z;
-    p.gj[o * 3 + 2] = -(gx * x + gy * y) / Z;
+    g3[0] = gx / Z;
+    g3[1] = gy / Z;
+    g3[2] = -(gx * x + gy * y) / Z;
+    if (p.gj) {
+      p.gj[o * 3] = g3[0];
+      p.gj[o * 3 + 1] = g3[1];
+      p.gj[o * 3 + 2] = g3[2];
+    }
   }
   l = mh_wave_sum(l);
   if (j == 0) p.loss[b] = l;
+  if (p.gtransl) {
+    const float t0 = mh_wave_sum(g3[0]), t1 = mh_wave_sum(g3[1]), t2 = mh_wave_sum(g3[2]);
+    if (j == 0) {
+      p.gtransl[(size_t)b * 3] = t0;
+      p.gtransl[(size_t)b * 3 + 1] = t1;
+      p.gtransl[(size_t)b * 3 + 2] = t2;
+    }
+  }
 }
 
 extern "C" int mh_project_joints_loss(int B, const float* joints, const float* K_host, const float* Kd_host,
@@ -84,6 +112,24 @@ extern "C" int mh_project_joints_loss(int B, const float* joints, const float* K
   for (int i = 0; i < 5; ++i) p.Kd[i] = Kd_host ? Kd_host[i] : 0.f;
   p.thr = thr; p.w = img_w; p.h = img_h; p.coef = coef;
   p.joints = joints; p.pose2d = pose2d; p.uv = uv; p.gj = gjoints; p.loss = loss;
+  p.NB = 1; p.local = nullptr; p.xscale = nullptr; p.transl = nullptr; p.gtransl = nullptr;
+  hipLaunchKernelGGL(k_project_loss, dim3(B), dim3(64), 0, (hipStream_t)stream, p);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+extern "C" int mh_warmup_project(int B, int NB, const float* local_joints, const float* xscale, const float* transl,
+                                 const float* K_host, const float* Kd_host, const float* pose2d, float thr, float coef,
+                                 float* gtransl, float* loss, void* stream) {
+  MH_CHECK(local_joints && transl && K_host && pose2d && gtransl && loss, "null argument");
+  MH_CHECK(B > 0 && NB > 0, "B and NB must be positive");
+  ProjP p;
+  p.B = B; p.mode = 1; p.has_kd = Kd_host != nullptr;
+  for (int i = 0; i < 9; ++i) p.K[i] = K_host[i];
+  for (int i = 0; i < 5; ++i) p.Kd[i] = Kd_host ? Kd_host[i] : 0.f;
+  p.thr = thr; p.w = 1.f; p.h = 1.f; p.coef = coef;
+  p.joints = nullptr; p.pose2d = pose2d; p.uv = nullptr; p.gj = nullptr; p.loss = loss;
+  p.NB = NB; p.local = local_joints; p.xscale = xscale; p.transl = transl; p.gtransl = gtransl;
   hipLaunchKernelGGL(k_project_loss, dim3(B), dim3(64), 0, (hipStream_t)stream, p);
   MH_LAUNCH_CHECK();
   return MH_OK;

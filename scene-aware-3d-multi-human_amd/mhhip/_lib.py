@@ -63,6 +63,19 @@ def lib():
         L.mh_one_euro_scan.argtypes = [vp, vp, ctypes.c_int, ctypes.c_size_t] + [ctypes.c_float] * 3 + [vp]
         L.mh_velocity_term.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_float, vp, vp, vp]
         L.mh_filtered_verts_term.argtypes = [ctypes.c_int, ctypes.c_size_t] + [vp] * 6 + [ctypes.c_float, vp, vp, vp]
+        u32p = vp
+        L.mh_warmup_project.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, c_float_p, c_float_p, vp,
+                                        ctypes.c_float, ctypes.c_float, vp, vp, vp]
+        L.mh_pack_masks.argtypes = [vp] + [ctypes.c_int] * 4 + [u32p, vp, vp]
+        L.mh_erode_bits.argtypes = [u32p, u32p] + [ctypes.c_int] * 3 + [vp]
+        L.mh_stage_gates.argtypes = [vp, vp, ctypes.c_int, ctypes.c_float, ctypes.c_float, vp, vp, vp]
+        L.mh_sil_mask_stats.argtypes = [u32p] + [ctypes.c_int] * 4 + [vp] * 8
+        L.mh_prior_terms.argtypes = [ctypes.c_int] * 3 + [vp] * 6 + [ctypes.c_float] * 2 + [vp] * 6
+        L.mh_reduce_sum.argtypes = [vp, ctypes.c_size_t, ctypes.c_float, vp, vp]
+        L.mh_lowest_vertex.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp]
+        L.mh_contact_knn.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp]
+        L.mh_contact_foot_terms.argtypes = [ctypes.c_int] * 4 + [vp] * 4 + [ctypes.c_float] * 2 + [vp] * 5
+        L.mh_scene_unproject.argtypes = [vp, ctypes.c_int, ctypes.c_int, c_float_p, vp, vp]
         _lib = L
     return _lib
 

@@ -1,0 +1,258 @@
+"""Device-resident state of one sequence (or one frame shard of it) and the per-cycle launch
+sequence.  All arithmetic is in the HIP library; this file owns buffers, pointers and order.
+
+Leaves live in ONE flat fp32 buffer so that a single RMSprop launch updates everything and the
+shared tail (betas, xscale) is one contiguous slice for the per-cycle RCCL all-reduce:
+
+    [ poses_T (T,N,3) | poses_smpl (T,N,72) | zmin_lin (T) | zmax_lin (T) | betas (N,10) | xscale (N) ]
+
+Constant per-frame inputs are staged to HBM once (the reference re-uploads every batch every
+cycle, optimizer.py:396-400): pose2d, reference poses, validity, depth maps, and the N float
+instance masks of a frame packed into one 32-bit word per pixel (raw and twice-eroded).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, engine
+from ._lib import check, ptr
+
+LOG_KEYS = ['loss_pose24j', 'loss_depth', 'loss_silhouette', 'reg_ref_poses', 'reg_scale', 'reg_contact',
+            'reg_foot_sliding', 'reg_vel', 'reg_filter_verts']
+COEF_KEYS = ['proj2d', 'depth', 'silhouette', 'reg_velocity', 'reg_verts_filter', 'reg_poses', 'reg_scales',
+             'reg_contact', 'reg_foot_sliding']
+
+
+def _dev(a, device, dtype=torch.float32):
+    if isinstance(a, torch.Tensor):
+        return a.to(device=device, dtype=dtype).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(device).contiguous()
+
+
+class SequenceEngine(object):
+    def __init__(self, model, image_size, num_frames, num_people, cam_K, cam_dist_coef=None, coefs=None,
+                 joint_confidence_thr=0.5, eps=1e-3, batch_size=10, max_cycles=1024):
+        self.m = model
+        self.dev = model.device
+        self.W, self.H = int(image_size[0]), int(image_size[1])
+        self.T, self.N = int(num_frames), int(num_people)
+        self.B = self.T * self.N
+        self.V = model.V
+        self.batch = int(batch_size)
+        self.nbatches = (self.T + self.batch - 1) // self.batch
+        self.K = np.ascontiguousarray(np.asarray(cam_K, np.float32).reshape(3, 3))
+        self.Kd = None if cam_dist_coef is None else np.ascontiguousarray(np.asarray(cam_dist_coef, np.float32))
+        c = {k: 1.0 for k in COEF_KEYS}
+        c.update(coefs or {})
+        self.c = c
+        self.thr, self.eps = float(joint_confidence_thr), float(eps)
+        T, N, B = self.T, self.N, self.B
+        self.sizes = [B * 3, B * 72, T, T, N * 10, N]
+        self.offs = np.concatenate([[0], np.cumsum(self.sizes)]).astype(np.int64)
+        n = int(self.offs[-1])
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=self.dev)
+        self.params, self.grads, self.sq, self.buf = z(n), z(n), z(n), z(n)
+        self.shared_lo = int(self.offs[4])          # betas | xscale: the all-reduced tail
+        self.ws = model.workspace(B)
+        self.ws2 = model.backward_workspace(B)
+        self.verts = z(B, self.V, 3)
+        self.vposed = z(B, self.V, 3)
+        self.gverts = None
+        self.kp = z(B, 17, 3)
+        self.gj = z(B, 17, 3)
+        self.uv = z(B, 17, 2)
+        self.loss2d = z(B)
+        self.prior_body = z(B)
+        self.loss3 = z(3)
+        self.vel_loss = z(1)
+        self.filt_loss = z(1)
+        self.log = z(max_cycles, 16)
+        self.tmp_log = z(16)
+        self.scene_pts = None
+        self.verts_filt = None
+        self.pT_filt = None
+        self.has_images = False
+        self.halo = None              # filled by the frame-sharded driver
+
+    def set_batch_size(self, batch_size):
+        """Frames per batch of the reference's dataloader: fixes the in-batch foot-sliding pairs and
+        the number of per-batch regulariser additions (optimizer.py:512-518, 531-539)."""
+        self.batch = int(batch_size)
+        self.nbatches = (self.T + self.batch - 1) // self.batch
+
+    # -- leaves as views -------------------------------------------------------------------------
+    def _view(self, buf, i, shape):
+        return buf[int(self.offs[i]):int(self.offs[i + 1])].view(*shape)
+
+    def leaf(self, name, buf=None):
+        buf = self.params if buf is None else buf
+        T, N = self.T, self.N
+        i, shape = {'poses_T': (0, (T, N, 3)), 'poses_smpl': (1, (T, N, 72)), 'zmin_lin': (2, (T,)),
+                    'zmax_lin': (3, (T,)), 'betas': (4, (N, 10)), 'xscale': (5, (N,))}[name]
+        return self._view(buf, i, shape)
+
+    def set_leaves(self, poses_T, poses_smpl, betas, zmin_lin, zmax_lin, xscale=None):
+        self.leaf('poses_T').copy_(_dev(poses_T, self.dev).view(self.T, self.N, 3))
+        self.leaf('poses_smpl').copy_(_dev(poses_smpl, self.dev).view(self.T, self.N, 72))
+        self.leaf('betas').copy_(_dev(betas, self.dev).view(self.N, 10))
+        self.leaf('zmin_lin').copy_(_dev(zmin_lin, self.dev).view(self.T))
+        self.leaf('zmax_lin').copy_(_dev(zmax_lin, self.dev).view(self.T))
+        if xscale is not None:
+            self.leaf('xscale').copy_(_dev(xscale, self.dev).view(self.N))
+        else:
+            self.leaf('xscale').zero_()
+        self.sq.zero_()
+        self.buf.zero_()
+
+    # -- staging ---------------------------------------------------------------------------------
+    def stage(self, pose2d, poses_ref, valid, betas_ref, seg_mask=None, depths=None):
+        T, N, H, W = self.T, self.N, self.H, self.W
+        L = _lib.lib()
+        st = _lib.stream_ptr(self.dev)
+        self.pose2d = _dev(pose2d, self.dev).view(self.B, 17, 3)
+        self.poses_ref = _dev(poses_ref, self.dev).view(self.B, 72)
+        self.valid = _dev(valid, self.dev).view(self.B)
+        self.betas_ref = _dev(betas_ref, self.dev).view(N, 10)
+        self.area = torch.zeros(self.B, dtype=torch.float32, device=self.dev)
+        self.p2d_valid = torch.zeros(self.B, dtype=torch.float32, device=self.dev)
+        self.mask_valid = torch.zeros(self.B, dtype=torch.float32, device=self.dev)
+        if seg_mask is not None:
+            self.bits = torch.zeros(T, H, W, dtype=torch.int32, device=self.dev)
+            self.ebits = torch.zeros_like(self.bits)
+            tmp = torch.zeros_like(self.bits)
+            # upload in slabs: the float masks are 4*N bytes/pixel, the packed form 4 bytes/pixel
+            slab = max(1, (256 << 20) // (N * H * W * 4))
+            for s in range(0, T, slab):
+                e = min(T, s + slab)
+                seg = _dev(seg_mask[s:e], self.dev)
+                check(L.mh_pack_masks(ptr(seg), e - s, N, H, W, ptr(self.bits[s:e]), ptr(self.area[s * N:e * N]), st))
+                torch.cuda.current_stream(self.dev).synchronize()
+            check(L.mh_erode_bits(ptr(self.bits), ptr(tmp), T, H, W, st))       # Erode2D(3) twice, optimizer.py:306-309
+            check(L.mh_erode_bits(ptr(tmp), ptr(self.ebits), T, H, W, st))
+            self.depths = _dev(depths, self.dev).view(T, H, W)
+            self.front = torch.zeros(self.B, dtype=torch.int32, device=self.dev)
+            self.sil_apply = torch.zeros(self.B, dtype=torch.float32, device=self.dev)
+            self.sil_D = torch.zeros(self.B, dtype=torch.float32, device=self.dev)
+            self.sil_S = torch.zeros(self.B, dtype=torch.float32, device=self.dev)
+            self.sil_body = torch.zeros(self.B, dtype=torch.float32, device=self.dev)
+            self.depth_body = torch.zeros(self.B, dtype=torch.float32, device=self.dev)
+            self.has_images = True
+        check(L.mh_stage_gates(ptr(self.pose2d), ptr(self.area), self.B, self.thr, 0.005 * H * W, ptr(self.p2d_valid),
+                               ptr(self.mask_valid), st))
+        self.low_idx = torch.zeros(self.B, dtype=torch.int32, device=self.dev)
+        self.low_xyz = torch.zeros(self.B, 3, dtype=torch.float32, device=self.dev)
+        self.dy = torch.zeros(self.B, dtype=torch.float32, device=self.dev)
+        self.batch_contact = torch.zeros(self.nbatches, dtype=torch.float32, device=self.dev)
+        self.batch_foot = torch.zeros(self.nbatches, dtype=torch.float32, device=self.dev)
+
+    def set_scene_points(self, pts):
+        """pts (M,3) camera-space scene points or None (optimizer.py:605-616)."""
+        self.scene_pts = None if pts is None else _dev(pts, self.dev).view(-1, 3)
+
+    def scene_from_depth(self, depth, mask):
+        d = _dev(depth, self.dev).view(self.H, self.W)
+        pts = torch.empty(self.H * self.W, 3, dtype=torch.float32, device=self.dev)
+        check(_lib.lib().mh_scene_unproject(ptr(d), self.H, self.W, self.K.ctypes.data_as(_lib.c_float_p), ptr(pts),
+                                            _lib.stream_ptr(self.dev)))
+        keep = _dev(np.asarray(mask, np.float32) if not isinstance(mask, torch.Tensor) else mask.float(), self.dev).view(-1) > 0.5
+        self.scene_pts = pts[keep].contiguous()      # compaction only: plumbing
+        return self.scene_pts
+
+    # -- forward of all local frames ---------------------------------------------------------------
+    def forward(self):
+        m = self.m
+        check(_lib.lib().mh_lbs_forward(m.handle, self.B, self.N, ptr(self.leaf('betas')), ptr(self.leaf('poses_smpl')),
+                                        ptr(self.leaf('xscale')), ptr(self.leaf('poses_T')), ptr(self.verts),
+                                        ptr(self.vposed), None, ptr(self.ws), _lib.stream_ptr(self.dev)))
+        check(_lib.lib().mh_joints_regress(m.handle, engine.REG_ALPHAPOSE, self.B, ptr(self.verts),
+                                           ptr(self.leaf('poses_T')), -1, ptr(self.kp), _lib.stream_ptr(self.dev)))
+
+    # -- one optimisation cycle (optimizer.py:375-575), gradients accumulated into self.grads -----
+    def cycle(self, row, use_images=True, raster=None):
+        L = _lib.lib()
+        st = _lib.stream_ptr(self.dev)
+        c = self.c
+        T, N, B = self.T, self.N, self.B
+        g = self.grads
+        g.zero_()
+        gpT, gposes = self.leaf('poses_T', g), self.leaf('poses_smpl', g)
+        gbetas, gxs = self.leaf('betas', g), self.leaf('xscale', g)
+        pT = self.leaf('poses_T')
+        self.forward()
+        Kp = self.K.ctypes.data_as(_lib.c_float_p)
+        Kdp = None if self.Kd is None else self.Kd.ctypes.data_as(_lib.c_float_p)
+        check(L.mh_project_joints_loss(B, ptr(self.kp), Kp, Kdp, ptr(self.pose2d), self.thr, 0, float(self.W),
+                                       float(self.H), float(c['proj2d']), ptr(self.uv), ptr(self.gj), ptr(self.loss2d), st))
+        check(L.mh_prior_terms(T, N, self.nbatches, ptr(self.leaf('poses_smpl')), ptr(self.poses_ref), ptr(self.valid),
+                               ptr(self.leaf('betas')), ptr(self.betas_ref), ptr(self.leaf('xscale')),
+                               float(c['reg_poses']), float(c['reg_scales']), ptr(gposes), ptr(gbetas), ptr(gxs),
+                               ptr(self.prior_body), ptr(self.loss3), st))
+        h = self.halo or {}
+        check(L.mh_velocity_term(T, N, ptr(pT), ptr(h.get('pT_prev')), ptr(h.get('pT_next')), float(c['reg_velocity']),
+                                 ptr(gpT), ptr(self.vel_loss), st))
+        scene = self.scene_pts is not None
+        filt = self.verts_filt is not None and self.pT_filt is not None
+        images = use_images and self.has_images
+        need_gv = scene or filt or (images and raster is not None)
+        gv = None
+        if need_gv:
+            if self.gverts is None:
+                self.gverts = torch.empty_like(self.verts)
+            gv = self.gverts
+            gv.zero_()
+        log = self.tmp_log
+        log.zero_()
+        if images:
+            check(L.mh_sil_mask_stats(ptr(self.bits), T, N, self.H, self.W, ptr(pT), ptr(self.p2d_valid),
+                                      ptr(self.mask_valid), ptr(self.front), ptr(self.sil_apply), ptr(self.sil_D),
+                                      ptr(self.sil_S), st))
+            if raster is not None:
+                raster(self, gv, log)
+            else:
+                # no rasteriser: alpha = 0, zbuf empty -> the mask-only silhouette term (tests only)
+                self.sil_body.copy_(self.sil_apply * self.sil_S / (self.sil_D + 1.0))
+                check(L.mh_reduce_sum(ptr(self.sil_body), B, 1.0, ptr(log[2:3]), st))
+        if scene:
+            check(L.mh_lowest_vertex(ptr(self.verts), B, self.V, ptr(self.low_idx), ptr(self.low_xyz), st))
+            check(L.mh_contact_knn(ptr(self.scene_pts), self.scene_pts.shape[0], ptr(self.low_xyz), B, 32, ptr(self.dy), st))
+            check(L.mh_contact_foot_terms(T, N, self.V, self.batch, ptr(self.verts), ptr(self.low_idx), ptr(self.low_xyz),
+                                          ptr(self.dy), float(c['reg_contact']), float(c['reg_foot_sliding']), ptr(gpT),
+                                          ptr(gv), ptr(self.batch_contact), ptr(self.batch_foot), st))
+            check(L.mh_reduce_sum(ptr(self.batch_contact), self.nbatches, 1.0, ptr(log[5:6]), st))
+            check(L.mh_reduce_sum(ptr(self.batch_foot), self.nbatches, 1.0, ptr(log[6:7]), st))
+        if filt:
+            E = N * self.V * 3
+            check(L.mh_filtered_verts_term(T, E, ptr(self.verts), ptr(self.verts_filt), ptr(h.get('v_prev')),
+                                           ptr(h.get('vf_prev')), ptr(h.get('v_next')), ptr(h.get('vf_next')),
+                                           float(c['reg_verts_filter']), ptr(gv), ptr(self.filt_loss), st))
+            log[8:9].copy_(self.filt_loss)
+        check(L.mh_lbs_backward(self.m.handle, B, N, ptr(self.leaf('betas')), ptr(self.leaf('poses_smpl')),
+                                ptr(self.leaf('xscale')), ptr(pT), ptr(self.vposed), ptr(gv), ptr(self.gj), ptr(gposes),
+                                ptr(gpT), ptr(gbetas), ptr(gxs), ptr(self.ws), ptr(self.ws2), st))
+        check(L.mh_reduce_sum(ptr(self.loss2d), B, 1.0, ptr(log[0:1]), st))
+        check(L.mh_reduce_sum(ptr(self.prior_body), B, 1.0, ptr(log[3:4]), st))
+        log[9:12].copy_(self.loss3)
+        log[7:8].copy_(self.vel_loss)
+        self.log[row].copy_(log)
+
+    def step(self, lr, alpha=0.5, momentum=0.9, eps=1e-8):
+        engine.rmsprop_step(self.params, self.grads, self.sq, self.buf, float(lr), alpha, momentum, eps)
+
+    # -- filters (optimizer.py:383-392) -------------------------------------------------------------
+    def update_filters(self, c1=0.01, b1=0.02, c2=0.001, b2=0.5):
+        self.pT_filt = engine.one_euro_scan(self.leaf('poses_T'), c1, b1)
+        self.forward()
+        self.verts_filt = engine.one_euro_scan(self.verts.view(self.T, -1), c2, b2).view(self.T, self.N, self.V, 3)
+
+    # -- logs back on the host (one D2H per fit) ---------------------------------------------------
+    def read_log(self, rows, nbatches_total=None):
+        raw = self.log[:rows].cpu().numpy().astype(np.float64)
+        nb = float(nbatches_total or self.nbatches)
+        out = []
+        for r in raw:
+            d = {'loss_pose24j': r[0] / nb, 'loss_depth': r[1] / nb, 'loss_silhouette': r[2] / nb,
+                 'reg_ref_poses': (r[3] + r[9]) / nb, 'reg_scale': r[10] + r[11], 'reg_contact': r[5] / nb,
+                 'reg_foot_sliding': r[6] / nb, 'reg_vel': r[7], 'reg_filter_verts': r[8]}
+            out.append({k: np.float32(v) for k, v in d.items()})
+        return out

@@ -1,0 +1,328 @@
+"""Drop-in for the reference's ``mhmocap.optimizer`` on MI355X.
+
+``SMPLDepthSequenceOptimizer`` keeps the constructor / ``init_optimized_variables`` / ``fit`` /
+``get_optimized_variables`` / ``update_scene_pointcloud`` / ``one_euro_filter`` signatures of
+reference ``mhmocap/optimizer.py:146-770`` so that ``predict.py:290-306, 332-344`` keeps working,
+but the work is organised for the GPU instead of for autograd:
+
+* the constant per-frame inputs are staged to HBM once (first pass over the dataloader) instead
+  of every batch of every cycle (reference optimizer.py:396-400);
+* one cycle = ONE pass over all frames: LBS forward -> residual kernels -> hand-written LBS
+  backward -> one fused RMSprop launch over a flat parameter buffer.  The reference's per-batch
+  ``backward()`` only accumulates gradients (optimizer.py:394-544), so the sums are identical;
+  the two batch-structure-dependent terms (in-batch foot-sliding pairs :512-518, per-batch scale
+  regulariser :531-539) are evaluated with the same batch partition (contiguous batches of the
+  dataloader's batch size, i.e. ``shuffle=False`` semantics);
+* losses are logged on the device and read back once per ``fit``.
+"""
+import os
+
+import numpy as np
+import torch
+
+from mhhip import _lib, engine
+from mhhip.sequence import SequenceEngine, COEF_KEYS
+from .smpl import SMPL
+from .transforms import get_focal, softplus_np
+
+try:
+    from tqdm import tqdm
+except Exception:  # pragma: no cover
+    tqdm = None
+
+
+class SMPLOptimizerBase(object):
+    """reference optimizer.py:32-143"""
+
+    def __init__(self, device=None, smpl_model_parameters_path='model_data/parameters',
+                 smpl_J_reg_extra_path='J_regressor_extra.npy', smpl_J_reg_h37m_path='J_regressor_h36m.npy',
+                 smpl_J_reg_alphapose_path='SMPL_AlphaPose_Regressor_RMSprop_6.npy',
+                 smpl_sparse_joints_key='joints_alphapose', pose24j_weights=None, pose17j_weights=None,
+                 smpl_data_struct=None):
+        if device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError('the MI355X build of mhmocap.optimizer needs a HIP device (no CPU fallback)')
+            device = 'cuda:0'
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('the MI355X build of mhmocap.optimizer needs a HIP device, got %s' % device)
+        assert smpl_sparse_joints_key == 'joints_alphapose', 'only the 17 AlphaPose key-points are accelerated'
+        self.smpl_model_parameters_path = os.path.abspath(smpl_model_parameters_path)
+        p = lambda f: os.path.join(smpl_model_parameters_path, f)
+        self.SMPLPY = SMPL(smpl_model_parameters_path, J_reg_extra9_path=p(smpl_J_reg_extra_path),
+                           J_reg_h36m17_path=p(smpl_J_reg_h37m_path), J_reg_alphapose_path=p(smpl_J_reg_alphapose_path),
+                           data_struct=smpl_data_struct).to(self.device)
+        self.faces_smpl = torch.tensor(np.asarray(self.SMPLPY.faces)[np.newaxis, :].astype(np.int32), device=self.device)
+        self.smpl_sparse_joints_key = smpl_sparse_joints_key
+        w17 = np.ones(17, np.float32) if pose17j_weights is None else np.asarray(pose17j_weights, np.float32)
+        w17 = len(w17) * w17 / np.sum(w17)
+        assert np.allclose(w17, 1.0), 'non-uniform key-point weights are not supported by the fused 2D kernel'
+        self.pose17j_weights = torch.tensor(w17[np.newaxis, :, np.newaxis], device=self.device)
+
+    def predict(self, poses_T, poses_smpl, betas_smpl, scale_factor):
+        res = self.SMPLPY(betas=torch.as_tensor(betas_smpl), poses=torch.as_tensor(poses_smpl))
+        verts = scale_factor * res['verts'].detach().cpu().numpy() + poses_T
+        joints = scale_factor * res[self.smpl_sparse_joints_key].detach().cpu().numpy() + poses_T
+        return verts, joints
+
+
+class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
+    """reference optimizer.py:146-770"""
+
+    def __init__(self, image_size, num_frames, fov=60, focal_length=None, znear=1.0, zfar=100.0, cam_K=None,
+                 cam_dist_coef=None, proj2d_loss_coef=1.0, depth_loss_coef=1.0, silhouette_loss_coef=1.0,
+                 reg_velocity_coef=1.0, reg_verts_filter_coef=1.0, reg_poses_coef=1.0, reg_scales_coef=1.0,
+                 reg_contact_coef=1.0, reg_foot_sliding_coef=1.0, joint_confidence_thr=0.5, eps=1e-3, **kargs):
+        self.use_rasteriser = kargs.pop('use_rasteriser', True)
+        self.scene_update = kargs.pop('scene_update', 'host')
+        super().__init__(**kargs)
+        if focal_length is None:
+            focal_length = get_focal(min(image_size), fov)
+        if cam_K is None:                                           # (sic) reference :194-197 swaps W/H here
+            self.cam_K = np.array([[focal_length, 0, image_size[1] / 2.0], [0, focal_length, image_size[0] / 2.0],
+                                   [0, 0, 1]], dtype=np.float32)
+        else:
+            self.cam_K = np.asarray(cam_K).astype(np.float32)
+        self.cam_dist_coef = cam_dist_coef
+        self.znear, self.zfar = znear, zfar
+        self.coefs = dict(proj2d=proj2d_loss_coef, depth=depth_loss_coef, silhouette=silhouette_loss_coef,
+                          reg_velocity=reg_velocity_coef, reg_verts_filter=reg_verts_filter_coef,
+                          reg_poses=reg_poses_coef, reg_scales=reg_scales_coef, reg_contact=reg_contact_coef,
+                          reg_foot_sliding=reg_foot_sliding_coef)
+        for k in COEF_KEYS:
+            setattr(self, {'proj2d': 'proj2d_loss_coef', 'depth': 'depth_loss_coef',
+                           'silhouette': 'silhouette_loss_coef'}.get(k, k + '_coef'), self.coefs[k])
+        self.joint_confidence_thr = joint_confidence_thr
+        self.eps = eps
+        self.num_frames = num_frames
+        self.img_w, self.img_h = image_size
+        self.min_delta_z = 1.0
+        self.engine = None
+        self.scene_depth = None
+        self.scene_pcd = None
+        self.poses_T_filtered = None
+        self.verts_filtered = None
+
+    # -- leaves, exposed with the reference's shapes ------------------------------------------------
+    @property
+    def poses_T(self):
+        return self.engine.leaf('poses_T').view(self.num_frames, self.num_people, 1, 3)
+
+    @property
+    def poses_smpl(self):
+        return self.engine.leaf('poses_smpl')
+
+    @property
+    def betas_smpl(self):
+        return self.engine.leaf('betas').view(1, self.num_people, 10)
+
+    @property
+    def xscale_factor(self):
+        return self.engine.leaf('xscale').view(1, self.num_people, 1, 1)
+
+    @property
+    def zmin_lin(self):
+        return self.engine.leaf('zmin_lin').view(self.num_frames, 1, 1)
+
+    @property
+    def zmax_lin(self):
+        return self.engine.leaf('zmax_lin').view(self.num_frames, 1, 1)
+
+    # -- reference optimizer.py:262-321 ---------------------------------------------------------------
+    def init_optimized_variables(self, pose2d, poses_smpl, betas_smpl, valid_smpl, scale_factor=None, num_iter=100):
+        assert (pose2d.shape[:2] == poses_smpl.shape[:2] == betas_smpl.shape[:2] == valid_smpl.shape[:2]), (
+            f'Error: invalid inputs {pose2d.shape}, {poses_smpl.shape}, {betas_smpl.shape}, {valid_smpl.shape}')
+        T, N = pose2d.shape[0:2]
+        assert T == self.num_frames, f'expected {self.num_frames} frames, got {T}'
+        self.num_people = N
+        if scale_factor is not None:
+            xscale = (np.log(scale_factor) / np.log(1.1)).astype(np.float32).reshape(N)
+            self.optim_scale_factor = False
+        else:
+            xscale = np.zeros(N, np.float32)
+            self.optim_scale_factor = True
+        self._pose2d_init = np.asarray(pose2d, np.float32)
+        self._poses_ref = np.asarray(poses_smpl, np.float32)
+        self._valid = (np.asarray(valid_smpl) > 0.7).astype(np.float32)       # :299
+        init_log, poses_T = self.__init_global_poses(pose2d, poses_smpl, betas_smpl, xscale, num_iter)
+        max_z = np.clip(np.max(poses_T[..., 2], axis=1), 2, None)            # (T,)  :292
+        avg_betas = np.mean(betas_smpl, axis=0).astype(np.float32)            # (N,10) :296
+        self._betas_ref = avg_betas
+        self._init_leaves = dict(poses_T=poses_T, poses_smpl=self._poses_ref, betas=avg_betas,
+                                 zmin_lin=np.ones_like(max_z), zmax_lin=2.0 * max_z, xscale=xscale)
+        self._build_engine(batch_size=10)
+        self.scene_depth = None
+        self.scene_pcd = None
+        self.poses_T_filtered = None
+        self.verts_filtered = None
+        return init_log
+
+    def _build_engine(self, batch_size):
+        m = self.SMPLPY.body_model
+        self.engine = SequenceEngine(m, (self.img_w, self.img_h), self.num_frames, self.num_people, self.cam_K,
+                                     self.cam_dist_coef, self.coefs, self.joint_confidence_thr, self.eps, batch_size)
+        self.engine.set_leaves(**self._init_leaves)
+        self.valid_smpl = torch.tensor(self._valid, device=self.device)
+        self._staged = False
+
+    # -- reference optimizer.py:710-770: only poses_T is a leaf, so SMPL runs once --------------------
+    def __init_global_poses(self, pose2d, poses_smpl, betas_smpl, xscale, num_iter, joints_thr=0.15):
+        T, N = pose2d.shape[0:2]
+        B = T * N
+        m = self.SMPLPY.body_model
+        dev = self.device
+        L = _lib.lib()
+        st = _lib.stream_ptr(dev)
+        f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+        verts, _, _, _ = m.lbs_forward(f32(betas_smpl).view(B, 10), f32(poses_smpl).view(B, 72), want_vposed=False)
+        local = m.joints_regress(engine.REG_ALPHAPOSE, verts)                 # (B,17,3), constant during warm-up
+        del verts
+        pT = f32(np.tile(np.array([[0, 0, 1]], np.float32), (B, 1)))          # :729
+        p2d, xs = f32(pose2d).view(B, 17, 3), f32(xscale)
+        g = torch.zeros_like(pT)
+        mom, var = torch.zeros_like(pT), torch.zeros_like(pT)
+        body_loss = torch.zeros(B, device=dev)
+        log_dev = torch.zeros(max(num_iter, 1), device=dev)
+        vel = torch.zeros(1, device=dev)
+        Kp = np.ascontiguousarray(self.cam_K.reshape(9)).ctypes.data_as(_lib.c_float_p)
+        Kd = None if self.cam_dist_coef is None else np.ascontiguousarray(self.cam_dist_coef, np.float32)
+        Kdp = None if Kd is None else Kd.ctypes.data_as(_lib.c_float_p)
+        lr = 0.5
+        for it in range(num_iter):
+            _lib.check(L.mh_warmup_project(B, N, _lib.ptr(local), _lib.ptr(xs), _lib.ptr(pT), Kp, Kdp, _lib.ptr(p2d),
+                                           joints_thr, float(self.coefs['proj2d']), _lib.ptr(g), _lib.ptr(body_loss), st))
+            _lib.check(L.mh_velocity_term(T, N, _lib.ptr(pT), None, None, float(self.coefs['reg_velocity']),
+                                          _lib.ptr(g), _lib.ptr(vel), st))
+            _lib.check(L.mh_reduce_sum(_lib.ptr(body_loss), B, 1.0, _lib.ptr(log_dev[it:it + 1]), st))
+            engine.adam_step(pT, g, mom, var, it + 1, lr)                     # Adam(lr=.5, betas=(.5,.5), eps=1e-6) :738
+            lr *= 0.95                                                        # ExponentialLR(0.95) :739
+        log = log_dev.cpu().numpy()
+        return [{'loss_2d': np.float32(v)} for v in log[:num_iter]], pT.view(T, N, 1, 3).cpu().numpy()
+
+    # -- staging the constant inputs (first pass over the dataloader) ---------------------------------
+    def _stage_from_dataloader(self, dataloader):
+        T, N = self.num_frames, self.num_people
+        H, W = self.img_h, self.img_w
+        bs = getattr(dataloader, 'batch_size', None)
+        first = True
+        have_img = True
+        store = {}
+        for data in dataloader:
+            idx = np.asarray(data['idxs']).reshape(-1).astype(np.int64)
+            if bs is None and first:
+                bs = len(idx)
+            for k in ['depths', 'seg_mask', 'pose2d', 'poses_smpl', 'images', 'backmasks']:
+                if k not in data:
+                    if k in ('depths', 'seg_mask'):
+                        have_img = False
+                    continue
+                a = data[k].numpy() if isinstance(data[k], torch.Tensor) else np.asarray(data[k])
+                if k not in store:
+                    store[k] = np.zeros((T,) + a.shape[1:], a.dtype)
+                store[k][idx] = a
+            first = False
+        self.engine.set_batch_size(int(bs))
+        self.engine.stage(store['pose2d'], store.get('poses_smpl', self._poses_ref), self._valid, self._betas_ref,
+                          store['seg_mask'] if have_img else None, store['depths'] if have_img else None)
+        self._images = store.get('images')
+        self._backmasks = store.get('backmasks')
+        self._staged = True
+
+    # -- reference optimizer.py:324-602 ---------------------------------------------------------------
+    def fit(self, dataloader, num_iter=250, min_cutoff1=0.01, min_cutoff2=0.001, beta1=0.02, beta2=0.5,
+            update_filters_every=25, verbose=False):
+        if not self._staged:
+            self._stage_from_dataloader(dataloader)
+        e = self.engine
+        if not self.optim_scale_factor:
+            print('WARNING!!! Not optimizing scale_factor!')
+        if num_iter > e.log.shape[0]:
+            e.log = torch.zeros(num_iter, 16, device=self.device)
+        raster = None
+        if self.use_rasteriser and e.has_images:
+            from mhhip import raster as _raster
+            raster = _raster.RasterTerms(e, self.znear, self.zfar)
+        lr = 0.01
+        cycles = range(num_iter)
+        if verbose and tqdm is not None:
+            cycles = tqdm(cycles)
+        for cycle in cycles:
+            if cycle >= 30 and cycle % update_filters_every == 0:            # :383-392
+                e.update_filters(min_cutoff1, beta1, min_cutoff2, beta2)
+                self.poses_T_filtered = e.pT_filt.view(self.num_frames, self.num_people, 1, 3)
+                self.verts_filtered = e.verts_filt
+            e.cycle(cycle, raster=raster)
+            if cycle >= 30 and self.scene_update == 'host' and e.has_images and self._backmasks is not None:
+                self._host_scene_update()                                     # :578-584
+            if not self.optim_scale_factor:
+                e.leaf('xscale', e.grads).zero_()
+            e.step(lr)                                                        # RMSprop(lr=.01, alpha=.5, momentum=.9) :355
+            lr *= 0.99                                                        # ExponentialLR(0.99) :356
+        self._finish_scene()
+        return e.read_log(num_iter)
+
+    def _host_scene_update(self):
+        from . import scene_host
+        e = self.engine
+        depths = scene_host.target_depths(e)                                  # (T,H,W) = 1/target_disp, :425-426
+        ma_image, ma_depth, ma_mask = scene_host.aggregate_scene_median(depths, self._images, self._backmasks)
+        self.scene_depth = scene_host.postprocess_depthmap(ma_depth, ma_mask, use_bilateral_filter=True)
+        self._ma = (ma_image, ma_mask)
+        self.update_scene_pointcloud(self.scene_depth, ma_mask)
+
+    def _finish_scene(self):
+        if getattr(self, '_ma', None) is None:
+            return
+        from . import scene_host
+        scene_img, scene_mask = self._ma[0].copy(), self._ma[1].astype(np.float32).copy()
+        while scene_mask.min() == 0:                                          # :595-600
+            scene_img, scene_mask = scene_host.fillin_values(scene_img, scene_mask, filter_size=11)
+        self.scene_img, self.scene_mask = scene_img, scene_mask
+
+    # -- reference optimizer.py:605-616 ---------------------------------------------------------------
+    def update_scene_pointcloud(self, scene_depth, scene_mask):
+        pts = self.engine.scene_from_depth(np.asarray(scene_depth, np.float32), np.asarray(scene_mask))
+        self.scene_pcd = pts.unsqueeze(0).unsqueeze(0)                        # (1,1,M,3)
+
+    # -- reference optimizer.py:619-636 ---------------------------------------------------------------
+    def get_optimized_variables(self):
+        e = self.engine
+        T, N = self.num_frames, self.num_people
+        zmin = e.leaf('zmin_lin').cpu().numpy().reshape(T, 1, 1)
+        zmax = e.leaf('zmax_lin').cpu().numpy().reshape(T, 1, 1)
+        min_z = softplus_np(zmin)
+        max_z = min_z + self.min_delta_z + softplus_np(zmax)
+        return {
+            'scale_factor': np.power(np.float32(1.1), e.leaf('xscale').cpu().numpy()).reshape(1, N, 1, 1),
+            'poses_T': e.leaf('poses_T').cpu().numpy().reshape(T, N, 1, 3),
+            'poses_smpl': e.leaf('poses_smpl').cpu().numpy(),
+            'betas_smpl': e.leaf('betas').cpu().numpy().reshape(1, N, 10),
+            'valid_smpl': self._valid.copy(),
+            'min_z': min_z, 'max_z': max_z,
+            'scene_depth': self.scene_depth if hasattr(self, 'scene_depth') else None,
+            'scene_img': self.scene_img if hasattr(self, 'scene_img') else None,
+            'scene_mask': self.scene_mask if hasattr(self, 'scene_mask') else None,
+        }
+
+    # -- reference optimizer.py:664-675 ---------------------------------------------------------------
+    def one_euro_filter(self, x, min_cutoff=0.1, beta=0.02, frame_rate=25):
+        x = torch.as_tensor(x).detach().to(self.device).float()
+        return engine.one_euro_scan(x, min_cutoff, beta, frame_rate)
+
+    # -- reference optimizer.py:639-661 (not called by any shipped entry point) ------------------------
+    def get_filtered_vertices_by_smpl(self, min_cutoff_T=0.004, min_cutoff_angles=0.1, beta_T=0.7, beta_angles=0.1,
+                                      frame_rate=25):
+        from .one_euro_filter import OneEuroFilter
+        poses_T = self.poses_T.cpu().numpy().copy()
+        pose = self.poses_smpl.cpu().numpy().copy()
+        fT = OneEuroFilter(0, poses_T[0], dx0=0 * poses_T[0], min_cutoff=min_cutoff_T, beta=beta_T, d_cutoff=1.0)
+        fP = OneEuroFilter(0, pose[0], dx0=0 * pose[0], min_cutoff=min_cutoff_angles, beta=beta_angles, d_cutoff=1.0)
+        for i in range(1, len(pose)):
+            poses_T[i] = fT(i / frame_rate, poses_T[i])
+            pose[i] = fP(i / frame_rate, pose[i])
+        T, N = self.num_frames, self.num_people
+        m = self.SMPLPY.body_model
+        verts, _, _, _ = m.lbs_forward(self.engine.leaf('betas'), torch.tensor(pose, device=self.device).view(-1, 72),
+                                       self.engine.leaf('xscale'), torch.tensor(poses_T, device=self.device).view(-1, 3),
+                                       want_vposed=False)
+        return verts.view(T, N, -1, 3)

@@ -1,0 +1,109 @@
+"""Host side of the scene update (reference optimizer.py:578-584, 595-600; fhsog.py:180-202;
+utils.py:91-135, 174-209).  The reference runs this part in numpy / OpenCV on the host once per
+cycle >= 30; it is SURVEY row f1 ("next": to be moved to the GPU).  OpenCV is not available in the
+build image, so the bilateral / Sobel / erode steps are restated in numpy following OpenCV's
+documented semantics (BORDER_REFLECT_101) -- this part is unpinned (no reference output exists)."""
+import numpy as np
+import torch
+
+
+def target_depths(engine):
+    """(T,H,W) metric depth 1/target_disp of every frame (optimizer.py:425-426)."""
+    zmin = engine.leaf('zmin_lin').double()
+    zmax = engine.leaf('zmax_lin').double()
+    min_z = torch.log(1.0 + torch.exp(zmin))
+    max_z = min_z + 1.0 + torch.log(1.0 + torch.exp(zmax))
+    inv_min, inv_max = (1.0 / min_z).float().view(-1, 1, 1), (1.0 / max_z).float().view(-1, 1, 1)
+    disp = engine.depths * (inv_min - inv_max) + inv_max
+    return (1.0 / disp).cpu().numpy()
+
+
+def aggregate_scene_median(depths, images, backmasks, depth_metric='median'):
+    """fhsog.py:180-202: per-pixel masked median over time of depth (and colour)."""
+    bkg_img = None
+    if images is not None:
+        m = np.ma.array(images, mask=np.tile(backmasks[..., np.newaxis] == 0, (1, 1, 1, 3)))
+        bkg_img = np.ma.median(m, axis=0).data.astype(np.uint8)
+    md = getattr(np.ma, depth_metric)(np.ma.array(depths, mask=backmasks == 0), axis=0)
+    return bkg_img, md.data.astype(np.float32), md.mask == 0
+
+
+def _reflect101(a, r):
+    return np.pad(a, r, mode='reflect')
+
+
+def _bilateral(src, d, sigma_color, sigma_space):
+    r = d // 2
+    p = _reflect101(src, r)
+    H, W = src.shape
+    num = np.zeros_like(src, dtype=np.float64)
+    den = np.zeros_like(src, dtype=np.float64)
+    for dy in range(-r, r + 1):
+        for dx in range(-r, r + 1):
+            if dy * dy + dx * dx > r * r:
+                continue                              # OpenCV uses a circular support
+            q = p[r + dy:r + dy + H, r + dx:r + dx + W]
+            w = np.exp(-(dy * dy + dx * dx) / (2.0 * sigma_space ** 2) - ((q - src) ** 2) / (2.0 * sigma_color ** 2))
+            num += w * q
+            den += w
+    return (num / den).astype(np.float32)
+
+
+def _sobel(src, dx, dy):
+    p = _reflect101(src.astype(np.float32), 1)
+    H, W = src.shape
+    k_s, k_d = np.array([1, 2, 1], np.float32), np.array([-1, 0, 1], np.float32)
+    kx, ky = (k_d, k_s) if dx else (k_s, k_d)
+    out = np.zeros((H, W), np.float32)
+    for i in range(3):
+        for j in range(3):
+            out += ky[i] * kx[j] * p[i:i + H, j:j + W]
+    return out
+
+
+def _erode3(m, iterations):
+    for _ in range(iterations):
+        p = np.pad(m, 1, mode='constant', constant_values=np.inf)
+        H, W = m.shape
+        out = m.copy()
+        for i in range(3):
+            for j in range(3):
+                out = np.minimum(out, p[i:i + H, j:j + W])
+        m = out
+    return m
+
+
+def fillin_values(x, mask, filter_size, metric='median'):
+    """utils.py:91-135: fill masked-out pixels from the valid ones of their window (one sweep)."""
+    assert x.shape[0:2] == mask.shape and filter_size > 1
+    fm = getattr(np, metric)
+    nx, nmask = x.copy(), mask.copy()
+    H, W = mask.shape
+    k = filter_size // 2
+    for r, c in zip(*np.nonzero(mask == 0)):
+        r0, r1, c0, c1 = max(0, r - k), min(H, r + k + 1), max(0, c - k), min(W, c + k + 1)
+        sel = mask[r0:r1, c0:c1] > 0
+        if sel.any():
+            nx[r, c] = fm(x[r0:r1, c0:c1][sel, ...], axis=0)   # reads the ORIGINAL values like the reference's v = nx[...] before overwrite order
+            nmask[r, c] = 1
+    return nx, nmask
+
+
+def postprocess_depthmap(depth, mask=None, fillin_ksize=7, use_bilateral_filter=False):
+    """utils.py:174-209."""
+    depth = np.asarray(depth, np.float32)
+    if use_bilateral_filter:
+        disp = _bilateral(1.0 / np.clip(depth, 0.01, 100), 9, 0.05, 25)
+        depth = 1.0 / np.clip(disp, 0.01, 100)
+    disp = 1.0 / np.clip(depth, 0.1, 100)
+    g_disp = np.abs(_sobel(disp, 1, 0)) + np.abs(_sobel(disp, 0, 1))
+    g_depth = np.abs(_sobel(depth, 1, 0)) + np.abs(_sobel(depth, 0, 1))
+    grad = g_disp / g_disp.std() + g_depth / g_depth.std()
+    edges = (grad > 3 * grad.mean()).astype(disp.dtype)
+    dmask = _erode3(1 - edges, 2)
+    if mask is not None:
+        dmask = dmask * mask
+    new_depth, new_mask = depth, dmask
+    while new_mask.min() < 1:
+        new_depth, new_mask = fillin_values(new_depth, new_mask, filter_size=fillin_ksize)
+    return new_depth

@@ -1,0 +1,52 @@
+"""Camera helpers with the call surface of reference ``mhmocap/transforms.py`` (the functions the
+optimisation path uses: :57-95, :114-130, :222-255, :263-265, :296-297).  Host-side scalars are
+numpy; the per-point device work of the hot path is fused into the HIP kernels
+(``mh_project_joints_loss``, ``mh_scene_unproject``, ``mh_raster_*``)."""
+import math
+
+import numpy as np
+
+
+def get_focal(w, theta):
+    return 0.5 * w / math.tan(math.pi * theta / 360.0)
+
+
+def get_fov(w, f):
+    return 360.0 * math.atan(0.5 * w / f) / math.pi
+
+
+def softplus_np(x):
+    return np.log(1.0 + np.exp(x))
+
+
+def inverse_softplus_np(s):
+    return np.log(np.exp(s) - 1.0)
+
+
+def compute_calibration_matrix(znear, zfar, cam_K, image_size):
+    """4x4 NDC projection for a (W, H) image: short side spans [-1, 1] (reference :222-255)."""
+    W, H = image_size
+    fx, fy, cx, cy = cam_K[0, 0], cam_K[1, 1], cam_K[0, 2], cam_K[1, 2]
+    if W > H:
+        s, u = 2 * fy / H, W / H
+        w1, h1 = u * (W - 2 * cx) / W, (H - 2 * cy) / H
+    elif H > W:
+        s, u = 2 * fx / W, H / W
+        w1, h1 = (W - 2 * cx) / W, u * (H - 2 * cy) / H
+    else:
+        s = 2 * (fx + fy) / (W + H)
+        w1, h1 = (W - 2 * cx) / W, (H - 2 * cy) / H
+    f1 = zfar / (zfar - znear)
+    f2 = -(zfar * znear) / (zfar - znear)
+    return np.array([[s, 0, w1, 0], [0, s, h1, 0], [0, 0, f1, f2], [0, 0, 1, 0]], np.float32)
+
+
+def camera_projection(pts3d, K, return_depth=False):
+    """numpy twin of the pinhole projection: pts3d (M,3), K (3,3)."""
+    uv = (pts3d[:, :2] / pts3d[:, 2:3]) @ K[:2, :2].T + K[:2, 2][None]
+    return np.concatenate([uv, pts3d[:, 2:]], -1) if return_depth else uv
+
+
+def camera_inverse_projection(ptsuvd, K):
+    xy = ptsuvd[:, 2:3] * ((ptsuvd[:, :2] - K[0:2, 2:3].T) @ np.linalg.inv(K[:2, :2].T))
+    return np.concatenate([xy, ptsuvd[:, 2:3]], axis=-1)

@@ -142,4 +142,5 @@ def test_capsule_body_render_is_sane():
     assert 20 < int(cover.sum()) < 400
     assert float(z[0][cover].min()) > 3.7 and float(z[0][cover].max()) < 4.3
     assert float(a.max()) > 0.9 and float(a[0, 0, 0]) == 0.0
-    assert float(a[0][cover].min()) > 0.3
+    # the depth pass has the wider blur band (1e-4 vs 2e-5): a few rim pixels have depth but no alpha
+    assert float((a[0][cover] > 0.5).float().mean()) > 0.8

@@ -210,6 +210,28 @@ int mh_contact_foot_terms(int T, int N, int V, int batch, const float* verts, co
 int mh_scene_unproject(const float* depth /*(H,W)*/, int H, int W, const float* K_host,
                        float* points /*(H*W,3)*/, void* stream);
 
+/* ---- a13/a14: differentiable z-buffer + soft silhouette fused with their residuals ------------
+ * Replaces, per cycle, for all T*N bodies at once: Meshes -> MeshRasterizer(K=8, blur 1e-4) ->
+ * zbuf[...,0]; MeshRenderer(K=4, blur 2e-5) + SoftSilhouetteShader (optimizer.py:211-232,
+ * 427-431, 447-448); the masked mean-log-disparity residual (optimizer.py:425-442,
+ * losses.py:19-30) and the occlusion-ordered silhouette residual (optimizer.py:450-477,
+ * losses.py:33-40); and the backward of all of it into the vertices and the depth-range leaves.
+ * PyTorch3D conventions: camera R = diag(-1,-1,1), NDC from transforms.py:222-255, pixel centres,
+ * perspective_correct = False, clipped barycentrics, no culling.  cam_K_host: HOST 3x3.
+ * In : verts (T*N,V,3) camera space; faces (F,3); bits / ebits (T,H,W) raw / twice-eroded
+ *      instance-mask words; depths (T,H,W) normalised disparity; zmin_lin, zmax_lin (T);
+ *      pose2d_valid (T*N); front, sil_apply, sil_D, sil_S from mh_sil_mask_stats.
+ * Out: gverts (T*N,V,3) += coef * dL/dverts (atomic; may be NULL = losses only);
+ *      gzmin, gzmax (T) += ; depth_body, sil_body (T*N) per-body loss values (un-weighted);
+ *      dinv_ws: 2*T*N floats of scratch.                                                        */
+int mh_raster_terms(int T, int N, int V, int F, int H, int W, const float* cam_K_host,
+                    const float* verts, const int32_t* faces, const uint32_t* bits,
+                    const uint32_t* ebits, const float* depths, const float* zmin_lin,
+                    const float* zmax_lin, const float* pose2d_valid, const uint32_t* front,
+                    const float* sil_apply, const float* sil_D, const float* sil_S,
+                    float coef_depth, float coef_sil, float eps, float* gverts, float* gzmin,
+                    float* gzmax, float* depth_body, float* sil_body, float* dinv_ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,501 @@
+// Differentiable z-buffer + soft silhouette of every body, fused with the depth and silhouette
+// residuals and their backward (reference optimizer.py:425-477 + losses.py:19-40; the rasteriser
+// itself is PyTorch3D's MeshRasterizer / SoftSilhouetteShader, restated from its published
+// semantics -- see oracle/raster_select.c for the provenance note).
+//
+// MI355X design: ONE workgroup per body keeps the body's screen window in LDS.
+//   * SMPL triangles are sub-pixel at MuPoTs resolution (13776 faces on ~600 px), so the pass is
+//     face-parallel: each thread walks the few pixel centres inside its face's blurred bbox and
+//     inserts (z, face) keys with 64-bit LDS atomics -- slot 0 is the nearest face of the
+//     blur=1e-4 pass (the only thing the reference reads from its K=8 rasterisation,
+//     optimizer.py:430), slots 1..4 the K=4 nearest faces of the blur=2e-5 silhouette pass
+//     (atomicMin cascade: the displaced key carries on to the next slot);
+//   * the residual sums, then the per-pixel gradients, are evaluated straight from LDS: no
+//     z-buffer / alpha image / fragment tensor ever reaches HBM (the reference materialises
+//     (b,N,H,W,8)+(b,N,H,W,4) fragments twice per batch);
+//   * bodies larger than the LDS window are processed in row strips (two sweeps).
+#include "mh_common.h"
+
+#define RS_CAP 1920          // window pixels resident in LDS per strip (5 x u64 each = 76.8 KB)
+#define RS_EMPTY 0xffffffffffffffffull
+#define R_KEPS 1e-8f
+#define BLUR_D 1e-4f         // optimizer.py:213
+#define BLUR_S 2e-5f         // optimizer.py:223
+#define SIGMA_S 1e-4f        // BlendParams.sigma default used by SoftSilhouetteShader
+
+struct RasterP {
+  int B, N, V, F, H, W;
+  float s, w1, h1;           // x_ndc = -s*x/z + w1, y_ndc = -s*y/z + h1 (transforms.py:222-255, R=diag(-1,-1,1))
+  const float* verts;
+  const int* faces;
+  const uint32_t* bits;
+  const uint32_t* ebits;
+  const float* depths;
+  const float* zmin_lin;
+  const float* zmax_lin;
+  const float* p2d_valid;
+  const uint32_t* front;
+  const float* sil_apply;
+  const float* sil_D;
+  const float* sil_S;
+  float coef_depth, coef_sil, eps;
+  float* gverts;
+  float* depth_body;
+  float* sil_body;
+  float* dinv;               // (B,2)
+};
+
+__device__ __forceinline__ float r_pix_to_ndc(int i, int S1, int S2) {
+  float range = 2.0f;
+  if (S1 > S2) range = ((float)S1 * range) / (float)S2;
+  const float offset = range / 2.0f;
+  return -offset + (range * (float)i + offset) / (float)S1;
+}
+// float pixel index (image order) of an NDC coordinate
+__device__ __forceinline__ float r_ndc_to_pix(float ndc, int S1, int S2) {
+  float range = 2.0f;
+  if (S1 > S2) range = ((float)S1 * range) / (float)S2;
+  return (float)S1 - 0.5f - (ndc + range / 2.0f) * (float)S1 / range;
+}
+__device__ __forceinline__ float r_edge(float px, float py, float ax, float ay, float bx, float by) {
+  return (px - ax) * (by - ay) - (py - ay) * (bx - ax);
+}
+// squared distance to segment ab; returns the clamped parameter in *t (deg: degenerate segment)
+__device__ __forceinline__ float r_seg(float px, float py, float ax, float ay, float bx, float by, float* t, bool* deg) {
+  const float bax = bx - ax, bay = by - ay;
+  const float l2 = bax * bax + bay * bay;
+  if (l2 <= R_KEPS) {
+    *t = 1.f;
+    *deg = true;
+    return (px - bx) * (px - bx) + (py - by) * (py - by);
+  }
+  float tt = (bax * (px - ax) + bay * (py - ay)) / l2;
+  tt = fminf(fmaxf(tt, 0.f), 1.f);
+  *t = tt;
+  *deg = false;
+  const float qx = ax + tt * bax - px, qy = ay + tt * bay - py;
+  return qx * qx + qy * qy;
+}
+
+struct Tri {
+  float x[3], y[3], z[3];     // NDC xy + view z
+  float cx[3], cy[3];         // camera-space x, y (for the projection adjoint)
+  int idx[3];
+};
+
+__device__ __forceinline__ void r_load_tri(const RasterP& p, const float* vb, int f, Tri& t) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int vi = p.faces[3 * f + k];
+    t.idx[k] = vi;
+    const float X = vb[(size_t)vi * 3], Y = vb[(size_t)vi * 3 + 1], Z = vb[(size_t)vi * 3 + 2];
+    t.cx[k] = X;
+    t.cy[k] = Y;
+    t.z[k] = Z;
+    t.x[k] = p.s * (-X) / Z + p.w1;
+    t.y[k] = p.s * (-Y) / Z + p.h1;
+  }
+}
+
+// scatter d/d(ndc x, ndc y, z) of one vertex to camera space
+__device__ __forceinline__ void r_scatter(const RasterP& p, float* gvb, const Tri& t, int k, float gxn, float gyn, float gz) {
+  const float Z = t.z[k];
+  const float gx = -p.s / Z * gxn, gy = -p.s / Z * gyn;
+  const float gzz = gz + p.s * (t.cx[k] * gxn + t.cy[k] * gyn) / (Z * Z);
+  float* o = gvb + (size_t)t.idx[k] * 3;
+  atomicAdd(o, gx);
+  atomicAdd(o + 1, gy);
+  atomicAdd(o + 2, gzz);
+}
+
+__device__ __forceinline__ float r_block_sum(float v, float* sh) {
+  v = mh_wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256, 2) void k_raster_terms(RasterP p) {
+  __shared__ unsigned long long keys[RS_CAP * 5];
+  __shared__ float sh[8];
+  __shared__ int swin[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int t = b / p.N, n = b % p.N;
+  const int H = p.H, W = p.W, P = H * W;
+  const float* vb = p.verts + (size_t)b * p.V * 3;
+  float* gvb = p.gverts ? p.gverts + (size_t)b * p.V * 3 : nullptr;
+
+  // ---- window of the body on screen -------------------------------------------------------------
+  float mnx = 1e30f, mny = 1e30f, mxx = -1e30f, mxy = -1e30f;
+  for (int v = tid; v < p.V; v += 256) {
+    const float X = vb[(size_t)v * 3], Y = vb[(size_t)v * 3 + 1], Z = vb[(size_t)v * 3 + 2];
+    if (Z > R_KEPS) {
+      const float fx = r_ndc_to_pix(p.s * (-X) / Z + p.w1, W, H), fy = r_ndc_to_pix(p.s * (-Y) / Z + p.h1, H, W);
+      mnx = fminf(mnx, fx); mxx = fmaxf(mxx, fx);
+      mny = fminf(mny, fy); mxy = fmaxf(mxy, fy);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mnx = fminf(mnx, __shfl_xor(mnx, o, 64)); mny = fminf(mny, __shfl_xor(mny, o, 64));
+    mxx = fmaxf(mxx, __shfl_xor(mxx, o, 64)); mxy = fmaxf(mxy, __shfl_xor(mxy, o, 64));
+  }
+  __shared__ float sbb[4][4];
+  if ((tid & 63) == 0) {
+    sbb[tid >> 6][0] = mnx; sbb[tid >> 6][1] = mny; sbb[tid >> 6][2] = mxx; sbb[tid >> 6][3] = mxy;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w) {
+      mnx = fminf(mnx, sbb[w][0]); mny = fminf(mny, sbb[w][1]);
+      mxx = fmaxf(mxx, sbb[w][2]); mxy = fmaxf(mxy, sbb[w][3]);
+    }
+    // clamp in float first: a body far outside the image must not overflow the int conversion
+    const float big = 1e6f;
+    mnx = fminf(fmaxf(mnx, -big), big); mxx = fminf(fmaxf(mxx, -big), big);
+    mny = fminf(fmaxf(mny, -big), big); mxy = fminf(fmaxf(mxy, -big), big);
+    swin[0] = max(0, (int)floorf(mnx) - 2);
+    swin[1] = max(0, (int)floorf(mny) - 2);
+    swin[2] = min(W - 1, (int)ceilf(mxx) + 2);
+    swin[3] = min(H - 1, (int)ceilf(mxy) + 2);
+  }
+  __syncthreads();
+  const int x0 = swin[0], y0 = swin[1], x1 = swin[2], y1 = swin[3];
+  const int ww = x1 - x0 + 1, wh = y1 - y0 + 1;
+
+  const float apply = p.sil_apply[b], Dn = p.sil_D[b], Sn = p.sil_S[b];
+  if (ww <= 0 || wh <= 0) {
+    if (tid == 0) {
+      p.depth_body[b] = 0.f;
+      p.sil_body[b] = apply * Sn / (Dn + 1.f);
+      p.dinv[(size_t)b * 2] = 0.f;
+      p.dinv[(size_t)b * 2 + 1] = 0.f;
+    }
+    return;
+  }
+  // depth range of this frame (optimizer.py:683-688) and the target disparity coefficients (:425)
+  const float min_z = logf(1.f + expf(p.zmin_lin[t]));
+  const float max_z = min_z + 1.f + logf(1.f + expf(p.zmax_lin[t]));
+  const float inv_min = 1.f / min_z, inv_max = 1.f / max_z;
+  const float dspan = inv_min - inv_max;
+  const float pvalid = p.p2d_valid[b];
+  const uint32_t fr = p.front[b];
+  const float blur_d = sqrtf(BLUR_D);
+
+  const int rows = max(1, RS_CAP / ww);
+  const int nstrips = (wh + rows - 1) / rows;
+  const int nsweeps = nstrips > 1 ? 2 : 1;
+  float sumA = 0.f, sumB = 0.f, sumC = 0.f, sumS1 = 0.f, sumS2 = 0.f, sumCorr = 0.f;   // block totals (uniform)
+
+  for (int sweep = 0; sweep < nsweeps; ++sweep) {
+    for (int strip = 0; strip < nstrips; ++strip) {
+      const int sy0 = y0 + strip * rows, sy1 = min(y1, sy0 + rows - 1);
+      const int npx = (sy1 - sy0 + 1) * ww;
+      __syncthreads();
+      for (int i = tid; i < npx * 5; i += 256) keys[i] = RS_EMPTY;
+      __syncthreads();
+      // ---- face-parallel scatter into the LDS window ---------------------------------------------
+      for (int f = tid; f < p.F; f += 256) {
+        Tri tr;
+        r_load_tri(p, vb, f, tr);
+        if (fminf(tr.z[0], fminf(tr.z[1], tr.z[2])) < R_KEPS) continue;
+        const float farea = r_edge(tr.x[0], tr.y[0], tr.x[1], tr.y[1], tr.x[2], tr.y[2]);
+        if (farea <= R_KEPS && farea >= -R_KEPS) continue;
+        const float bxmin = fminf(tr.x[0], fminf(tr.x[1], tr.x[2])) - blur_d, bxmax = fmaxf(tr.x[0], fmaxf(tr.x[1], tr.x[2])) + blur_d;
+        const float bymin = fminf(tr.y[0], fminf(tr.y[1], tr.y[2])) - blur_d, bymax = fmaxf(tr.y[0], fmaxf(tr.y[1], tr.y[2])) + blur_d;
+        // NDC decreases with the pixel index
+        const int xa = max(x0, (int)floorf(r_ndc_to_pix(bxmax, W, H)) - 1), xb = min(x1, (int)ceilf(r_ndc_to_pix(bxmin, W, H)) + 1);
+        const int ya = max(sy0, (int)floorf(r_ndc_to_pix(bymax, H, W)) - 1), yb = min(sy1, (int)ceilf(r_ndc_to_pix(bymin, H, W)) + 1);
+        const float area = r_edge(tr.x[2], tr.y[2], tr.x[0], tr.y[0], tr.x[1], tr.y[1]) + R_KEPS;
+        for (int yi = ya; yi <= yb; ++yi) {
+          const float yf = r_pix_to_ndc(H - 1 - yi, H, W);
+          if (yf > bymax || yf < bymin) continue;
+          for (int xi = xa; xi <= xb; ++xi) {
+            const float xf = r_pix_to_ndc(W - 1 - xi, W, H);
+            if (xf > bxmax || xf < bxmin) continue;
+            const float w0 = r_edge(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2]) / area;
+            const float w1 = r_edge(xf, yf, tr.x[2], tr.y[2], tr.x[0], tr.y[0]) / area;
+            const float w2 = r_edge(xf, yf, tr.x[0], tr.y[0], tr.x[1], tr.y[1]) / area;
+            const bool inside = w0 > 0.f && w1 > 0.f && w2 > 0.f;
+            const float c0 = fmaxf(w0, 0.f), c1 = fmaxf(w1, 0.f), c2 = fmaxf(w2, 0.f);
+            const float cs = fmaxf(c0 + c1 + c2, 1e-5f);
+            const float pz = (c0 / cs) * tr.z[0] + (c1 / cs) * tr.z[1] + (c2 / cs) * tr.z[2];
+            if (pz < 0.f) continue;
+            float tt;
+            bool dg;
+            const float d = fminf(fminf(r_seg(xf, yf, tr.x[0], tr.y[0], tr.x[1], tr.y[1], &tt, &dg),
+                                        r_seg(xf, yf, tr.x[0], tr.y[0], tr.x[2], tr.y[2], &tt, &dg)),
+                                  r_seg(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2], &tt, &dg));
+            if (!inside && d >= BLUR_D) continue;
+            unsigned long long key = ((unsigned long long)__float_as_uint(pz) << 32) | (unsigned)f;
+            unsigned long long* q = keys + (size_t)((yi - sy0) * ww + (xi - x0)) * 5;
+            if (key < q[0]) atomicMin(&q[0], key);
+            if (inside || d < BLUR_S) {
+#pragma unroll
+              for (int k = 1; k < 5; ++k) {
+                if (key >= q[k] && k == 4) break;           // not among the 4 nearest any more
+                const unsigned long long old = atomicMin(&q[k], key);
+                if (old == RS_EMPTY) break;                 // took a free slot
+                key = old > key ? old : key;                // the displaced (larger) key moves on
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+      // ---- pass A: residual sums (first sweep), pass B: gradients (last sweep) ---------------------
+      const bool doA = sweep == 0, doB = sweep == nsweeps - 1;
+      float lA = 0.f, lB = 0.f, lC = 0.f, lS1 = 0.f, lS2 = 0.f, lCorr = 0.f;
+      if (doA) {
+        for (int i = tid; i < npx; i += 256) {
+          const int yi = sy0 + i / ww, xi = x0 + i % ww;
+          const size_t gp = (size_t)t * P + (size_t)yi * W + xi;
+          const uint32_t wb = p.bits[gp];
+          const unsigned long long k0 = keys[(size_t)i * 5];
+          if (k0 != RS_EMPTY) {
+            const float z = __uint_as_float((unsigned)(k0 >> 32));
+            const float m = (z > 0.f ? 1.f : 0.f) * (float)((p.ebits[gp] >> n) & 1u) * pvalid;     // :432-438
+            if (m != 0.f) {
+              const float pred = 1.f / fmaxf(z + 0.2f, p.eps);                                    // :440
+              const float dh = p.depths[gp];
+              const float tg = dh * dspan + inv_max;                                              // :425
+              lA += logf(fmaxf(pred, 1e-3f));
+              lB += logf(fmaxf(tg, 1e-3f));
+              lC += 1.f;
+              if (tg >= 1e-3f) {
+                lS1 += dh / tg;
+                lS2 += (1.f - dh) / tg;
+              }
+            }
+          }
+          // soft silhouette of this pixel
+          float qprod = 1.f;
+          const float yf = r_pix_to_ndc(H - 1 - yi, H, W), xf = r_pix_to_ndc(W - 1 - xi, W, H);
+          for (int k = 1; k < 5; ++k) {
+            const unsigned long long kk = keys[(size_t)i * 5 + k];
+            if (kk == RS_EMPTY) break;
+            Tri tr;
+            r_load_tri(p, vb, (int)(kk & 0xffffffffu), tr);
+            const float area = r_edge(tr.x[2], tr.y[2], tr.x[0], tr.y[0], tr.x[1], tr.y[1]) + R_KEPS;
+            const bool inside = r_edge(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2]) / area > 0.f &&
+                                r_edge(xf, yf, tr.x[2], tr.y[2], tr.x[0], tr.y[0]) / area > 0.f &&
+                                r_edge(xf, yf, tr.x[0], tr.y[0], tr.x[1], tr.y[1]) / area > 0.f;
+            float tt;
+            bool dg;
+            const float d = fminf(fminf(r_seg(xf, yf, tr.x[0], tr.y[0], tr.x[1], tr.y[1], &tt, &dg),
+                                        r_seg(xf, yf, tr.x[0], tr.y[0], tr.x[2], tr.y[2], &tt, &dg)),
+                                  r_seg(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2], &tt, &dg));
+            const float sd = inside ? -d : d;
+            const float pk = 1.f / (1.f + expf(sd / SIGMA_S));                                   // sigmoid(-sd/sigma)
+            qprod *= 1.f - pk;
+          }
+          const float alpha = 1.f - qprod;
+          if ((wb & fr) == 0u) {                                                                  // 1 - acc
+            const float seg = (float)((wb >> n) & 1u);
+            lCorr += alpha * alpha - 2.f * alpha * seg;
+          }
+        }
+        sumA += r_block_sum(lA, sh);
+        sumB += r_block_sum(lB, sh);
+        sumC += r_block_sum(lC, sh);
+        sumS1 += r_block_sum(lS1, sh);
+        sumS2 += r_block_sum(lS2, sh);
+        sumCorr += r_block_sum(lCorr, sh);
+      }
+      if (doB && gvb) {
+        const float cnt = sumC + 1.f;
+        const float diff = sumA / cnt - sumB / cnt;                                               // losses.py:24-27
+        const float gA = p.coef_depth * 2.f * diff / cnt;
+        const float gAlphaScale = p.coef_sil * apply * 2.f / (Dn + 1.f);
+        for (int i = tid; i < npx; i += 256) {
+          const int yi = sy0 + i / ww, xi = x0 + i % ww;
+          const size_t gp = (size_t)t * P + (size_t)yi * W + xi;
+          const float yf = r_pix_to_ndc(H - 1 - yi, H, W), xf = r_pix_to_ndc(W - 1 - xi, W, H);
+          const unsigned long long k0 = keys[(size_t)i * 5];
+          if (k0 != RS_EMPTY && gA != 0.f) {
+            const float z = __uint_as_float((unsigned)(k0 >> 32));
+            const float m = (z > 0.f ? 1.f : 0.f) * (float)((p.ebits[gp] >> n) & 1u) * pvalid;
+            const float zc = z + 0.2f;
+            if (m != 0.f && zc > p.eps && 1.f / zc > 1e-3f) {
+              const float gpz = gA * (-1.f / zc);
+              Tri tr;
+              r_load_tri(p, vb, (int)(k0 & 0xffffffffu), tr);
+              const float area = r_edge(tr.x[2], tr.y[2], tr.x[0], tr.y[0], tr.x[1], tr.y[1]) + R_KEPS;
+              float w[3] = {r_edge(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2]) / area,
+                            r_edge(xf, yf, tr.x[2], tr.y[2], tr.x[0], tr.y[0]) / area,
+                            r_edge(xf, yf, tr.x[0], tr.y[0], tr.x[1], tr.y[1]) / area};
+              const float c[3] = {fmaxf(w[0], 0.f), fmaxf(w[1], 0.f), fmaxf(w[2], 0.f)};
+              const float craw = c[0] + c[1] + c[2];
+              const float cs = fmaxf(craw, 1e-5f);
+              // pz = sum (c_i/cs) z_i
+              float gwc[3], gz[3];
+              float dotg = 0.f;
+#pragma unroll
+              for (int k = 0; k < 3; ++k) {
+                gz[k] = gpz * c[k] / cs;
+                gwc[k] = gpz * tr.z[k];          // d/d(normalised clipped weight)
+                dotg += gwc[k] * c[k];
+              }
+              float gw[3];
+#pragma unroll
+              for (int k = 0; k < 3; ++k) {
+                float gc = gwc[k] / cs - (craw > 1e-5f ? dotg / (cs * cs) : 0.f);
+                gw[k] = w[k] > 0.f ? gc : 0.f;
+              }
+              // w_i = e_i / area
+              const float ge[3] = {gw[0] / area, gw[1] / area, gw[2] / area};
+              const float garea = -(gw[0] * w[0] + gw[1] * w[1] + gw[2] * w[2]) / area;
+              float gx[3] = {0, 0, 0}, gy[3] = {0, 0, 0};
+              // e0 = edge(p; v1, v2), e1 = edge(p; v2, v0), e2 = edge(p; v0, v1); area = edge(v2; v0, v1)
+#define EDGE_ADJ(gE, A, Bv)                                     \
+  gx[A] += (gE) * (yf - tr.y[Bv]);  gy[A] += (gE) * (tr.x[Bv] - xf); \
+  gx[Bv] += (gE) * (-(yf - tr.y[A])); gy[Bv] += (gE) * (xf - tr.x[A]);
+              EDGE_ADJ(ge[0], 1, 2)
+              EDGE_ADJ(ge[1], 2, 0)
+              EDGE_ADJ(ge[2], 0, 1)
+#undef EDGE_ADJ
+              // area = (x2-x0)(y1-y0) - (y2-y0)(x1-x0)
+              gx[2] += garea * (tr.y[1] - tr.y[0]);  gy[2] += garea * (-(tr.x[1] - tr.x[0]));
+              gx[0] += garea * (tr.y[2] - tr.y[1]);  gy[0] += garea * (tr.x[1] - tr.x[2]);
+              gx[1] += garea * (-(tr.y[2] - tr.y[0])); gy[1] += garea * (tr.x[2] - tr.x[0]);
+#pragma unroll
+              for (int k = 0; k < 3; ++k) r_scatter(p, gvb, tr, k, gx[k], gy[k], gz[k]);
+            }
+          }
+          // silhouette
+          const uint32_t wb = p.bits[gp];
+          if (gAlphaScale != 0.f && (wb & fr) == 0u) {
+            float pk[4], sgn[4], tpar[4];
+            int ea[4], eb[4], fidx[4];
+            bool dgn[4];
+            int ns = 0;
+            float qprod = 1.f;
+            for (int k = 1; k < 5; ++k) {
+              const unsigned long long kk = keys[(size_t)i * 5 + k];
+              if (kk == RS_EMPTY) break;
+              Tri tr;
+              r_load_tri(p, vb, (int)(kk & 0xffffffffu), tr);
+              const float area = r_edge(tr.x[2], tr.y[2], tr.x[0], tr.y[0], tr.x[1], tr.y[1]) + R_KEPS;
+              const bool inside = r_edge(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2]) / area > 0.f &&
+                                  r_edge(xf, yf, tr.x[2], tr.y[2], tr.x[0], tr.y[0]) / area > 0.f &&
+                                  r_edge(xf, yf, tr.x[0], tr.y[0], tr.x[1], tr.y[1]) / area > 0.f;
+              float t01, t02, t12;
+              bool g01, g02, g12;
+              const float d01 = r_seg(xf, yf, tr.x[0], tr.y[0], tr.x[1], tr.y[1], &t01, &g01);
+              const float d02 = r_seg(xf, yf, tr.x[0], tr.y[0], tr.x[2], tr.y[2], &t02, &g02);
+              const float d12 = r_seg(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2], &t12, &g12);
+              float d;
+              if (d01 <= d02 && d01 <= d12) { d = d01; ea[ns] = 0; eb[ns] = 1; tpar[ns] = t01; dgn[ns] = g01; }
+              else if (d02 <= d01 && d02 <= d12) { d = d02; ea[ns] = 0; eb[ns] = 2; tpar[ns] = t02; dgn[ns] = g02; }
+              else { d = d12; ea[ns] = 1; eb[ns] = 2; tpar[ns] = t12; dgn[ns] = g12; }
+              const float sd = inside ? -d : d;
+              pk[ns] = 1.f / (1.f + expf(sd / SIGMA_S));
+              sgn[ns] = inside ? -1.f : 1.f;
+              fidx[ns] = (int)(kk & 0xffffffffu);
+              qprod *= 1.f - pk[ns];
+              ++ns;
+            }
+            const float alpha = 1.f - qprod;
+            const float seg = (float)((wb >> n) & 1u);
+            const float galpha = gAlphaScale * (alpha - seg);
+            if (galpha != 0.f) {
+              for (int k = 0; k < ns; ++k) {
+                // d alpha / d sd_k = -(1/sigma) p_k prod_j (1 - p_j)
+                const float gd = galpha * (-(1.f / SIGMA_S)) * pk[k] * qprod * sgn[k];
+                if (gd == 0.f) continue;
+                Tri tr;
+                r_load_tri(p, vb, fidx[k], tr);
+                const int a = ea[k], bb = eb[k];
+                const float tt = tpar[k];
+                float qx, qy, ga, gb;
+                if (dgn[k]) { qx = tr.x[bb] - xf; qy = tr.y[bb] - yf; ga = 0.f; gb = 1.f; }
+                else {
+                  qx = tr.x[a] + tt * (tr.x[bb] - tr.x[a]) - xf;
+                  qy = tr.y[a] + tt * (tr.y[bb] - tr.y[a]) - yf;
+                  ga = 1.f - tt; gb = tt;
+                }
+                r_scatter(p, gvb, tr, a, gd * ga * 2.f * qx, gd * ga * 2.f * qy, 0.f);
+                r_scatter(p, gvb, tr, bb, gd * gb * 2.f * qx, gd * gb * 2.f * qy, 0.f);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  if (tid == 0) {
+    const float cnt = sumC + 1.f;
+    const float diff = sumA / cnt - sumB / cnt;
+    p.depth_body[b] = diff * diff;
+    p.sil_body[b] = apply * (Sn + sumCorr) / (Dn + 1.f);
+    // d/d(1/min_z), d/d(1/max_z) through the target disparity
+    const float gB = p.coef_depth * (-2.f) * diff / cnt;
+    p.dinv[(size_t)b * 2] = gB * sumS1;
+    p.dinv[(size_t)b * 2 + 1] = gB * sumS2;
+  }
+}
+
+// chain of the depth-range leaves (optimizer.py:683-688): min_z = softplus(zmin),
+// max_z = min_z.detach() + 1 + softplus(zmax)
+__global__ void k_depth_range_grads(int T, int N, const float* dinv, const float* zmin_lin, const float* zmax_lin,
+                                    float* gzmin, float* gzmax) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  float g0 = 0.f, g1 = 0.f;
+  for (int n = 0; n < N; ++n) {
+    g0 += dinv[((size_t)t * N + n) * 2];
+    g1 += dinv[((size_t)t * N + n) * 2 + 1];
+  }
+  const float e0 = expf(zmin_lin[t]), e1 = expf(zmax_lin[t]);
+  const float min_z = logf(1.f + e0);
+  const float max_z = min_z + 1.f + logf(1.f + e1);
+  gzmin[t] += g0 * (-1.f / (min_z * min_z)) * (e0 / (1.f + e0));
+  gzmax[t] += g1 * (-1.f / (max_z * max_z)) * (e1 / (1.f + e1));
+}
+
+extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const float* cam_K_host, const float* verts,
+                               const int32_t* faces, const uint32_t* bits, const uint32_t* ebits, const float* depths,
+                               const float* zmin_lin, const float* zmax_lin, const float* pose2d_valid,
+                               const uint32_t* front, const float* sil_apply, const float* sil_D, const float* sil_S,
+                               float coef_depth, float coef_sil, float eps, float* gverts, float* gzmin, float* gzmax,
+                               float* depth_body, float* sil_body, float* dinv_ws, void* stream) {
+  MH_CHECK(cam_K_host && verts && faces && bits && ebits && depths && zmin_lin && zmax_lin && pose2d_valid && front &&
+               sil_apply && sil_D && sil_S && depth_body && sil_body && dinv_ws,
+           "null argument");
+  MH_CHECK(T > 0 && N > 0 && N <= 32 && V > 0 && F > 0 && H > 0 && W > 0, "empty input");
+  MH_CHECK(W <= RS_CAP, "image wider than the LDS window capacity");
+  RasterP p;
+  p.B = T * N; p.N = N; p.V = V; p.F = F; p.H = H; p.W = W;
+  // transforms.py:222-255 with image_size = (W, H)
+  const float fx = cam_K_host[0], fy = cam_K_host[4], cx = cam_K_host[2], cy = cam_K_host[5];
+  if (W > H) {
+    p.s = 2.f * fy / H;
+    const float u = (float)W / H;
+    p.w1 = u * (W - 2.f * cx) / W;
+    p.h1 = (H - 2.f * cy) / H;
+  } else if (H > W) {
+    p.s = 2.f * fx / W;
+    const float u = (float)H / W;
+    p.w1 = (W - 2.f * cx) / W;
+    p.h1 = u * (H - 2.f * cy) / H;
+  } else {
+    p.s = 2.f * (fx + fy) / (W + H);
+    p.w1 = (W - 2.f * cx) / W;
+    p.h1 = (H - 2.f * cy) / H;
+  }
+  p.verts = verts; p.faces = faces; p.bits = bits; p.ebits = ebits; p.depths = depths;
+  p.zmin_lin = zmin_lin; p.zmax_lin = zmax_lin; p.p2d_valid = pose2d_valid; p.front = front;
+  p.sil_apply = sil_apply; p.sil_D = sil_D; p.sil_S = sil_S;
+  p.coef_depth = coef_depth; p.coef_sil = coef_sil; p.eps = eps;
+  p.gverts = gverts; p.depth_body = depth_body; p.sil_body = sil_body; p.dinv = dinv_ws;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_raster_terms, dim3(p.B), dim3(256), 0, st, p);
+  MH_LAUNCH_CHECK();
+  if (gzmin && gzmax) {
+    hipLaunchKernelGGL(k_depth_range_grads, dim3((T + 127) / 128), dim3(128), 0, st, T, N, (const float*)dinv_ws, zmin_lin,
+                       zmax_lin, gzmin, gzmax);
+    MH_LAUNCH_CHECK();
+  }
+  return MH_OK;
+}

@@ -1,0 +1,33 @@
+"""Binding of the fused rasteriser + depth / silhouette residual kernel (``mh_raster_terms``)."""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, ptr
+
+
+class RasterTerms(object):
+    """Callable handed to ``SequenceEngine.cycle``: adds the depth and silhouette terms of all
+    local frames (reference optimizer.py:425-477) to ``gverts`` / the depth-range gradients and
+    writes the two loss sums into the cycle's log row."""
+
+    def __init__(self, engine, znear=1.0, zfar=100.0):
+        e = engine
+        self.faces = torch.as_tensor(np.ascontiguousarray(np.asarray(e.m.faces).astype(np.int32))).to(e.dev)
+        self.dinv = torch.zeros(e.B * 2, dtype=torch.float32, device=e.dev)
+        self.K = np.ascontiguousarray(e.K.reshape(9))
+
+    def __call__(self, e, gverts, log, with_grads=True):
+        L = _lib.lib()
+        st = _lib.stream_ptr(e.dev)
+        g = e.grads
+        check(L.mh_raster_terms(e.T, e.N, e.V, self.faces.shape[0], e.H, e.W, self.K.ctypes.data_as(_lib.c_float_p),
+                                ptr(e.verts), ptr(self.faces), ptr(e.bits), ptr(e.ebits), ptr(e.depths),
+                                ptr(e.leaf('zmin_lin')), ptr(e.leaf('zmax_lin')), ptr(e.p2d_valid), ptr(e.front),
+                                ptr(e.sil_apply), ptr(e.sil_D), ptr(e.sil_S), float(e.c['depth']),
+                                float(e.c['silhouette']), float(e.eps), ptr(gverts) if with_grads else None,
+                                ptr(e.leaf('zmin_lin', g)) if with_grads else None,
+                                ptr(e.leaf('zmax_lin', g)) if with_grads else None, ptr(e.depth_body), ptr(e.sil_body),
+                                ptr(self.dinv), st))
+        check(L.mh_reduce_sum(ptr(e.depth_body), e.B, 1.0, ptr(log[1:2]), st))
+        check(L.mh_reduce_sum(ptr(e.sil_body), e.B, 1.0, ptr(log[2:3]), st))

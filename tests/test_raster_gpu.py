@@ -1,0 +1,141 @@
+"""GPU parity of the fused rasteriser + depth / silhouette residual kernel (mh_raster_terms)
+against the oracle (oracle/raster_oracle.py selection + torch autograd): per-body loss values,
+dL/dverts, dL/dzmin_lin, dL/dzmax_lin.  The oracle itself is pinned analytically
+(tests/test_raster_oracle.py); PyTorch3D is unavailable, so this term is "parity unpinned"
+with respect to the reference."""
+import numpy as np
+import pytest
+import torch
+
+from mhhip import synthetic
+from oracle import fit_oracle as fo
+from oracle import lbs_oracle as lo
+from oracle import raster_oracle as ro
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(T, N, W, H, seed, zlo, zhi):
+    rng = np.random.RandomState(seed)
+    sp = synthetic.make_sequence_params(N, T, seed)
+    pT = sp['trans_gt'].copy()
+    pT[..., 2] = rng.uniform(zlo, zhi, (T, N))
+    pT[..., 0] = rng.uniform(-0.25, 0.25, (T, N)) * pT[..., 2]
+    pT[..., 1] = rng.uniform(-0.05, 0.1, (T, N))
+    return sp, pT.astype(np.float32), rng
+
+
+def _run_case(smpl_struct, smpl_regs, T, N, W, H, seed, zlo=3.0, zhi=6.0):
+    from mhhip import engine
+    from mhhip.sequence import SequenceEngine
+    from mhhip.raster import RasterTerms
+    K = synthetic.default_cam_K((W, H), 60.0)
+    sp, pT, rng = _scene(T, N, W, H, seed, zlo, zhi)
+    model = engine.BodyModel(smpl_struct, smpl_regs)
+    omodel = lo.BodyModel(smpl_struct, smpl_regs)
+    faces = np.asarray(smpl_struct.f).astype(np.int64)
+    betas = sp['betas_gt']
+    coefs = dict(depth=0.05, silhouette=0.1)
+    e = SequenceEngine(model, (W, H), T, N, K, None, coefs, batch_size=2)
+    zmin = rng.uniform(0.5, 1.5, T).astype(np.float32)
+    zmax = rng.uniform(4.0, 9.0, T).astype(np.float32)
+    e.set_leaves(pT, sp['poses_gt'], betas, zmin, zmax, rng.normal(0, 0.5, N).astype(np.float32))
+    # masks: silhouette of a slightly different pose, so that alpha - seg is non-trivial
+    with torch.no_grad():
+        be = torch.tensor(betas)[None].expand(T, N, 10).reshape(-1, 10)
+        out = lo.smpl_forward(omodel, be, torch.tensor(sp['poses_init']).view(-1, 72))
+        s = torch.pow(torch.tensor(1.1), e.leaf('xscale').cpu())[None, :, None, None]
+        v0 = s * out['verts'].view(T, N, -1, 3) + torch.tensor(pT).view(T, N, 1, 3) + torch.tensor([0.03, -0.02, 0.0])
+        _, a0 = ro.render(v0.view(T * N, -1, 3), faces, K, (W, H))
+    seg = (a0.view(T, N, H, W) > 0.5).float().numpy()
+    seg[0, 0] = 0                                                  # an empty mask
+    depths = rng.uniform(0, 1, (T, H, W)).astype(np.float32)
+    pose2d = np.zeros((T, N, 17, 3), np.float32)
+    pose2d[..., 2] = 0.9
+    if T > 1:
+        pose2d[1, N - 1, :, 2] = 0.1                               # a body without a valid 2D pose
+    e.stage(pose2d, sp['poses_init'], sp['valid'], betas, seg, depths)
+    e.forward()
+    L = __import__('mhhip._lib', fromlist=['lib']).lib()
+    from mhhip._lib import ptr, check, stream_ptr
+    check(L.mh_sil_mask_stats(ptr(e.bits), T, N, H, W, ptr(e.leaf('poses_T')), ptr(e.p2d_valid), ptr(e.mask_valid),
+                              ptr(e.front), ptr(e.sil_apply), ptr(e.sil_D), ptr(e.sil_S), stream_ptr(e.dev)))
+    gv = torch.zeros_like(e.verts)
+    e.grads.zero_()
+    log = torch.zeros(16, device=e.dev)
+    RasterTerms(e)(e, gv, log)
+    torch.cuda.synchronize()
+
+    # ---- oracle -----------------------------------------------------------------------------------
+    verts = e.verts.cpu().clone().requires_grad_(True)
+    tzmin = torch.tensor(zmin, requires_grad=True)
+    tzmax = torch.tensor(zmax, requires_grad=True)
+    zbuf, alpha = ro.render(verts, faces, K, (W, H))
+    zbuf, alpha = zbuf.view(T, N, H, W), alpha.view(T, N, H, W)
+    tseg = torch.tensor(seg)
+    conf = (torch.tensor(pose2d[..., 2:3]) >= 0.5).float()
+    p2d_valid = (conf.sum(dim=(2, 3)) >= 2).float()
+    mask_valid = (tseg.sum(dim=(2, 3)) >= 0.005 * H * W).float()
+    min_z = fo.softplus(tzmin).view(T, 1, 1)
+    max_z = min_z.detach() + 1.0 + fo.softplus(tzmax).view(T, 1, 1)
+    tgt = torch.tensor(depths) * (1.0 / min_z - 1.0 / max_z) + 1.0 / max_z
+    m = (zbuf > 0).float() * fo.erode3x3(fo.erode3x3(tseg)) * p2d_valid[..., None, None]
+    pred = 1.0 / torch.clamp(zbuf + 0.2, min=1e-3)
+    lp = m * torch.log(torch.clamp(pred, min=1e-3))
+    lt = m * torch.log(torch.clamp(tgt.unsqueeze(1), min=1e-3))
+    cnt = m.sum(dim=(2, 3)) + 1
+    depth_tn = (lp.sum(dim=(2, 3)) / cnt - lt.sum(dim=(2, 3)) / cnt) ** 2
+    order = torch.argsort(torch.tensor(pT)[..., 2], dim=1)
+    sil_tn = torch.zeros(T, N)
+    sil_list = []
+    for t in range(T):
+        acc = torch.zeros(H, W)
+        for r in range(N):
+            n = int(order[t, r])
+            if float(mask_valid[t, r] * p2d_valid[t, r]) > 0:
+                sil_list.append((t, n, fo.masked_mse_loss(alpha[t, n], tseg[t, n], 1 - acc)))
+            acc = ((acc + tseg[t, n]) > 0).float()
+    total = coefs['depth'] * depth_tn.sum() + coefs['silhouette'] * sum(x[2] for x in sil_list)
+    total.backward()
+    want_sil = np.zeros((T, N), np.float32)
+    for t, n, v in sil_list:
+        want_sil[t, n] = float(v)
+    return dict(e=e, gv=gv.cpu().numpy(), want_gv=verts.grad.numpy(), depth=e.depth_body.cpu().numpy().reshape(T, N),
+                want_depth=depth_tn.detach().numpy(), sil=e.sil_body.cpu().numpy().reshape(T, N), want_sil=want_sil,
+                gzmin=e.leaf('zmin_lin', e.grads).cpu().numpy(), gzmax=e.leaf('zmax_lin', e.grads).cpu().numpy(),
+                want_gzmin=tzmin.grad.numpy(), want_gzmax=tzmax.grad.numpy(), log=log.cpu().numpy(),
+                zbuf=zbuf.detach().numpy())
+
+
+def _check(r):
+    assert (r['zbuf'] > 0).sum() > 50, 'test scene does not cover any pixels'
+    np.testing.assert_allclose(r['depth'], r['want_depth'], rtol=2e-3, atol=1e-6)
+    np.testing.assert_allclose(r['sil'], r['want_sil'], rtol=2e-3, atol=1e-6)
+    np.testing.assert_allclose(r['log'][1], r['want_depth'].sum(), rtol=2e-3, atol=1e-6)
+    np.testing.assert_allclose(r['log'][2], r['want_sil'].sum(), rtol=2e-3, atol=1e-6)
+    np.testing.assert_allclose(r['gzmin'], r['want_gzmin'], atol=2e-3 * max(np.abs(r['want_gzmin']).max(), 1e-8))
+    np.testing.assert_allclose(r['gzmax'], r['want_gzmax'], atol=2e-3 * max(np.abs(r['want_gzmax']).max(), 1e-8))
+    g, w = r['gv'], r['want_gv']
+    scale = np.abs(w).max()
+    assert scale > 0
+    err = np.abs(g - w)
+    # float atomics + the rare pixel whose blur-band test flips in the last ulp: demand a tight match on
+    # all but a handful of vertices, and a tight match in aggregate
+    assert (err > 2e-3 * scale).sum() <= 6, (err > 2e-3 * scale).sum()
+    assert np.abs(g.sum(axis=1) - w.sum(axis=1)).max() < 5e-3 * np.abs(w).sum(axis=1).max()
+
+
+def test_raster_terms_small(smpl_struct, smpl_regs):
+    _check(_run_case(smpl_struct, smpl_regs, T=3, N=2, W=60, H=34, seed=5))
+
+
+def test_raster_terms_portrait_and_square(smpl_struct, smpl_regs):
+    _check(_run_case(smpl_struct, smpl_regs, T=2, N=2, W=34, H=60, seed=6))
+    _check(_run_case(smpl_struct, smpl_regs, T=2, N=2, W=40, H=40, seed=7))
+
+
+def test_raster_terms_strips(smpl_struct, smpl_regs):
+    """bodies close to the camera: the screen window exceeds the LDS capacity -> row strips, two sweeps"""
+    r = _run_case(smpl_struct, smpl_regs, T=1, N=2, W=160, H=96, seed=8, zlo=1.6, zhi=2.0)
+    assert (r['zbuf'] > 0).sum() > 1920
+    _check(r)

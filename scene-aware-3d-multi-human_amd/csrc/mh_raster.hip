@@ -43,6 +43,8 @@ struct RasterP {
   float* depth_body;
   float* sil_body;
   float* dinv;               // (B,2)
+  float* zbuf_out;           // (B,H,W) or null: nearest-face depth image (caller pre-fills with -1)
+  float* alpha_out;          // (B,H,W) or null: soft silhouette image (caller pre-fills with 0)
 };
 
 __device__ __forceinline__ float r_pix_to_ndc(int i, int S1, int S2) {
@@ -295,6 +297,8 @@ __global__ __launch_bounds__(256, 2) void k_raster_terms(RasterP p) {
             const float seg = (float)((wb >> n) & 1u);
             lCorr += alpha * alpha - 2.f * alpha * seg;
           }
+          if (p.zbuf_out && k0 != RS_EMPTY) p.zbuf_out[(size_t)b * P + (size_t)yi * W + xi] = __uint_as_float((unsigned)(k0 >> 32));
+          if (p.alpha_out) p.alpha_out[(size_t)b * P + (size_t)yi * W + xi] = alpha;
         }
         sumA += r_block_sum(lA, sh);
         sumB += r_block_sum(lB, sh);
@@ -454,12 +458,17 @@ __global__ void k_depth_range_grads(int T, int N, const float* dinv, const float
   gzmax[t] += g1 * (-1.f / (max_z * max_z)) * (e1 / (1.f + e1));
 }
 
+__global__ void k_fill(float* x, size_t n, float v) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] = v;
+}
+
 extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const float* cam_K_host, const float* verts,
                                const int32_t* faces, const uint32_t* bits, const uint32_t* ebits, const float* depths,
                                const float* zmin_lin, const float* zmax_lin, const float* pose2d_valid,
                                const uint32_t* front, const float* sil_apply, const float* sil_D, const float* sil_S,
                                float coef_depth, float coef_sil, float eps, float* gverts, float* gzmin, float* gzmax,
-                               float* depth_body, float* sil_body, float* dinv_ws, void* stream) {
+                               float* depth_body, float* sil_body, float* dinv_ws, float* zbuf_out, float* alpha_out,
+                               void* stream) {
   MH_CHECK(cam_K_host && verts && faces && bits && ebits && depths && zmin_lin && zmax_lin && pose2d_valid && front &&
                sil_apply && sil_D && sil_S && depth_body && sil_body && dinv_ws,
            "null argument");
@@ -489,7 +498,13 @@ extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const f
   p.sil_apply = sil_apply; p.sil_D = sil_D; p.sil_S = sil_S;
   p.coef_depth = coef_depth; p.coef_sil = coef_sil; p.eps = eps;
   p.gverts = gverts; p.depth_body = depth_body; p.sil_body = sil_body; p.dinv = dinv_ws;
+  p.zbuf_out = zbuf_out; p.alpha_out = alpha_out;
   hipStream_t st = (hipStream_t)stream;
+  if (zbuf_out) {   // -1 = empty, like fragments.zbuf
+    hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, st, zbuf_out, (size_t)p.B * H * W, -1.f);
+    MH_LAUNCH_CHECK();
+  }
+  if (alpha_out) MH_HIP(hipMemsetAsync(alpha_out, 0, (size_t)p.B * H * W * sizeof(float), st));
   hipLaunchKernelGGL(k_raster_terms, dim3(p.B), dim3(256), 0, st, p);
   MH_LAUNCH_CHECK();
   if (gzmin && gzmax) {

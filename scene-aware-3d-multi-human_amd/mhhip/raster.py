@@ -17,7 +17,7 @@ class RasterTerms(object):
         self.dinv = torch.zeros(e.B * 2, dtype=torch.float32, device=e.dev)
         self.K = np.ascontiguousarray(e.K.reshape(9))
 
-    def __call__(self, e, gverts, log, with_grads=True):
+    def __call__(self, e, gverts, log, with_grads=True, zbuf_out=None, alpha_out=None):
         L = _lib.lib()
         st = _lib.stream_ptr(e.dev)
         g = e.grads
@@ -28,6 +28,25 @@ class RasterTerms(object):
                                 float(e.c['silhouette']), float(e.eps), ptr(gverts) if with_grads else None,
                                 ptr(e.leaf('zmin_lin', g)) if with_grads else None,
                                 ptr(e.leaf('zmax_lin', g)) if with_grads else None, ptr(e.depth_body), ptr(e.sil_body),
-                                ptr(self.dinv), st))
+                                ptr(self.dinv), ptr(zbuf_out), ptr(alpha_out), st))
         check(L.mh_reduce_sum(ptr(e.depth_body), e.B, 1.0, ptr(log[1:2]), st))
         check(L.mh_reduce_sum(ptr(e.sil_body), e.B, 1.0, ptr(log[2:3]), st))
+
+
+def render(model, verts, cam_K, image_size):
+    """Nearest-face depth (-1 = empty) and soft-silhouette images of B bodies: (B,H,W) each.
+    Inspection / synthetic-data helper on top of ``mh_raster_terms`` (losses disabled)."""
+    W, H = int(image_size[0]), int(image_size[1])
+    B, V = verts.shape[0], verts.shape[1]
+    dev = verts.device
+    faces = torch.as_tensor(np.ascontiguousarray(np.asarray(model.faces).astype(np.int32))).to(dev)
+    zi = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
+    zf = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+    bits, depths, tz, ones = zi(B, H, W), zf(B, H, W), zf(B), torch.ones(B, device=dev)
+    zbuf, alpha = torch.empty(B, H, W, device=dev), torch.empty(B, H, W, device=dev)
+    K = np.ascontiguousarray(np.asarray(cam_K, np.float32).reshape(9))
+    check(_lib.lib().mh_raster_terms(B, 1, V, faces.shape[0], H, W, K.ctypes.data_as(_lib.c_float_p), ptr(verts.contiguous()),
+                                     ptr(faces), ptr(bits), ptr(bits), ptr(depths), ptr(tz), ptr(tz), ptr(ones), ptr(zi(B)),
+                                     ptr(tz), ptr(ones), ptr(tz), 0.0, 0.0, 1e-3, None, None, None, ptr(zf(B)), ptr(zf(B)),
+                                     ptr(zf(2 * B)), ptr(zbuf), ptr(alpha), _lib.stream_ptr(dev)))
+    return zbuf, alpha

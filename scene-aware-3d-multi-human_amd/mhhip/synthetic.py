@@ -181,7 +181,7 @@ def _rodrigues_np(r):
     return np.eye(3) + math.sin(a) * K + (1 - math.cos(a)) * (K @ K)
 
 
-def make_sequence_params(num_people, num_frames, seed):
+def make_sequence_params(num_people, num_frames, seed, z_range=(3.0, 8.0)):
     """Ground-truth and ROMP-like initial parameters for an N x T sequence."""
     rng = np.random.RandomState(seed)
     N, T = num_people, num_frames
@@ -197,13 +197,13 @@ def make_sequence_params(num_people, num_frames, seed):
     pos = np.zeros((T, N, 3))
     pos[0, :, 0] = rng.uniform(-2, 2, N)
     pos[0, :, 1] = rng.uniform(0.15, 0.25, N)
-    pos[0, :, 2] = rng.uniform(3, 8, N)
+    pos[0, :, 2] = rng.uniform(z_range[0], z_range[1], N)
     vel = rng.uniform(-0.03, 0.03, (N, 3)) * np.array([1, 0.0, 1])
     for t in range(1, T):
         vel = np.clip(vel + rng.normal(0, 0.004, (N, 3)) * np.array([1, 0.0, 1]), -0.05, 0.05)
         pos[t] = pos[t - 1] + vel
         pos[t, :, 0] = np.clip(pos[t, :, 0], -2.5, 2.5)
-        pos[t, :, 2] = np.clip(pos[t, :, 2], 2.8, 8.5)
+        pos[t, :, 2] = np.clip(pos[t, :, 2], z_range[0] - 0.2, z_range[1] + 0.5)
     poses_init = theta + rng.normal(0, 0.05, theta.shape)
     poses_init[..., 66:] = 0.0
     betas_init = betas_gt[None] + rng.normal(0, 0.3, (T, N, NUM_BETAS))

@@ -1,0 +1,247 @@
+#!/usr/bin/env python
+"""Headline benchmark: optimizer iterations/sec of the scene-constrained SMPL optimisation loop
+(one iteration = one ``fit`` cycle: all frames' residuals with the full nine-term loss stack,
+hand-written backward, one RMSprop step; reference optimizer.py:375-587) on the MuPoTs-shaped
+configuration BASELINE.json quotes the target on: 4 humans x 200 frames at 240x135, batch 10.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: frames are sharded over the ranks (weak scaling: every rank owns 200 frames of a
+4 x 200*N sequence); one RCCL all-reduce on the shared shape/scale gradients per iteration plus
+the one-frame halos (mhhip/sharded.py).  ``value`` counts iterations/sec in units of the 4x200
+configuration (iterations/sec x frames/200), i.e. at N=1 it is plain iterations/sec.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'scene-aware-3d-multi-human_amd'))
+sys.path.insert(0, ROOT)
+
+COEFS = dict(proj2d=1.0, depth=0.05, silhouette=0.1, reg_poses=0.002, reg_scales=1e-4, reg_velocity=0.05,
+             reg_verts_filter=0.002, reg_contact=0.001, reg_foot_sliding=0.01)   # configs/predict_mupots.yml:17-25
+N_PEOPLE, T_LOCAL, IMG, BATCH = 4, 200, (240, 135), 10
+# algorithmic bytes / flops of the LBS+projection kernels per human.frame.iteration (fwd+bwd)
+LBS_BYTES_PER_BODY = 167028.0
+LBS_FLOPS_PER_BODY = 38.0e6
+LBS_CONST_BYTES = 19.35e6          # model constants, once per launch
+PEAK_HBM_GBS = 8000.0
+PEAK_F32_MFMA_TFLOPS = 157.3
+
+
+def build_optimizer(struct, regs, tmp, num_frames, device, K):
+    from mhmocap.optimizer import SMPLDepthSequenceOptimizer
+    for k, fn in [('extra9', 'J_regressor_extra.npy'), ('h36m', 'J_regressor_h36m.npy'),
+                  ('alphapose', 'SMPL_AlphaPose_Regressor_RMSprop_6.npy')]:
+        np.save(os.path.join(tmp, fn), regs[k])
+    c = COEFS
+    return SMPLDepthSequenceOptimizer(
+        image_size=IMG, num_frames=num_frames, cam_K=K, device=device, smpl_model_parameters_path=tmp,
+        smpl_data_struct=struct, scene_update='none', proj2d_loss_coef=c['proj2d'], depth_loss_coef=c['depth'],
+        silhouette_loss_coef=c['silhouette'], reg_velocity_coef=c['reg_velocity'],
+        reg_verts_filter_coef=c['reg_verts_filter'], reg_poses_coef=c['reg_poses'], reg_scales_coef=c['reg_scales'],
+        reg_contact_coef=c['reg_contact'], reg_foot_sliding_coef=c['reg_foot_sliding'])
+
+
+def ground_scene(K, W, H):
+    ys = (np.arange(H, dtype=np.float32) + 0.5 - K[1, 2]) / K[1, 1]
+    d = np.minimum(np.where(ys[:, None] > 1e-3, 1.15 / np.maximum(ys[:, None], 1e-3), 10.0), 10.0)
+    return np.tile(d, (1, W)).astype(np.float32)
+
+
+def cpu_baseline(struct, regs, K, seq, pT0, frames, cycles):
+    """The oracle (CPU restatement, torch-CPU + C face selection) on a bounded sample of the same
+    workload: `frames` frames x 4 humans at 240x135, full loss stack, `cycles` cycles."""
+    from oracle import fit_oracle as fo, lbs_oracle as lo, raster_oracle as ro
+    W, H = IMG
+    model = lo.BodyModel(struct, regs)
+    faces = np.asarray(struct.f).astype(np.int64)
+    o = fo.SequenceOracle(model, IMG, frames, K, coefs=COEFS, rasteriser=ro.make_rasteriser(faces, K, IMG))
+    o.xscale = torch.zeros(1, N_PEOPLE, 1, 1)
+    sl = slice(0, frames)
+    o.init_optimized_variables(seq['pose2d'][sl], seq['poses_smpl'][sl], seq['betas_smpl'][sl], seq['valid_smpl'][sl],
+                               poses_T=pT0[sl])
+    o.update_scene_pointcloud(ground_scene(K, W, H), seq['backmasks'][sl].min(axis=0) > 0)
+    batches = []
+    for s in range(0, frames, BATCH):
+        b = slice(s, min(frames, s + BATCH))
+        batches.append(dict(idxs=torch.arange(b.start, b.stop), pose2d=torch.tensor(seq['pose2d'][b]),
+                            seg_mask=torch.tensor(seq['seg_mask'][b]), depths=torch.tensor(seq['depths'][b]),
+                            poses_smpl=torch.tensor(seq['poses_smpl'][b])))
+    o.cycle_grads(batches)                      # untimed first touch
+    t0 = time.perf_counter()
+    o.fit(batches, cycles)
+    dt = time.perf_counter() - t0
+    return o, dt / cycles
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-frames', type=int, default=10)
+    ap.add_argument('--cpu-cycles', type=int, default=2)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    device = 'cuda:%d' % local_rank
+    torch.cuda.set_device(local_rank)
+
+    import tempfile
+    from mhhip import build as mhbuild, synthetic, synthetic_seq, sharded
+    from mhhip.raster import RasterTerms
+    if rank == 0:
+        mhbuild.build()
+    if world > 1:
+        dist.barrier()
+    struct = synthetic.make_smpl_struct(1)
+    regs = synthetic.make_extra_regressors(1, struct)
+    K = synthetic.default_cam_K(IMG, 60.0)
+    tmp = tempfile.mkdtemp()
+    opt = build_optimizer(struct, regs, tmp, T_LOCAL, device, K)
+    model = opt.SMPLPY.body_model
+    seq = synthetic_seq.make_sequence(model, N_PEOPLE, T_LOCAL, IMG, 1003 + rank, cam_K=K)
+    opt.init_optimized_variables(seq['pose2d'], seq['poses_smpl'], seq['betas_smpl'], seq['valid_smpl'], num_iter=100)
+    pT0 = opt.poses_T.cpu().numpy().copy()
+    dl = torch.utils.data.DataLoader(synthetic_seq.SequenceDataset(seq), batch_size=BATCH, shuffle=False)
+    opt._stage_from_dataloader(dl)
+    W, H = IMG
+    opt.scene_depth = ground_scene(K, W, H)
+    opt.update_scene_pointcloud(opt.scene_depth, seq['backmasks'].min(axis=0) > 0)     # contact term live
+    e = opt.engine
+    sh = sharded.ShardedSequence(e, rank * T_LOCAL, world * T_LOCAL)
+    raster = RasterTerms(e)
+    sh.update_filters()                                                                # filtered-vertex term live
+    lr = 0.01
+
+    def one_cycle(c):
+        nonlocal lr
+        if c % 25 == 0 and c > 0:
+            sh.update_filters()
+        sh.cycle(c % e.log.shape[0], raster=raster)
+        sh.step(lr)
+        lr *= 0.99
+
+    for c in range(args.warmup):
+        one_cycle(c)
+    e.enable_timing(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for c in range(args.steps):
+        one_cycle(args.warmup + c)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kern = e.timing_summary()
+    e.enable_timing(False)
+    log = sh.read_log(1)
+
+    if rank == 0:
+        ms = 1e3 * dt / args.steps
+        its = args.steps / dt
+        bodies = N_PEOPLE * T_LOCAL
+        lbs_ms = kern.get('lbs_forward', 0.0) + kern.get('lbs_backward', 0.0)
+        dom = max(kern, key=kern.get) if kern else None
+        lbs_bytes = LBS_BYTES_PER_BODY * bodies + 2 * LBS_CONST_BYTES
+        lbs_flops = LBS_FLOPS_PER_BODY * bodies
+        roof = None
+        if lbs_ms > 0:
+            tf = lbs_flops / (lbs_ms * 1e-3) / 1e12
+            roof = {'kernel': 'LBS+projection (k_pose_fwd,k_skin_fwd,k_skin_bwd,k_pose_bwd)', 'bound': 'mfma',
+                    'achieved': round(tf, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(tf / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                    'launch_ms': round(lbs_ms, 4), 'algorithmic_bytes': lbs_bytes, 'algorithmic_flops': lbs_flops,
+                    'hbm_achieved_GBs': round(lbs_bytes / (lbs_ms * 1e-3) / 1e9, 1),
+                    'hbm_frac': round(lbs_bytes / (lbs_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                    'dominant_group': dom}
+        out = {
+            'metric': 'optimizer iterations/sec (N humans x T frames)', 'value': round(its * world, 3),
+            'unit': 'iterations/s (4 humans x 200 frames per iteration unit)', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'MuPoTs TS13-shape 4 humans x %d frames, 240x135, batch 10, full nine-term loss stack '
+                                   '(2D joints, raster depth, soft silhouette, contact, foot sliding, priors, velocity, '
+                                   'filtered vertices) + RMSprop; scene injected (ground plane), one-euro filters live'
+                                   % (T_LOCAL * world),
+                       'humans': N_PEOPLE, 'frames': T_LOCAL * world, 'frames_per_gpu': T_LOCAL, 'image': list(IMG),
+                       'parallelism': 'frames sharded x%d, RCCL all-reduce on betas/scale grads' % world},
+            'roofline': roof, 'kernel_ms': {k: round(v, 4) for k, v in kern.items()},
+            'loss_first_cycle': {k: float(v) for k, v in log[0].items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            ncores = os.cpu_count() or 1
+            ncores = min(ncores, 16)
+            torch.set_num_threads(ncores)
+            o, cpu_s = cpu_baseline(struct, regs, K, seq, pT0, args.cpu_frames, args.cpu_cycles)
+            cpu_its = 1.0 / (cpu_s * (T_LOCAL / float(args.cpu_frames)))
+            out['cpu_baseline'] = {
+                'value': round(cpu_its, 6), 'unit': 'iterations/s (4 humans x 200 frames per iteration unit)',
+                'cores': ncores, 'kind': 'port',
+                'sample': '%d cycles of the CPU oracle (torch-CPU LBS/losses + C face selection) on the first %d of the '
+                          '200 frames (x4 humans, 240x135, same nine-term stack); per-cycle time scaled by 200/%d'
+                          % (args.cpu_cycles, args.cpu_frames, args.cpu_frames),
+                'sec_per_cycle_sample': round(cpu_s, 3)}
+            out['speedup_vs_cpu_port'] = round(its / cpu_its, 1)
+            # MPJPE (mm) between the GPU path and the CPU oracle after the same cycles on the sample
+            from oracle import lbs_oracle as lo
+            opt2 = build_optimizer(struct, regs, tmp, args.cpu_frames, device, K)
+            sl = slice(0, args.cpu_frames)
+            opt2.init_optimized_variables(seq['pose2d'][sl], seq['poses_smpl'][sl], seq['betas_smpl'][sl],
+                                          seq['valid_smpl'][sl], num_iter=0)
+            opt2.engine.leaf('poses_T').copy_(torch.tensor(pT0[sl]).view(args.cpu_frames, N_PEOPLE, 3))
+            mz = np.clip(np.max(pT0[sl][..., 0, 2], axis=1), 2, None)
+            opt2.engine.leaf('zmax_lin').copy_(torch.tensor(2.0 * mz))
+            sub = {k: v[sl] for k, v in seq.items() if isinstance(v, np.ndarray) and v.shape[:1] == (T_LOCAL,)}
+            dl2 = torch.utils.data.DataLoader(synthetic_seq.SequenceDataset(sub), batch_size=BATCH, shuffle=False)
+            opt2.scene_depth = ground_scene(K, W, H)
+            opt2.update_scene_pointcloud(opt2.scene_depth, seq['backmasks'][sl].min(axis=0) > 0)
+            opt2.fit(dl2, num_iter=args.cpu_cycles)
+            ov, wv = opt2.get_optimized_variables(), o.optimized_variables()
+            om = lo.BodyModel(struct, regs)
+
+            def joints(v):
+                B = args.cpu_frames * N_PEOPLE
+                be = torch.tensor(v['betas_smpl']).expand(args.cpu_frames, N_PEOPLE, 10).reshape(B, 10)
+                j = lo.smpl_forward(om, be, torch.tensor(v['poses_smpl']).view(B, 72))['joints_alphapose']
+                s = torch.tensor(v['scale_factor']).view(1, N_PEOPLE, 1, 1)
+                return s * j.view(args.cpu_frames, N_PEOPLE, 17, 3) + torch.tensor(v['poses_T'])
+            with torch.no_grad():
+                d = (joints(ov) - joints(wv)).norm(dim=-1).mean()
+            out['mpjpe_mm_vs_cpu_oracle'] = round(float(d) * 1000.0, 4)
+            out['mpjpe_note'] = '17 key-points, %d frames x 4 humans, after %d identical cycles from identical inputs' % (
+                args.cpu_frames, args.cpu_cycles)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -143,6 +143,16 @@ int mh_adam_step(float* params, const float* grads, float* exp_avg, float* exp_a
 int mh_one_euro_scan(const float* x, float* y, int T, size_t E, float min_cutoff, float beta,
                      float frame_rate, void* stream);
 
+/* frame-sharded form: this rank holds frames [first_frame, first_frame+T) of the sequence.
+ * time_before = the float32 running time stamp after frame first_frame-1 (host-computable),
+ * xprev_in / dxprev_in (E) = filtered value and filtered derivative of frame first_frame-1 from
+ * the previous rank (NULL on the first rank); dxprev_out (E) = state handed to the next rank
+ * (its xprev is y[T-1]).                                                                      */
+int mh_one_euro_scan_shard(const float* x, float* y, int T, size_t E, float min_cutoff, float beta,
+                           float frame_rate, int first_frame, float time_before,
+                           const float* xprev_in, const float* dxprev_in, float* dxprev_out,
+                           void* stream);
+
 /* ---- a18: temporal terms (optimizer.py:560-575) ---------------------------------------------
  * velocity: loss = sum_t ||pT[t]-pT[t-1]||^2 over t=1..T-1; gpT += coef * d loss.
  * prev_halo / next_halo (N,3): poses_T of the frame before the first / after the last local

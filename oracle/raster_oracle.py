@@ -86,21 +86,21 @@ def _seg_d2(px, py, ax, ay, bx, by):
 
 def fragments(verts_ndc, faces, pix_to_face, H, W):
     """Differentiable per-(pixel, k) z (clipped barycentric interpolation) and signed squared
-    distance for the selected faces.  verts_ndc (B,V,3) torch, pix_to_face (B,H,W,K)."""
-    B = verts_ndc.shape[0]
+    distance for the selected faces.  verts_ndc (B,V,3) torch, pix_to_face (B,H,W,K).
+    Only the occupied (pixel, k) entries are evaluated (a body covers a few percent of the image)."""
     xs, ys = pixel_centres_ndc(H, W)
-    px = torch.tensor(xs, dtype=verts_ndc.dtype).view(1, 1, W, 1)
-    py = torch.tensor(ys, dtype=verts_ndc.dtype).view(1, H, 1, 1)
     p2f = torch.as_tensor(pix_to_face)
     valid = p2f >= 0
-    fidx = torch.clamp(p2f, min=0)
+    bi, yi, xi, ki = torch.nonzero(valid, as_tuple=True)
+    dt = verts_ndc.dtype
+    px = torch.tensor(xs, dtype=dt)[xi]
+    py = torch.tensor(ys, dtype=dt)[yi]
     ft = torch.as_tensor(np.asarray(faces, np.int64))
-    tri = ft[fidx]                                               # (B,H,W,K,3)
-    bi = torch.arange(B).view(B, 1, 1, 1, 1).expand_as(tri)
-    v = verts_ndc[bi, tri]                                       # (B,H,W,K,3,3)
-    x0, y0, z0 = v[..., 0, 0], v[..., 0, 1], v[..., 0, 2]
-    x1, y1, z1 = v[..., 1, 0], v[..., 1, 1], v[..., 1, 2]
-    x2, y2, z2 = v[..., 2, 0], v[..., 2, 1], v[..., 2, 2]
+    tri = ft[p2f[bi, yi, xi, ki]]                                # (M,3)
+    v = verts_ndc[bi[:, None], tri]                              # (M,3,3)
+    x0, y0, z0 = v[:, 0, 0], v[:, 0, 1], v[:, 0, 2]
+    x1, y1, z1 = v[:, 1, 0], v[:, 1, 1], v[:, 1, 2]
+    x2, y2, z2 = v[:, 2, 0], v[:, 2, 1], v[:, 2, 2]
     area = _edge(x2, y2, x0, y0, x1, y1) + K_EPS
     w0 = _edge(px, py, x1, y1, x2, y2) / area
     w1 = _edge(px, py, x2, y2, x0, y0) / area
@@ -115,8 +115,10 @@ def fragments(verts_ndc, faces, pix_to_face, H, W):
     pick02 = (~pick01) & (d02 <= d01) & (d02 <= d12)
     dist = torch.where(pick01, d01, torch.where(pick02, d02, d12))
     sdist = torch.where(inside, -dist, dist)
-    neg = torch.full_like(pz, -1.0)
-    return torch.where(valid, pz, neg), torch.where(valid, sdist, neg), valid
+    shape = tuple(p2f.shape)
+    zout = torch.full(shape, -1.0, dtype=dt).index_put((bi, yi, xi, ki), pz)
+    dout = torch.full(shape, -1.0, dtype=dt).index_put((bi, yi, xi, ki), sdist)
+    return zout, dout, valid
 
 
 def render(verts, faces, cam_K, image_size, znear=1.0, zfar=100.0, sigma=1e-4):

@@ -190,14 +190,28 @@ extern "C" int mh_adam_step(float* params, const float* grads, float* exp_avg, f
 // =============================================================================================
 // a19: one-euro filter, sequential in t, parallel over channels
 // =============================================================================================
-__global__ void k_one_euro(const float* x, float* y, int T, size_t E, float min_cutoff, float beta, float frame_rate) {
+__global__ void k_one_euro(const float* x, float* y, int T, size_t E, float min_cutoff, float beta, float frame_rate,
+                           int i0, float t0, const float* xprev_in, const float* dxprev_in, float* dxprev_out) {
   const float two_pi = 6.283185307179586f;
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < E; e += (size_t)gridDim.x * blockDim.x) {
-    float xp = x[e], dxp = 0.f, tp = 0.f, ti = 0.f;
-    y[e] = xp;
-    for (int i = 1; i < T; ++i) {
+    float xp, dxp, tp, ti;
+    int first;
+    if (xprev_in) {            // continuing a sequence whose frames [0, i0) live on another rank
+      xp = xprev_in[e];
+      dxp = dxprev_in[e];
+      tp = ti = t0;
+      first = 0;
+    } else {
+      xp = x[e];
+      dxp = 0.f;
+      tp = ti = 0.f;
+      y[e] = xp;
+      first = 1;
+    }
+    for (int k = first; k < T; ++k) {
+      const int i = i0 + k;                                   // global frame index
       ti = __fadd_rn(ti, (float)((double)i / (double)frame_rate));     // optimizer.py:671 (float32 running sum)
-      const float xi = x[(size_t)i * E + e];
+      const float xi = x[(size_t)k * E + e];
       // numpy evaluates every product/sum separately in float32: no FMA contraction here
       const float te = __fsub_rn(ti, tp);
       float r = __fmul_rn(two_pi, te);                        // d_cutoff = 1
@@ -208,23 +222,39 @@ __global__ void k_one_euro(const float* x, float* y, int T, size_t E, float min_
       r = __fmul_rn(__fmul_rn(two_pi, cutoff), te);
       const float a = __fdiv_rn(r, __fadd_rn(r, 1.f));
       const float xh = __fadd_rn(__fmul_rn(a, xi), __fmul_rn(__fsub_rn(1.f, a), xp));
-      y[(size_t)i * E + e] = xh;
+      y[(size_t)k * E + e] = xh;
       xp = xh;
       dxp = dxh;
       tp = ti;
     }
+    if (dxprev_out) dxprev_out[e] = dxp;
   }
+}
+
+static int one_euro_launch(const float* x, float* y, int T, size_t E, float min_cutoff, float beta, float frame_rate,
+                           int i0, float t0, const float* xprev_in, const float* dxprev_in, float* dxprev_out,
+                           void* stream) {
+  MH_CHECK(x && y, "null argument");
+  MH_CHECK(T >= 1 && E >= 1, "empty input");
+  MH_CHECK((xprev_in == nullptr) == (dxprev_in == nullptr), "state arrays come in pairs");
+  MH_CHECK(xprev_in || i0 == 0, "a shard that does not start the sequence needs the incoming state");
+  const size_t nb = (E + 255) / 256;
+  hipLaunchKernelGGL(k_one_euro, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, (hipStream_t)stream, x, y, T, E,
+                     min_cutoff, beta, frame_rate, i0, t0, xprev_in, dxprev_in, dxprev_out);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
 }
 
 extern "C" int mh_one_euro_scan(const float* x, float* y, int T, size_t E, float min_cutoff, float beta,
                                 float frame_rate, void* stream) {
-  MH_CHECK(x && y, "null argument");
-  MH_CHECK(T >= 1 && E >= 1, "empty input");
-  const size_t nb = (E + 255) / 256;
-  hipLaunchKernelGGL(k_one_euro, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, (hipStream_t)stream, x, y, T, E,
-                     min_cutoff, beta, frame_rate);
-  MH_LAUNCH_CHECK();
-  return MH_OK;
+  return one_euro_launch(x, y, T, E, min_cutoff, beta, frame_rate, 0, 0.f, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int mh_one_euro_scan_shard(const float* x, float* y, int T, size_t E, float min_cutoff, float beta,
+                                      float frame_rate, int first_frame, float time_before, const float* xprev_in,
+                                      const float* dxprev_in, float* dxprev_out, void* stream) {
+  return one_euro_launch(x, y, T, E, min_cutoff, beta, frame_rate, first_frame, time_before, xprev_in, dxprev_in,
+                         dxprev_out, stream);
 }
 
 // =============================================================================================

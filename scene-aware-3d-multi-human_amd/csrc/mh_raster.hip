@@ -16,7 +16,6 @@
 //   * bodies larger than the LDS window are processed in row strips (two sweeps).
 #include "mh_common.h"
 
-#define RS_CAP 1920          // window pixels resident in LDS per strip (5 x u64 each = 76.8 KB)
 #define RS_EMPTY 0xffffffffffffffffull
 #define R_KEPS 1e-8f
 #define BLUR_D 1e-4f         // optimizer.py:213
@@ -45,6 +44,7 @@ struct RasterP {
   float* dinv;               // (B,2)
   float* zbuf_out;           // (B,H,W) or null: nearest-face depth image (caller pre-fills with -1)
   float* alpha_out;          // (B,H,W) or null: soft silhouette image (caller pre-fills with 0)
+  int cap;                   // window pixels resident in LDS per strip
 };
 
 __device__ __forceinline__ float r_pix_to_ndc(int i, int S1, int S2) {
@@ -110,27 +110,76 @@ __device__ __forceinline__ void r_scatter(const RasterP& p, float* gvb, const Tr
   atomicAdd(o + 2, gzz);
 }
 
+#define RB 512               // threads per body
+#define RQ_CAP 4096          // (face, pixel) candidate pairs queued per chunk of RB faces
+
 __device__ __forceinline__ float r_block_sum(float v, float* sh) {
   v = mh_wave_sum(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
   __syncthreads();
-  return sh[0] + sh[1] + sh[2] + sh[3];
+  float a = 0.f;
+#pragma unroll
+  for (int w = 0; w < RB / 64; ++w) a += sh[w];
+  return a;
 }
 
-__global__ __launch_bounds__(256, 2) void k_raster_terms(RasterP p) {
-  __shared__ unsigned long long keys[RS_CAP * 5];
-  __shared__ float sh[8];
+// one (face, pixel-centre) candidate: interpolated depth with clipped barycentrics, inside test and
+// squared distance to the triangle (CheckPixelInsideFace).  T9 = x0,y0,z0,x1,y1,z1,x2,y2,z2 (NDC).
+__device__ __forceinline__ void r_eval(const float* T9, float xf, float yf, float* pz, bool* inside, float* dist) {
+  const float x0 = T9[0], y0 = T9[1], z0 = T9[2], x1 = T9[3], y1 = T9[4], z1 = T9[5], x2 = T9[6], y2 = T9[7], z2 = T9[8];
+  const float area = r_edge(x2, y2, x0, y0, x1, y1) + R_KEPS;
+  const float w0 = r_edge(xf, yf, x1, y1, x2, y2) / area;
+  const float w1 = r_edge(xf, yf, x2, y2, x0, y0) / area;
+  const float w2 = r_edge(xf, yf, x0, y0, x1, y1) / area;
+  *inside = w0 > 0.f && w1 > 0.f && w2 > 0.f;
+  const float c0 = fmaxf(w0, 0.f), c1 = fmaxf(w1, 0.f), c2 = fmaxf(w2, 0.f);
+  const float cs = fmaxf(c0 + c1 + c2, 1e-5f);
+  *pz = (c0 / cs) * z0 + (c1 / cs) * z1 + (c2 / cs) * z2;
+  float tt;
+  bool dg;
+  *dist = fminf(fminf(r_seg(xf, yf, x0, y0, x1, y1, &tt, &dg), r_seg(xf, yf, x0, y0, x2, y2, &tt, &dg)),
+                r_seg(xf, yf, x1, y1, x2, y2, &tt, &dg));
+}
+
+// insert one candidate into the LDS window: slot 0 = nearest face of the blur-1e-4 pass, slots 1..4 =
+// the 4 nearest faces of the blur-2e-5 pass (atomicMin cascade, the displaced key moves on)
+__device__ __forceinline__ void r_insert(unsigned long long* q, float pz, bool inside, float d, int f) {
+  if (pz < 0.f || (!inside && d >= BLUR_D)) return;
+  unsigned long long key = ((unsigned long long)__float_as_uint(pz) << 32) | (unsigned)f;
+  if (key < q[0]) atomicMin(&q[0], key);
+  if (inside || d < BLUR_S) {
+#pragma unroll
+    for (int k = 1; k < 5; ++k) {
+      if (k == 4 && key >= q[4]) break;
+      const unsigned long long old = atomicMin(&q[k], key);
+      if (old == RS_EMPTY) break;
+      key = old > key ? old : key;
+    }
+  }
+}
+
+__global__ __launch_bounds__(RB, 2) void k_raster_terms(RasterP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
+  unsigned long long* keys = (unsigned long long*)rsm;                       // [cap][5]
+  float* sTri = (float*)(rsm + (size_t)p.cap * 40);                          // [RB][9]
+  unsigned* queue = (unsigned*)(sTri + RB * 9);                              // [RQ_CAP]
+  float* sXf = (float*)(queue + RQ_CAP);                                     // [W] NDC x of the pixel columns
+  float* sYf = sXf + p.W;                                                    // [H]
+  __shared__ float sh[RB / 64];
   __shared__ int swin[4];
+  __shared__ unsigned qcount;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int t = b / p.N, n = b % p.N;
   const int H = p.H, W = p.W, P = H * W;
   const float* vb = p.verts + (size_t)b * p.V * 3;
   float* gvb = p.gverts ? p.gverts + (size_t)b * p.V * 3 : nullptr;
+  for (int i = tid; i < W; i += RB) sXf[i] = r_pix_to_ndc(W - 1 - i, W, H);
+  for (int i = tid; i < H; i += RB) sYf[i] = r_pix_to_ndc(H - 1 - i, H, W);
 
   // ---- window of the body on screen -------------------------------------------------------------
   float mnx = 1e30f, mny = 1e30f, mxx = -1e30f, mxy = -1e30f;
-  for (int v = tid; v < p.V; v += 256) {
+  for (int v = tid; v < p.V; v += RB) {
     const float X = vb[(size_t)v * 3], Y = vb[(size_t)v * 3 + 1], Z = vb[(size_t)v * 3 + 2];
     if (Z > R_KEPS) {
       const float fx = r_ndc_to_pix(p.s * (-X) / Z + p.w1, W, H), fy = r_ndc_to_pix(p.s * (-Y) / Z + p.h1, H, W);
@@ -143,13 +192,13 @@ __global__ __launch_bounds__(256, 2) void k_raster_terms(RasterP p) {
     mnx = fminf(mnx, __shfl_xor(mnx, o, 64)); mny = fminf(mny, __shfl_xor(mny, o, 64));
     mxx = fmaxf(mxx, __shfl_xor(mxx, o, 64)); mxy = fmaxf(mxy, __shfl_xor(mxy, o, 64));
   }
-  __shared__ float sbb[4][4];
+  __shared__ float sbb[RB / 64][4];
   if ((tid & 63) == 0) {
     sbb[tid >> 6][0] = mnx; sbb[tid >> 6][1] = mny; sbb[tid >> 6][2] = mxx; sbb[tid >> 6][3] = mxy;
   }
   __syncthreads();
   if (tid == 0) {
-    for (int w = 1; w < 4; ++w) {
+    for (int w = 1; w < RB / 64; ++w) {
       mnx = fminf(mnx, sbb[w][0]); mny = fminf(mny, sbb[w][1]);
       mxx = fmaxf(mxx, sbb[w][2]); mxy = fmaxf(mxy, sbb[w][3]);
     }
@@ -185,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void k_raster_terms(RasterP p) {
   const uint32_t fr = p.front[b];
   const float blur_d = sqrtf(BLUR_D);
 
-  const int rows = max(1, RS_CAP / ww);
+  const int rows = max(1, p.cap / ww);
   const int nstrips = (wh + rows - 1) / rows;
   const int nsweeps = nstrips > 1 ? 2 : 1;
   float sumA = 0.f, sumB = 0.f, sumC = 0.f, sumS1 = 0.f, sumS2 = 0.f, sumCorr = 0.f;   // block totals (uniform)
@@ -195,62 +244,68 @@ __global__ __launch_bounds__(256, 2) void k_raster_terms(RasterP p) {
       const int sy0 = y0 + strip * rows, sy1 = min(y1, sy0 + rows - 1);
       const int npx = (sy1 - sy0 + 1) * ww;
       __syncthreads();
-      for (int i = tid; i < npx * 5; i += 256) keys[i] = RS_EMPTY;
-      __syncthreads();
-      // ---- face-parallel scatter into the LDS window ---------------------------------------------
-      for (int f = tid; f < p.F; f += 256) {
-        Tri tr;
-        r_load_tri(p, vb, f, tr);
-        if (fminf(tr.z[0], fminf(tr.z[1], tr.z[2])) < R_KEPS) continue;
-        const float farea = r_edge(tr.x[0], tr.y[0], tr.x[1], tr.y[1], tr.x[2], tr.y[2]);
-        if (farea <= R_KEPS && farea >= -R_KEPS) continue;
-        const float bxmin = fminf(tr.x[0], fminf(tr.x[1], tr.x[2])) - blur_d, bxmax = fmaxf(tr.x[0], fmaxf(tr.x[1], tr.x[2])) + blur_d;
-        const float bymin = fminf(tr.y[0], fminf(tr.y[1], tr.y[2])) - blur_d, bymax = fmaxf(tr.y[0], fmaxf(tr.y[1], tr.y[2])) + blur_d;
-        // NDC decreases with the pixel index
-        const int xa = max(x0, (int)floorf(r_ndc_to_pix(bxmax, W, H)) - 1), xb = min(x1, (int)ceilf(r_ndc_to_pix(bxmin, W, H)) + 1);
-        const int ya = max(sy0, (int)floorf(r_ndc_to_pix(bymax, H, W)) - 1), yb = min(sy1, (int)ceilf(r_ndc_to_pix(bymin, H, W)) + 1);
-        const float area = r_edge(tr.x[2], tr.y[2], tr.x[0], tr.y[0], tr.x[1], tr.y[1]) + R_KEPS;
-        for (int yi = ya; yi <= yb; ++yi) {
-          const float yf = r_pix_to_ndc(H - 1 - yi, H, W);
-          if (yf > bymax || yf < bymin) continue;
-          for (int xi = xa; xi <= xb; ++xi) {
-            const float xf = r_pix_to_ndc(W - 1 - xi, W, H);
-            if (xf > bxmax || xf < bxmin) continue;
-            const float w0 = r_edge(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2]) / area;
-            const float w1 = r_edge(xf, yf, tr.x[2], tr.y[2], tr.x[0], tr.y[0]) / area;
-            const float w2 = r_edge(xf, yf, tr.x[0], tr.y[0], tr.x[1], tr.y[1]) / area;
-            const bool inside = w0 > 0.f && w1 > 0.f && w2 > 0.f;
-            const float c0 = fmaxf(w0, 0.f), c1 = fmaxf(w1, 0.f), c2 = fmaxf(w2, 0.f);
-            const float cs = fmaxf(c0 + c1 + c2, 1e-5f);
-            const float pz = (c0 / cs) * tr.z[0] + (c1 / cs) * tr.z[1] + (c2 / cs) * tr.z[2];
-            if (pz < 0.f) continue;
-            float tt;
-            bool dg;
-            const float d = fminf(fminf(r_seg(xf, yf, tr.x[0], tr.y[0], tr.x[1], tr.y[1], &tt, &dg),
-                                        r_seg(xf, yf, tr.x[0], tr.y[0], tr.x[2], tr.y[2], &tt, &dg)),
-                                  r_seg(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2], &tt, &dg));
-            if (!inside && d >= BLUR_D) continue;
-            unsigned long long key = ((unsigned long long)__float_as_uint(pz) << 32) | (unsigned)f;
-            unsigned long long* q = keys + (size_t)((yi - sy0) * ww + (xi - x0)) * 5;
-            if (key < q[0]) atomicMin(&q[0], key);
-            if (inside || d < BLUR_S) {
+      for (int i = tid; i < npx * 5; i += RB) keys[i] = RS_EMPTY;
+      // ---- face-parallel scatter into the LDS window, in chunks of RB faces ------------------------
+      // step 1 (one face per thread): project, reject, and queue the pixel centres inside the blurred
+      // bbox; step 2 (one queued pair per thread): the expensive per-pair evaluation runs with full
+      // lanes instead of inside divergent per-face loops.
+      for (int chunk = 0; chunk < p.F; chunk += RB) {
+        if (tid == 0) qcount = 0u;
+        __syncthreads();
+        const int f = chunk + tid;
+        if (f < p.F) {
+          Tri tr;
+          r_load_tri(p, vb, f, tr);
+          float* T9 = sTri + tid * 9;
 #pragma unroll
-              for (int k = 1; k < 5; ++k) {
-                if (key >= q[k] && k == 4) break;           // not among the 4 nearest any more
-                const unsigned long long old = atomicMin(&q[k], key);
-                if (old == RS_EMPTY) break;                 // took a free slot
-                key = old > key ? old : key;                // the displaced (larger) key moves on
+          for (int k = 0; k < 3; ++k) { T9[3 * k] = tr.x[k]; T9[3 * k + 1] = tr.y[k]; T9[3 * k + 2] = tr.z[k]; }
+          const float farea = r_edge(tr.x[0], tr.y[0], tr.x[1], tr.y[1], tr.x[2], tr.y[2]);
+          const bool ok = fminf(tr.z[0], fminf(tr.z[1], tr.z[2])) >= R_KEPS && !(farea <= R_KEPS && farea >= -R_KEPS);
+          if (ok) {
+            const float bxmin = fminf(tr.x[0], fminf(tr.x[1], tr.x[2])) - blur_d, bxmax = fmaxf(tr.x[0], fmaxf(tr.x[1], tr.x[2])) + blur_d;
+            const float bymin = fminf(tr.y[0], fminf(tr.y[1], tr.y[2])) - blur_d, bymax = fmaxf(tr.y[0], fmaxf(tr.y[1], tr.y[2])) + blur_d;
+            // NDC decreases with the pixel index
+            const int xa = max(x0, (int)floorf(r_ndc_to_pix(bxmax, W, H)) - 1), xb = min(x1, (int)ceilf(r_ndc_to_pix(bxmin, W, H)) + 1);
+            const int ya = max(sy0, (int)floorf(r_ndc_to_pix(bymax, H, W)) - 1), yb = min(sy1, (int)ceilf(r_ndc_to_pix(bymin, H, W)) + 1);
+            for (int yi = ya; yi <= yb; ++yi) {
+              const float yf = sYf[yi];
+              if (yf > bymax || yf < bymin) continue;
+              for (int xi = xa; xi <= xb; ++xi) {
+                const float xf = sXf[xi];
+                if (xf > bxmax || xf < bxmin) continue;
+                const unsigned poff = (unsigned)((yi - sy0) * ww + (xi - x0));
+                const unsigned pos = atomicAdd(&qcount, 1u);
+                if (pos < RQ_CAP) {
+                  queue[pos] = ((unsigned)tid << 16) | poff;
+                } else {          // queue full (very large faces): evaluate in place
+                  float pz, d;
+                  bool inside;
+                  r_eval(T9, xf, yf, &pz, &inside, &d);
+                  r_insert(keys + (size_t)poff * 5, pz, inside, d, f);
+                }
               }
             }
           }
         }
+        __syncthreads();
+        const int nq = (int)min(qcount, (unsigned)RQ_CAP);
+        for (int i = tid; i < nq; i += RB) {
+          const unsigned e = queue[i];
+          const int lf = (int)(e >> 16), poff = (int)(e & 0xffffu);
+          const int yi = sy0 + poff / ww, xi = x0 + poff % ww;
+          float pz, d;
+          bool inside;
+          r_eval(sTri + lf * 9, sXf[xi], sYf[yi], &pz, &inside, &d);
+          r_insert(keys + (size_t)poff * 5, pz, inside, d, chunk + lf);
+        }
+        __syncthreads();
       }
       __syncthreads();
       // ---- pass A: residual sums (first sweep), pass B: gradients (last sweep) ---------------------
       const bool doA = sweep == 0, doB = sweep == nsweeps - 1;
       float lA = 0.f, lB = 0.f, lC = 0.f, lS1 = 0.f, lS2 = 0.f, lCorr = 0.f;
       if (doA) {
-        for (int i = tid; i < npx; i += 256) {
+        for (int i = tid; i < npx; i += RB) {
           const int yi = sy0 + i / ww, xi = x0 + i % ww;
           const size_t gp = (size_t)t * P + (size_t)yi * W + xi;
           const uint32_t wb = p.bits[gp];
@@ -312,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void k_raster_terms(RasterP p) {
         const float diff = sumA / cnt - sumB / cnt;                                               // losses.py:24-27
         const float gA = p.coef_depth * 2.f * diff / cnt;
         const float gAlphaScale = p.coef_sil * apply * 2.f / (Dn + 1.f);
-        for (int i = tid; i < npx; i += 256) {
+        for (int i = tid; i < npx; i += RB) {
           const int yi = sy0 + i / ww, xi = x0 + i % ww;
           const size_t gp = (size_t)t * P + (size_t)yi * W + xi;
           const float yf = r_pix_to_ndc(H - 1 - yi, H, W), xf = r_pix_to_ndc(W - 1 - xi, W, H);
@@ -473,7 +528,6 @@ extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const f
                sil_apply && sil_D && sil_S && depth_body && sil_body && dinv_ws,
            "null argument");
   MH_CHECK(T > 0 && N > 0 && N <= 32 && V > 0 && F > 0 && H > 0 && W > 0, "empty input");
-  MH_CHECK(W <= RS_CAP, "image wider than the LDS window capacity");
   RasterP p;
   p.B = T * N; p.N = N; p.V = V; p.F = F; p.H = H; p.W = W;
   // transforms.py:222-255 with image_size = (W, H)
@@ -505,7 +559,19 @@ extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const f
     MH_LAUNCH_CHECK();
   }
   if (alpha_out) MH_HIP(hipMemsetAsync(alpha_out, 0, (size_t)p.B * H * W * sizeof(float), st));
-  hipLaunchKernelGGL(k_raster_terms, dim3(p.B), dim3(256), 0, st, p);
+  // LDS budget (160 KiB per CU, one body per CU): keys get what the face staging leaves over
+  const size_t fixed = (size_t)RB * 9 * 4 + (size_t)RQ_CAP * 4 + (size_t)(W + H) * 4 + 1024 /* static + slack */;
+  const size_t lds_total = 160 * 1024;
+  MH_CHECK(fixed + (size_t)W * 40 <= lds_total, "image too wide for the LDS window");
+  p.cap = (int)((lds_total - fixed) / 40);
+  if (p.cap > 65535) p.cap = 65535;            // pixel offsets are 16 bits in the candidate queue
+  const size_t lds = (size_t)p.cap * 40 + (size_t)RB * 9 * 4 + (size_t)RQ_CAP * 4 + (size_t)(W + H) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    MH_HIP(hipFuncSetAttribute((const void*)k_raster_terms, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_total - 1024)));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_raster_terms, dim3(p.B), dim3(RB), lds, st, p);
   MH_LAUNCH_CHECK();
   if (gzmin && gzmax) {
     hipLaunchKernelGGL(k_depth_range_grads, dim3((T + 127) / 128), dim3(128), 0, st, T, N, (const float*)dinv_ws, zmin_lin,

@@ -43,6 +43,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise MhError('%s is missing: build it with `python -m mhhip.build` (hipcc, gfx950). '
                           'There is no CPU fallback.' % LIB_PATH)
+        # torch first: it ships its own HIP/HSA runtime libraries with the same SONAMEs as /opt/rocm; two
+        # different runtimes in one process see no devices, so ours must bind to the ones torch loaded
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         L.mh_last_error.restype = ctypes.c_char_p
         L.mh_model_faces.restype = vp
@@ -61,6 +64,7 @@ def lib():
         L.mh_rmsprop_step.argtypes = [vp, vp, vp, vp, ctypes.c_size_t] + [ctypes.c_float] * 4 + [vp]
         L.mh_adam_step.argtypes = [vp, vp, vp, vp, ctypes.c_size_t, ctypes.c_int] + [ctypes.c_float] * 4 + [vp]
         L.mh_one_euro_scan.argtypes = [vp, vp, ctypes.c_int, ctypes.c_size_t] + [ctypes.c_float] * 3 + [vp]
+        L.mh_one_euro_scan_shard.argtypes = [vp, vp, ctypes.c_int, ctypes.c_size_t] + [ctypes.c_float] * 3 + [ctypes.c_int, ctypes.c_float, vp, vp, vp, vp]
         L.mh_velocity_term.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_float, vp, vp, vp]
         L.mh_filtered_verts_term.argtypes = [ctypes.c_int, ctypes.c_size_t] + [vp] * 6 + [ctypes.c_float, vp, vp, vp]
         u32p = vp

@@ -27,7 +27,7 @@ def build(force=False, verbose=False):
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
-           '-Wno-unused-result'] + sources() + ['-o', LIB + '.tmp']
+           '-Wno-unused-result', '-munsafe-fp-atomics'] + sources() + ['-o', LIB + '.tmp']
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True)

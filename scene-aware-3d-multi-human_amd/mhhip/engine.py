@@ -184,6 +184,28 @@ def one_euro_scan(x, min_cutoff, beta, frame_rate=25.0):
     return y
 
 
+def one_euro_time_before(first_frame, frame_rate=25.0):
+    """float32 running time stamp after frame ``first_frame - 1`` (reference optimizer.py:671)."""
+    t = np.float32(0)
+    for i in range(1, int(first_frame)):
+        t = np.float32(t + np.float32(i / frame_rate))
+    return float(t)
+
+
+def one_euro_scan_shard(x, min_cutoff, beta, first_frame, state_in=None, frame_rate=25.0):
+    """x (T_local, ...) -> y, state_out=(y[-1], dxhat[-1]) for the next rank."""
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    T = x.shape[0]
+    E = x.numel() // T
+    dx_out = torch.empty(E, dtype=torch.float32, device=x.device)
+    xp, dxp = (None, None) if state_in is None else state_in
+    check(_lib.lib().mh_one_euro_scan_shard(ptr(x), ptr(y), T, E, float(min_cutoff), float(beta), float(frame_rate),
+                                            int(first_frame), one_euro_time_before(first_frame, frame_rate),
+                                            ptr(xp), ptr(dxp), ptr(dx_out), _lib.stream_ptr(x.device)))
+    return y, (y[-1].reshape(-1).contiguous(), dx_out)
+
+
 def velocity_term(pT, coef, gpT, prev_halo=None, next_halo=None):
     T, N = pT.shape[0], pT.shape[1]
     loss = torch.empty(1, dtype=torch.float32, device=pT.device)

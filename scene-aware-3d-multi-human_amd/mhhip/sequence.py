@@ -74,6 +74,29 @@ class SequenceEngine(object):
         self.pT_filt = None
         self.has_images = False
         self.halo = None              # filled by the frame-sharded driver
+        self.timing = None            # {name: [(start_event, end_event), ...]} when enabled by bench.py
+
+    def enable_timing(self, on=True):
+        self.timing = {} if on else None
+
+    def _tic(self, name):
+        if self.timing is None:
+            return None
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.timing.setdefault(name, []).append((a, b))
+        a.record(torch.cuda.current_stream(self.dev))
+        return b
+
+    def _toc(self, ev):
+        if ev is not None:
+            ev.record(torch.cuda.current_stream(self.dev))
+
+    def timing_summary(self):
+        """mean milliseconds per launch group (call after a synchronize)."""
+        out = {}
+        for k, evs in (self.timing or {}).items():
+            out[k] = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        return out
 
     def set_batch_size(self, batch_size):
         """Frames per batch of the reference's dataloader: fixes the in-batch foot-sliding pairs and
@@ -162,24 +185,34 @@ class SequenceEngine(object):
     # -- forward of all local frames ---------------------------------------------------------------
     def forward(self):
         m = self.m
+        ev = self._tic('lbs_forward')
         check(_lib.lib().mh_lbs_forward(m.handle, self.B, self.N, ptr(self.leaf('betas')), ptr(self.leaf('poses_smpl')),
                                         ptr(self.leaf('xscale')), ptr(self.leaf('poses_T')), ptr(self.verts),
                                         ptr(self.vposed), None, ptr(self.ws), _lib.stream_ptr(self.dev)))
+        self._toc(ev)
         check(_lib.lib().mh_joints_regress(m.handle, engine.REG_ALPHAPOSE, self.B, ptr(self.verts),
                                            ptr(self.leaf('poses_T')), -1, ptr(self.kp), _lib.stream_ptr(self.dev)))
 
     # -- one optimisation cycle (optimizer.py:375-575), gradients accumulated into self.grads -----
     def cycle(self, row, use_images=True, raster=None):
+        self.cycle_begin()
+        self.cycle_finish(row, use_images, raster)
+
+    def cycle_begin(self):
+        """zero the gradient buffer and run the LBS forward of all local frames (the frame-sharded
+        driver exchanges boundary vertices between this and ``cycle_finish``)."""
+        self.grads.zero_()
+        self.forward()
+
+    def cycle_finish(self, row, use_images=True, raster=None):
         L = _lib.lib()
         st = _lib.stream_ptr(self.dev)
         c = self.c
         T, N, B = self.T, self.N, self.B
         g = self.grads
-        g.zero_()
         gpT, gposes = self.leaf('poses_T', g), self.leaf('poses_smpl', g)
         gbetas, gxs = self.leaf('betas', g), self.leaf('xscale', g)
         pT = self.leaf('poses_T')
-        self.forward()
         Kp = self.K.ctypes.data_as(_lib.c_float_p)
         Kdp = None if self.Kd is None else self.Kd.ctypes.data_as(_lib.c_float_p)
         check(L.mh_project_joints_loss(B, ptr(self.kp), Kp, Kdp, ptr(self.pose2d), self.thr, 0, float(self.W),
@@ -208,12 +241,15 @@ class SequenceEngine(object):
                                       ptr(self.mask_valid), ptr(self.front), ptr(self.sil_apply), ptr(self.sil_D),
                                       ptr(self.sil_S), st))
             if raster is not None:
+                ev = self._tic('raster_terms')
                 raster(self, gv, log)
+                self._toc(ev)
             else:
                 # no rasteriser: alpha = 0, zbuf empty -> the mask-only silhouette term (tests only)
                 self.sil_body.copy_(self.sil_apply * self.sil_S / (self.sil_D + 1.0))
                 check(L.mh_reduce_sum(ptr(self.sil_body), B, 1.0, ptr(log[2:3]), st))
         if scene:
+            ev = self._tic('scene_terms')
             check(L.mh_lowest_vertex(ptr(self.verts), B, self.V, ptr(self.low_idx), ptr(self.low_xyz), st))
             check(L.mh_contact_knn(ptr(self.scene_pts), self.scene_pts.shape[0], ptr(self.low_xyz), B, 32, ptr(self.dy), st))
             check(L.mh_contact_foot_terms(T, N, self.V, self.batch, ptr(self.verts), ptr(self.low_idx), ptr(self.low_xyz),
@@ -221,15 +257,20 @@ class SequenceEngine(object):
                                           ptr(gv), ptr(self.batch_contact), ptr(self.batch_foot), st))
             check(L.mh_reduce_sum(ptr(self.batch_contact), self.nbatches, 1.0, ptr(log[5:6]), st))
             check(L.mh_reduce_sum(ptr(self.batch_foot), self.nbatches, 1.0, ptr(log[6:7]), st))
+            self._toc(ev)
         if filt:
             E = N * self.V * 3
+            ev = self._tic('filtered_verts')
             check(L.mh_filtered_verts_term(T, E, ptr(self.verts), ptr(self.verts_filt), ptr(h.get('v_prev')),
                                            ptr(h.get('vf_prev')), ptr(h.get('v_next')), ptr(h.get('vf_next')),
                                            float(c['reg_verts_filter']), ptr(gv), ptr(self.filt_loss), st))
+            self._toc(ev)
             log[8:9].copy_(self.filt_loss)
+        ev = self._tic('lbs_backward')
         check(L.mh_lbs_backward(self.m.handle, B, N, ptr(self.leaf('betas')), ptr(self.leaf('poses_smpl')),
                                 ptr(self.leaf('xscale')), ptr(pT), ptr(self.vposed), ptr(gv), ptr(self.gj), ptr(gposes),
                                 ptr(gpT), ptr(gbetas), ptr(gxs), ptr(self.ws), ptr(self.ws2), st))
+        self._toc(ev)
         check(L.mh_reduce_sum(ptr(self.loss2d), B, 1.0, ptr(log[0:1]), st))
         check(L.mh_reduce_sum(ptr(self.prior_body), B, 1.0, ptr(log[3:4]), st))
         log[9:12].copy_(self.loss3)
@@ -244,6 +285,9 @@ class SequenceEngine(object):
         self.pT_filt = engine.one_euro_scan(self.leaf('poses_T'), c1, b1)
         self.forward()
         self.verts_filt = engine.one_euro_scan(self.verts.view(self.T, -1), c2, b2).view(self.T, self.N, self.V, 3)
+
+    def one_euro_shard(self, x, min_cutoff, beta, first_frame, state_in=None):
+        return engine.one_euro_scan_shard(x, min_cutoff, beta, first_frame, state_in)
 
     # -- logs back on the host (one D2H per fit) ---------------------------------------------------
     def read_log(self, rows, nbatches_total=None):

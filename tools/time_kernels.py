@@ -1,0 +1,58 @@
+"""Micro-timings of the hot kernels on the C3 workload (developer tool, not part of the product)."""
+import os, sys, time, tempfile
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'scene-aware-3d-multi-human_amd')]
+import bench
+from mhhip import synthetic, synthetic_seq
+from mhhip.raster import RasterTerms
+
+
+def timeit(fn, n=10):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+
+def main():
+    T = int(os.environ.get('T', '200'))
+    struct = synthetic.make_smpl_struct(1); regs = synthetic.make_extra_regressors(1, struct)
+    K = synthetic.default_cam_K(bench.IMG, 60.0)
+    tmp = tempfile.mkdtemp()
+    opt = bench.build_optimizer(struct, regs, tmp, T, 'cuda:0', K)
+    seq = synthetic_seq.make_sequence(opt.SMPLPY.body_model, 4, T, bench.IMG, 1003, cam_K=K)
+    opt.init_optimized_variables(seq['pose2d'], seq['poses_smpl'], seq['betas_smpl'], seq['valid_smpl'], num_iter=20)
+    dl = torch.utils.data.DataLoader(synthetic_seq.SequenceDataset(seq), batch_size=10, shuffle=False)
+    opt._stage_from_dataloader(dl)
+    e = opt.engine
+    opt.scene_depth = bench.ground_scene(K, *bench.IMG)
+    opt.update_scene_pointcloud(opt.scene_depth, seq['backmasks'].min(axis=0) > 0)
+    r = RasterTerms(e)
+    e.cycle(0, raster=r)
+    gv = torch.zeros_like(e.verts); log = torch.zeros(16, device='cuda:0')
+    v = e.verts
+    u = K[0, 0] * v[..., 0] / v[..., 2] + K[0, 2]; w = K[1, 1] * v[..., 1] / v[..., 2] + K[1, 2]
+    ww = (u.amax(1).clamp(0, 239) - u.amin(1).clamp(0, 239) + 5); wh = (w.amax(1).clamp(0, 134) - w.amin(1).clamp(0, 134) + 5)
+    area = (ww * wh)
+    print('window px: mean %.0f max %.0f; >1920: %d of %d; z range %.2f..%.2f' % (area.mean(), area.max(), (area > 1920).sum(), area.numel(), v[..., 2].min(), v[..., 2].max()))
+    print('seg coverage px/body', seq['seg_mask'].sum() / (T * 4))
+    print('raster fwd+bwd  ms', timeit(lambda: r(e, gv, log)))
+    print('raster fwd only ms', timeit(lambda: r(e, gv, log, with_grads=False)))
+    print('lbs fwd ms', timeit(lambda: e.forward()))
+    from mhhip import _lib
+    from mhhip._lib import ptr, check
+    L = _lib.lib(); st = _lib.stream_ptr(e.dev)
+    print('lowest ms', timeit(lambda: check(L.mh_lowest_vertex(ptr(e.verts), e.B, e.V, ptr(e.low_idx), ptr(e.low_xyz), st))))
+    print('knn ms (M=%d)' % e.scene_pts.shape[0], timeit(lambda: check(L.mh_contact_knn(ptr(e.scene_pts), e.scene_pts.shape[0], ptr(e.low_xyz), e.B, 32, ptr(e.dy), st))))
+
+
+if __name__ == '__main__':
+    main()
+
+
+def window_stats():
+    pass

@@ -91,8 +91,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-frames', type=int, default=10)
-    ap.add_argument('--cpu-cycles', type=int, default=2)
+    ap.add_argument('--cpu-frames', type=int, default=20)
+    ap.add_argument('--cpu-cycles', type=int, default=3)
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))

@@ -3,17 +3,27 @@
 // itself is PyTorch3D's MeshRasterizer / SoftSilhouetteShader, restated from its published
 // semantics -- see oracle/raster_select.c for the provenance note).
 //
-// MI355X design: ONE workgroup per body keeps the body's screen window in LDS.
-//   * SMPL triangles are sub-pixel at MuPoTs resolution (13776 faces on ~600 px), so the pass is
-//     face-parallel: each thread walks the few pixel centres inside its face's blurred bbox and
-//     inserts (z, face) keys with 64-bit LDS atomics -- slot 0 is the nearest face of the
-//     blur=1e-4 pass (the only thing the reference reads from its K=8 rasterisation,
-//     optimizer.py:430), slots 1..4 the K=4 nearest faces of the blur=2e-5 silhouette pass
-//     (atomicMin cascade: the displaced key carries on to the next slot);
-//   * the residual sums, then the per-pixel gradients, are evaluated straight from LDS: no
-//     z-buffer / alpha image / fragment tensor ever reaches HBM (the reference materialises
-//     (b,N,H,W,8)+(b,N,H,W,4) fragments twice per batch);
-//   * bodies larger than the LDS window are processed in row strips (two sweeps).
+// MI355X design.  SMPL triangles are sub-pixel at MuPoTs resolution (13776 faces on a few hundred
+// pixels), so rasterisation is FACE-parallel with the per-pixel K-nearest lists kept in LDS:
+//   k_raster_windows     one wave per body: screen window of the body (bbox of projected vertices)
+//   k_raster_strip_table one block: cuts every window into row strips of <= R_CAP pixels and
+//                        prefix-sums them into a work list (device-side: no host sync); a close-up
+//                        body becomes many strips, so the work per workgroup is bounded and the
+//                        launch load-balances (the first version, one body per workgroup, was
+//                        tail-bound by the nearest body)
+//   k_raster_strip       one workgroup per strip: faces are staged in chunks (projection + bbox
+//                        rejection per face), the (face, pixel-centre) pairs inside the blurred bbox
+//                        are compacted into an LDS queue (wave-aggregated append) and evaluated with
+//                        full lanes; 64-bit (z, face) keys go into the strip's LDS window with
+//                        ds_min_rtn_u64: slot 0 = nearest face of the blur 1e-4 pass (all the
+//                        reference reads of its K=8 rasterisation, optimizer.py:430), slots 1..4 =
+//                        the K=4 nearest of the blur 2e-5 silhouette pass (atomic-min cascade: the
+//                        displaced key moves on to the next slot).  The finished window is written
+//                        to HBM once (40 B per window pixel).
+//   k_raster_sums        per strip: residual sums of the depth and silhouette terms
+//   k_raster_grads       per strip: per-pixel gradients scattered to the vertices (float atomics)
+// No (b,N,H,W,K) fragment tensor, z-buffer or alpha image is materialised (the reference builds
+// two of them per batch).
 #include "mh_common.h"
 
 #define RS_EMPTY 0xffffffffffffffffull
@@ -21,6 +31,10 @@
 #define BLUR_D 1e-4f         // optimizer.py:213
 #define BLUR_S 2e-5f         // optimizer.py:223
 #define SIGMA_S 1e-4f        // BlendParams.sigma default used by SoftSilhouetteShader
+#define RB 256               // threads per strip workgroup
+#define RQ_CAP 2048          // (face, pixel) candidate pairs queued per chunk of RB faces
+#define R_CAP 640            // window pixels per strip (5 x u64 each = 25.6 KB of LDS; 3 workgroups per CU)
+#define RT 13                // floats staged per face: 9 NDC coordinates, 1/area, 1/|edge|^2 x 3
 
 struct RasterP {
   int B, N, V, F, H, W;
@@ -41,10 +55,21 @@ struct RasterP {
   float* gverts;
   float* depth_body;
   float* sil_body;
-  float* dinv;               // (B,2)
-  float* zbuf_out;           // (B,H,W) or null: nearest-face depth image (caller pre-fills with -1)
-  float* alpha_out;          // (B,H,W) or null: soft silhouette image (caller pre-fills with 0)
-  int cap;                   // window pixels resident in LDS per strip
+  float* zbuf_out;           // (B,H,W) or null
+  float* alpha_out;          // (B,H,W) or null
+  // workspace
+  int max_strips;
+  int* win;                  // [B][4] x0,y0,ww,wh (ww <= 0: nothing on screen)
+  int* body_first;           // [B] first strip of the body
+  int* body_ns;              // [B] strips of the body
+  int* total;                // [1] number of strips
+  int* strip_body;           // [max_strips]
+  int* strip_row0;           // [max_strips]
+  int* strip_rows;           // [max_strips]
+  long long* strip_koff;     // [max_strips] first window pixel of the strip in gkeys
+  float* partial;            // [max_strips][6]
+  float* dinv;               // [B][2]
+  unsigned long long* gkeys; // [sum of window pixels][5]
 };
 
 __device__ __forceinline__ float r_pix_to_ndc(int i, int S1, int S2) {
@@ -110,9 +135,6 @@ __device__ __forceinline__ void r_scatter(const RasterP& p, float* gvb, const Tr
   atomicAdd(o + 2, gzz);
 }
 
-#define RB 512               // threads per body
-#define RQ_CAP 4096          // (face, pixel) candidate pairs queued per chunk of RB faces
-
 __device__ __forceinline__ float r_block_sum(float v, float* sh) {
   v = mh_wave_sum(v);
   __syncthreads();
@@ -159,30 +181,18 @@ __device__ __forceinline__ void r_insert(unsigned long long* q, float pz, bool i
   }
 }
 
-__global__ __launch_bounds__(RB, 2) void k_raster_terms(RasterP p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
-  unsigned long long* keys = (unsigned long long*)rsm;                       // [cap][5]
-  float* sTri = (float*)(rsm + (size_t)p.cap * 40);                          // [RB][9]
-  unsigned* queue = (unsigned*)(sTri + RB * 9);                              // [RQ_CAP]
-  float* sXf = (float*)(queue + RQ_CAP);                                     // [W] NDC x of the pixel columns
-  float* sYf = sXf + p.W;                                                    // [H]
-  __shared__ float sh[RB / 64];
-  __shared__ int swin[4];
-  __shared__ unsigned qcount;
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int t = b / p.N, n = b % p.N;
-  const int H = p.H, W = p.W, P = H * W;
+// =============================================================================================
+// windows and strips
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_raster_windows(RasterP p) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= p.B) return;
   const float* vb = p.verts + (size_t)b * p.V * 3;
-  float* gvb = p.gverts ? p.gverts + (size_t)b * p.V * 3 : nullptr;
-  for (int i = tid; i < W; i += RB) sXf[i] = r_pix_to_ndc(W - 1 - i, W, H);
-  for (int i = tid; i < H; i += RB) sYf[i] = r_pix_to_ndc(H - 1 - i, H, W);
-
-  // ---- window of the body on screen -------------------------------------------------------------
   float mnx = 1e30f, mny = 1e30f, mxx = -1e30f, mxy = -1e30f;
-  for (int v = tid; v < p.V; v += RB) {
+  for (int v = lane; v < p.V; v += 64) {
     const float X = vb[(size_t)v * 3], Y = vb[(size_t)v * 3 + 1], Z = vb[(size_t)v * 3 + 2];
     if (Z > R_KEPS) {
-      const float fx = r_ndc_to_pix(p.s * (-X) / Z + p.w1, W, H), fy = r_ndc_to_pix(p.s * (-Y) / Z + p.h1, H, W);
+      const float fx = r_ndc_to_pix(p.s * (-X) / Z + p.w1, p.W, p.H), fy = r_ndc_to_pix(p.s * (-Y) / Z + p.h1, p.H, p.W);
       mnx = fminf(mnx, fx); mxx = fmaxf(mxx, fx);
       mny = fminf(mny, fy); mxy = fmaxf(mxy, fy);
     }
@@ -192,306 +202,485 @@ __global__ __launch_bounds__(RB, 2) void k_raster_terms(RasterP p) {
     mnx = fminf(mnx, __shfl_xor(mnx, o, 64)); mny = fminf(mny, __shfl_xor(mny, o, 64));
     mxx = fmaxf(mxx, __shfl_xor(mxx, o, 64)); mxy = fmaxf(mxy, __shfl_xor(mxy, o, 64));
   }
-  __shared__ float sbb[RB / 64][4];
-  if ((tid & 63) == 0) {
-    sbb[tid >> 6][0] = mnx; sbb[tid >> 6][1] = mny; sbb[tid >> 6][2] = mxx; sbb[tid >> 6][3] = mxy;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    for (int w = 1; w < RB / 64; ++w) {
-      mnx = fminf(mnx, sbb[w][0]); mny = fminf(mny, sbb[w][1]);
-      mxx = fmaxf(mxx, sbb[w][2]); mxy = fmaxf(mxy, sbb[w][3]);
-    }
+  if (lane == 0) {
     // clamp in float first: a body far outside the image must not overflow the int conversion
     const float big = 1e6f;
     mnx = fminf(fmaxf(mnx, -big), big); mxx = fminf(fmaxf(mxx, -big), big);
     mny = fminf(fmaxf(mny, -big), big); mxy = fminf(fmaxf(mxy, -big), big);
-    swin[0] = max(0, (int)floorf(mnx) - 2);
-    swin[1] = max(0, (int)floorf(mny) - 2);
-    swin[2] = min(W - 1, (int)ceilf(mxx) + 2);
-    swin[3] = min(H - 1, (int)ceilf(mxy) + 2);
+    const int x0 = max(0, (int)floorf(mnx) - 2), y0 = max(0, (int)floorf(mny) - 2);
+    const int x1 = min(p.W - 1, (int)ceilf(mxx) + 2), y1 = min(p.H - 1, (int)ceilf(mxy) + 2);
+    p.win[b * 4] = x0;
+    p.win[b * 4 + 1] = y0;
+    p.win[b * 4 + 2] = x1 - x0 + 1;
+    p.win[b * 4 + 3] = y1 - y0 + 1;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_raster_strip_table(RasterP p) {
+  __shared__ int s_ns[1024];
+  __shared__ long long s_px[1024];
+  __shared__ int carry_ns;
+  __shared__ long long carry_px;
+  if (threadIdx.x == 0) {
+    carry_ns = 0;
+    carry_px = 0;
   }
   __syncthreads();
-  const int x0 = swin[0], y0 = swin[1], x1 = swin[2], y1 = swin[3];
-  const int ww = x1 - x0 + 1, wh = y1 - y0 + 1;
-
-  const float apply = p.sil_apply[b], Dn = p.sil_D[b], Sn = p.sil_S[b];
-  if (ww <= 0 || wh <= 0) {
-    if (tid == 0) {
-      p.depth_body[b] = 0.f;
-      p.sil_body[b] = apply * Sn / (Dn + 1.f);
-      p.dinv[(size_t)b * 2] = 0.f;
-      p.dinv[(size_t)b * 2 + 1] = 0.f;
+  for (int base = 0; base < p.B; base += 1024) {
+    const int b = base + threadIdx.x;
+    int ww = 0, wh = 0, rows = 1, ns = 0;
+    if (b < p.B) {
+      ww = p.win[b * 4 + 2];
+      wh = p.win[b * 4 + 3];
+      if (ww > 0 && wh > 0) {
+        rows = max(1, R_CAP / ww);
+        ns = (wh + rows - 1) / rows;
+      } else {
+        ww = wh = 0;
+      }
     }
-    return;
+    s_ns[threadIdx.x] = ns;
+    s_px[threadIdx.x] = (long long)ww * wh;
+    __syncthreads();
+    // inclusive scan (Hillis-Steele)
+    for (int o = 1; o < 1024; o <<= 1) {
+      int a = 0;
+      long long c = 0;
+      if ((int)threadIdx.x >= o) {
+        a = s_ns[threadIdx.x - o];
+        c = s_px[threadIdx.x - o];
+      }
+      __syncthreads();
+      s_ns[threadIdx.x] += a;
+      s_px[threadIdx.x] += c;
+      __syncthreads();
+    }
+    const int first = carry_ns + s_ns[threadIdx.x] - ns;
+    const long long koff = carry_px + s_px[threadIdx.x] - (long long)ww * wh;
+    if (b < p.B) {
+      p.body_first[b] = first;
+      p.body_ns[b] = ns;
+      const int y0 = p.win[b * 4 + 1];
+      for (int k = 0; k < ns; ++k) {
+        const int r0 = k * rows, nr = min(rows, wh - r0);
+        p.strip_body[first + k] = b;
+        p.strip_row0[first + k] = y0 + r0;
+        p.strip_rows[first + k] = nr;
+        p.strip_koff[first + k] = koff + (long long)r0 * ww;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) {
+      carry_ns += s_ns[1023];
+      carry_px += s_px[1023];
+    }
+    __syncthreads();
   }
-  // depth range of this frame (optimizer.py:683-688) and the target disparity coefficients (:425)
-  const float min_z = logf(1.f + expf(p.zmin_lin[t]));
-  const float max_z = min_z + 1.f + logf(1.f + expf(p.zmax_lin[t]));
-  const float inv_min = 1.f / min_z, inv_max = 1.f / max_z;
-  const float dspan = inv_min - inv_max;
-  const float pvalid = p.p2d_valid[b];
-  const uint32_t fr = p.front[b];
+  if (threadIdx.x == 0) p.total[0] = carry_ns;
+}
+
+// =============================================================================================
+// rasterisation of one strip into LDS
+// =============================================================================================
+// squared distance to segment ab with the staged 1/|ab|^2 (il < 0 marks a degenerate segment)
+__device__ __forceinline__ float r_seg_fast(float px, float py, float ax, float ay, float bx, float by, float il) {
+  if (il < 0.f) return (px - bx) * (px - bx) + (py - by) * (py - by);
+  const float bax = bx - ax, bay = by - ay;
+  const float tt = fminf(fmaxf((bax * (px - ax) + bay * (py - ay)) * il, 0.f), 1.f);
+  const float qx = ax + tt * bax - px, qy = ay + tt * bay - py;
+  return qx * qx + qy * qy;
+}
+
+// the selection-time twin of r_eval: per-face reciprocals are staged once per face, the only
+// per-pair reciprocal is v_rcp_f32 of the clipped weight sum.  Values agree with r_eval to ~1 ulp;
+// the residual kernels re-evaluate the SELECTED faces with r_eval, so only near-tie orderings and
+// blur-band membership can differ in the last ulp.
+__device__ __forceinline__ void r_eval_fast(const float* T, float xf, float yf, float* pz, bool* inside, float* dist) {
+  const float x0 = T[0], y0 = T[1], z0 = T[2], x1 = T[3], y1 = T[4], z1 = T[5], x2 = T[6], y2 = T[7], z2 = T[8];
+  const float ia = T[9];
+  const float w0 = r_edge(xf, yf, x1, y1, x2, y2) * ia;
+  const float w1 = r_edge(xf, yf, x2, y2, x0, y0) * ia;
+  const float w2 = r_edge(xf, yf, x0, y0, x1, y1) * ia;
+  *inside = w0 > 0.f && w1 > 0.f && w2 > 0.f;
+  const float c0 = fmaxf(w0, 0.f), c1 = fmaxf(w1, 0.f), c2 = fmaxf(w2, 0.f);
+  const float ics = __builtin_amdgcn_rcpf(fmaxf(c0 + c1 + c2, 1e-5f));
+  *pz = (c0 * ics) * z0 + (c1 * ics) * z1 + (c2 * ics) * z2;
+  *dist = fminf(fminf(r_seg_fast(xf, yf, x0, y0, x1, y1, T[10]), r_seg_fast(xf, yf, x0, y0, x2, y2, T[11])),
+                r_seg_fast(xf, yf, x1, y1, x2, y2, T[12]));
+}
+
+struct RawTri {
+  float X[3], Y[3], Z[3];
+};
+__device__ __forceinline__ void r_load_raw(const RasterP& p, const float* vb, int f, RawTri& t) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int vi = p.faces[3 * f + k];
+    t.X[k] = vb[(size_t)vi * 3];
+    t.Y[k] = vb[(size_t)vi * 3 + 1];
+    t.Z[k] = vb[(size_t)vi * 3 + 2];
+  }
+}
+
+__global__ __launch_bounds__(RB) void k_raster_strip(RasterP p) {
+  __shared__ unsigned long long keys[R_CAP * 5];
+  __shared__ float sTri[RB * RT];
+  __shared__ unsigned queue[RQ_CAP];
+  __shared__ float sXf[R_CAP];      // NDC x of the window columns
+  __shared__ float sYf[R_CAP];      // NDC y of the strip rows
+  __shared__ unsigned qcount;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int H = p.H, W = p.W;
   const float blur_d = sqrtf(BLUR_D);
-
-  const int rows = max(1, p.cap / ww);
-  const int nstrips = (wh + rows - 1) / rows;
-  const int nsweeps = nstrips > 1 ? 2 : 1;
-  float sumA = 0.f, sumB = 0.f, sumC = 0.f, sumS1 = 0.f, sumS2 = 0.f, sumCorr = 0.f;   // block totals (uniform)
-
-  for (int sweep = 0; sweep < nsweeps; ++sweep) {
-    for (int strip = 0; strip < nstrips; ++strip) {
-      const int sy0 = y0 + strip * rows, sy1 = min(y1, sy0 + rows - 1);
-      const int npx = (sy1 - sy0 + 1) * ww;
+  const int total = p.total[0];
+  const float rx = W > H ? 2.f * (float)W / (float)H : 2.f, ry = H > W ? 2.f * (float)H / (float)W : 2.f;
+  const float kx = (float)W / rx, ky = (float)H / ry;      // pixels per NDC unit (approximate index only)
+  for (int s = blockIdx.x; s < total; s += gridDim.x) {
+    const int b = p.strip_body[s];
+    const int x0 = p.win[b * 4], ww = p.win[b * 4 + 2];
+    const int sy0 = p.strip_row0[s], nrows = p.strip_rows[s], sy1 = sy0 + nrows - 1;
+    const int x1 = x0 + ww - 1;
+    const int npx = nrows * ww;
+    const float* vb = p.verts + (size_t)b * p.V * 3;
+    __syncthreads();
+    for (int i = tid; i < npx * 5; i += RB) keys[i] = RS_EMPTY;
+    for (int i = tid; i < ww; i += RB) sXf[i] = r_pix_to_ndc(W - 1 - (x0 + i), W, H);
+    for (int i = tid; i < nrows; i += RB) sYf[i] = r_pix_to_ndc(H - 1 - (sy0 + i), H, W);
+    __syncthreads();
+    // strip bounds in NDC for the cheap per-face rejection (NDC decreases with the pixel index)
+    const float sx_hi = sXf[0], sx_lo = sXf[ww - 1], sy_hi = sYf[0], sy_lo = sYf[nrows - 1];
+    RawTri nxt;
+    if (tid < p.F) r_load_raw(p, vb, tid, nxt);
+    for (int chunk = 0; chunk < p.F; chunk += RB) {
+      const int f = chunk + tid;
+      const RawTri cur = nxt;
+      if (f + RB < p.F) r_load_raw(p, vb, f + RB, nxt);     // in flight while this chunk is processed
+      if (tid == 0) qcount = 0u;
+      // ---- step 1: one face per lane: project, reject, count the pixel centres in the blurred bbox ----
+      int xa = 0, xb = -1, ya = 0, yb = -1, cnt = 0;
+      if (f < p.F) {
+        float tx[3], ty[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          tx[k] = p.s * (-cur.X[k]) / cur.Z[k] + p.w1;
+          ty[k] = p.s * (-cur.Y[k]) / cur.Z[k] + p.h1;
+        }
+        const float farea = r_edge(tx[0], ty[0], tx[1], ty[1], tx[2], ty[2]);
+        const float bxmin = fminf(tx[0], fminf(tx[1], tx[2])) - blur_d, bxmax = fmaxf(tx[0], fmaxf(tx[1], tx[2])) + blur_d;
+        const float bymin = fminf(ty[0], fminf(ty[1], ty[2])) - blur_d, bymax = fmaxf(ty[0], fmaxf(ty[1], ty[2])) + blur_d;
+        const bool ok = fminf(cur.Z[0], fminf(cur.Z[1], cur.Z[2])) >= R_KEPS && !(farea <= R_KEPS && farea >= -R_KEPS) &&
+                        bxmin <= sx_hi && bxmax >= sx_lo && bymin <= sy_hi && bymax >= sy_lo;
+        if (ok) {
+          float* T = sTri + tid * RT;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) { T[3 * k] = tx[k]; T[3 * k + 1] = ty[k]; T[3 * k + 2] = cur.Z[k]; }
+          T[9] = 1.f / (r_edge(tx[2], ty[2], tx[0], ty[0], tx[1], ty[1]) + R_KEPS);
+          const float l01 = (tx[1] - tx[0]) * (tx[1] - tx[0]) + (ty[1] - ty[0]) * (ty[1] - ty[0]);
+          const float l02 = (tx[2] - tx[0]) * (tx[2] - tx[0]) + (ty[2] - ty[0]) * (ty[2] - ty[0]);
+          const float l12 = (tx[2] - tx[1]) * (tx[2] - tx[1]) + (ty[2] - ty[1]) * (ty[2] - ty[1]);
+          T[10] = l01 <= R_KEPS ? -1.f : 1.f / l01;
+          T[11] = l02 <= R_KEPS ? -1.f : 1.f / l02;
+          T[12] = l12 <= R_KEPS ? -1.f : 1.f / l12;
+          // approximate pixel range, then the exact test on the tabulated pixel-centre NDC values
+          xa = max(x0, (int)floorf((float)W - 0.5f - (bxmax + 0.5f * rx) * kx) - 1);
+          xb = min(x1, (int)ceilf((float)W - 0.5f - (bxmin + 0.5f * rx) * kx) + 1);
+          ya = max(sy0, (int)floorf((float)H - 0.5f - (bymax + 0.5f * ry) * ky) - 1);
+          yb = min(sy1, (int)ceilf((float)H - 0.5f - (bymin + 0.5f * ry) * ky) + 1);
+          while (xa <= xb && sXf[xa - x0] > bxmax) ++xa;
+          while (xb >= xa && sXf[xb - x0] < bxmin) --xb;
+          while (ya <= yb && sYf[ya - sy0] > bymax) ++ya;
+          while (yb >= ya && sYf[yb - sy0] < bymin) --yb;
+          cnt = max(0, xb - xa + 1) * max(0, yb - ya + 1);
+        }
+      }
+      // wave-aggregated append: prefix sum of the counts inside the wave, one LDS atomic per wave
+      int incl = cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+      }
+      const int wave_total = __shfl(incl, 63, 64);
       __syncthreads();
-      for (int i = tid; i < npx * 5; i += RB) keys[i] = RS_EMPTY;
-      // ---- face-parallel scatter into the LDS window, in chunks of RB faces ------------------------
-      // step 1 (one face per thread): project, reject, and queue the pixel centres inside the blurred
-      // bbox; step 2 (one queued pair per thread): the expensive per-pair evaluation runs with full
-      // lanes instead of inside divergent per-face loops.
-      for (int chunk = 0; chunk < p.F; chunk += RB) {
-        if (tid == 0) qcount = 0u;
-        __syncthreads();
-        const int f = chunk + tid;
-        if (f < p.F) {
+      unsigned base = 0;
+      if (lane == 63 && wave_total > 0) base = atomicAdd(&qcount, (unsigned)wave_total);
+      base = __shfl(base, 63, 64);
+      int pos = (int)base + incl - cnt;
+      if (cnt > 0) {
+        const int nx = xb - xa + 1;
+        int yi = ya, xi = xa;
+        for (int k = 0; k < cnt; ++k, ++pos) {
+          const unsigned poff = (unsigned)((yi - sy0) * ww + (xi - x0));
+          if (pos < RQ_CAP) {
+            queue[pos] = ((unsigned)tid << 16) | poff;
+          } else {            // queue full (very large faces): evaluate in place
+            float pz, d;
+            bool inside;
+            r_eval_fast(sTri + tid * RT, sXf[xi - x0], sYf[yi - sy0], &pz, &inside, &d);
+            r_insert(keys + (size_t)poff * 5, pz, inside, d, f);
+          }
+          if (++xi > xa + nx - 1) { xi = xa; ++yi; }
+        }
+      }
+      __syncthreads();
+      // ---- step 2: one queued (face, pixel) pair per lane -------------------------------------------
+      const int nq = (int)min(qcount, (unsigned)RQ_CAP);
+      for (int i = tid; i < nq; i += RB) {
+        const unsigned e = queue[i];
+        const int lf = (int)(e >> 16), poff = (int)(e & 0xffffu);
+        const int ry_ = poff / ww, rx_ = poff - ry_ * ww;
+        float pz, d;
+        bool inside;
+        r_eval_fast(sTri + lf * RT, sXf[rx_], sYf[ry_], &pz, &inside, &d);
+        r_insert(keys + (size_t)poff * 5, pz, inside, d, chunk + lf);
+      }
+      __syncthreads();
+    }
+    // finished window -> HBM (40 B per pixel, coalesced)
+    unsigned long long* gk = p.gkeys + (size_t)p.strip_koff[s] * 5;
+    for (int i = tid; i < npx * 5; i += RB) gk[i] = keys[i];
+  }
+}
+
+// =============================================================================================
+// residual sums per strip (optimizer.py:432-442, 447-477)
+// =============================================================================================
+__device__ __forceinline__ float r_alpha(const RasterP& p, const float* vb, const unsigned long long* q, float xf, float yf) {
+  float qprod = 1.f;
+  for (int k = 1; k < 5; ++k) {
+    const unsigned long long kk = q[k];
+    if (kk == RS_EMPTY) break;
+    Tri tr;
+    r_load_tri(p, vb, (int)(kk & 0xffffffffu), tr);
+    const float T9[9] = {tr.x[0], tr.y[0], tr.z[0], tr.x[1], tr.y[1], tr.z[1], tr.x[2], tr.y[2], tr.z[2]};
+    float pz, d;
+    bool inside;
+    r_eval(T9, xf, yf, &pz, &inside, &d);
+    const float sd = inside ? -d : d;
+    qprod *= 1.f - 1.f / (1.f + expf(sd / SIGMA_S));          // 1 - sigmoid(-sd/sigma)
+  }
+  return 1.f - qprod;
+}
+
+__global__ __launch_bounds__(RB) void k_raster_sums(RasterP p) {
+  __shared__ float sh[RB / 64];
+  const int tid = threadIdx.x;
+  const int H = p.H, W = p.W, P = H * W;
+  const int total = p.total[0];
+  for (int s = blockIdx.x; s < total; s += gridDim.x) {
+    const int b = p.strip_body[s], t = b / p.N, n = b % p.N;
+    const int x0 = p.win[b * 4], ww = p.win[b * 4 + 2];
+    const int sy0 = p.strip_row0[s], npx = p.strip_rows[s] * ww;
+    const float* vb = p.verts + (size_t)b * p.V * 3;
+    const unsigned long long* gk = p.gkeys + (size_t)p.strip_koff[s] * 5;
+    const float min_z = logf(1.f + expf(p.zmin_lin[t]));                    // optimizer.py:683-688
+    const float max_z = min_z + 1.f + logf(1.f + expf(p.zmax_lin[t]));
+    const float inv_min = 1.f / min_z, inv_max = 1.f / max_z, dspan = inv_min - inv_max;
+    const float pvalid = p.p2d_valid[b];
+    const uint32_t fr = p.front[b];
+    float lA = 0.f, lB = 0.f, lC = 0.f, lS1 = 0.f, lS2 = 0.f, lCorr = 0.f;
+    for (int i = tid; i < npx; i += RB) {
+      const int yi = sy0 + i / ww, xi = x0 + i % ww;
+      const size_t gp = (size_t)t * P + (size_t)yi * W + xi;
+      const unsigned long long* q = gk + (size_t)i * 5;
+      const unsigned long long k0 = q[0];
+      if (k0 != RS_EMPTY) {
+        const float z = __uint_as_float((unsigned)(k0 >> 32));
+        const float m = (z > 0.f ? 1.f : 0.f) * (float)((p.ebits[gp] >> n) & 1u) * pvalid;     // :432-438
+        if (m != 0.f) {
+          const float pred = 1.f / fmaxf(z + 0.2f, p.eps);                                    // :440
+          const float dh = p.depths[gp];
+          const float tg = dh * dspan + inv_max;                                              // :425
+          lA += logf(fmaxf(pred, 1e-3f));
+          lB += logf(fmaxf(tg, 1e-3f));
+          lC += 1.f;
+          if (tg >= 1e-3f) {
+            lS1 += dh / tg;
+            lS2 += (1.f - dh) / tg;
+          }
+        }
+        if (p.zbuf_out) p.zbuf_out[(size_t)b * P + (size_t)yi * W + xi] = z;
+      }
+      if (q[1] != RS_EMPTY) {
+        const float alpha = r_alpha(p, vb, q, r_pix_to_ndc(W - 1 - xi, W, H), r_pix_to_ndc(H - 1 - yi, H, W));
+        const uint32_t wb = p.bits[gp];
+        if ((wb & fr) == 0u) {                                                                  // 1 - acc
+          const float seg = (float)((wb >> n) & 1u);
+          lCorr += alpha * alpha - 2.f * alpha * seg;
+        }
+        if (p.alpha_out) p.alpha_out[(size_t)b * P + (size_t)yi * W + xi] = alpha;
+      }
+    }
+    lA = r_block_sum(lA, sh); lB = r_block_sum(lB, sh); lC = r_block_sum(lC, sh);
+    lS1 = r_block_sum(lS1, sh); lS2 = r_block_sum(lS2, sh); lCorr = r_block_sum(lCorr, sh);
+    if (tid == 0) {
+      float* o = p.partial + (size_t)s * 6;
+      o[0] = lA; o[1] = lB; o[2] = lC; o[3] = lS1; o[4] = lS2; o[5] = lCorr;
+    }
+  }
+}
+
+// per-body totals (fixed order over the body's strips)
+__device__ __forceinline__ void r_body_sums(const RasterP& p, int b, float out[6]) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) out[k] = 0.f;
+  const int first = p.body_first[b], ns = p.body_ns[b];
+  for (int s = first; s < first + ns; ++s)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) out[k] += p.partial[(size_t)s * 6 + k];
+}
+
+// per-body loss values + depth-range partials (also covers bodies that are entirely off screen)
+__global__ void k_raster_body_out(RasterP p) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= p.B) return;
+  float S[6];
+  r_body_sums(p, b, S);
+  const float cnt = S[2] + 1.f;
+  const float diff = S[0] / cnt - S[1] / cnt;                                                  // losses.py:24-27
+  p.depth_body[b] = diff * diff;
+  p.sil_body[b] = p.sil_apply[b] * (p.sil_S[b] + S[5]) / (p.sil_D[b] + 1.f);                  // losses.py:35-38
+  const float gB = p.coef_depth * (-2.f) * diff / cnt;
+  p.dinv[(size_t)b * 2] = gB * S[3];          // d/d(1/min_z) through the target disparity
+  p.dinv[(size_t)b * 2 + 1] = gB * S[4];      // d/d(1/max_z)
+}
+
+// =============================================================================================
+// gradients per strip
+// =============================================================================================
+__global__ __launch_bounds__(RB) void k_raster_grads(RasterP p) {
+  const int tid = threadIdx.x;
+  const int H = p.H, W = p.W, P = H * W;
+  const int total = p.total[0];
+  for (int s = blockIdx.x; s < total; s += gridDim.x) {
+    const int b = p.strip_body[s], t = b / p.N, n = b % p.N;
+    const int x0 = p.win[b * 4], ww = p.win[b * 4 + 2];
+    const int sy0 = p.strip_row0[s], npx = p.strip_rows[s] * ww;
+    const float* vb = p.verts + (size_t)b * p.V * 3;
+    float* gvb = p.gverts + (size_t)b * p.V * 3;
+    const unsigned long long* gk = p.gkeys + (size_t)p.strip_koff[s] * 5;
+    float S[6];
+    r_body_sums(p, b, S);
+    const float cnt = S[2] + 1.f;
+    const float diff = S[0] / cnt - S[1] / cnt;
+    const float gA = p.coef_depth * 2.f * diff / cnt;
+    const float gAlphaScale = p.coef_sil * p.sil_apply[b] * 2.f / (p.sil_D[b] + 1.f);
+    const float pvalid = p.p2d_valid[b];
+    const uint32_t fr = p.front[b];
+    for (int i = tid; i < npx; i += RB) {
+      const int yi = sy0 + i / ww, xi = x0 + i % ww;
+      const size_t gp = (size_t)t * P + (size_t)yi * W + xi;
+      const float yf = r_pix_to_ndc(H - 1 - yi, H, W), xf = r_pix_to_ndc(W - 1 - xi, W, H);
+      const unsigned long long* q = gk + (size_t)i * 5;
+      const unsigned long long k0 = q[0];
+      if (k0 != RS_EMPTY && gA != 0.f) {
+        const float z = __uint_as_float((unsigned)(k0 >> 32));
+        const float m = (z > 0.f ? 1.f : 0.f) * (float)((p.ebits[gp] >> n) & 1u) * pvalid;
+        const float zc = z + 0.2f;
+        if (m != 0.f && zc > p.eps && 1.f / zc > 1e-3f) {
+          const float gpz = gA * (-1.f / zc);
           Tri tr;
-          r_load_tri(p, vb, f, tr);
-          float* T9 = sTri + tid * 9;
+          r_load_tri(p, vb, (int)(k0 & 0xffffffffu), tr);
+          const float area = r_edge(tr.x[2], tr.y[2], tr.x[0], tr.y[0], tr.x[1], tr.y[1]) + R_KEPS;
+          float w[3] = {r_edge(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2]) / area,
+                        r_edge(xf, yf, tr.x[2], tr.y[2], tr.x[0], tr.y[0]) / area,
+                        r_edge(xf, yf, tr.x[0], tr.y[0], tr.x[1], tr.y[1]) / area};
+          const float c[3] = {fmaxf(w[0], 0.f), fmaxf(w[1], 0.f), fmaxf(w[2], 0.f)};
+          const float craw = c[0] + c[1] + c[2];
+          const float cs = fmaxf(craw, 1e-5f);
+          // pz = sum (c_i/cs) z_i
+          float gwc[3], gz[3];
+          float dotg = 0.f;
 #pragma unroll
-          for (int k = 0; k < 3; ++k) { T9[3 * k] = tr.x[k]; T9[3 * k + 1] = tr.y[k]; T9[3 * k + 2] = tr.z[k]; }
-          const float farea = r_edge(tr.x[0], tr.y[0], tr.x[1], tr.y[1], tr.x[2], tr.y[2]);
-          const bool ok = fminf(tr.z[0], fminf(tr.z[1], tr.z[2])) >= R_KEPS && !(farea <= R_KEPS && farea >= -R_KEPS);
-          if (ok) {
-            const float bxmin = fminf(tr.x[0], fminf(tr.x[1], tr.x[2])) - blur_d, bxmax = fmaxf(tr.x[0], fmaxf(tr.x[1], tr.x[2])) + blur_d;
-            const float bymin = fminf(tr.y[0], fminf(tr.y[1], tr.y[2])) - blur_d, bymax = fmaxf(tr.y[0], fmaxf(tr.y[1], tr.y[2])) + blur_d;
-            // NDC decreases with the pixel index
-            const int xa = max(x0, (int)floorf(r_ndc_to_pix(bxmax, W, H)) - 1), xb = min(x1, (int)ceilf(r_ndc_to_pix(bxmin, W, H)) + 1);
-            const int ya = max(sy0, (int)floorf(r_ndc_to_pix(bymax, H, W)) - 1), yb = min(sy1, (int)ceilf(r_ndc_to_pix(bymin, H, W)) + 1);
-            for (int yi = ya; yi <= yb; ++yi) {
-              const float yf = sYf[yi];
-              if (yf > bymax || yf < bymin) continue;
-              for (int xi = xa; xi <= xb; ++xi) {
-                const float xf = sXf[xi];
-                if (xf > bxmax || xf < bxmin) continue;
-                const unsigned poff = (unsigned)((yi - sy0) * ww + (xi - x0));
-                const unsigned pos = atomicAdd(&qcount, 1u);
-                if (pos < RQ_CAP) {
-                  queue[pos] = ((unsigned)tid << 16) | poff;
-                } else {          // queue full (very large faces): evaluate in place
-                  float pz, d;
-                  bool inside;
-                  r_eval(T9, xf, yf, &pz, &inside, &d);
-                  r_insert(keys + (size_t)poff * 5, pz, inside, d, f);
-                }
-              }
-            }
+          for (int k = 0; k < 3; ++k) {
+            gz[k] = gpz * c[k] / cs;
+            gwc[k] = gpz * tr.z[k];          // d/d(normalised clipped weight)
+            dotg += gwc[k] * c[k];
           }
-        }
-        __syncthreads();
-        const int nq = (int)min(qcount, (unsigned)RQ_CAP);
-        for (int i = tid; i < nq; i += RB) {
-          const unsigned e = queue[i];
-          const int lf = (int)(e >> 16), poff = (int)(e & 0xffffu);
-          const int yi = sy0 + poff / ww, xi = x0 + poff % ww;
-          float pz, d;
-          bool inside;
-          r_eval(sTri + lf * 9, sXf[xi], sYf[yi], &pz, &inside, &d);
-          r_insert(keys + (size_t)poff * 5, pz, inside, d, chunk + lf);
-        }
-        __syncthreads();
-      }
-      __syncthreads();
-      // ---- pass A: residual sums (first sweep), pass B: gradients (last sweep) ---------------------
-      const bool doA = sweep == 0, doB = sweep == nsweeps - 1;
-      float lA = 0.f, lB = 0.f, lC = 0.f, lS1 = 0.f, lS2 = 0.f, lCorr = 0.f;
-      if (doA) {
-        for (int i = tid; i < npx; i += RB) {
-          const int yi = sy0 + i / ww, xi = x0 + i % ww;
-          const size_t gp = (size_t)t * P + (size_t)yi * W + xi;
-          const uint32_t wb = p.bits[gp];
-          const unsigned long long k0 = keys[(size_t)i * 5];
-          if (k0 != RS_EMPTY) {
-            const float z = __uint_as_float((unsigned)(k0 >> 32));
-            const float m = (z > 0.f ? 1.f : 0.f) * (float)((p.ebits[gp] >> n) & 1u) * pvalid;     // :432-438
-            if (m != 0.f) {
-              const float pred = 1.f / fmaxf(z + 0.2f, p.eps);                                    // :440
-              const float dh = p.depths[gp];
-              const float tg = dh * dspan + inv_max;                                              // :425
-              lA += logf(fmaxf(pred, 1e-3f));
-              lB += logf(fmaxf(tg, 1e-3f));
-              lC += 1.f;
-              if (tg >= 1e-3f) {
-                lS1 += dh / tg;
-                lS2 += (1.f - dh) / tg;
-              }
-            }
-          }
-          // soft silhouette of this pixel
-          float qprod = 1.f;
-          const float yf = r_pix_to_ndc(H - 1 - yi, H, W), xf = r_pix_to_ndc(W - 1 - xi, W, H);
-          for (int k = 1; k < 5; ++k) {
-            const unsigned long long kk = keys[(size_t)i * 5 + k];
-            if (kk == RS_EMPTY) break;
-            Tri tr;
-            r_load_tri(p, vb, (int)(kk & 0xffffffffu), tr);
-            const float area = r_edge(tr.x[2], tr.y[2], tr.x[0], tr.y[0], tr.x[1], tr.y[1]) + R_KEPS;
-            const bool inside = r_edge(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2]) / area > 0.f &&
-                                r_edge(xf, yf, tr.x[2], tr.y[2], tr.x[0], tr.y[0]) / area > 0.f &&
-                                r_edge(xf, yf, tr.x[0], tr.y[0], tr.x[1], tr.y[1]) / area > 0.f;
-            float tt;
-            bool dg;
-            const float d = fminf(fminf(r_seg(xf, yf, tr.x[0], tr.y[0], tr.x[1], tr.y[1], &tt, &dg),
-                                        r_seg(xf, yf, tr.x[0], tr.y[0], tr.x[2], tr.y[2], &tt, &dg)),
-                                  r_seg(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2], &tt, &dg));
-            const float sd = inside ? -d : d;
-            const float pk = 1.f / (1.f + expf(sd / SIGMA_S));                                   // sigmoid(-sd/sigma)
-            qprod *= 1.f - pk;
-          }
-          const float alpha = 1.f - qprod;
-          if ((wb & fr) == 0u) {                                                                  // 1 - acc
-            const float seg = (float)((wb >> n) & 1u);
-            lCorr += alpha * alpha - 2.f * alpha * seg;
-          }
-          if (p.zbuf_out && k0 != RS_EMPTY) p.zbuf_out[(size_t)b * P + (size_t)yi * W + xi] = __uint_as_float((unsigned)(k0 >> 32));
-          if (p.alpha_out) p.alpha_out[(size_t)b * P + (size_t)yi * W + xi] = alpha;
-        }
-        sumA += r_block_sum(lA, sh);
-        sumB += r_block_sum(lB, sh);
-        sumC += r_block_sum(lC, sh);
-        sumS1 += r_block_sum(lS1, sh);
-        sumS2 += r_block_sum(lS2, sh);
-        sumCorr += r_block_sum(lCorr, sh);
-      }
-      if (doB && gvb) {
-        const float cnt = sumC + 1.f;
-        const float diff = sumA / cnt - sumB / cnt;                                               // losses.py:24-27
-        const float gA = p.coef_depth * 2.f * diff / cnt;
-        const float gAlphaScale = p.coef_sil * apply * 2.f / (Dn + 1.f);
-        for (int i = tid; i < npx; i += RB) {
-          const int yi = sy0 + i / ww, xi = x0 + i % ww;
-          const size_t gp = (size_t)t * P + (size_t)yi * W + xi;
-          const float yf = r_pix_to_ndc(H - 1 - yi, H, W), xf = r_pix_to_ndc(W - 1 - xi, W, H);
-          const unsigned long long k0 = keys[(size_t)i * 5];
-          if (k0 != RS_EMPTY && gA != 0.f) {
-            const float z = __uint_as_float((unsigned)(k0 >> 32));
-            const float m = (z > 0.f ? 1.f : 0.f) * (float)((p.ebits[gp] >> n) & 1u) * pvalid;
-            const float zc = z + 0.2f;
-            if (m != 0.f && zc > p.eps && 1.f / zc > 1e-3f) {
-              const float gpz = gA * (-1.f / zc);
-              Tri tr;
-              r_load_tri(p, vb, (int)(k0 & 0xffffffffu), tr);
-              const float area = r_edge(tr.x[2], tr.y[2], tr.x[0], tr.y[0], tr.x[1], tr.y[1]) + R_KEPS;
-              float w[3] = {r_edge(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2]) / area,
-                            r_edge(xf, yf, tr.x[2], tr.y[2], tr.x[0], tr.y[0]) / area,
-                            r_edge(xf, yf, tr.x[0], tr.y[0], tr.x[1], tr.y[1]) / area};
-              const float c[3] = {fmaxf(w[0], 0.f), fmaxf(w[1], 0.f), fmaxf(w[2], 0.f)};
-              const float craw = c[0] + c[1] + c[2];
-              const float cs = fmaxf(craw, 1e-5f);
-              // pz = sum (c_i/cs) z_i
-              float gwc[3], gz[3];
-              float dotg = 0.f;
+          float gw[3];
 #pragma unroll
-              for (int k = 0; k < 3; ++k) {
-                gz[k] = gpz * c[k] / cs;
-                gwc[k] = gpz * tr.z[k];          // d/d(normalised clipped weight)
-                dotg += gwc[k] * c[k];
-              }
-              float gw[3];
-#pragma unroll
-              for (int k = 0; k < 3; ++k) {
-                float gc = gwc[k] / cs - (craw > 1e-5f ? dotg / (cs * cs) : 0.f);
-                gw[k] = w[k] > 0.f ? gc : 0.f;
-              }
-              // w_i = e_i / area
-              const float ge[3] = {gw[0] / area, gw[1] / area, gw[2] / area};
-              const float garea = -(gw[0] * w[0] + gw[1] * w[1] + gw[2] * w[2]) / area;
-              float gx[3] = {0, 0, 0}, gy[3] = {0, 0, 0};
-              // e0 = edge(p; v1, v2), e1 = edge(p; v2, v0), e2 = edge(p; v0, v1); area = edge(v2; v0, v1)
-#define EDGE_ADJ(gE, A, Bv)                                     \
-  gx[A] += (gE) * (yf - tr.y[Bv]);  gy[A] += (gE) * (tr.x[Bv] - xf); \
+          for (int k = 0; k < 3; ++k) {
+            const float gc = gwc[k] / cs - (craw > 1e-5f ? dotg / (cs * cs) : 0.f);
+            gw[k] = w[k] > 0.f ? gc : 0.f;
+          }
+          // w_i = e_i / area
+          const float ge[3] = {gw[0] / area, gw[1] / area, gw[2] / area};
+          const float garea = -(gw[0] * w[0] + gw[1] * w[1] + gw[2] * w[2]) / area;
+          float gx[3] = {0, 0, 0}, gy[3] = {0, 0, 0};
+          // e0 = edge(p; v1, v2), e1 = edge(p; v2, v0), e2 = edge(p; v0, v1); area = edge(v2; v0, v1)
+#define EDGE_ADJ(gE, A, Bv)                                           \
+  gx[A] += (gE) * (yf - tr.y[Bv]);  gy[A] += (gE) * (tr.x[Bv] - xf);  \
   gx[Bv] += (gE) * (-(yf - tr.y[A])); gy[Bv] += (gE) * (xf - tr.x[A]);
-              EDGE_ADJ(ge[0], 1, 2)
-              EDGE_ADJ(ge[1], 2, 0)
-              EDGE_ADJ(ge[2], 0, 1)
+          EDGE_ADJ(ge[0], 1, 2)
+          EDGE_ADJ(ge[1], 2, 0)
+          EDGE_ADJ(ge[2], 0, 1)
 #undef EDGE_ADJ
-              // area = (x2-x0)(y1-y0) - (y2-y0)(x1-x0)
-              gx[2] += garea * (tr.y[1] - tr.y[0]);  gy[2] += garea * (-(tr.x[1] - tr.x[0]));
-              gx[0] += garea * (tr.y[2] - tr.y[1]);  gy[0] += garea * (tr.x[1] - tr.x[2]);
-              gx[1] += garea * (-(tr.y[2] - tr.y[0])); gy[1] += garea * (tr.x[2] - tr.x[0]);
+          // area = (x2-x0)(y1-y0) - (y2-y0)(x1-x0)
+          gx[2] += garea * (tr.y[1] - tr.y[0]);  gy[2] += garea * (-(tr.x[1] - tr.x[0]));
+          gx[0] += garea * (tr.y[2] - tr.y[1]);  gy[0] += garea * (tr.x[1] - tr.x[2]);
+          gx[1] += garea * (-(tr.y[2] - tr.y[0])); gy[1] += garea * (tr.x[2] - tr.x[0]);
 #pragma unroll
-              for (int k = 0; k < 3; ++k) r_scatter(p, gvb, tr, k, gx[k], gy[k], gz[k]);
+          for (int k = 0; k < 3; ++k) r_scatter(p, gvb, tr, k, gx[k], gy[k], gz[k]);
+        }
+      }
+      // silhouette
+      const uint32_t wb = p.bits[gp];
+      if (gAlphaScale != 0.f && (wb & fr) == 0u && q[1] != RS_EMPTY) {
+        float pk[4], sgn[4], tpar[4];
+        int ea[4], eb[4], fidx[4];
+        bool dgn[4];
+        int ns = 0;
+        float qprod = 1.f;
+        for (int k = 1; k < 5; ++k) {
+          const unsigned long long kk = q[k];
+          if (kk == RS_EMPTY) break;
+          Tri tr;
+          r_load_tri(p, vb, (int)(kk & 0xffffffffu), tr);
+          const float area = r_edge(tr.x[2], tr.y[2], tr.x[0], tr.y[0], tr.x[1], tr.y[1]) + R_KEPS;
+          const bool inside = r_edge(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2]) / area > 0.f &&
+                              r_edge(xf, yf, tr.x[2], tr.y[2], tr.x[0], tr.y[0]) / area > 0.f &&
+                              r_edge(xf, yf, tr.x[0], tr.y[0], tr.x[1], tr.y[1]) / area > 0.f;
+          float t01, t02, t12;
+          bool g01, g02, g12;
+          const float d01 = r_seg(xf, yf, tr.x[0], tr.y[0], tr.x[1], tr.y[1], &t01, &g01);
+          const float d02 = r_seg(xf, yf, tr.x[0], tr.y[0], tr.x[2], tr.y[2], &t02, &g02);
+          const float d12 = r_seg(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2], &t12, &g12);
+          float d;
+          if (d01 <= d02 && d01 <= d12) { d = d01; ea[ns] = 0; eb[ns] = 1; tpar[ns] = t01; dgn[ns] = g01; }
+          else if (d02 <= d01 && d02 <= d12) { d = d02; ea[ns] = 0; eb[ns] = 2; tpar[ns] = t02; dgn[ns] = g02; }
+          else { d = d12; ea[ns] = 1; eb[ns] = 2; tpar[ns] = t12; dgn[ns] = g12; }
+          const float sd = inside ? -d : d;
+          pk[ns] = 1.f / (1.f + expf(sd / SIGMA_S));
+          sgn[ns] = inside ? -1.f : 1.f;
+          fidx[ns] = (int)(kk & 0xffffffffu);
+          qprod *= 1.f - pk[ns];
+          ++ns;
+        }
+        const float alpha = 1.f - qprod;
+        const float seg = (float)((wb >> n) & 1u);
+        const float galpha = gAlphaScale * (alpha - seg);
+        if (galpha != 0.f) {
+          for (int k = 0; k < ns; ++k) {
+            // d alpha / d sd_k = -(1/sigma) p_k prod_j (1 - p_j)
+            const float gd = galpha * (-(1.f / SIGMA_S)) * pk[k] * qprod * sgn[k];
+            if (gd == 0.f) continue;
+            Tri tr;
+            r_load_tri(p, vb, fidx[k], tr);
+            const int a = ea[k], bb = eb[k];
+            const float tt = tpar[k];
+            float qx, qy, ga, gb;
+            if (dgn[k]) { qx = tr.x[bb] - xf; qy = tr.y[bb] - yf; ga = 0.f; gb = 1.f; }
+            else {
+              qx = tr.x[a] + tt * (tr.x[bb] - tr.x[a]) - xf;
+              qy = tr.y[a] + tt * (tr.y[bb] - tr.y[a]) - yf;
+              ga = 1.f - tt; gb = tt;
             }
-          }
-          // silhouette
-          const uint32_t wb = p.bits[gp];
-          if (gAlphaScale != 0.f && (wb & fr) == 0u) {
-            float pk[4], sgn[4], tpar[4];
-            int ea[4], eb[4], fidx[4];
-            bool dgn[4];
-            int ns = 0;
-            float qprod = 1.f;
-            for (int k = 1; k < 5; ++k) {
-              const unsigned long long kk = keys[(size_t)i * 5 + k];
-              if (kk == RS_EMPTY) break;
-              Tri tr;
-              r_load_tri(p, vb, (int)(kk & 0xffffffffu), tr);
-              const float area = r_edge(tr.x[2], tr.y[2], tr.x[0], tr.y[0], tr.x[1], tr.y[1]) + R_KEPS;
-              const bool inside = r_edge(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2]) / area > 0.f &&
-                                  r_edge(xf, yf, tr.x[2], tr.y[2], tr.x[0], tr.y[0]) / area > 0.f &&
-                                  r_edge(xf, yf, tr.x[0], tr.y[0], tr.x[1], tr.y[1]) / area > 0.f;
-              float t01, t02, t12;
-              bool g01, g02, g12;
-              const float d01 = r_seg(xf, yf, tr.x[0], tr.y[0], tr.x[1], tr.y[1], &t01, &g01);
-              const float d02 = r_seg(xf, yf, tr.x[0], tr.y[0], tr.x[2], tr.y[2], &t02, &g02);
-              const float d12 = r_seg(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2], &t12, &g12);
-              float d;
-              if (d01 <= d02 && d01 <= d12) { d = d01; ea[ns] = 0; eb[ns] = 1; tpar[ns] = t01; dgn[ns] = g01; }
-              else if (d02 <= d01 && d02 <= d12) { d = d02; ea[ns] = 0; eb[ns] = 2; tpar[ns] = t02; dgn[ns] = g02; }
-              else { d = d12; ea[ns] = 1; eb[ns] = 2; tpar[ns] = t12; dgn[ns] = g12; }
-              const float sd = inside ? -d : d;
-              pk[ns] = 1.f / (1.f + expf(sd / SIGMA_S));
-              sgn[ns] = inside ? -1.f : 1.f;
-              fidx[ns] = (int)(kk & 0xffffffffu);
-              qprod *= 1.f - pk[ns];
-              ++ns;
-            }
-            const float alpha = 1.f - qprod;
-            const float seg = (float)((wb >> n) & 1u);
-            const float galpha = gAlphaScale * (alpha - seg);
-            if (galpha != 0.f) {
-              for (int k = 0; k < ns; ++k) {
-                // d alpha / d sd_k = -(1/sigma) p_k prod_j (1 - p_j)
-                const float gd = galpha * (-(1.f / SIGMA_S)) * pk[k] * qprod * sgn[k];
-                if (gd == 0.f) continue;
-                Tri tr;
-                r_load_tri(p, vb, fidx[k], tr);
-                const int a = ea[k], bb = eb[k];
-                const float tt = tpar[k];
-                float qx, qy, ga, gb;
-                if (dgn[k]) { qx = tr.x[bb] - xf; qy = tr.y[bb] - yf; ga = 0.f; gb = 1.f; }
-                else {
-                  qx = tr.x[a] + tt * (tr.x[bb] - tr.x[a]) - xf;
-                  qy = tr.y[a] + tt * (tr.y[bb] - tr.y[a]) - yf;
-                  ga = 1.f - tt; gb = tt;
-                }
-                r_scatter(p, gvb, tr, a, gd * ga * 2.f * qx, gd * ga * 2.f * qy, 0.f);
-                r_scatter(p, gvb, tr, bb, gd * gb * 2.f * qx, gd * gb * 2.f * qy, 0.f);
-              }
-            }
+            r_scatter(p, gvb, tr, a, gd * ga * 2.f * qx, gd * ga * 2.f * qy, 0.f);
+            r_scatter(p, gvb, tr, bb, gd * gb * 2.f * qx, gd * gb * 2.f * qy, 0.f);
           }
         }
       }
     }
-  }
-  if (tid == 0) {
-    const float cnt = sumC + 1.f;
-    const float diff = sumA / cnt - sumB / cnt;
-    p.depth_body[b] = diff * diff;
-    p.sil_body[b] = apply * (Sn + sumCorr) / (Dn + 1.f);
-    // d/d(1/min_z), d/d(1/max_z) through the target disparity
-    const float gB = p.coef_depth * (-2.f) * diff / cnt;
-    p.dinv[(size_t)b * 2] = gB * sumS1;
-    p.dinv[(size_t)b * 2 + 1] = gB * sumS2;
   }
 }
 
@@ -517,17 +706,30 @@ __global__ void k_fill(float* x, size_t n, float v) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] = v;
 }
 
+static size_t r_align(size_t x) { return (x + 255) & ~(size_t)255; }
+static int r_max_strips(int B, int H, int W) {
+  const int rows = R_CAP / W > 0 ? R_CAP / W : 1;      // narrowest strips happen for full-width windows
+  return B * ((H + rows - 1) / rows);
+}
+
+extern "C" size_t mh_raster_workspace_bytes(int T, int N, int H, int W) {
+  const size_t B = (size_t)T * N, ms = (size_t)r_max_strips((int)B, H, W);
+  return r_align(B * 4 * 4) + 2 * r_align(B * 4) + r_align(4) + 3 * r_align(ms * 4) + r_align(ms * 8) + r_align(ms * 6 * 4) +
+         r_align(B * 2 * 4) + r_align(B * (size_t)H * W * 5 * 8);
+}
+
 extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const float* cam_K_host, const float* verts,
                                const int32_t* faces, const uint32_t* bits, const uint32_t* ebits, const float* depths,
                                const float* zmin_lin, const float* zmax_lin, const float* pose2d_valid,
                                const uint32_t* front, const float* sil_apply, const float* sil_D, const float* sil_S,
                                float coef_depth, float coef_sil, float eps, float* gverts, float* gzmin, float* gzmax,
-                               float* depth_body, float* sil_body, float* dinv_ws, float* zbuf_out, float* alpha_out,
+                               float* depth_body, float* sil_body, void* ws, float* zbuf_out, float* alpha_out,
                                void* stream) {
   MH_CHECK(cam_K_host && verts && faces && bits && ebits && depths && zmin_lin && zmax_lin && pose2d_valid && front &&
-               sil_apply && sil_D && sil_S && depth_body && sil_body && dinv_ws,
+               sil_apply && sil_D && sil_S && depth_body && sil_body && ws,
            "null argument");
   MH_CHECK(T > 0 && N > 0 && N <= 32 && V > 0 && F > 0 && H > 0 && W > 0, "empty input");
+  MH_CHECK(W <= R_CAP, "image wider than one LDS strip");
   RasterP p;
   p.B = T * N; p.N = N; p.V = V; p.F = F; p.H = H; p.W = W;
   // transforms.py:222-255 with image_size = (W, H)
@@ -551,30 +753,48 @@ extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const f
   p.zmin_lin = zmin_lin; p.zmax_lin = zmax_lin; p.p2d_valid = pose2d_valid; p.front = front;
   p.sil_apply = sil_apply; p.sil_D = sil_D; p.sil_S = sil_S;
   p.coef_depth = coef_depth; p.coef_sil = coef_sil; p.eps = eps;
-  p.gverts = gverts; p.depth_body = depth_body; p.sil_body = sil_body; p.dinv = dinv_ws;
+  p.gverts = gverts; p.depth_body = depth_body; p.sil_body = sil_body;
   p.zbuf_out = zbuf_out; p.alpha_out = alpha_out;
+  // carve the workspace
+  const size_t B = (size_t)p.B;
+  p.max_strips = r_max_strips(p.B, H, W);
+  const size_t ms = (size_t)p.max_strips;
+  char* c = (char*)ws;
+  p.win = (int*)c; c += r_align(B * 4 * 4);
+  p.body_first = (int*)c; c += r_align(B * 4);
+  p.body_ns = (int*)c; c += r_align(B * 4);
+  p.total = (int*)c; c += r_align(4);
+  p.strip_body = (int*)c; c += r_align(ms * 4);
+  p.strip_row0 = (int*)c; c += r_align(ms * 4);
+  p.strip_rows = (int*)c; c += r_align(ms * 4);
+  p.strip_koff = (long long*)c; c += r_align(ms * 8);
+  p.partial = (float*)c; c += r_align(ms * 6 * 4);
+  p.dinv = (float*)c; c += r_align(B * 2 * 4);
+  p.gkeys = (unsigned long long*)c;
   hipStream_t st = (hipStream_t)stream;
   if (zbuf_out) {   // -1 = empty, like fragments.zbuf
     hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, st, zbuf_out, (size_t)p.B * H * W, -1.f);
     MH_LAUNCH_CHECK();
   }
   if (alpha_out) MH_HIP(hipMemsetAsync(alpha_out, 0, (size_t)p.B * H * W * sizeof(float), st));
-  // LDS budget (160 KiB per CU, one body per CU): keys get what the face staging leaves over
-  const size_t fixed = (size_t)RB * 9 * 4 + (size_t)RQ_CAP * 4 + (size_t)(W + H) * 4 + 1024 /* static + slack */;
-  const size_t lds_total = 160 * 1024;
-  MH_CHECK(fixed + (size_t)W * 40 <= lds_total, "image too wide for the LDS window");
-  p.cap = (int)((lds_total - fixed) / 40);
-  if (p.cap > 65535) p.cap = 65535;            // pixel offsets are 16 bits in the candidate queue
-  const size_t lds = (size_t)p.cap * 40 + (size_t)RB * 9 * 4 + (size_t)RQ_CAP * 4 + (size_t)(W + H) * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    MH_HIP(hipFuncSetAttribute((const void*)k_raster_terms, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_total - 1024)));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(k_raster_terms, dim3(p.B), dim3(RB), lds, st, p);
+  hipLaunchKernelGGL(k_raster_windows, dim3((p.B + 3) / 4), dim3(256), 0, st, p);
   MH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_raster_strip_table, dim3(1), dim3(1024), 0, st, p);
+  MH_LAUNCH_CHECK();
+  // persistent grids over the device-side work list (the strip count is only known on the device)
+  const int grid = 256 * 3 * 4;
+  hipLaunchKernelGGL(k_raster_strip, dim3(grid), dim3(RB), 0, st, p);
+  MH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_raster_sums, dim3(grid), dim3(RB), 0, st, p);
+  MH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_raster_body_out, dim3((p.B + 255) / 256), dim3(256), 0, st, p);
+  MH_LAUNCH_CHECK();
+  if (gverts) {
+    hipLaunchKernelGGL(k_raster_grads, dim3(grid), dim3(RB), 0, st, p);
+    MH_LAUNCH_CHECK();
+  }
   if (gzmin && gzmax) {
-    hipLaunchKernelGGL(k_depth_range_grads, dim3((T + 127) / 128), dim3(128), 0, st, T, N, (const float*)dinv_ws, zmin_lin,
+    hipLaunchKernelGGL(k_depth_range_grads, dim3((T + 127) / 128), dim3(128), 0, st, T, N, (const float*)p.dinv, zmin_lin,
                        zmax_lin, gzmin, gzmax);
     MH_LAUNCH_CHECK();
   }

@@ -16,7 +16,7 @@ Per cycle the ranks exchange, over ``torch.distributed`` (backend "nccl" == RCCL
 
 The reference has no distributed path at all; this file is new functionality and is
 parity-tested against the single-process run.  The compute engine is duck-typed (``SequenceEngine``
-on the GPU; the CPU tests plug in an oracle-backed engine with the same methods).
+on the GPU; the CPU tests plug in a torch-CPU stand-in with the same methods).
 """
 import numpy as np
 import torch

@@ -1,0 +1,147 @@
+"""torch-CPU stand-in for ``mhhip.sequence.SequenceEngine`` with the same duck-typed interface, so
+that the frame-sharded driver (mhhip/sharded.py: halo exchange, shared-gradient all-reduce, one-euro
+state hand-off) can be exercised with world_size > 1 on the gloo backend without a GPU.  The maths
+comes from the oracle (tests may use it); only the raster-free terms are modelled."""
+import math
+
+import numpy as np
+import torch
+
+from oracle import fit_oracle as fo
+from oracle import lbs_oracle as lo
+
+
+def one_euro_shard_np(x, min_cutoff, beta, first_frame, state, frame_rate=25):
+    y = np.array(x, dtype=np.float32, copy=True)
+    two_pi = 2 * math.pi
+    if state is None:
+        x_prev, dx_prev = y[0].copy(), np.zeros_like(y[0])
+        t_prev = np.zeros_like(y[0])
+        start = 1
+    else:
+        x_prev, dx_prev = state[0].reshape(y[0].shape).copy(), state[1].reshape(y[0].shape).copy()
+        t = np.float32(0)
+        for i in range(1, first_frame):
+            t = np.float32(t + np.float32(i / frame_rate))
+        t_prev = np.full_like(y[0], t)
+        start = 0
+    time_i = t_prev.copy()
+    for k in range(start, len(y)):
+        i = first_frame + k
+        time_i = time_i + (i / frame_rate)
+        xi = y[k].copy()
+        t_e = time_i - t_prev
+        r = two_pi * 1.0 * t_e
+        a_d = r / (r + 1)
+        dx_hat = a_d * ((xi - x_prev) / t_e) + (1 - a_d) * dx_prev
+        r = two_pi * (float(min_cutoff) + float(beta) * np.abs(dx_hat)) * t_e
+        a = r / (r + 1)
+        x_hat = a * xi + (1 - a) * x_prev
+        x_prev, dx_prev, t_prev = x_hat, dx_hat, time_i
+        y[k] = x_hat
+    return y, (x_prev.reshape(-1).copy(), dx_prev.reshape(-1).copy())
+
+
+class CpuShardEngine(object):
+    def __init__(self, model, image_size, T, N, cam_K, coefs, batch_size, pose2d, poses_ref, valid, betas_ref):
+        self.model, self.T, self.N, self.B = model, T, N, T * N
+        self.W, self.H = image_size
+        self.K = torch.tensor(np.asarray(cam_K, np.float32))[None]
+        self.c = coefs
+        self.batch = batch_size
+        self.nbatches = (T + batch_size - 1) // batch_size
+        B = self.B
+        self.sizes = [B * 3, B * 72, T, T, N * 10, N]
+        self.offs = np.concatenate([[0], np.cumsum(self.sizes)]).astype(np.int64)
+        n = int(self.offs[-1])
+        self.params, self.grads = torch.zeros(n), torch.zeros(n)
+        self.sq, self.buf = torch.zeros(n), torch.zeros(n)
+        self.shared_lo = int(self.offs[4])
+        self.pose2d = torch.tensor(pose2d).view(B, 17, 3)
+        self.poses_ref = torch.tensor(poses_ref).view(B, 72)
+        self.valid = torch.tensor(valid).view(B, 1)
+        self.betas_ref = torch.tensor(betas_ref).view(N, 10)
+        self.verts = None
+        self.verts_filt = None
+        self.pT_filt = None
+        self.halo = None
+        self.log = torch.zeros(64, 16)
+
+    def leaf(self, name, buf=None):
+        buf = self.params if buf is None else buf
+        T, N = self.T, self.N
+        i, shape = {'poses_T': (0, (T, N, 3)), 'poses_smpl': (1, (T, N, 72)), 'zmin_lin': (2, (T,)),
+                    'zmax_lin': (3, (T,)), 'betas': (4, (N, 10)), 'xscale': (5, (N,))}[name]
+        return buf[int(self.offs[i]):int(self.offs[i + 1])].view(*shape)
+
+    def _verts(self, p):
+        T, N = self.T, self.N
+        be = self.leaf('betas', p).unsqueeze(0).expand(T, N, 10).reshape(-1, 10)
+        out = lo.smpl_forward(self.model, be, self.leaf('poses_smpl', p).reshape(-1, 72))
+        s = torch.pow(torch.tensor(1.1), self.leaf('xscale', p)).view(1, N, 1, 1)
+        pT = self.leaf('poses_T', p).view(T, N, 1, 3)
+        return s * out['verts'].view(T, N, -1, 3) + pT, s * out['joints_alphapose'].view(T, N, 17, 3) + pT
+
+    def forward(self):
+        with torch.no_grad():
+            self.verts = self._verts(self.params)[0].reshape(self.B, -1, 3).clone()
+
+    def cycle_begin(self):
+        self.grads.zero_()
+        self.forward()
+
+    def cycle_finish(self, row, use_images=True, raster=None):
+        T, N, c = self.T, self.N, self.c
+        p = self.params.clone().requires_grad_(True)
+        verts, joints = self._verts(p)
+        uv = fo.project_points(joints.view(-1, 17, 3), self.K.expand(self.B, 3, 3)).view(self.B, 17, 2)
+        conf = (self.pose2d[..., 2:3] >= 0.5).float()
+        nrm = torch.tensor([float(self.W), float(self.H)])
+        l2d = ((conf * uv / nrm - conf * self.pose2d[..., :2] / nrm) ** 2).sum()
+        pr = (self.valid * self.poses_ref - self.valid * self.leaf('poses_smpl', p).view(-1, 72)).abs().sum()
+        lb = T * (self.leaf('betas', p) - self.betas_ref).abs().sum()
+        s = torch.pow(torch.tensor(1.1), self.leaf('xscale', p))
+        s_avg, s_per = ((s - 1).sum()) ** 2, ((s - 1) ** 2).mean()
+        h = self.halo or {}
+        pT = self.leaf('poses_T', p)
+        seq = [pT] if h.get('pT_prev') is None else [h['pT_prev'].view(1, N, 3), pT]
+        own = torch.cat(seq)                                   # pairs (t-1, t) owned by the owner of t
+        vel = ((own[1:] - own[:-1]) ** 2).sum()
+        if h.get('pT_next') is not None:                       # the neighbour's pair still pulls on our last frame
+            vel_n = ((h['pT_next'].view(N, 3) - pT[-1]) ** 2).sum()
+        else:
+            vel_n = torch.zeros(())
+        filt = torch.zeros(())
+        filt_n = torch.zeros(())
+        if self.verts_filt is not None and self.pT_filt is not None:
+            v = verts.view(T, -1)
+            vf = self.verts_filt.view(T, -1)
+            if h.get('v_prev') is not None:
+                v = torch.cat([h['v_prev'].view(1, -1), v])
+                vf = torch.cat([h['vf_prev'].view(1, -1), vf])
+            filt = (((v[1:] - v[:-1]) - (vf[1:] - vf[:-1])) ** 2).sum()
+            if h.get('v_next') is not None:
+                filt_n = (((h['v_next'].view(-1) - v[-1]) - (h['vf_next'].view(-1) - vf[-1])) ** 2).sum()
+        total = (c['proj2d'] * l2d + c['reg_poses'] * (pr + lb)
+                 + self.nbatches * (c['reg_scales'] * s_per + float(c['reg_scales'] > 0) * s_avg)
+                 + c['reg_velocity'] * (vel + vel_n) + c['reg_verts_filter'] * (filt + filt_n))
+        total.backward()
+        self.grads.copy_(p.grad)
+        row_t = torch.zeros(16)
+        row_t[0], row_t[3], row_t[9], row_t[10], row_t[11] = l2d.detach(), pr.detach(), lb.detach(), s_avg.detach(), s_per.detach()
+        row_t[7], row_t[8] = vel.detach(), filt.detach()
+        self.log[row] = row_t
+
+    def step(self, lr):
+        fo.rmsprop_step(self.params, self.grads, self.sq, self.buf, lr)
+
+    def one_euro_shard(self, x, min_cutoff, beta, first_frame, state_in=None):
+        st = None if state_in is None else (state_in[0].numpy(), state_in[1].numpy())
+        y, out = one_euro_shard_np(x.detach().numpy(), min_cutoff, beta, first_frame, st)
+        return torch.tensor(y), (torch.tensor(out[0]), torch.tensor(out[1]))
+
+    def read_log(self, rows, nbatches_total=None):
+        raw = self.log[:rows].numpy().astype(np.float64)
+        nb = float(nbatches_total or self.nbatches)
+        return [{'loss_pose24j': r[0] / nb, 'reg_ref_poses': (r[3] + r[9]) / nb, 'reg_scale': r[10] + r[11],
+                 'reg_vel': r[7], 'reg_filter_verts': r[8]} for r in raw]

@@ -233,12 +233,12 @@ int mh_scene_unproject(const float* depth /*(H,W)*/, int H, int W, const float* 
  *      pose2d_valid (T*N); front, sil_apply, sil_D, sil_S from mh_sil_mask_stats.
  * Out: gverts (T*N,V,3) += coef * dL/dverts (atomic; may be NULL = losses only);
  *      gzmin, gzmax (T) += ; depth_body, sil_body (T*N) per-body loss values (un-weighted);
- *      ws: mh_raster_workspace_bytes(T,N,H,W) bytes of scratch (work list + the per-pixel
+ *      ws: mh_raster_workspace_bytes(T,N,V,F,H,W) bytes of scratch (work list + the per-pixel
  *      K-nearest windows; sized for the worst case of every body filling the image, only the
  *      windows actually covered are touched); zbuf_out / alpha_out (T*N,H,W) or NULL: the rendered
  *      nearest-face depth (-1 = empty) and soft-silhouette images (inspection / data synthesis;
  *      the optimisation loop never materialises them).                                          */
-size_t mh_raster_workspace_bytes(int T, int N, int H, int W);
+size_t mh_raster_workspace_bytes(int T, int N, int V, int F, int H, int W);
 int mh_raster_terms(int T, int N, int V, int F, int H, int W, const float* cam_K_host,
                     const float* verts, const int32_t* faces, const uint32_t* bits,
                     const uint32_t* ebits, const float* depths, const float* zmin_lin,

@@ -31,8 +31,8 @@
 #define BLUR_D 1e-4f         // optimizer.py:213
 #define BLUR_S 2e-5f         // optimizer.py:223
 #define SIGMA_S 1e-4f        // BlendParams.sigma default used by SoftSilhouetteShader
-#define RB 256               // threads per strip workgroup
-#define RQ_CAP 2048          // (face, pixel) candidate pairs queued per chunk of RB faces
+#define RB 512               // threads per strip workgroup
+#define RB_LOG2 9
 #define R_CAP 640            // window pixels per strip (5 x u64 each = 25.6 KB of LDS; 3 workgroups per CU)
 #define RT 13                // floats staged per face: 9 NDC coordinates, 1/area, 1/|edge|^2 x 3
 
@@ -70,6 +70,8 @@ struct RasterP {
   float* partial;            // [max_strips][6]
   float* dinv;               // [B][2]
   unsigned long long* gkeys; // [sum of window pixels][5]
+  float* ndc;                // [B][V][3] projected vertices (NDC x, y, view z)
+  unsigned* frows;           // [B][F] conservative pixel-row range of every face: lo | hi << 16 (lo > hi: skip)
 };
 
 __device__ __forceinline__ float r_pix_to_ndc(int i, int S1, int S2) {
@@ -191,8 +193,11 @@ __global__ __launch_bounds__(256) void k_raster_windows(RasterP p) {
   float mnx = 1e30f, mny = 1e30f, mxx = -1e30f, mxy = -1e30f;
   for (int v = lane; v < p.V; v += 64) {
     const float X = vb[(size_t)v * 3], Y = vb[(size_t)v * 3 + 1], Z = vb[(size_t)v * 3 + 2];
+    const float xn = p.s * (-X) / Z + p.w1, yn = p.s * (-Y) / Z + p.h1;
+    float* o = p.ndc + ((size_t)b * p.V + v) * 3;
+    o[0] = xn; o[1] = yn; o[2] = Z;
     if (Z > R_KEPS) {
-      const float fx = r_ndc_to_pix(p.s * (-X) / Z + p.w1, p.W, p.H), fy = r_ndc_to_pix(p.s * (-Y) / Z + p.h1, p.H, p.W);
+      const float fx = r_ndc_to_pix(xn, p.W, p.H), fy = r_ndc_to_pix(yn, p.H, p.W);
       mnx = fminf(mnx, fx); mxx = fmaxf(mxx, fx);
       mny = fminf(mny, fy); mxy = fmaxf(mxy, fy);
     }
@@ -295,41 +300,64 @@ __device__ __forceinline__ float r_seg_fast(float px, float py, float ax, float 
 // per-pair reciprocal is v_rcp_f32 of the clipped weight sum.  Values agree with r_eval to ~1 ulp;
 // the residual kernels re-evaluate the SELECTED faces with r_eval, so only near-tie orderings and
 // blur-band membership can differ in the last ulp.
-__device__ __forceinline__ void r_eval_fast(const float* T, float xf, float yf, float* pz, bool* inside, float* dist) {
+// (An early exit for candidates provably outside the blur band -- distance to the line of a violated
+// edge -- was measured and does not pay inside a 64-wide divergent loop: some lane always survives.)
+__device__ __forceinline__ bool r_eval_fast(const float* T, float xf, float yf, float* pz, bool* inside, float* dist) {
   const float x0 = T[0], y0 = T[1], z0 = T[2], x1 = T[3], y1 = T[4], z1 = T[5], x2 = T[6], y2 = T[7], z2 = T[8];
   const float ia = T[9];
-  const float w0 = r_edge(xf, yf, x1, y1, x2, y2) * ia;
-  const float w1 = r_edge(xf, yf, x2, y2, x0, y0) * ia;
-  const float w2 = r_edge(xf, yf, x0, y0, x1, y1) * ia;
-  *inside = w0 > 0.f && w1 > 0.f && w2 > 0.f;
+  const float e0 = r_edge(xf, yf, x1, y1, x2, y2), e1 = r_edge(xf, yf, x2, y2, x0, y0), e2 = r_edge(xf, yf, x0, y0, x1, y1);
+  const float w0 = e0 * ia, w1 = e1 * ia, w2 = e2 * ia;
+  const bool in = w0 > 0.f && w1 > 0.f && w2 > 0.f;
+  *inside = in;
   const float c0 = fmaxf(w0, 0.f), c1 = fmaxf(w1, 0.f), c2 = fmaxf(w2, 0.f);
   const float ics = __builtin_amdgcn_rcpf(fmaxf(c0 + c1 + c2, 1e-5f));
   *pz = (c0 * ics) * z0 + (c1 * ics) * z1 + (c2 * ics) * z2;
-  *dist = fminf(fminf(r_seg_fast(xf, yf, x0, y0, x1, y1, T[10]), r_seg_fast(xf, yf, x0, y0, x2, y2, T[11])),
-                r_seg_fast(xf, yf, x1, y1, x2, y2, T[12]));
+  *dist = in ? 0.f
+             : fminf(fminf(r_seg_fast(xf, yf, x0, y0, x1, y1, T[10]), r_seg_fast(xf, yf, x0, y0, x2, y2, T[11])),
+                     r_seg_fast(xf, yf, x1, y1, x2, y2, T[12]));
+  return true;
 }
 
-struct RawTri {
-  float X[3], Y[3], Z[3];
-};
-__device__ __forceinline__ void r_load_raw(const RasterP& p, const float* vb, int f, RawTri& t) {
+// conservative pixel-row range of every face (one pass per body instead of one per strip): a strip
+// then rejects a face with one 4-byte load.
+__global__ __launch_bounds__(256) void k_raster_face_rows(RasterP p) {
+  const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+  if (i >= (size_t)p.B * p.F) return;
+  const int b = (int)(i / p.F), f = (int)(i - (size_t)b * p.F);
+  const float* nb = p.ndc + (size_t)b * p.V * 3;
+  float x[3], y[3], z[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const int vi = p.faces[3 * f + k];
-    t.X[k] = vb[(size_t)vi * 3];
-    t.Y[k] = vb[(size_t)vi * 3 + 1];
-    t.Z[k] = vb[(size_t)vi * 3 + 2];
+    x[k] = nb[(size_t)vi * 3]; y[k] = nb[(size_t)vi * 3 + 1]; z[k] = nb[(size_t)vi * 3 + 2];
   }
+  const float farea = r_edge(x[0], y[0], x[1], y[1], x[2], y[2]);
+  unsigned out = 1u;                                     // lo = 1 > hi = 0: skipped
+  if (fminf(z[0], fminf(z[1], z[2])) >= R_KEPS && !(farea <= R_KEPS && farea >= -R_KEPS)) {
+    const float blur_d = sqrtf(BLUR_D);
+    const float bymin = fminf(y[0], fminf(y[1], y[2])) - blur_d, bymax = fmaxf(y[0], fmaxf(y[1], y[2])) + blur_d;
+    const float lo = floorf(r_ndc_to_pix(bymax, p.H, p.W)) - 1.f, hi = ceilf(r_ndc_to_pix(bymin, p.H, p.W)) + 1.f;
+    if (hi >= 0.f && lo <= (float)(p.H - 1)) {
+      const unsigned ulo = (unsigned)fmaxf(lo, 0.f), uhi = (unsigned)fminf(hi, (float)(p.H - 1));
+      out = ulo | (uhi << 16);
+    }
+  }
+  p.frows[i] = out;
 }
+
+#define RCH 1024             // faces tested per chunk (4 per thread)
 
 __global__ __launch_bounds__(RB) void k_raster_strip(RasterP p) {
   __shared__ unsigned long long keys[R_CAP * 5];
-  __shared__ float sTri[RB * RT];
-  __shared__ unsigned queue[RQ_CAP];
-  __shared__ float sXf[R_CAP];      // NDC x of the window columns
-  __shared__ float sYf[R_CAP];      // NDC y of the strip rows
-  __shared__ unsigned qcount;
-  const int tid = threadIdx.x, lane = tid & 63;
+  __shared__ float sTri[RB * RT];           // staged faces of the current round
+  __shared__ int sPre[RB + 1];              // exclusive prefix of the candidate counts
+  __shared__ int sXa[RB], sYa[RB], sNx[RB];
+  __shared__ unsigned short okl[RCH];       // faces of the chunk that overlap the strip rows
+  __shared__ float sXf[R_CAP];              // NDC x of the window columns
+  __shared__ float sYf[R_CAP];              // NDC y of the strip rows
+  __shared__ unsigned okn;
+  __shared__ int swave[RB / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = p.H, W = p.W;
   const float blur_d = sqrtf(BLUR_D);
   const int total = p.total[0];
@@ -341,100 +369,120 @@ __global__ __launch_bounds__(RB) void k_raster_strip(RasterP p) {
     const int sy0 = p.strip_row0[s], nrows = p.strip_rows[s], sy1 = sy0 + nrows - 1;
     const int x1 = x0 + ww - 1;
     const int npx = nrows * ww;
-    const float* vb = p.verts + (size_t)b * p.V * 3;
+    const float* nb = p.ndc + (size_t)b * p.V * 3;
+    const unsigned* fr = p.frows + (size_t)b * p.F;
     __syncthreads();
     for (int i = tid; i < npx * 5; i += RB) keys[i] = RS_EMPTY;
     for (int i = tid; i < ww; i += RB) sXf[i] = r_pix_to_ndc(W - 1 - (x0 + i), W, H);
     for (int i = tid; i < nrows; i += RB) sYf[i] = r_pix_to_ndc(H - 1 - (sy0 + i), H, W);
-    __syncthreads();
-    // strip bounds in NDC for the cheap per-face rejection (NDC decreases with the pixel index)
-    const float sx_hi = sXf[0], sx_lo = sXf[ww - 1], sy_hi = sYf[0], sy_lo = sYf[nrows - 1];
-    RawTri nxt;
-    if (tid < p.F) r_load_raw(p, vb, tid, nxt);
-    for (int chunk = 0; chunk < p.F; chunk += RB) {
-      const int f = chunk + tid;
-      const RawTri cur = nxt;
-      if (f + RB < p.F) r_load_raw(p, vb, f + RB, nxt);     // in flight while this chunk is processed
-      if (tid == 0) qcount = 0u;
-      // ---- step 1: one face per lane: project, reject, count the pixel centres in the blurred bbox ----
-      int xa = 0, xb = -1, ya = 0, yb = -1, cnt = 0;
-      if (f < p.F) {
-        float tx[3], ty[3];
+    for (int chunk = 0; chunk < p.F; chunk += RCH) {
+      if (tid == 0) okn = 0u;
+      __syncthreads();
+      // ---- phase A: which faces of the chunk touch the strip rows (one 4-byte load per face) --------
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          tx[k] = p.s * (-cur.X[k]) / cur.Z[k] + p.w1;
-          ty[k] = p.s * (-cur.Y[k]) / cur.Z[k] + p.h1;
+      for (int u = 0; u < RCH / RB; ++u) {
+        const int lf = u * RB + tid, f = chunk + lf;
+        bool ok = false;
+        if (f < p.F) {
+          const unsigned r = fr[f];
+          const int lo = (int)(r & 0xffffu), hi = (int)(r >> 16);
+          ok = lo <= hi && lo <= sy1 && hi >= sy0;
         }
-        const float farea = r_edge(tx[0], ty[0], tx[1], ty[1], tx[2], ty[2]);
-        const float bxmin = fminf(tx[0], fminf(tx[1], tx[2])) - blur_d, bxmax = fmaxf(tx[0], fmaxf(tx[1], tx[2])) + blur_d;
-        const float bymin = fminf(ty[0], fminf(ty[1], ty[2])) - blur_d, bymax = fmaxf(ty[0], fmaxf(ty[1], ty[2])) + blur_d;
-        const bool ok = fminf(cur.Z[0], fminf(cur.Z[1], cur.Z[2])) >= R_KEPS && !(farea <= R_KEPS && farea >= -R_KEPS) &&
-                        bxmin <= sx_hi && bxmax >= sx_lo && bymin <= sy_hi && bymax >= sy_lo;
-        if (ok) {
-          float* T = sTri + tid * RT;
+        const unsigned long long m = __ballot(ok);
+        unsigned base = 0;
+        if (lane == 0 && m) base = atomicAdd(&okn, (unsigned)__popcll(m));
+        base = __shfl(base, 0, 64);
+        if (ok) okl[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)lf;
+      }
+      __syncthreads();
+      const int n_ok = (int)okn;
+      for (int seg = 0; seg < n_ok; seg += RB) {
+        // ---- phase B: stage up to RB overlapping faces, count their candidate pixel centres ----------
+        int cnt = 0;
+        if (seg + tid < n_ok) {
+          const int f = chunk + (int)okl[seg + tid];
+          float tx[3], ty[3], tz[3];
 #pragma unroll
-          for (int k = 0; k < 3; ++k) { T[3 * k] = tx[k]; T[3 * k + 1] = ty[k]; T[3 * k + 2] = cur.Z[k]; }
-          T[9] = 1.f / (r_edge(tx[2], ty[2], tx[0], ty[0], tx[1], ty[1]) + R_KEPS);
-          const float l01 = (tx[1] - tx[0]) * (tx[1] - tx[0]) + (ty[1] - ty[0]) * (ty[1] - ty[0]);
-          const float l02 = (tx[2] - tx[0]) * (tx[2] - tx[0]) + (ty[2] - ty[0]) * (ty[2] - ty[0]);
-          const float l12 = (tx[2] - tx[1]) * (tx[2] - tx[1]) + (ty[2] - ty[1]) * (ty[2] - ty[1]);
-          T[10] = l01 <= R_KEPS ? -1.f : 1.f / l01;
-          T[11] = l02 <= R_KEPS ? -1.f : 1.f / l02;
-          T[12] = l12 <= R_KEPS ? -1.f : 1.f / l12;
+          for (int k = 0; k < 3; ++k) {
+            const int vi = p.faces[3 * f + k];
+            tx[k] = nb[(size_t)vi * 3]; ty[k] = nb[(size_t)vi * 3 + 1]; tz[k] = nb[(size_t)vi * 3 + 2];
+          }
+          const float bxmin = fminf(tx[0], fminf(tx[1], tx[2])) - blur_d, bxmax = fmaxf(tx[0], fmaxf(tx[1], tx[2])) + blur_d;
+          const float bymin = fminf(ty[0], fminf(ty[1], ty[2])) - blur_d, bymax = fmaxf(ty[0], fmaxf(ty[1], ty[2])) + blur_d;
           // approximate pixel range, then the exact test on the tabulated pixel-centre NDC values
-          xa = max(x0, (int)floorf((float)W - 0.5f - (bxmax + 0.5f * rx) * kx) - 1);
-          xb = min(x1, (int)ceilf((float)W - 0.5f - (bxmin + 0.5f * rx) * kx) + 1);
-          ya = max(sy0, (int)floorf((float)H - 0.5f - (bymax + 0.5f * ry) * ky) - 1);
-          yb = min(sy1, (int)ceilf((float)H - 0.5f - (bymin + 0.5f * ry) * ky) + 1);
+          int xa = max(x0, (int)floorf((float)W - 0.5f - (bxmax + 0.5f * rx) * kx) - 1);
+          int xb = min(x1, (int)ceilf((float)W - 0.5f - (bxmin + 0.5f * rx) * kx) + 1);
+          int ya = max(sy0, (int)floorf((float)H - 0.5f - (bymax + 0.5f * ry) * ky) - 1);
+          int yb = min(sy1, (int)ceilf((float)H - 0.5f - (bymin + 0.5f * ry) * ky) + 1);
           while (xa <= xb && sXf[xa - x0] > bxmax) ++xa;
           while (xb >= xa && sXf[xb - x0] < bxmin) --xb;
           while (ya <= yb && sYf[ya - sy0] > bymax) ++ya;
           while (yb >= ya && sYf[yb - sy0] < bymin) --yb;
           cnt = max(0, xb - xa + 1) * max(0, yb - ya + 1);
-        }
-      }
-      // wave-aggregated append: prefix sum of the counts inside the wave, one LDS atomic per wave
-      int incl = cnt;
+          if (cnt > 0) {
+            float* T = sTri + tid * RT;
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += v;
-      }
-      const int wave_total = __shfl(incl, 63, 64);
-      __syncthreads();
-      unsigned base = 0;
-      if (lane == 63 && wave_total > 0) base = atomicAdd(&qcount, (unsigned)wave_total);
-      base = __shfl(base, 63, 64);
-      int pos = (int)base + incl - cnt;
-      if (cnt > 0) {
-        const int nx = xb - xa + 1;
-        int yi = ya, xi = xa;
-        for (int k = 0; k < cnt; ++k, ++pos) {
-          const unsigned poff = (unsigned)((yi - sy0) * ww + (xi - x0));
-          if (pos < RQ_CAP) {
-            queue[pos] = ((unsigned)tid << 16) | poff;
-          } else {            // queue full (very large faces): evaluate in place
+            for (int k = 0; k < 3; ++k) { T[3 * k] = tx[k]; T[3 * k + 1] = ty[k]; T[3 * k + 2] = tz[k]; }
+            T[9] = 1.f / (r_edge(tx[2], ty[2], tx[0], ty[0], tx[1], ty[1]) + R_KEPS);
+            const float l01 = (tx[1] - tx[0]) * (tx[1] - tx[0]) + (ty[1] - ty[0]) * (ty[1] - ty[0]);
+            const float l02 = (tx[2] - tx[0]) * (tx[2] - tx[0]) + (ty[2] - ty[0]) * (ty[2] - ty[0]);
+            const float l12 = (tx[2] - tx[1]) * (tx[2] - tx[1]) + (ty[2] - ty[1]) * (ty[2] - ty[1]);
+            T[10] = l01 <= R_KEPS ? -1.f : 1.f / l01;
+            T[11] = l02 <= R_KEPS ? -1.f : 1.f / l02;
+            T[12] = l12 <= R_KEPS ? -1.f : 1.f / l12;
+            sXa[tid] = xa; sYa[tid] = ya; sNx[tid] = xb - xa + 1;
+          }
+        }
+        // block-wide exclusive scan of the counts
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int v = __shfl_up(incl, o, 64);
+          if (lane >= o) incl += v;
+        }
+        if (lane == 63) swave[wave] = incl;
+        __syncthreads();
+        int woff = 0;
+#pragma unroll
+        for (int w = 0; w < RB / 64; ++w) woff += (w < wave) ? swave[w] : 0;
+        sPre[tid] = woff + incl - cnt;
+        if (tid == RB - 1) sPre[RB] = woff + incl;
+        __syncthreads();
+        // ---- phase C: all (face, pixel) pairs of the round, split evenly over the workgroup: every
+        // thread walks a contiguous run of pairs, so the staged face stays in registers while the run
+        // stays inside one face, and neighbouring lanes work on different faces (few LDS collisions)
+        const int npairs = sPre[RB];
+        const int per = (npairs + RB - 1) / RB;
+        const int j0 = tid * per, j1 = min(j0 + per, npairs);
+        if (j0 < j1) {
+          int lo = 0, hi = RB;                           // largest o with sPre[o] <= j0
+#pragma unroll
+          for (int it = 0; it < RB_LOG2; ++it) {
+            const int mid = (lo + hi) >> 1;
+            if (sPre[mid] <= j0) lo = mid; else hi = mid;
+          }
+          float T[RT];
+          int nx = 1, kx_ = 0, ky_ = 0, xa = 0, ya = 0, nextp = -1;
+          for (int j = j0; j < j1; ++j) {
+            if (j >= nextp) {                            // first pair of the run, or the face changed
+              while (sPre[lo + 1] <= j) ++lo;
+#pragma unroll
+              for (int q = 0; q < RT; ++q) T[q] = sTri[lo * RT + q];
+              nx = sNx[lo]; xa = sXa[lo] - x0; ya = sYa[lo] - sy0;
+              const int k = j - sPre[lo];
+              ky_ = k / nx; kx_ = k - ky_ * nx;
+              nextp = sPre[lo + 1];
+            }
+            const int xi = xa + kx_, yi = ya + ky_;
             float pz, d;
             bool inside;
-            r_eval_fast(sTri + tid * RT, sXf[xi - x0], sYf[yi - sy0], &pz, &inside, &d);
-            r_insert(keys + (size_t)poff * 5, pz, inside, d, f);
+            if (r_eval_fast(T, sXf[xi], sYf[yi], &pz, &inside, &d))
+              r_insert(keys + (size_t)(yi * ww + xi) * 5, pz, inside, d, chunk + (int)okl[seg + lo]);
+            if (++kx_ == nx) { kx_ = 0; ++ky_; }
           }
-          if (++xi > xa + nx - 1) { xi = xa; ++yi; }
         }
+        __syncthreads();
       }
-      __syncthreads();
-      // ---- step 2: one queued (face, pixel) pair per lane -------------------------------------------
-      const int nq = (int)min(qcount, (unsigned)RQ_CAP);
-      for (int i = tid; i < nq; i += RB) {
-        const unsigned e = queue[i];
-        const int lf = (int)(e >> 16), poff = (int)(e & 0xffffu);
-        const int ry_ = poff / ww, rx_ = poff - ry_ * ww;
-        float pz, d;
-        bool inside;
-        r_eval_fast(sTri + lf * RT, sXf[rx_], sYf[ry_], &pz, &inside, &d);
-        r_insert(keys + (size_t)poff * 5, pz, inside, d, chunk + lf);
-      }
-      __syncthreads();
     }
     // finished window -> HBM (40 B per pixel, coalesced)
     unsigned long long* gk = p.gkeys + (size_t)p.strip_koff[s] * 5;
@@ -707,16 +755,18 @@ __global__ void k_fill(float* x, size_t n, float v) {
 }
 
 static size_t r_align(size_t x) { return (x + 255) & ~(size_t)255; }
+static size_t r_ws_extra(size_t B, int V, int F) { return r_align(B * V * 3 * 4) + r_align(B * F * 4); }
 static int r_max_strips(int B, int H, int W) {
   const int rows = R_CAP / W > 0 ? R_CAP / W : 1;      // narrowest strips happen for full-width windows
   return B * ((H + rows - 1) / rows);
 }
 
-extern "C" size_t mh_raster_workspace_bytes(int T, int N, int H, int W) {
+extern "C" size_t mh_raster_workspace_bytes(int T, int N, int V, int F, int H, int W) {
   const size_t B = (size_t)T * N, ms = (size_t)r_max_strips((int)B, H, W);
-  return r_align(B * 4 * 4) + 2 * r_align(B * 4) + r_align(4) + 3 * r_align(ms * 4) + r_align(ms * 8) + r_align(ms * 6 * 4) +
+  return r_ws_extra(B, V, F) + r_align(B * 4 * 4) + 2 * r_align(B * 4) + r_align(4) + 3 * r_align(ms * 4) + r_align(ms * 8) + r_align(ms * 6 * 4) +
          r_align(B * 2 * 4) + r_align(B * (size_t)H * W * 5 * 8);
 }
+
 
 extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const float* cam_K_host, const float* verts,
                                const int32_t* faces, const uint32_t* bits, const uint32_t* ebits, const float* depths,
@@ -730,6 +780,7 @@ extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const f
            "null argument");
   MH_CHECK(T > 0 && N > 0 && N <= 32 && V > 0 && F > 0 && H > 0 && W > 0, "empty input");
   MH_CHECK(W <= R_CAP, "image wider than one LDS strip");
+  MH_CHECK(H <= 65535 && F <= 65535, "face row ranges and staged face ids are 16 bits");
   RasterP p;
   p.B = T * N; p.N = N; p.V = V; p.F = F; p.H = H; p.W = W;
   // transforms.py:222-255 with image_size = (W, H)
@@ -770,6 +821,8 @@ extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const f
   p.strip_koff = (long long*)c; c += r_align(ms * 8);
   p.partial = (float*)c; c += r_align(ms * 6 * 4);
   p.dinv = (float*)c; c += r_align(B * 2 * 4);
+  p.ndc = (float*)c; c += r_align(B * V * 3 * 4);
+  p.frows = (unsigned*)c; c += r_align(B * F * 4);
   p.gkeys = (unsigned long long*)c;
   hipStream_t st = (hipStream_t)stream;
   if (zbuf_out) {   // -1 = empty, like fragments.zbuf
@@ -780,6 +833,8 @@ extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const f
   hipLaunchKernelGGL(k_raster_windows, dim3((p.B + 3) / 4), dim3(256), 0, st, p);
   MH_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_raster_strip_table, dim3(1), dim3(1024), 0, st, p);
+  MH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_raster_face_rows, dim3((unsigned)((B * F + 255) / 256)), dim3(256), 0, st, p);
   MH_LAUNCH_CHECK();
   // persistent grids over the device-side work list (the strip count is only known on the device)
   const int grid = 256 * 3 * 4;

@@ -81,7 +81,7 @@ def lib():
         L.mh_contact_foot_terms.argtypes = [ctypes.c_int] * 4 + [vp] * 4 + [ctypes.c_float] * 2 + [vp] * 5
         L.mh_scene_unproject.argtypes = [vp, ctypes.c_int, ctypes.c_int, c_float_p, vp, vp]
         L.mh_raster_workspace_bytes.restype = ctypes.c_size_t
-        L.mh_raster_workspace_bytes.argtypes = [ctypes.c_int] * 4
+        L.mh_raster_workspace_bytes.argtypes = [ctypes.c_int] * 6
         L.mh_raster_terms.argtypes = [ctypes.c_int] * 6 + [c_float_p] + [vp] * 12 + [ctypes.c_float] * 3 + [vp] * 9
         _lib = L
     return _lib

@@ -14,7 +14,7 @@ class RasterTerms(object):
     def __init__(self, engine, znear=1.0, zfar=100.0):
         e = engine
         self.faces = torch.as_tensor(np.ascontiguousarray(np.asarray(e.m.faces).astype(np.int32))).to(e.dev)
-        self.ws = torch.empty(_lib.lib().mh_raster_workspace_bytes(e.T, e.N, e.H, e.W), dtype=torch.uint8, device=e.dev)
+        self.ws = torch.empty(_lib.lib().mh_raster_workspace_bytes(e.T, e.N, e.V, self.faces.shape[0], e.H, e.W), dtype=torch.uint8, device=e.dev)
         self.K = np.ascontiguousarray(e.K.reshape(9))
 
     def __call__(self, e, gverts, log, with_grads=True, zbuf_out=None, alpha_out=None):
@@ -45,7 +45,7 @@ def render(model, verts, cam_K, image_size):
     bits, depths, tz, ones = zi(B, H, W), zf(B, H, W), zf(B), torch.ones(B, device=dev)
     zbuf, alpha = torch.empty(B, H, W, device=dev), torch.empty(B, H, W, device=dev)
     K = np.ascontiguousarray(np.asarray(cam_K, np.float32).reshape(9))
-    ws = torch.empty(_lib.lib().mh_raster_workspace_bytes(B, 1, H, W), dtype=torch.uint8, device=dev)
+    ws = torch.empty(_lib.lib().mh_raster_workspace_bytes(B, 1, V, faces.shape[0], H, W), dtype=torch.uint8, device=dev)
     check(_lib.lib().mh_raster_terms(B, 1, V, faces.shape[0], H, W, K.ctypes.data_as(_lib.c_float_p), ptr(verts.contiguous()),
                                      ptr(faces), ptr(bits), ptr(bits), ptr(depths), ptr(tz), ptr(tz), ptr(ones), ptr(zi(B)),
                                      ptr(tz), ptr(ones), ptr(tz), 0.0, 0.0, 1e-3, None, None, None, ptr(zf(B)), ptr(zf(B)),

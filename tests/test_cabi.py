@@ -24,7 +24,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert L.mh_version() >= 1
     assert L.mh_device_count() >= 0
     assert L.mh_lbs_workspace_bytes(800) > 800 * 24 * 12 * 4
-    assert L.mh_raster_workspace_bytes(200, 4, 135, 240) > 0
+    assert L.mh_raster_workspace_bytes(200, 4, 6890, 13776, 135, 240) > 0
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='checks the behaviour of a GPU-less host')

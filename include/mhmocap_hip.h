@@ -248,6 +248,32 @@ int mh_raster_terms(int T, int N, int V, int F, int H, int W, const float* cam_K
                     float* gzmax, float* depth_body, float* sil_body, void* ws,
                     float* zbuf_out, float* alpha_out, void* stream);
 
+/* ---- stand-alone forms of losses.py:19-40 and morphology.py:6-41 (call compatibility of
+ * mhmocap.losses / mhmocap.morphology; the optimiser uses the fused kernels above) --------------
+ * mh_avg_depth_loss: rows = b*N maps of P pixels; `tru` has rows/group maps (group = N when the
+ * target is (b,1,H,W)).  row_sums (rows,3) = {sum m*log(clamp pred), sum m*log(clamp true), sum m};
+ * the loss is sum_r ((s0 - s1)/(s2+1))^2 (host adds rows_loss from row_sums, or reads it back).
+ * _backward: gpred (rows,P), gtrue_rows (rows,P) [caller sums the group], scaled by grad_out.      */
+int mh_avg_depth_loss(const float* pred, const float* tru, const float* mask, int rows, int group,
+                      size_t P, float eps, float* row_sums, float* row_loss, void* stream);
+int mh_avg_depth_loss_backward(const float* pred, const float* tru, const float* mask, int rows,
+                               int group, size_t P, float eps, const float* row_sums,
+                               float grad_out, float* gpred, float* gtrue_rows, void* stream);
+/* sums2 = { sum((mask*(a-b))^2), sum(mask) }; loss = sums2[0] / (sums2[1] + 1)                     */
+int mh_masked_mse(const float* a, const float* b, const float* mask, size_t n, float* sums2, void* stream);
+int mh_masked_mse_backward(const float* a, const float* b, const float* mask, size_t n,
+                           const float* sums2, float grad_out, float* ga, void* stream);
+/* binary erosion (dilate = 0) / dilation (dilate = 1) with a k x k window of ones on float maps    */
+int mh_morph_f32(const float* in, float* out, int n_images, int H, int W, int kernel_size,
+                 int dilate, void* stream);
+
+/* generic forms of camera_projection_torch / camera_inverse_projection_torch (transforms.py:57-95,
+ * 114-130): pts (B,M,3), K_dev (B,3,3) DEVICE, Kd_host 5 HOST coefficients or NULL;
+ * out (B,M,2) or (B,M,3) with the depth appended (return_depth).                                 */
+int mh_project_points(int B, int M, const float* pts, const float* K_dev, const float* Kd_host,
+                      int with_depth, float* out, void* stream);
+int mh_unproject_points(int B, int M, const float* uvd, const float* K_dev, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

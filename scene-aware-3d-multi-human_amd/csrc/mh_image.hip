@@ -279,3 +279,138 @@ extern "C" int mh_reduce_sum(const float* x, size_t n, float scale, float* out, 
   MH_LAUNCH_CHECK();
   return MH_OK;
 }
+
+// =============================================================================================
+// stand-alone forms of the two loss builders of losses.py and of morphology.py (call compatibility
+// for users of mhmocap.losses / mhmocap.morphology; the optimiser itself uses the fused kernels)
+// =============================================================================================
+// losses.py:19-30: rows r = (frame, person); true rows are shared by `group` consecutive rows
+__global__ __launch_bounds__(256) void k_depth_loss_rows(const float* pred, const float* tru, const float* mask, size_t P,
+                                                         int group, float eps, float* sums /*[R][3]*/) {
+  __shared__ float s[3][4];
+  const int r = blockIdx.x;
+  const float* pr = pred + (size_t)r * P;
+  const float* tr = tru + (size_t)(r / group) * P;
+  const float* mk = mask + (size_t)r * P;
+  float a = 0.f, b = 0.f, c = 0.f;
+  for (size_t i = threadIdx.x; i < P; i += 256) {
+    const float m = mk[i];
+    a += m * logf(fmaxf(pr[i], eps));
+    b += m * logf(fmaxf(tr[i], eps));
+    c += m;
+  }
+  a = mh_wave_sum(a); b = mh_wave_sum(b); c = mh_wave_sum(c);
+  if ((threadIdx.x & 63) == 0) { s[0][threadIdx.x >> 6] = a; s[1][threadIdx.x >> 6] = b; s[2][threadIdx.x >> 6] = c; }
+  __syncthreads();
+  if (threadIdx.x < 3) sums[(size_t)r * 3 + threadIdx.x] = s[threadIdx.x][0] + s[threadIdx.x][1] + s[threadIdx.x][2] + s[threadIdx.x][3];
+}
+
+__global__ __launch_bounds__(256) void k_depth_loss_grads(const float* pred, const float* tru, const float* mask, size_t P,
+                                                          int group, float eps, const float* sums, float gout, float* gpred,
+                                                          float* gtrue_rows) {
+  const int r = blockIdx.x;
+  const float cnt = sums[(size_t)r * 3 + 2] + 1.f;
+  const float diff = sums[(size_t)r * 3] / cnt - sums[(size_t)r * 3 + 1] / cnt;
+  const float g = gout * 2.f * diff / cnt;
+  const float* pr = pred + (size_t)r * P;
+  const float* tr = tru + (size_t)(r / group) * P;
+  const float* mk = mask + (size_t)r * P;
+  for (size_t i = threadIdx.x; i < P; i += 256) {
+    const float m = mk[i];
+    if (gpred) gpred[(size_t)r * P + i] = pr[i] >= eps ? g * m / pr[i] : 0.f;
+    if (gtrue_rows) gtrue_rows[(size_t)r * P + i] = tr[i] >= eps ? -g * m / tr[i] : 0.f;
+  }
+}
+
+extern "C" int mh_avg_depth_loss(const float* pred, const float* tru, const float* mask, int rows, int group, size_t P,
+                                 float eps, float* row_sums, float* row_loss, void* stream) {
+  MH_CHECK(pred && tru && mask && row_sums && row_loss, "null argument");
+  MH_CHECK(rows > 0 && group > 0 && P > 0, "empty input");
+  hipLaunchKernelGGL(k_depth_loss_rows, dim3(rows), dim3(256), 0, (hipStream_t)stream, pred, tru, mask, P, group, eps, row_sums);
+  MH_LAUNCH_CHECK();
+  (void)row_loss;
+  return MH_OK;
+}
+
+extern "C" int mh_avg_depth_loss_backward(const float* pred, const float* tru, const float* mask, int rows, int group,
+                                          size_t P, float eps, const float* row_sums, float grad_out, float* gpred,
+                                          float* gtrue_rows, void* stream) {
+  MH_CHECK(pred && tru && mask && row_sums, "null argument");
+  MH_CHECK(rows > 0 && group > 0 && P > 0, "empty input");
+  hipLaunchKernelGGL(k_depth_loss_grads, dim3(rows), dim3(256), 0, (hipStream_t)stream, pred, tru, mask, P, group, eps,
+                     row_sums, grad_out, gpred, gtrue_rows);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+// losses.py:33-40: sums[0] = sum((mask*(a-b))^2), sums[1] = sum(mask) (single block, fixed order)
+__global__ __launch_bounds__(1024) void k_mse_sums(const float* a, const float* b, const float* mask, size_t n, float* sums) {
+  __shared__ float s[2][16];
+  float x = 0.f, c = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += 1024) {
+    const float m = mask[i], d = m * (a[i] - b[i]);
+    x += d * d;
+    c += m;
+  }
+  x = mh_wave_sum(x); c = mh_wave_sum(c);
+  if ((threadIdx.x & 63) == 0) { s[0][threadIdx.x >> 6] = x; s[1][threadIdx.x >> 6] = c; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += s[threadIdx.x][w];
+    sums[threadIdx.x] = t;
+  }
+}
+__global__ void k_mse_grad(const float* a, const float* b, const float* mask, size_t n, const float* sums, float gout, float* ga) {
+  const float inv = gout * 2.f / (sums[1] + 1.f);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float m = mask[i];
+    ga[i] = inv * m * m * (a[i] - b[i]);
+  }
+}
+
+extern "C" int mh_masked_mse(const float* a, const float* b, const float* mask, size_t n, float* sums2, void* stream) {
+  MH_CHECK(a && b && mask && sums2, "null argument");
+  MH_CHECK(n > 0, "empty input");
+  hipLaunchKernelGGL(k_mse_sums, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, b, mask, n, sums2);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+extern "C" int mh_masked_mse_backward(const float* a, const float* b, const float* mask, size_t n, const float* sums2,
+                                      float grad_out, float* ga, void* stream) {
+  MH_CHECK(a && b && mask && sums2 && ga, "null argument");
+  const size_t nb = (n + 255) / 256;
+  hipLaunchKernelGGL(k_mse_grad, dim3((unsigned)(nb < 2048 ? nb : 2048)), dim3(256), 0, (hipStream_t)stream, a, b, mask, n, sums2,
+                     grad_out, ga);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+// morphology.py:21-34 on float maps: erode = 1 - clamp(sum over the k x k window of (x < .5)), dilate =
+// clamp(sum of (x >= .5)); zero padding outside the image
+__global__ void k_morph_f32(const float* in, float* out, int n_img, int H, int W, int k, int dilate) {
+  const size_t n = (size_t)n_img * H * W;
+  const int r = k / 2;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const float* img = in + (i / ((size_t)H * W)) * (size_t)H * W;
+    bool hit = false;
+    for (int dy = -r; dy <= r; ++dy)
+      for (int dx = -r; dx <= r; ++dx) {
+        const int yy = y + dy, xx = x + dx;
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+        const float v = img[(size_t)yy * W + xx];
+        hit |= dilate ? (v >= 0.5f) : (v < 0.5f);
+      }
+    out[i] = dilate ? (hit ? 1.f : 0.f) : (hit ? 0.f : 1.f);
+  }
+}
+extern "C" int mh_morph_f32(const float* in, float* out, int n_images, int H, int W, int kernel_size, int dilate, void* stream) {
+  MH_CHECK(in && out && in != out, "null or aliased argument");
+  MH_CHECK(n_images > 0 && H > 0 && W > 0 && kernel_size > 0 && (kernel_size & 1), "bad shape / even kernel");
+  const size_t nb = ((size_t)n_images * H * W + 255) / 256;
+  hipLaunchKernelGGL(k_morph_f32, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, (hipStream_t)stream, in, out, n_images,
+                     H, W, kernel_size, dilate);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}

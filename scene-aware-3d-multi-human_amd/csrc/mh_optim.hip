@@ -362,3 +362,61 @@ extern "C" int mh_filtered_verts_term(int T, size_t E, const float* verts, const
   MH_LAUNCH_CHECK();
   return MH_OK;
 }
+
+// =============================================================================================
+// generic forms of transforms.py:57-95 / 114-130 (call compatibility of mhmocap.transforms)
+// =============================================================================================
+__global__ void k_project_points(int B, int M, const float* pts, const float* K, int has_kd, float k1, float k2, float p1,
+                                 float p2, float k3, int with_depth, float* out) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * M) return;
+  const float* Kb = K + (i / M) * 9;
+  const float X = pts[i * 3], Y = pts[i * 3 + 1], Z = pts[i * 3 + 2];
+  float x = X / Z, y = Y / Z;
+  if (has_kd) {
+    const float r = x * x + y * y;
+    const float rad = 1 + k1 * r + k2 * r * r + k3 * r * r * r;
+    const float xx = x * rad + 2 * p1 * x * y + p2 * (r + 2 * x * x);
+    const float yy = y * rad + 2 * p2 * y * y + p1 * (r + 2 * y * y);
+    x = xx;
+    y = yy;
+  }
+  const int os = with_depth ? 3 : 2;
+  out[i * os] = x * Kb[0] + y * Kb[1] + Kb[2];
+  out[i * os + 1] = x * Kb[3] + y * Kb[4] + Kb[5];
+  if (with_depth) out[i * 3 + 2] = Z;
+}
+
+extern "C" int mh_project_points(int B, int M, const float* pts, const float* K_dev, const float* Kd_host, int with_depth,
+                                 float* out, void* stream) {
+  MH_CHECK(pts && K_dev && out, "null argument");
+  MH_CHECK(B > 0 && M > 0, "empty input");
+  const float* d = Kd_host;
+  hipLaunchKernelGGL(k_project_points, dim3((unsigned)(((size_t)B * M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, M,
+                     pts, K_dev, d != nullptr, d ? d[0] : 0.f, d ? d[1] : 0.f, d ? d[2] : 0.f, d ? d[3] : 0.f, d ? d[4] : 0.f,
+                     with_depth, out);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+__global__ void k_unproject_points(int B, int M, const float* uvd, const float* K, float* out) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * M) return;
+  const float* Kb = K + (i / M) * 9;
+  // [u - cx, v - cy] . inv(K[:2,:2]^T)
+  const float a = Kb[0], b = Kb[3], c = Kb[1], d = Kb[4];     // K[:2,:2]^T = [[a, b], [c, d]]
+  const float det = a * d - b * c;
+  const float u = uvd[i * 3] - Kb[2], v = uvd[i * 3 + 1] - Kb[5], z = uvd[i * 3 + 2];
+  out[i * 3] = z * (u * (d / det) + v * (-c / det));
+  out[i * 3 + 1] = z * (u * (-b / det) + v * (a / det));
+  out[i * 3 + 2] = z;
+}
+
+extern "C" int mh_unproject_points(int B, int M, const float* uvd, const float* K_dev, float* out, void* stream) {
+  MH_CHECK(uvd && K_dev && out, "null argument");
+  MH_CHECK(B > 0 && M > 0, "empty input");
+  hipLaunchKernelGGL(k_unproject_points, dim3((unsigned)(((size_t)B * M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, M,
+                     uvd, K_dev, out);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}

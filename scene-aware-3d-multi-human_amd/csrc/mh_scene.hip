@@ -63,9 +63,12 @@ extern "C" int mh_lowest_vertex(const float* verts, int B, int V, int32_t* low_i
 // a compare unless one of them beats the current K-th distance.
 // ---------------------------------------------------------------------------------------------
 #define KNN_CAP 128   // 32 kept + up to 64 new, padded to a power of two for the bitonic network
+#define KNN_WAVES 4   // waves (point ranges) per query
 
-__device__ __forceinline__ void knn_sort128(float* d, float* y, int lane) {
-  // ascending bitonic sort of 128 (key d, payload y) pairs by one wave: 2 elements per lane
+// ascending bitonic sort of 128 (key d, payload y) pairs by ONE wave: 2 elements per lane.  The list is
+// private to the wave; LDS executes a wave's instructions in order, so no workgroup barrier is needed
+// (volatile keeps the compiler from caching list elements in registers).
+__device__ __forceinline__ void knn_sort128(volatile float* d, volatile float* y, int lane) {
   for (int k = 2; k <= KNN_CAP; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
 #pragma unroll
@@ -84,27 +87,31 @@ __device__ __forceinline__ void knn_sort128(float* d, float* y, int lane) {
           }
         }
       }
-      __syncthreads();   // single-wave block: orders the LDS exchanges
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }
 
-__global__ __launch_bounds__(64) void k_contact_knn(const float* pts, int M, const float* low_xyz, int K, float* dy) {
-  __shared__ float sd[KNN_CAP];
-  __shared__ float sy[KNN_CAP];
-  const int b = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(64 * KNN_WAVES) void k_contact_knn(const float* pts, int M, const float* low_xyz, int K, float* dy) {
+  __shared__ float sd_all[KNN_WAVES][KNN_CAP];
+  __shared__ float sy_all[KNN_WAVES][KNN_CAP];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  volatile float* sd = sd_all[wave];
+  volatile float* sy = sy_all[wave];
   const float qx = low_xyz[(size_t)b * 3], qy = low_xyz[(size_t)b * 3 + 1], qz = low_xyz[(size_t)b * 3 + 2];
   sd[lane] = INFINITY;
   sd[lane + 64] = INFINITY;
   sy[lane] = 0.f;
   sy[lane + 64] = 0.f;
-  __syncthreads();
-  float tau = INFINITY;   // current K-th best distance (wave-uniform)
+  __builtin_amdgcn_wave_barrier();
+  float tau = INFINITY;   // current K-th best distance of this wave's range (wave-uniform)
   int fill = K;           // slots [0,K) hold the kept set (INF until filled), new candidates go to [K, ...)
-  for (int base = 0; base < M; base += 64) {
+  const int per = (M + KNN_WAVES - 1) / KNN_WAVES;
+  const int m0 = wave * per, m1 = min(M, m0 + per);
+  for (int base = m0; base < m1; base += 64) {
     const int i = base + lane;
     float d2 = INFINITY, py = 0.f;
-    if (i < M) {
+    if (i < m1) {
       const float dx = pts[(size_t)i * 3] - qx;
       py = pts[(size_t)i * 3 + 1];
       const float dyy = py - qy, dz = pts[(size_t)i * 3 + 2] - qz;
@@ -119,28 +126,45 @@ __global__ __launch_bounds__(64) void k_contact_knn(const float* pts, int M, con
       sy[pos] = py;
     }
     fill += __popcll(m);
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     if (fill > KNN_CAP - 64) {   // not enough room for another full chunk: keep the best K
       knn_sort128(sd, sy, lane);
       tau = sd[K - 1];
       if (lane + K < KNN_CAP) sd[lane + K] = INFINITY;
       if (lane + 64 + K < KNN_CAP) sd[lane + 64 + K] = INFINITY;
       fill = K;
-      __syncthreads();   // single-wave block: orders the LDS exchanges
+      __builtin_amdgcn_wave_barrier();
     }
   }
   knn_sort128(sd, sy, lane);
-  const int kk = M < K ? M : K;
-  float s = (lane < kk) ? sy[lane] : 0.f;
-  s = mh_wave_sum(s);
-  if (lane == 0) dy[b] = s / (float)kk - qy;     // (mean of the nearest points - lowest vertex).y, :500-502
+  __syncthreads();
+  if (wave == 0) {
+    // merge the K best of every range: 4 x 32 = 128 entries, one more sort
+    float md[2], my[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int e = lane + 64 * h, w = e / 32, r = e % 32;
+      const bool ok = w < KNN_WAVES && r < K;
+      md[h] = ok ? sd_all[w][r] : INFINITY;
+      my[h] = ok ? sy_all[w][r] : 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    sd[lane] = md[0]; sd[lane + 64] = md[1];
+    sy[lane] = my[0]; sy[lane + 64] = my[1];
+    __builtin_amdgcn_wave_barrier();
+    knn_sort128(sd, sy, lane);
+    const int kk = M < K ? M : K;
+    float s = (lane < kk) ? sy[lane] : 0.f;
+    s = mh_wave_sum(s);
+    if (lane == 0) dy[b] = s / (float)kk - qy;     // (mean of the nearest points - lowest vertex).y, :500-502
+  }
 }
 
 extern "C" int mh_contact_knn(const float* points, int M, const float* low_xyz, int B, int k, float* dy, void* stream) {
   MH_CHECK(points && low_xyz && dy, "null argument");
   MH_CHECK(M > 0 && B > 0, "empty input");
   MH_CHECK(k >= 1 && k <= 32, "k must be in 1..32");
-  hipLaunchKernelGGL(k_contact_knn, dim3(B), dim3(64), 0, (hipStream_t)stream, points, M, low_xyz, k, dy);
+  hipLaunchKernelGGL(k_contact_knn, dim3(B), dim3(64 * KNN_WAVES), 0, (hipStream_t)stream, points, M, low_xyz, k, dy);
   MH_LAUNCH_CHECK();
   return MH_OK;
 }

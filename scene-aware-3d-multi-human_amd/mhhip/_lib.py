@@ -83,6 +83,13 @@ def lib():
         L.mh_raster_workspace_bytes.restype = ctypes.c_size_t
         L.mh_raster_workspace_bytes.argtypes = [ctypes.c_int] * 6
         L.mh_raster_terms.argtypes = [ctypes.c_int] * 6 + [c_float_p] + [vp] * 12 + [ctypes.c_float] * 3 + [vp] * 9
+        L.mh_avg_depth_loss.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_float, vp, vp, vp]
+        L.mh_avg_depth_loss_backward.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_float, vp, ctypes.c_float, vp, vp, vp]
+        L.mh_masked_mse.argtypes = [vp, vp, vp, ctypes.c_size_t, vp, vp]
+        L.mh_masked_mse_backward.argtypes = [vp, vp, vp, ctypes.c_size_t, vp, ctypes.c_float, vp, vp]
+        L.mh_morph_f32.argtypes = [vp, vp] + [ctypes.c_int] * 5 + [vp]
+        L.mh_project_points.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, c_float_p, ctypes.c_int, vp, vp]
+        L.mh_unproject_points.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
         _lib = L
     return _lib
 

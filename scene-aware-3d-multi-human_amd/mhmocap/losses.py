@@ -1,0 +1,69 @@
+"""Drop-in for the two loss builders of reference ``mhmocap/losses.py`` that the optimisation path
+uses (``build_avg_depth_loss_fn`` :19-30, ``build_masked_mse_loss_fn`` :33-40), backed by HIP kernels
+(``mh_avg_depth_loss*``, ``mh_masked_mse*``) with hand-written backward.  The reference's other
+builders are dead code.  The sequence optimiser itself uses the fused raster kernels."""
+import torch
+
+from mhhip import _lib
+from mhhip._lib import check, ptr
+
+
+class _AvgDepthLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y_pred, y_true, mask, eps):
+        b, n = y_pred.shape[0], y_pred.shape[1]
+        P = y_pred[0, 0].numel()
+        assert y_true.shape[0] == b and y_true.shape[1] in (1, n), 'target must be (b,1,H,W) or (b,N,H,W)'
+        group = n if y_true.shape[1] == 1 else 1
+        pr, tr, mk = y_pred.contiguous().float(), y_true.contiguous().float(), mask.expand_as(y_pred).contiguous().float()
+        sums = torch.empty(b * n, 3, dtype=torch.float32, device=pr.device)
+        check(_lib.lib().mh_avg_depth_loss(ptr(pr), ptr(tr), ptr(mk), b * n, group, P, float(eps), ptr(sums), ptr(sums),
+                                           _lib.stream_ptr(pr.device)))
+        ctx.save_for_backward(pr, tr, mk, sums)
+        ctx.meta = (b, n, P, group, float(eps), y_pred.shape, y_true.shape)
+        cnt = sums[:, 2] + 1
+        return ((sums[:, 0] / cnt - sums[:, 1] / cnt) ** 2).sum()
+
+    @staticmethod
+    def backward(ctx, gout):
+        pr, tr, mk, sums = ctx.saved_tensors
+        b, n, P, group, eps, ps, ts = ctx.meta
+        gp = torch.empty_like(pr) if ctx.needs_input_grad[0] else None
+        gt = torch.empty_like(pr) if ctx.needs_input_grad[1] else None
+        check(_lib.lib().mh_avg_depth_loss_backward(ptr(pr), ptr(tr), ptr(mk), b * n, group, P, eps, ptr(sums),
+                                                    float(gout), ptr(gp), ptr(gt), _lib.stream_ptr(pr.device)))
+        if gt is not None:
+            gt = gt.view(ps)
+            gt = gt.sum(dim=1, keepdim=True) if group > 1 else gt
+            gt = gt.view(ts)
+        return (gp.view(ps) if gp is not None else None), gt, None, None
+
+
+class _MaskedMse(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y1, y2, mask):
+        a, b, m = y1.contiguous().float(), y2.expand_as(y1).contiguous().float(), mask.expand_as(y1).contiguous().float()
+        sums = torch.empty(2, dtype=torch.float32, device=a.device)
+        check(_lib.lib().mh_masked_mse(ptr(a), ptr(b), ptr(m), a.numel(), ptr(sums), _lib.stream_ptr(a.device)))
+        ctx.save_for_backward(a, b, m, sums)
+        return sums[0] / (sums[1] + 1.0)
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, b, m, sums = ctx.saved_tensors
+        ga = torch.empty_like(a)
+        check(_lib.lib().mh_masked_mse_backward(ptr(a), ptr(b), ptr(m), a.numel(), ptr(sums), float(gout), ptr(ga),
+                                                _lib.stream_ptr(a.device)))
+        return ga, None, None
+
+
+def build_avg_depth_loss_fn(eps=1e-3):
+    def _depth_loss_fn(y_pred, y_true, mask):
+        return _AvgDepthLoss.apply(y_pred, y_true, mask, eps)
+    return _depth_loss_fn
+
+
+def build_masked_mse_loss_fn():
+    def _masked_mse_loss_fn(y1, y2, mask):
+        return _MaskedMse.apply(y1, y2, mask)
+    return _masked_mse_loss_fn

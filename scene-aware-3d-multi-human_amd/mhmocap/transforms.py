@@ -7,6 +7,11 @@ import math
 import numpy as np
 
 
+def _hip():
+    from mhhip import _lib
+    return _lib
+
+
 def get_focal(w, theta):
     return 0.5 * w / math.tan(math.pi * theta / 360.0)
 
@@ -50,3 +55,34 @@ def camera_projection(pts3d, K, return_depth=False):
 def camera_inverse_projection(ptsuvd, K):
     xy = ptsuvd[:, 2:3] * ((ptsuvd[:, :2] - K[0:2, 2:3].T) @ np.linalg.inv(K[:2, :2].T))
     return np.concatenate([xy, ptsuvd[:, 2:3]], axis=-1)
+
+
+def camera_projection_torch(pts3d, K, return_depth=False, Kd=None):
+    """pts3d (N,M,3), K (N,3,3) device tensors -> (N,M,2) pixels (reference :57-95); forward only."""
+    import torch
+    L = _hip()
+    p = pts3d.contiguous().float()
+    Kc = K.contiguous().float()
+    N, M = p.shape[0], p.shape[1]
+    out = torch.empty(N, M, 3 if return_depth else 2, dtype=torch.float32, device=p.device)
+    kd = None if Kd is None else np.ascontiguousarray(np.asarray(Kd, np.float32).reshape(5))
+    L.check(L.lib().mh_project_points(N, M, L.ptr(p), L.ptr(Kc), None if kd is None else kd.ctypes.data_as(L.c_float_p),
+                                      1 if return_depth else 0, L.ptr(out), L.stream_ptr(p.device)))
+    return out
+
+
+def camera_inverse_projection_torch(ptsuvd, K):
+    """ptsuvd (N,M,3) pixels + depth, K (N,3,3) -> camera-space points (reference :114-130)."""
+    import torch
+    L = _hip()
+    p = ptsuvd.contiguous().float()
+    Kc = K.contiguous().float()
+    out = torch.empty_like(p)
+    L.check(L.lib().mh_unproject_points(p.shape[0], p.shape[1], L.ptr(p), L.ptr(Kc), L.ptr(out), L.stream_ptr(p.device)))
+    return out
+
+
+def softplus(x):
+    """reference :296-297 (naive form); a one-liner on tensors, kept for call compatibility"""
+    import torch
+    return torch.log(1.0 + torch.exp(x))

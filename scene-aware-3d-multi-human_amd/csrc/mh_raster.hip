@@ -126,15 +126,42 @@ __device__ __forceinline__ void r_load_tri(const RasterP& p, const float* vb, in
   }
 }
 
+// Gradient scatter.  Neighbouring pixels of a strip hit the same few hundred vertices (each
+// silhouette pixel touches 4 faces x 2 vertices x 3 components), so contributions are first summed in a
+// per-workgroup LDS hash table (vertex id -> 3 floats, LDS float atomics) and flushed with ONE global
+// atomic per touched vertex component; a full table falls back to direct global atomics.
+#define RH_SLOTS 2048
+#define RH_PROBES 12
+struct GradAcc {
+  int* id;        // [RH_SLOTS], -1 = empty
+  float* val;     // [RH_SLOTS][3]
+  float* gvb;     // global dL/dverts of this body
+};
+__device__ __forceinline__ void r_acc_add(const GradAcc& a, int vid, float gx, float gy, float gz) {
+  unsigned h = ((unsigned)vid * 2654435761u) >> 21;            // 11 bits
+#pragma unroll 1
+  for (int pr = 0; pr < RH_PROBES; ++pr) {
+    int cur = a.id[h];
+    if (cur == -1) cur = atomicCAS(&a.id[h], -1, vid);
+    if (cur == -1 || cur == vid) {
+      atomicAdd(&a.val[h * 3], gx);
+      atomicAdd(&a.val[h * 3 + 1], gy);
+      atomicAdd(&a.val[h * 3 + 2], gz);
+      return;
+    }
+    h = (h + 1) & (RH_SLOTS - 1);
+  }
+  float* o = a.gvb + (size_t)vid * 3;
+  atomicAdd(o, gx);
+  atomicAdd(o + 1, gy);
+  atomicAdd(o + 2, gz);
+}
 // scatter d/d(ndc x, ndc y, z) of one vertex to camera space
-__device__ __forceinline__ void r_scatter(const RasterP& p, float* gvb, const Tri& t, int k, float gxn, float gyn, float gz) {
+__device__ __forceinline__ void r_scatter(const RasterP& p, const GradAcc& a, const Tri& t, int k, float gxn, float gyn, float gz) {
   const float Z = t.z[k];
   const float gx = -p.s / Z * gxn, gy = -p.s / Z * gyn;
   const float gzz = gz + p.s * (t.cx[k] * gxn + t.cy[k] * gyn) / (Z * Z);
-  float* o = gvb + (size_t)t.idx[k] * 3;
-  atomicAdd(o, gx);
-  atomicAdd(o + 1, gy);
-  atomicAdd(o + 2, gzz);
+  r_acc_add(a, t.idx[k], gx, gy, gzz);
 }
 
 __device__ __forceinline__ float r_block_sum(float v, float* sh) {
@@ -597,7 +624,12 @@ __global__ void k_raster_body_out(RasterP p) {
 // gradients per strip
 // =============================================================================================
 __global__ __launch_bounds__(RB) void k_raster_grads(RasterP p) {
+  __shared__ int hid[RH_SLOTS];
+  __shared__ float hval[RH_SLOTS * 3];
   const int tid = threadIdx.x;
+  for (int i = tid; i < RH_SLOTS; i += RB) hid[i] = -1;
+  for (int i = tid; i < RH_SLOTS * 3; i += RB) hval[i] = 0.f;
+  __syncthreads();
   const int H = p.H, W = p.W, P = H * W;
   const int total = p.total[0];
   for (int s = blockIdx.x; s < total; s += gridDim.x) {
@@ -606,6 +638,8 @@ __global__ __launch_bounds__(RB) void k_raster_grads(RasterP p) {
     const int sy0 = p.strip_row0[s], npx = p.strip_rows[s] * ww;
     const float* vb = p.verts + (size_t)b * p.V * 3;
     float* gvb = p.gverts + (size_t)b * p.V * 3;
+    GradAcc acc;
+    acc.id = hid; acc.val = hval; acc.gvb = gvb;
     const unsigned long long* gk = p.gkeys + (size_t)p.strip_koff[s] * 5;
     float S[6];
     r_body_sums(p, b, S);
@@ -668,7 +702,7 @@ __global__ __launch_bounds__(RB) void k_raster_grads(RasterP p) {
           gx[0] += garea * (tr.y[2] - tr.y[1]);  gy[0] += garea * (tr.x[1] - tr.x[2]);
           gx[1] += garea * (-(tr.y[2] - tr.y[0])); gy[1] += garea * (tr.x[2] - tr.x[0]);
 #pragma unroll
-          for (int k = 0; k < 3; ++k) r_scatter(p, gvb, tr, k, gx[k], gy[k], gz[k]);
+          for (int k = 0; k < 3; ++k) r_scatter(p, acc, tr, k, gx[k], gy[k], gz[k]);
         }
       }
       // silhouette
@@ -723,12 +757,26 @@ __global__ __launch_bounds__(RB) void k_raster_grads(RasterP p) {
               qy = tr.y[a] + tt * (tr.y[bb] - tr.y[a]) - yf;
               ga = 1.f - tt; gb = tt;
             }
-            r_scatter(p, gvb, tr, a, gd * ga * 2.f * qx, gd * ga * 2.f * qy, 0.f);
-            r_scatter(p, gvb, tr, bb, gd * gb * 2.f * qx, gd * gb * 2.f * qy, 0.f);
+            r_scatter(p, acc, tr, a, gd * ga * 2.f * qx, gd * ga * 2.f * qy, 0.f);
+            r_scatter(p, acc, tr, bb, gd * gb * 2.f * qx, gd * gb * 2.f * qy, 0.f);
           }
         }
       }
     }
+    // flush the table: one global atomic per touched vertex component
+    __syncthreads();
+    for (int i = tid; i < RH_SLOTS; i += RB) {
+      const int vid = hid[i];
+      if (vid >= 0) {
+        float* o = gvb + (size_t)vid * 3;
+        atomicAdd(o, hval[i * 3]);
+        atomicAdd(o + 1, hval[i * 3 + 1]);
+        atomicAdd(o + 2, hval[i * 3 + 2]);
+        hid[i] = -1;
+        hval[i * 3] = 0.f; hval[i * 3 + 1] = 0.f; hval[i * 3 + 2] = 0.f;
+      }
+    }
+    __syncthreads();
   }
 }
 

@@ -108,7 +108,20 @@ __global__ __launch_bounds__(64 * KNN_WAVES) void k_contact_knn(const float* pts
   int fill = K;           // slots [0,K) hold the kept set (INF until filled), new candidates go to [K, ...)
   const int per = (M + KNN_WAVES - 1) / KNN_WAVES;
   const int m0 = wave * per, m1 = min(M, m0 + per);
-  for (int base = m0; base < m1; base += 64) {
+  // Scene points arrive in raster order (distance to the query varies monotonically over long runs),
+  // which would tighten tau only slowly and trigger a sort per chunk.  Visiting the 64-point chunks in
+  // a strided pseudo-random order makes the first few chunks a sample of the whole range.
+  const int nchunks = (max(m1 - m0, 0) + 63) / 64;
+  int stride = (int)(0.618f * (float)nchunks) | 1;
+  while (stride > 1) {
+    int a = stride, c = nchunks;
+    while (c) { const int t = a % c; a = c; c = t; }
+    if (a == 1) break;
+    stride -= 2;
+  }
+  if (stride < 1) stride = 1;
+  for (int cidx = 0, cc = 0; cidx < nchunks; ++cidx, cc = (cc + stride) % nchunks) {
+    const int base = m0 + cc * 64;
     const int i = base + lane;
     float d2 = INFINITY, py = 0.f;
     if (i < m1) {

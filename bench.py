@@ -91,6 +91,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--eager', action='store_true', help='launch every kernel from the host instead of replaying captured graphs')
     ap.add_argument('--cpu-frames', type=int, default=20)
     ap.add_argument('--cpu-cycles', type=int, default=3)
     args = ap.parse_args()
@@ -132,25 +133,21 @@ def main():
     sh = sharded.ShardedSequence(e, rank * T_LOCAL, world * T_LOCAL)
     raster = RasterTerms(e)
     sh.update_filters()                                                                # filtered-vertex term live
-    lr = 0.01
-
-    def one_cycle(c):
-        nonlocal lr
+    def one_cycle(c, graphs):
         if c % 25 == 0 and c > 0:
             sh.update_filters()
-        sh.cycle(c % e.log.shape[0], raster=raster)
-        sh.step(lr)
-        lr *= 0.99
+        sh.cycle(c % e.log.shape[0], raster=raster, graphs=graphs)
+        sh.step()                     # RMSprop with the device-resident lr (x0.99 per cycle)
 
+    use_graphs = not args.eager
     for c in range(args.warmup):
-        one_cycle(c)
-    e.enable_timing(True)
+        one_cycle(c, use_graphs)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for c in range(args.steps):
-        one_cycle(args.warmup + c)
+        one_cycle(args.warmup + c, use_graphs)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -159,6 +156,15 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # per-kernel durations: HIP events cannot be read back from inside a replayed graph, so the same
+    # launch sequence runs once more eagerly with events around the kernel groups (same kernels, same
+    # stream, same data; only the launch mechanism differs)
+    e.enable_timing(True)
+    for c in range(args.steps):
+        one_cycle(args.warmup + args.steps + c, False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
     kern = e.timing_summary()
     e.enable_timing(False)
     log = sh.read_log(1)
@@ -185,7 +191,7 @@ def main():
             'metric': 'optimizer iterations/sec (N humans x T frames)', 'value': round(its * world, 3),
             'unit': 'iterations/s (4 humans x 200 frames per iteration unit)', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'launch': 'eager' if args.eager else 'hipGraph replay',
             'config': {'workload': 'MuPoTs TS13-shape 4 humans x %d frames, 240x135, batch 10, full nine-term loss stack '
                                    '(2D joints, raster depth, soft silhouette, contact, foot sliding, priors, velocity, '
                                    'filtered vertices) + RMSprop; scene injected (ground plane), one-euro filters live'

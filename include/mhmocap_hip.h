@@ -135,6 +135,12 @@ int mh_warmup_project(int B, int NB, const float* local_joints /*(B,17,3)*/, con
 /* ---- a20: optimiser updates (optimizer.py:355-356, 586-587, 738-739, 764-765) --------------- */
 int mh_rmsprop_step(float* params, const float* grads, float* square_avg, float* momentum_buf,
                     size_t n, float lr, float alpha, float momentum, float eps, void* stream);
+/* the same update with the learning rate resident on the device (lr_dev[0]); afterwards
+ * lr_dev[0] *= gamma (ExponentialLR).  No host scalar changes between calls, so the whole cycle can
+ * be captured in a hipGraph and replayed.                                                      */
+int mh_rmsprop_step_dev(float* params, const float* grads, float* square_avg, float* momentum_buf,
+                        size_t n, float* lr_dev, float gamma, float alpha, float momentum, float eps,
+                        void* stream);
 int mh_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n,
                  int step, float lr, float beta1, float beta2, float eps, void* stream);
 

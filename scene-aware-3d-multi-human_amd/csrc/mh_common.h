@@ -7,7 +7,7 @@
 
 #include "../../include/mhmocap_hip.h"
 
-#define MH_KD 220       // rows of the k-major basis planes: 10 shape + 207 pose + 3 zero
+#define MH_KD 224       // rows of the k-major basis planes: 10 shape + 207 pose + 7 zero
 #define MH_FS 224       // MH_FEAT_STRIDE
 #define MH_NJ 24
 #define MH_NKP 17

@@ -100,7 +100,7 @@ template <int NMAX>
 __global__ __launch_bounds__(256) void k_sil_stats(const uint32_t* bits, int N, int P, const float* pT,
                                                    const float* p2d_valid, const float* mask_valid, uint32_t* front,
                                                    float* apply, float* D, float* S) {
-  const int t = blockIdx.x;
+  const int t = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
   __shared__ uint32_t sfront[32];
   __shared__ float sred[2][32][4];
   if (threadIdx.x < N) {
@@ -116,8 +116,10 @@ __global__ __launch_bounds__(256) void k_sil_stats(const uint32_t* bits, int N, 
       }
     }
     sfront[n] = f;
-    front[(size_t)t * N + n] = f;
-    apply[(size_t)t * N + n] = mask_valid[(size_t)t * N + rank] * p2d_valid[(size_t)t * N + rank];   // optimizer.py:472 (sic)
+    if (part == 0) {
+      front[(size_t)t * N + n] = f;
+      apply[(size_t)t * N + n] = mask_valid[(size_t)t * N + rank] * p2d_valid[(size_t)t * N + rank];   // optimizer.py:472 (sic)
+    }
   }
   __syncthreads();
   float d[NMAX], s[NMAX];
@@ -127,7 +129,8 @@ __global__ __launch_bounds__(256) void k_sil_stats(const uint32_t* bits, int N, 
     d[n] = s[n] = 0.f;
     fr[n] = n < N ? sfront[n] : 0xffffffffu;
   }
-  for (int p = threadIdx.x; p < P; p += 256) {
+  const int p_lo = (int)((long long)P * part / nparts), p_hi = (int)((long long)P * (part + 1) / nparts);
+  for (int p = p_lo + threadIdx.x; p < p_hi; p += 256) {
     const uint32_t w = bits[(size_t)t * P + p];
 #pragma unroll
     for (int n = 0; n < NMAX; ++n) {
@@ -148,8 +151,9 @@ __global__ __launch_bounds__(256) void k_sil_stats(const uint32_t* bits, int N, 
   __syncthreads();
   if (threadIdx.x < N) {
     const int n = threadIdx.x;
-    D[(size_t)t * N + n] = sred[0][n][0] + sred[0][n][1] + sred[0][n][2] + sred[0][n][3];
-    S[(size_t)t * N + n] = sred[1][n][0] + sred[1][n][1] + sred[1][n][2] + sred[1][n][3];
+    // pixel counts: integers below 2^24, so the float atomics are exact and order-free
+    atomicAdd(&D[(size_t)t * N + n], sred[0][n][0] + sred[0][n][1] + sred[0][n][2] + sred[0][n][3]);
+    atomicAdd(&S[(size_t)t * N + n], sred[1][n][0] + sred[1][n][1] + sred[1][n][2] + sred[1][n][3]);
   }
 }
 
@@ -158,7 +162,10 @@ extern "C" int mh_sil_mask_stats(const uint32_t* bits, int T, int N, int H, int 
                                  float* D, float* S, void* stream) {
   MH_CHECK(bits && pT && pose2d_valid && mask_valid && front && apply && D && S, "null argument");
   MH_CHECK(T > 0 && N > 0 && N <= 32, "need 1..32 people per frame");
-#define SIL_LAUNCH(NM) hipLaunchKernelGGL(k_sil_stats<NM>, dim3(T), dim3(256), 0, (hipStream_t)stream, bits, N, \
+  const int parts = T >= 2048 ? 1 : (T >= 512 ? 4 : 8);
+  MH_HIP(hipMemsetAsync(D, 0, (size_t)T * N * sizeof(float), (hipStream_t)stream));
+  MH_HIP(hipMemsetAsync(S, 0, (size_t)T * N * sizeof(float), (hipStream_t)stream));
+#define SIL_LAUNCH(NM) hipLaunchKernelGGL(k_sil_stats<NM>, dim3(T, parts), dim3(256), 0, (hipStream_t)stream, bits, N, \
                                           H * W, pT, pose2d_valid, mask_valid, front, apply, D, S)
   if (N <= 4) SIL_LAUNCH(4);
   else if (N <= 8) SIL_LAUNCH(8);

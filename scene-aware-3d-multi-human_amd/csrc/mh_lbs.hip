@@ -167,15 +167,33 @@ __global__ __launch_bounds__(256) void k_skin_fwd(SkinFwdP p) {
   const float* Dx = p.D + (size_t)v;
   const size_t plane = (size_t)MH_KD * p.VP;
   f32x16 ax = {0}, ay = {0}, az = {0};
-#pragma unroll 4
-  for (int s = 0; s < 109; ++s) {     // K = 218 (217 used)
-    const int k = 2 * s + lh;
-    const float a = fT[k * 32];
+  // K = 224 (217 used, the rest zero) in 14 groups of 8 two-k steps; the operands of group g+1 are loaded
+  // into the second register set while the 24 MFMAs of group g issue (explicit double buffering: the
+  // loads come from L2, ~600-800 cycles away, and one group is 1536 MFMA cycles)
+  float ra[2][8], rx[2][8], ry[2][8], rz[2][8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int k = 2 * u + lh;
     const float* d = Dx + (size_t)k * p.VP;
-    const float bx = d[0], by = d[plane], bz = d[2 * plane];
-    ax = MFMA32(a, bx, ax);
-    ay = MFMA32(a, by, ay);
-    az = MFMA32(a, bz, az);
+    ra[0][u] = fT[k * 32]; rx[0][u] = d[0]; ry[0][u] = d[plane]; rz[0][u] = d[2 * plane];
+  }
+#pragma unroll
+  for (int g8 = 0; g8 < 14; ++g8) {
+    const int cur = g8 & 1, nxt = cur ^ 1;
+    if (g8 + 1 < 14) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = 2 * (8 * (g8 + 1) + u) + lh;
+        const float* d = Dx + (size_t)k * p.VP;
+        ra[nxt][u] = fT[k * 32]; rx[nxt][u] = d[0]; ry[nxt][u] = d[plane]; rz[nxt][u] = d[2 * plane];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      ax = MFMA32(ra[cur][u], rx[cur][u], ax);
+      ay = MFMA32(ra[cur][u], ry[cur][u], ay);
+      az = MFMA32(ra[cur][u], rz[cur][u], az);
+    }
   }
   if (v >= p.V) return;
   const float t0 = p.vt[(size_t)v * 3], t1 = p.vt[(size_t)v * 3 + 1], t2 = p.vt[(size_t)v * 3 + 2];

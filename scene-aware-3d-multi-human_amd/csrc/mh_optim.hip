@@ -161,6 +161,35 @@ extern "C" int mh_rmsprop_step(float* params, const float* grads, float* square_
   return MH_OK;
 }
 
+// device-resident learning rate (lets a captured hipGraph replay the step while the ExponentialLR
+// schedule of optimizer.py:356 advances): p -= lr[0] * buf, then lr[0] *= gamma in a second launch
+__global__ void k_rmsprop_dev(float* p, const float* g, float* sq, float* buf, size_t n, const float* lr_dev, float alpha,
+                              float mom, float eps) {
+  const float lr = lr_dev[0];
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float s = alpha * sq[i] + (1.f - alpha) * gi * gi;
+    sq[i] = s;
+    const float b = mom * buf[i] + gi / (sqrtf(s) + eps);
+    buf[i] = b;
+    p[i] = p[i] - lr * b;
+  }
+}
+__global__ void k_scale_scalar(float* x, float gamma) { x[0] *= gamma; }
+
+extern "C" int mh_rmsprop_step_dev(float* params, const float* grads, float* square_avg, float* momentum_buf, size_t n,
+                                   float* lr_dev, float gamma, float alpha, float momentum, float eps, void* stream) {
+  MH_CHECK(params && grads && square_avg && momentum_buf && lr_dev, "null argument");
+  if (n == 0) return MH_OK;
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(k_rmsprop_dev, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, square_avg, momentum_buf,
+                     n, (const float*)lr_dev, alpha, momentum, eps);
+  MH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_scale_scalar, dim3(1), dim3(1), 0, (hipStream_t)stream, lr_dev, gamma);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
 __global__ void k_adam(float* p, const float* g, float* m, float* v, size_t n, float step_size, float b1, float b2,
                        float inv_sqrt_bc2, float eps) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -303,23 +332,30 @@ extern "C" int mh_velocity_term(int T, int N, const float* pT, const float* prev
 __global__ __launch_bounds__(256) void k_filtered_verts(int T, size_t E, const float* v, const float* vf,
                                                         const float* pv, const float* pvf, const float* nv,
                                                         const float* nvf, float coef, float* gv, float* partial) {
+  // grid = (chunks of E, T): no index division; the t-1 / t+1 rows are re-read through L2
   __shared__ float s[256];
+  const int t = blockIdx.y;
+  const float* vc = v + (size_t)t * E;
+  const float* fc = vf + (size_t)t * E;
+  const float* vp = t > 0 ? vc - E : pv;
+  const float* fp = t > 0 ? fc - E : pvf;
+  const float* vn = t + 1 < T ? vc + E : nv;
+  const float* fn = t + 1 < T ? fc + E : nvf;
+  float* g = gv + (size_t)t * E;
   float acc = 0.f;
-  const size_t n = (size_t)T * E;
-  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    const size_t t = i / E, e = i - t * E;
-    const float c = v[i], cf = vf[i];
-    float g = 0.f;
-    if (t > 0 || pv) {
-      const float d = (c - (t > 0 ? v[i - E] : pv[e])) - (cf - (t > 0 ? vf[i - E] : pvf[e]));
-      acc += d * d;
-      g += 2.f * d;
+  for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < E; e += (size_t)gridDim.x * 256) {
+    const float c = vc[e], cf = fc[e];
+    float gr = 0.f;
+    if (vp) {
+      const float d = (c - vp[e]) - (cf - fp[e]);
+      acc += d * d;          // the pair (t-1, t) belongs to the owner of t
+      gr += 2.f * d;
     }
-    if (t + 1 < (size_t)T || nv) {
-      const float d = ((t + 1 < (size_t)T ? v[i + E] : nv[e]) - c) - ((t + 1 < (size_t)T ? vf[i + E] : nvf[e]) - cf);
-      g -= 2.f * d;
+    if (vn) {
+      const float d = (vn[e] - c) - (fn[e] - cf);
+      gr -= 2.f * d;
     }
-    gv[i] += coef * g;
+    g[e] += coef * gr;
   }
   s[threadIdx.x] = acc;
   __syncthreads();
@@ -327,7 +363,7 @@ __global__ __launch_bounds__(256) void k_filtered_verts(int T, size_t E, const f
     if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) partial[blockIdx.x] = s[0];
+  if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s[0];
 }
 
 __global__ __launch_bounds__(256) void k_sum_partials(const float* partial, int n, float* out) {
@@ -343,8 +379,9 @@ __global__ __launch_bounds__(256) void k_sum_partials(const float* partial, int 
   if (threadIdx.x == 0) out[0] = s[0];
 }
 
-#define FV_BLOCKS 1024
-static float* g_fv_partial = nullptr;   // FV_BLOCKS floats of scratch, allocated once per process
+#define FV_XBLOCKS 16
+static float* g_fv_partial = nullptr;   // per-block partial sums, allocated once per process
+static size_t g_fv_cap = 0;
 
 extern "C" int mh_filtered_verts_term(int T, size_t E, const float* verts, const float* verts_filt,
                                       const float* prev_v, const float* prev_vf, const float* next_v,
@@ -353,12 +390,17 @@ extern "C" int mh_filtered_verts_term(int T, size_t E, const float* verts, const
   MH_CHECK(T >= 1 && E >= 1, "empty input");
   MH_CHECK((prev_v == nullptr) == (prev_vf == nullptr) && (next_v == nullptr) == (next_vf == nullptr),
            "halo vertices and filtered halo vertices come in pairs");
-  if (!g_fv_partial) MH_HIP(hipMalloc((void**)&g_fv_partial, FV_BLOCKS * sizeof(float)));
+  const size_t nblk = (size_t)FV_XBLOCKS * T;
+  if (nblk > g_fv_cap) {
+    if (g_fv_partial) (void)hipFree(g_fv_partial);
+    MH_HIP(hipMalloc((void**)&g_fv_partial, nblk * sizeof(float)));
+    g_fv_cap = nblk;
+  }
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_filtered_verts, dim3(FV_BLOCKS), dim3(256), 0, st, T, E, verts, verts_filt, prev_v, prev_vf,
+  hipLaunchKernelGGL(k_filtered_verts, dim3(FV_XBLOCKS, T), dim3(256), 0, st, T, E, verts, verts_filt, prev_v, prev_vf,
                      next_v, next_vf, coef, gverts, g_fv_partial);
   MH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, (const float*)g_fv_partial, FV_BLOCKS, loss_out);
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, (const float*)g_fv_partial, (int)nblk, loss_out);
   MH_LAUNCH_CHECK();
   return MH_OK;
 }

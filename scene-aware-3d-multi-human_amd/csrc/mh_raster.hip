@@ -214,11 +214,11 @@ __device__ __forceinline__ void r_insert(unsigned long long* q, float pz, bool i
 // windows and strips
 // =============================================================================================
 __global__ __launch_bounds__(256) void k_raster_windows(RasterP p) {
-  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (b >= p.B) return;
+  __shared__ float sbb[4][4];
+  const int b = blockIdx.x, tid = threadIdx.x;
   const float* vb = p.verts + (size_t)b * p.V * 3;
   float mnx = 1e30f, mny = 1e30f, mxx = -1e30f, mxy = -1e30f;
-  for (int v = lane; v < p.V; v += 64) {
+  for (int v = tid; v < p.V; v += 256) {
     const float X = vb[(size_t)v * 3], Y = vb[(size_t)v * 3 + 1], Z = vb[(size_t)v * 3 + 2];
     const float xn = p.s * (-X) / Z + p.w1, yn = p.s * (-Y) / Z + p.h1;
     float* o = p.ndc + ((size_t)b * p.V + v) * 3;
@@ -234,7 +234,15 @@ __global__ __launch_bounds__(256) void k_raster_windows(RasterP p) {
     mnx = fminf(mnx, __shfl_xor(mnx, o, 64)); mny = fminf(mny, __shfl_xor(mny, o, 64));
     mxx = fmaxf(mxx, __shfl_xor(mxx, o, 64)); mxy = fmaxf(mxy, __shfl_xor(mxy, o, 64));
   }
-  if (lane == 0) {
+  if ((tid & 63) == 0) {
+    sbb[tid >> 6][0] = mnx; sbb[tid >> 6][1] = mny; sbb[tid >> 6][2] = mxx; sbb[tid >> 6][3] = mxy;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w) {
+      mnx = fminf(mnx, sbb[w][0]); mny = fminf(mny, sbb[w][1]);
+      mxx = fmaxf(mxx, sbb[w][2]); mxy = fmaxf(mxy, sbb[w][3]);
+    }
     // clamp in float first: a body far outside the image must not overflow the int conversion
     const float big = 1e6f;
     mnx = fminf(fmaxf(mnx, -big), big); mxx = fminf(fmaxf(mxx, -big), big);
@@ -878,7 +886,7 @@ extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const f
     MH_LAUNCH_CHECK();
   }
   if (alpha_out) MH_HIP(hipMemsetAsync(alpha_out, 0, (size_t)p.B * H * W * sizeof(float), st));
-  hipLaunchKernelGGL(k_raster_windows, dim3((p.B + 3) / 4), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(k_raster_windows, dim3(p.B), dim3(256), 0, st, p);
   MH_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_raster_strip_table, dim3(1), dim3(1024), 0, st, p);
   MH_LAUNCH_CHECK();

@@ -62,6 +62,7 @@ def lib():
         L.mh_project_joints_loss.argtypes = [ctypes.c_int, vp, c_float_p, c_float_p, vp, ctypes.c_float, ctypes.c_int,
                                              ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp]
         L.mh_rmsprop_step.argtypes = [vp, vp, vp, vp, ctypes.c_size_t] + [ctypes.c_float] * 4 + [vp]
+        L.mh_rmsprop_step_dev.argtypes = [vp, vp, vp, vp, ctypes.c_size_t, vp] + [ctypes.c_float] * 4 + [vp]
         L.mh_adam_step.argtypes = [vp, vp, vp, vp, ctypes.c_size_t, ctypes.c_int] + [ctypes.c_float] * 4 + [vp]
         L.mh_one_euro_scan.argtypes = [vp, vp, ctypes.c_int, ctypes.c_size_t] + [ctypes.c_float] * 3 + [vp]
         L.mh_one_euro_scan_shard.argtypes = [vp, vp, ctypes.c_int, ctypes.c_size_t] + [ctypes.c_float] * 3 + [ctypes.c_int, ctypes.c_float, vp, vp, vp, vp]

@@ -275,10 +275,52 @@ class SequenceEngine(object):
         check(L.mh_reduce_sum(ptr(self.prior_body), B, 1.0, ptr(log[3:4]), st))
         log[9:12].copy_(self.loss3)
         log[7:8].copy_(self.vel_loss)
-        self.log[row].copy_(log)
+        if row is not None:
+            self.log[row].copy_(log)
 
     def step(self, lr, alpha=0.5, momentum=0.9, eps=1e-8):
         engine.rmsprop_step(self.params, self.grads, self.sq, self.buf, float(lr), alpha, momentum, eps)
+
+    # -- hipGraph replay of a cycle -------------------------------------------------------------------
+    # A cycle is ~45 launches of 5-600 us kernels; replaying it as a captured graph removes the host
+    # launch gaps.  Everything a captured launch reads must keep its address and no host scalar may
+    # change between replays: the log row goes through a staging row, the learning rate lives on the
+    # device.  Capture is per configuration (raster / scene / filters on or off).
+    def _graph_key(self, raster):
+        return (raster is not None, self.scene_pts is not None and id(self.scene_pts),
+                self.verts_filt is not None and self.pT_filt is not None, self.halo is None)
+
+    def replay(self, key, fn):
+        """Run ``fn`` (a fixed launch sequence on static buffers) through a captured graph; the first
+        call runs it eagerly (lazy allocations, one-time attribute calls) and captures it."""
+        if not hasattr(self, '_graphs'):
+            self._graphs = {}
+        g = self._graphs.get(key)
+        if g is None:
+            fn()
+            torch.cuda.current_stream(self.dev).synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
+            self._graphs[key] = g
+        else:
+            g.replay()
+
+    def cycle_graphed(self, row, raster=None):
+        """``cycle`` through a captured graph (single-process form; the sharded driver replays
+        ``cycle_begin`` / ``cycle_finish`` separately around its exchanges)."""
+        def body():
+            self.cycle_begin()
+            self.cycle_finish(None, raster=raster)
+        self.replay(('full',) + self._graph_key(raster), body)
+        self.log[row].copy_(self.tmp_log)
+
+    def step_dev(self, alpha=0.5, momentum=0.9, eps=1e-8, gamma=0.99, lr0=0.01):
+        if not hasattr(self, 'lr_dev'):
+            self.lr_dev = torch.full((1,), lr0, dtype=torch.float32, device=self.dev)
+        check(_lib.lib().mh_rmsprop_step_dev(ptr(self.params), ptr(self.grads), ptr(self.sq), ptr(self.buf),
+                                             self.params.numel(), ptr(self.lr_dev), gamma, alpha, momentum, eps,
+                                             _lib.stream_ptr(self.dev)))
 
     # -- filters (optimizer.py:383-392) -------------------------------------------------------------
     def update_filters(self, c1=0.01, b1=0.02, c2=0.001, b2=0.5):

@@ -47,6 +47,7 @@ class ShardedSequence(object):
         self.is_first = self.first_frame == 0
         self.is_last = self.first_frame + engine.T >= self.total_frames
         self._vf_halo = None
+        self._hbuf = {}
 
     # -- neighbour exchange: every rank contributes its first and last frame ------------------------
     def _gather_boundaries(self, x):
@@ -60,22 +61,51 @@ class ShardedSequence(object):
         nxt = None if self.is_last else out[self.rank + 1][0].contiguous()
         return prev, nxt
 
-    def cycle(self, row, raster=None):
+    def _static(self, name, t):
+        """halo tensors live at fixed addresses so that captured launches can read them"""
+        if t is None:
+            return None
+        buf = self._hbuf.get(name)
+        if buf is None or buf.shape != t.shape:
+            buf = torch.empty_like(t)
+            self._hbuf[name] = buf
+        buf.copy_(t)
+        return buf
+
+    def cycle(self, row, raster=None, graphs=False):
         e = self.e
+        if self.world == 1:
+            e.halo = None
+            if graphs:
+                e.cycle_graphed(row, raster=raster)
+            else:
+                e.cycle(row, raster=raster)
+            return
         halo = {}
-        halo['pT_prev'], halo['pT_next'] = self._gather_boundaries(e.leaf('poses_T'))
-        e.cycle_begin()
+        pp, pn = self._gather_boundaries(e.leaf('poses_T'))
+        halo['pT_prev'], halo['pT_next'] = self._static('pT_prev', pp), self._static('pT_next', pn)
+        if graphs:
+            e.replay(('begin',), e.cycle_begin)
+        else:
+            e.cycle_begin()
         if e.verts_filt is not None and e.pT_filt is not None:
-            v = e.verts.view(e.T, -1)
-            halo['v_prev'], halo['v_next'] = self._gather_boundaries(v)
+            vp, vn = self._gather_boundaries(e.verts.view(e.T, -1))
+            halo['v_prev'], halo['v_next'] = self._static('v_prev', vp), self._static('v_next', vn)
             halo['vf_prev'], halo['vf_next'] = self._vf_halo
         e.halo = halo
-        e.cycle_finish(row, raster=raster)
-        if self.world > 1:
-            dist.all_reduce(e.grads[e.shared_lo:], op=dist.ReduceOp.SUM, group=self.group)
+        if graphs:
+            e.replay(('finish',) + e._graph_key(raster), lambda: e.cycle_finish(None, raster=raster))
+            e.log[row].copy_(e.tmp_log)
+        else:
+            e.cycle_finish(row, raster=raster)
+        dist.all_reduce(e.grads[e.shared_lo:], op=dist.ReduceOp.SUM, group=self.group)
 
-    def step(self, lr):
-        self.e.step(lr)
+    def step(self, lr=None):
+        """lr given: host-side schedule; lr None: the device-resident schedule (graph friendly)"""
+        if lr is None:
+            self.e.step_dev()
+        else:
+            self.e.step(lr)
 
     # -- one-euro filters with the state handed down the ranks (optimizer.py:383-392) ----------------
     def _scan(self, x, c, b):
@@ -99,7 +129,8 @@ class ShardedSequence(object):
         e.pT_filt = self._scan(e.leaf('poses_T'), c1, b1)
         e.forward()
         e.verts_filt = self._scan(e.verts.view(e.T, -1), c2, b2).view(e.verts.shape[0] // e.N, e.N, -1, 3)
-        self._vf_halo = self._gather_boundaries(e.verts_filt.view(e.T, -1))
+        a, b = self._gather_boundaries(e.verts_filt.view(e.T, -1))
+        self._vf_halo = (self._static('vf_prev', a), self._static('vf_next', b))
 
     # -- logs: raw sums are all-reduced once, at the end ----------------------------------------------
     def read_log(self, rows):

@@ -43,6 +43,12 @@ def main():
     print('raster fwd+bwd  ms', timeit(lambda: r(e, gv, log)))
     print('raster fwd only ms', timeit(lambda: r(e, gv, log, with_grads=False)))
     print('lbs fwd ms', timeit(lambda: e.forward()))
+    from mhhip import _lib as _l
+    from mhhip._lib import ptr as _p, check as _c
+    def bwd():
+        g = e.grads
+        _c(_l.lib().mh_lbs_backward(e.m.handle, e.B, e.N, _p(e.leaf('betas')), _p(e.leaf('poses_smpl')), _p(e.leaf('xscale')), _p(e.leaf('poses_T')), _p(e.vposed), _p(gv), _p(e.gj), _p(e.leaf('poses_smpl', g)), _p(e.leaf('poses_T', g)), _p(e.leaf('betas', g)), _p(e.leaf('xscale', g)), _p(e.ws), _p(e.ws2), _l.stream_ptr(e.dev)))
+    print('lbs bwd ms', timeit(bwd))
     from mhhip import _lib
     from mhhip._lib import ptr, check
     L = _lib.lib(); st = _lib.stream_ptr(e.dev)

@@ -126,32 +126,31 @@ __device__ __forceinline__ void r_load_tri(const RasterP& p, const float* vb, in
   }
 }
 
-// Gradient scatter.  Neighbouring pixels of a strip hit the same few hundred vertices (each
-// silhouette pixel touches 4 faces x 2 vertices x 3 components), so contributions are first summed in a
-// per-workgroup LDS hash table (vertex id -> 3 floats, LDS float atomics) and flushed with ONE global
-// atomic per touched vertex component; a full table falls back to direct global atomics.
-#define RH_SLOTS 2048
-#define RH_PROBES 12
+// the same from the projected-vertex buffer written by k_raster_windows (no divisions); the camera-space
+// x, y needed by the projection adjoint follow from x_ndc = -s X / Z + w1
+__device__ __forceinline__ void r_load_tri_ndc(const RasterP& p, const float* nb, int f, Tri& t) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int vi = p.faces[3 * f + k];
+    t.idx[k] = vi;
+    const float xn = nb[(size_t)vi * 3], yn = nb[(size_t)vi * 3 + 1], Z = nb[(size_t)vi * 3 + 2];
+    t.x[k] = xn; t.y[k] = yn; t.z[k] = Z;
+    t.cx[k] = -(xn - p.w1) * Z / p.s;
+    t.cy[k] = -(yn - p.h1) * Z / p.s;
+  }
+}
+
+// Gradient scatter.  One workgroup owns one body: every contribution of the body's window pixels is
+// summed into an LDS table indexed directly by the vertex (V x 3 floats = 82 KB for SMPL, LDS float
+// atomics), then added to dL/dverts with plain coalesced read-modify-writes -- no global atomics.
+// Bodies whose table does not fit in LDS (V > RG_MAXV) scatter with global atomics instead.
+#define RG_MAXV 13000
 struct GradAcc {
-  int* id;        // [RH_SLOTS], -1 = empty
-  float* val;     // [RH_SLOTS][3]
+  float* tab;     // LDS [V][3] or null
   float* gvb;     // global dL/dverts of this body
 };
 __device__ __forceinline__ void r_acc_add(const GradAcc& a, int vid, float gx, float gy, float gz) {
-  unsigned h = ((unsigned)vid * 2654435761u) >> 21;            // 11 bits
-#pragma unroll 1
-  for (int pr = 0; pr < RH_PROBES; ++pr) {
-    int cur = a.id[h];
-    if (cur == -1) cur = atomicCAS(&a.id[h], -1, vid);
-    if (cur == -1 || cur == vid) {
-      atomicAdd(&a.val[h * 3], gx);
-      atomicAdd(&a.val[h * 3 + 1], gy);
-      atomicAdd(&a.val[h * 3 + 2], gz);
-      return;
-    }
-    h = (h + 1) & (RH_SLOTS - 1);
-  }
-  float* o = a.gvb + (size_t)vid * 3;
+  float* o = (a.tab ? a.tab : a.gvb) + (size_t)vid * 3;
   atomicAdd(o, gx);
   atomicAdd(o + 1, gy);
   atomicAdd(o + 2, gz);
@@ -528,13 +527,13 @@ __global__ __launch_bounds__(RB) void k_raster_strip(RasterP p) {
 // =============================================================================================
 // residual sums per strip (optimizer.py:432-442, 447-477)
 // =============================================================================================
-__device__ __forceinline__ float r_alpha(const RasterP& p, const float* vb, const unsigned long long* q, float xf, float yf) {
+__device__ __forceinline__ float r_alpha(const RasterP& p, const float* nb, const unsigned long long* q, float xf, float yf) {
   float qprod = 1.f;
   for (int k = 1; k < 5; ++k) {
     const unsigned long long kk = q[k];
     if (kk == RS_EMPTY) break;
     Tri tr;
-    r_load_tri(p, vb, (int)(kk & 0xffffffffu), tr);
+    r_load_tri_ndc(p, nb, (int)(kk & 0xffffffffu), tr);
     const float T9[9] = {tr.x[0], tr.y[0], tr.z[0], tr.x[1], tr.y[1], tr.z[1], tr.x[2], tr.y[2], tr.z[2]};
     float pz, d;
     bool inside;
@@ -554,7 +553,7 @@ __global__ __launch_bounds__(RB) void k_raster_sums(RasterP p) {
     const int b = p.strip_body[s], t = b / p.N, n = b % p.N;
     const int x0 = p.win[b * 4], ww = p.win[b * 4 + 2];
     const int sy0 = p.strip_row0[s], npx = p.strip_rows[s] * ww;
-    const float* vb = p.verts + (size_t)b * p.V * 3;
+    const float* vb = p.ndc + (size_t)b * p.V * 3;
     const unsigned long long* gk = p.gkeys + (size_t)p.strip_koff[s] * 5;
     const float min_z = logf(1.f + expf(p.zmin_lin[t]));                    // optimizer.py:683-688
     const float max_z = min_z + 1.f + logf(1.f + expf(p.zmax_lin[t]));
@@ -632,23 +631,27 @@ __global__ void k_raster_body_out(RasterP p) {
 // gradients per strip
 // =============================================================================================
 __global__ __launch_bounds__(RB) void k_raster_grads(RasterP p) {
-  __shared__ int hid[RH_SLOTS];
-  __shared__ float hval[RH_SLOTS * 3];
+  extern __shared__ __attribute__((aligned(16))) float gtab[];     // [V][3] when it fits
   const int tid = threadIdx.x;
-  for (int i = tid; i < RH_SLOTS; i += RB) hid[i] = -1;
-  for (int i = tid; i < RH_SLOTS * 3; i += RB) hval[i] = 0.f;
-  __syncthreads();
   const int H = p.H, W = p.W, P = H * W;
-  const int total = p.total[0];
-  for (int s = blockIdx.x; s < total; s += gridDim.x) {
-    const int b = p.strip_body[s], t = b / p.N, n = b % p.N;
-    const int x0 = p.win[b * 4], ww = p.win[b * 4 + 2];
-    const int sy0 = p.strip_row0[s], npx = p.strip_rows[s] * ww;
-    const float* vb = p.verts + (size_t)b * p.V * 3;
+  const bool use_tab = p.V <= RG_MAXV;
+  for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
+    const int ns = p.body_ns[b];
+    if (ns == 0) continue;
+    const int t = b / p.N, n = b % p.N;
+    const int x0 = p.win[b * 4], ww = p.win[b * 4 + 2], y0 = p.win[b * 4 + 1], wh = p.win[b * 4 + 3];
+    const int npx = ww * wh;
+    const int sy0 = y0;
+    const float* vb = p.ndc + (size_t)b * p.V * 3;
     float* gvb = p.gverts + (size_t)b * p.V * 3;
+    __syncthreads();
+    if (use_tab)
+      for (int i = tid; i < p.V * 3; i += RB) gtab[i] = 0.f;
+    __syncthreads();
     GradAcc acc;
-    acc.id = hid; acc.val = hval; acc.gvb = gvb;
-    const unsigned long long* gk = p.gkeys + (size_t)p.strip_koff[s] * 5;
+    acc.tab = use_tab ? gtab : nullptr; acc.gvb = gvb;
+    // the strips of a body are consecutive in the work list, so its window is one contiguous key range
+    const unsigned long long* gk = p.gkeys + (size_t)p.strip_koff[p.body_first[b]] * 5;
     float S[6];
     r_body_sums(p, b, S);
     const float cnt = S[2] + 1.f;
@@ -670,7 +673,7 @@ __global__ __launch_bounds__(RB) void k_raster_grads(RasterP p) {
         if (m != 0.f && zc > p.eps && 1.f / zc > 1e-3f) {
           const float gpz = gA * (-1.f / zc);
           Tri tr;
-          r_load_tri(p, vb, (int)(k0 & 0xffffffffu), tr);
+          r_load_tri_ndc(p, vb, (int)(k0 & 0xffffffffu), tr);
           const float area = r_edge(tr.x[2], tr.y[2], tr.x[0], tr.y[0], tr.x[1], tr.y[1]) + R_KEPS;
           float w[3] = {r_edge(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2]) / area,
                         r_edge(xf, yf, tr.x[2], tr.y[2], tr.x[0], tr.y[0]) / area,
@@ -713,19 +716,26 @@ __global__ __launch_bounds__(RB) void k_raster_grads(RasterP p) {
           for (int k = 0; k < 3; ++k) r_scatter(p, acc, tr, k, gx[k], gy[k], gz[k]);
         }
       }
-      // silhouette
+      // silhouette: the (up to) four selected faces are fetched together (independent gathers in
+      // flight), evaluated, and scattered from registers
       const uint32_t wb = p.bits[gp];
       if (gAlphaScale != 0.f && (wb & fr) == 0u && q[1] != RS_EMPTY) {
-        float pk[4], sgn[4], tpar[4];
-        int ea[4], eb[4], fidx[4];
-        bool dgn[4];
-        int ns = 0;
+        Tri trs[4];
+        bool have[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned long long kk = q[k + 1];
+          have[k] = kk != RS_EMPTY;
+          if (have[k]) r_load_tri_ndc(p, vb, (int)(kk & 0xffffffffu), trs[k]);
+        }
+        float pk[4], sgn[4], gqx[4], gqy[4], wa[4], wb_[4];
+        int ea[4], eb[4];
         float qprod = 1.f;
-        for (int k = 1; k < 5; ++k) {
-          const unsigned long long kk = q[k];
-          if (kk == RS_EMPTY) break;
-          Tri tr;
-          r_load_tri(p, vb, (int)(kk & 0xffffffffu), tr);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          pk[k] = 0.f; sgn[k] = 0.f; gqx[k] = gqy[k] = wa[k] = wb_[k] = 0.f; ea[k] = 0; eb[k] = 1;
+          if (!have[k]) continue;
+          const Tri& tr = trs[k];
           const float area = r_edge(tr.x[2], tr.y[2], tr.x[0], tr.y[0], tr.x[1], tr.y[1]) + R_KEPS;
           const bool inside = r_edge(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2]) / area > 0.f &&
                               r_edge(xf, yf, tr.x[2], tr.y[2], tr.x[0], tr.y[0]) / area > 0.f &&
@@ -735,56 +745,53 @@ __global__ __launch_bounds__(RB) void k_raster_grads(RasterP p) {
           const float d01 = r_seg(xf, yf, tr.x[0], tr.y[0], tr.x[1], tr.y[1], &t01, &g01);
           const float d02 = r_seg(xf, yf, tr.x[0], tr.y[0], tr.x[2], tr.y[2], &t02, &g02);
           const float d12 = r_seg(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2], &t12, &g12);
-          float d;
-          if (d01 <= d02 && d01 <= d12) { d = d01; ea[ns] = 0; eb[ns] = 1; tpar[ns] = t01; dgn[ns] = g01; }
-          else if (d02 <= d01 && d02 <= d12) { d = d02; ea[ns] = 0; eb[ns] = 2; tpar[ns] = t02; dgn[ns] = g02; }
-          else { d = d12; ea[ns] = 1; eb[ns] = 2; tpar[ns] = t12; dgn[ns] = g12; }
+          float d, tt;
+          bool dg;
+          int a, bb;
+          if (d01 <= d02 && d01 <= d12) { d = d01; a = 0; bb = 1; tt = t01; dg = g01; }
+          else if (d02 <= d01 && d02 <= d12) { d = d02; a = 0; bb = 2; tt = t02; dg = g02; }
+          else { d = d12; a = 1; bb = 2; tt = t12; dg = g12; }
+          const float xa_ = a == 0 ? tr.x[0] : tr.x[1], ya_ = a == 0 ? tr.y[0] : tr.y[1];
+          const float xb_ = bb == 1 ? tr.x[1] : tr.x[2], yb_ = bb == 1 ? tr.y[1] : tr.y[2];
+          if (dg) { gqx[k] = xb_ - xf; gqy[k] = yb_ - yf; wa[k] = 0.f; wb_[k] = 1.f; }
+          else {
+            gqx[k] = xa_ + tt * (xb_ - xa_) - xf;
+            gqy[k] = ya_ + tt * (yb_ - ya_) - yf;
+            wa[k] = 1.f - tt; wb_[k] = tt;
+          }
+          ea[k] = a; eb[k] = bb;
           const float sd = inside ? -d : d;
-          pk[ns] = 1.f / (1.f + expf(sd / SIGMA_S));
-          sgn[ns] = inside ? -1.f : 1.f;
-          fidx[ns] = (int)(kk & 0xffffffffu);
-          qprod *= 1.f - pk[ns];
-          ++ns;
+          pk[k] = 1.f / (1.f + expf(sd / SIGMA_S));
+          sgn[k] = inside ? -1.f : 1.f;
+          qprod *= 1.f - pk[k];
         }
         const float alpha = 1.f - qprod;
         const float seg = (float)((wb >> n) & 1u);
         const float galpha = gAlphaScale * (alpha - seg);
         if (galpha != 0.f) {
-          for (int k = 0; k < ns; ++k) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (!have[k]) continue;
             // d alpha / d sd_k = -(1/sigma) p_k prod_j (1 - p_j)
             const float gd = galpha * (-(1.f / SIGMA_S)) * pk[k] * qprod * sgn[k];
             if (gd == 0.f) continue;
-            Tri tr;
-            r_load_tri(p, vb, fidx[k], tr);
-            const int a = ea[k], bb = eb[k];
-            const float tt = tpar[k];
-            float qx, qy, ga, gb;
-            if (dgn[k]) { qx = tr.x[bb] - xf; qy = tr.y[bb] - yf; ga = 0.f; gb = 1.f; }
-            else {
-              qx = tr.x[a] + tt * (tr.x[bb] - tr.x[a]) - xf;
-              qy = tr.y[a] + tt * (tr.y[bb] - tr.y[a]) - yf;
-              ga = 1.f - tt; gb = tt;
+            // vertex picks without dynamic register indexing
+            const Tri& tr = trs[k];
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+              const float w = (v == ea[k] ? wa[k] : 0.f) + (v == eb[k] ? wb_[k] : 0.f);
+              if (w != 0.f) r_scatter(p, acc, tr, v, gd * w * 2.f * gqx[k], gd * w * 2.f * gqy[k], 0.f);
             }
-            r_scatter(p, acc, tr, a, gd * ga * 2.f * qx, gd * ga * 2.f * qy, 0.f);
-            r_scatter(p, acc, tr, bb, gd * gb * 2.f * qx, gd * gb * 2.f * qy, 0.f);
           }
         }
       }
     }
-    // flush the table: one global atomic per touched vertex component
     __syncthreads();
-    for (int i = tid; i < RH_SLOTS; i += RB) {
-      const int vid = hid[i];
-      if (vid >= 0) {
-        float* o = gvb + (size_t)vid * 3;
-        atomicAdd(o, hval[i * 3]);
-        atomicAdd(o + 1, hval[i * 3 + 1]);
-        atomicAdd(o + 2, hval[i * 3 + 2]);
-        hid[i] = -1;
-        hval[i * 3] = 0.f; hval[i * 3 + 1] = 0.f; hval[i * 3 + 2] = 0.f;
+    if (use_tab)
+      for (int i = tid; i < p.V * 3; i += RB) {
+        const float g = gtab[i];
+        if (g != 0.f) gvb[i] += g;
       }
-    }
-    __syncthreads();
   }
 }
 
@@ -901,7 +908,13 @@ extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const f
   hipLaunchKernelGGL(k_raster_body_out, dim3((p.B + 255) / 256), dim3(256), 0, st, p);
   MH_LAUNCH_CHECK();
   if (gverts) {
-    hipLaunchKernelGGL(k_raster_grads, dim3(grid), dim3(RB), 0, st, p);
+    const size_t tab = V <= RG_MAXV ? (size_t)V * 3 * sizeof(float) : 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+      MH_HIP(hipFuncSetAttribute((const void*)k_raster_grads, hipFuncAttributeMaxDynamicSharedMemorySize, RG_MAXV * 3 * 4));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(k_raster_grads, dim3(p.B < 4096 ? p.B : 4096), dim3(RB), tab, st, p);
     MH_LAUNCH_CHECK();
   }
   if (gzmin && gzmax) {

@@ -214,6 +214,13 @@ int mh_lowest_vertex(const float* verts /*(B,V,3)*/, int B, int V, int32_t* low_
  * full argsort over M, optimizer.py:494-502); if M < k all M points are used.              */
 int mh_contact_knn(const float* points /*(M,3)*/, int M, const float* low_xyz, int B, int k,
                    float* dy /*(B)*/, void* stream);
+/* the same neighbours through a uniform grid over the scene cloud: build once per scene update
+ * (mh_scene_grid_build: bbox, counting sort into cells), then every query visits cells in growing
+ * shells until its k-th distance is final.  grid_ws: mh_scene_grid_bytes(M) bytes owned by the caller. */
+size_t mh_scene_grid_bytes(int M);
+int mh_scene_grid_build(const float* points /*(M,3)*/, int M, void* grid_ws, void* stream);
+int mh_contact_knn_grid(const void* grid_ws, int M, const float* low_xyz, int B, int k,
+                        float* dy /*(B)*/, void* stream);
 /* contact: sum |dy+0.02| per batch, gpT.y += coef * (-sign(dy+0.02)); foot sliding between
  * IN-BATCH consecutive frames (batch = frames per batch, optimizer.py:512-518), gverts +=
  * (atomic).  batch_contact / batch_foot: one value per batch (nbatches = ceil(T/batch)).     */

@@ -298,3 +298,325 @@ extern "C" int mh_scene_unproject(const float* depth, int H, int W, const float*
   MH_LAUNCH_CHECK();
   return MH_OK;
 }
+
+// =============================================================================================
+// uniform-grid k-nearest neighbours.  All queries of a cycle share one scene cloud, so the cloud is
+// bucketed once per scene update (counting sort into cells) and every query visits cells in growing
+// Chebyshev shells until the k-th best distance is provably final (points of shell rho+1 are at least
+// rho * cell away).  Exactly the same neighbour set as the brute-force scan, ~50x fewer distance
+// evaluations for M = 2e4..2e5.
+// =============================================================================================
+#define GRID_MAX_CELLS (1 << 20)
+
+struct GridHdr {        // device-resident header (written by k_grid_setup)
+  float mn[3];
+  float cell;
+  int dim[3];
+  int ncells;
+};
+
+__global__ __launch_bounds__(1024) void k_grid_setup(const float* pts, int M, GridHdr* hdr, int* counts, int max_cells) {
+  __shared__ float smn[3][16], smx[3][16];
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = threadIdx.x; i < M; i += 1024)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = pts[(size_t)i * 3 + c];
+      mn[c] = fminf(mn[c], v);
+      mx[c] = fmaxf(mx[c], v);
+    }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mn[c] = fminf(mn[c], __shfl_xor(mn[c], o, 64));
+      mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { smn[c][threadIdx.x >> 6] = mn[c]; smx[c][threadIdx.x >> 6] = mx[c]; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float ext[3];
+    for (int c = 0; c < 3; ++c) {
+      for (int w = 1; w < 16; ++w) { mn[c] = fminf(mn[c], smn[c][w]); mx[c] = fmaxf(mx[c], smx[c][w]); }
+      ext[c] = fmaxf(mx[c] - mn[c], 1e-3f);
+    }
+    // the clouds are surfaces: aim at ~16 points per occupied cell of the largest face of the bbox
+    const float area = fmaxf(ext[0] * ext[1], fmaxf(ext[1] * ext[2], ext[0] * ext[2]));
+    float cell = fminf(fmaxf(sqrtf(area * 16.f / (float)M), 0.02f), 4.f);
+    int d[3];
+    for (;;) {
+      long long n = 1;
+      for (int c = 0; c < 3; ++c) { d[c] = (int)(ext[c] / cell) + 1; n *= d[c]; }
+      if (n <= max_cells) break;
+      cell *= 1.26f;
+    }
+    hdr->cell = cell;
+    for (int c = 0; c < 3; ++c) { hdr->mn[c] = mn[c]; hdr->dim[c] = d[c]; }
+    hdr->ncells = d[0] * d[1] * d[2];
+  }
+  __syncthreads();
+  const int nc = hdr->ncells;
+  for (int i = threadIdx.x; i <= nc; i += 1024) counts[i] = 0;
+}
+
+__device__ __forceinline__ int grid_cell(const GridHdr* h, float x, float y, float z) {
+  const int cx = min(max((int)((x - h->mn[0]) / h->cell), 0), h->dim[0] - 1);
+  const int cy = min(max((int)((y - h->mn[1]) / h->cell), 0), h->dim[1] - 1);
+  const int cz = min(max((int)((z - h->mn[2]) / h->cell), 0), h->dim[2] - 1);
+  return (cz * h->dim[1] + cy) * h->dim[0] + cx;
+}
+
+__global__ void k_grid_count(const float* pts, int M, const GridHdr* hdr, int* counts, int* pcell) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const int c = grid_cell(hdr, pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2]);
+  pcell[i] = c;
+  atomicAdd(&counts[c], 1);
+}
+
+// exclusive scan of counts[0..ncells] in place (single block), also resets the fill cursors
+__global__ __launch_bounds__(1024) void k_grid_scan(const GridHdr* hdr, int* counts, int* cursor) {
+  __shared__ int s[1024];
+  __shared__ int carry;
+  const int nc = hdr->ncells;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nc; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < nc ? counts[i] : 0;
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      int a = 0;
+      if ((int)threadIdx.x >= o) a = s[threadIdx.x - o];
+      __syncthreads();
+      s[threadIdx.x] += a;
+      __syncthreads();
+    }
+    if (i < nc) {
+      const int start = carry + s[threadIdx.x] - v;
+      counts[i] = start;
+      cursor[i] = start;
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += s[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) counts[nc] = carry;
+}
+
+__global__ void k_grid_scatter(const float* pts, int M, const int* pcell, int* cursor, float* sorted) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const int pos = atomicAdd(&cursor[pcell[i]], 1);
+  sorted[(size_t)pos * 3] = pts[(size_t)i * 3];
+  sorted[(size_t)pos * 3 + 1] = pts[(size_t)i * 3 + 1];
+  sorted[(size_t)pos * 3 + 2] = pts[(size_t)i * 3 + 2];
+}
+
+static size_t g_align(size_t x) { return (x + 255) & ~(size_t)255; }
+struct GridWs {
+  GridHdr* hdr;
+  int* start;     // [GRID_MAX_CELLS + 1]
+  int* cursor;    // [GRID_MAX_CELLS]
+  int* pcell;     // [M]
+  float* sorted;  // [M][3]
+};
+static GridWs grid_carve(void* ws, int M) {
+  char* c = (char*)ws;
+  GridWs g;
+  g.hdr = (GridHdr*)c; c += g_align(sizeof(GridHdr));
+  g.start = (int*)c; c += g_align((size_t)(GRID_MAX_CELLS + 1) * 4);
+  g.cursor = (int*)c; c += g_align((size_t)GRID_MAX_CELLS * 4);
+  g.pcell = (int*)c; c += g_align((size_t)M * 4);
+  g.sorted = (float*)c;
+  return g;
+}
+
+extern "C" size_t mh_scene_grid_bytes(int M) {
+  return g_align(sizeof(GridHdr)) + g_align((size_t)(GRID_MAX_CELLS + 1) * 4) + g_align((size_t)GRID_MAX_CELLS * 4) +
+         g_align((size_t)(M > 0 ? M : 1) * 4) + g_align((size_t)(M > 0 ? M : 1) * 12);
+}
+
+extern "C" int mh_scene_grid_build(const float* points, int M, void* grid_ws, void* stream) {
+  MH_CHECK(points && grid_ws, "null argument");
+  MH_CHECK(M > 0, "empty scene");
+  GridWs g = grid_carve(grid_ws, M);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(1024), 0, st, points, M, g.hdr, g.start, GRID_MAX_CELLS);
+  MH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_grid_count, dim3((M + 255) / 256), dim3(256), 0, st, points, M, (const GridHdr*)g.hdr, g.start, g.pcell);
+  MH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_grid_scan, dim3(1), dim3(1024), 0, st, (const GridHdr*)g.hdr, g.start, g.cursor);
+  MH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_grid_scatter, dim3((M + 255) / 256), dim3(256), 0, st, points, M, (const int*)g.pcell, g.cursor, g.sorted);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+// one wave per query
+__global__ __launch_bounds__(64) void k_contact_knn_grid(const GridHdr* hdr, const int* start, const float* sorted, int M,
+                                                         const float* low_xyz, int K, float* dy) {
+  __shared__ float sd_s[KNN_CAP];
+  __shared__ float sy_s[KNN_CAP];
+  volatile float* sd = sd_s;
+  volatile float* sy = sy_s;
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float qx = low_xyz[(size_t)b * 3], qy = low_xyz[(size_t)b * 3 + 1], qz = low_xyz[(size_t)b * 3 + 2];
+  sd[lane] = INFINITY; sd[lane + 64] = INFINITY;
+  sy[lane] = 0.f; sy[lane + 64] = 0.f;
+  __builtin_amdgcn_wave_barrier();
+  const float cell = hdr->cell;
+  const int dx = hdr->dim[0], dyy = hdr->dim[1], dz = hdr->dim[2];
+  // cell of the query clamped into the grid: for q outside the (convex) bbox with projection q', every cloud point p
+  // has |p-q| >= |p-q'|, so the shell bound below stays valid
+  const int cqx = min(max((int)floorf((qx - hdr->mn[0]) / cell), 0), dx - 1),
+            cqy = min(max((int)floorf((qy - hdr->mn[1]) / cell), 0), dyy - 1),
+            cqz = min(max((int)floorf((qz - hdr->mn[2]) / cell), 0), dz - 1);
+  float tau = INFINITY;
+  int fill = K, found = 0;
+  const int kk = M < K ? M : K;
+  // enough shells to cover the whole grid from wherever the query is
+  const int rmax = max(max(max(cqx, dx - 1 - cqx), max(cqy, dyy - 1 - cqy)), max(cqz, dz - 1 - cqz));
+  // the points of a run of x-adjacent cells are contiguous in the sorted cloud
+  auto scan = [&](int p0, int p1) {
+    for (int base = p0; base < p1; base += 64) {
+      const int i = base + lane;
+      float d2 = INFINITY, py = 0.f;
+      if (i < p1) {
+        const float ex = sorted[(size_t)i * 3] - qx;
+        py = sorted[(size_t)i * 3 + 1];
+        const float ey = py - qy, ez = sorted[(size_t)i * 3 + 2] - qz;
+        d2 = ex * ex + ey * ey + ez * ez;
+      }
+      const bool take = d2 < tau;
+      const unsigned long long m = __ballot(take);
+      if (m == 0ull) continue;
+      if (take) {
+        const int pos = fill + __popcll(m & ((1ull << lane) - 1ull));
+        sd[pos] = d2;
+        sy[pos] = py;
+      }
+      fill += __popcll(m);
+      found += __popcll(m);
+      __builtin_amdgcn_wave_barrier();
+      if (fill > KNN_CAP - 64) {
+        knn_sort128(sd, sy, lane);
+        tau = sd[K - 1];
+        if (lane + K < KNN_CAP) sd[lane + K] = INFINITY;
+        if (lane + 64 + K < KNN_CAP) sd[lane + 64 + K] = INFINITY;
+        fill = K;
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  };
+  auto tighten = [&]() {
+    knn_sort128(sd, sy, lane);
+    tau = sd[K - 1];
+    if (lane + K < KNN_CAP) sd[lane + K] = INFINITY;
+    if (lane + 64 + K < KNN_CAP) sd[lane + 64 + K] = INFINITY;
+    fill = K;
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto axis_gap = [&](float q, float lo, float hi) { return fmaxf(fmaxf(lo - q, q - hi), 0.f); };
+  const float mnx = hdr->mn[0], mny = hdr->mn[1], mnz = hdr->mn[2];
+  for (int rho = 0; rho <= rmax; ++rho) {
+    if (rho >= 1 && found >= kk && tau <= (float)(rho - 1) * cell * (float)(rho - 1) * cell) break;
+    const int side = 2 * rho + 1, nrows = side * side;
+    for (int rbase = 0; rbase < nrows; rbase += 64) {
+      // lane -> one (y,z) row of the shell: rows on the border of the square contribute the whole x run,
+      // interior rows only the two end cells.  key = squared distance from the query to the run's box.
+      const int r = rbase + lane;
+      int a0 = 0, a1 = 0, b0 = 0, b1 = 0, rowbase = 0, x0 = 0, x1 = -1;
+      float keya = INFINITY, keyb = INFINITY, dyz2 = 0.f;
+      if (r < nrows) {
+        const int oy = r / side - rho, oz = r % side - rho;
+        const int cy = cqy + oy, cz = cqz + oz;
+        if (cy >= 0 && cy < dyy && cz >= 0 && cz < dz) {
+          rowbase = (cz * dyy + cy) * dx;
+          const float gy = axis_gap(qy, mny + cy * cell, mny + (cy + 1) * cell);
+          const float gz = axis_gap(qz, mnz + cz * cell, mnz + (cz + 1) * cell);
+          dyz2 = gy * gy + gz * gz;
+          const bool border = (oy == -rho || oy == rho || oz == -rho || oz == rho);
+          if (border) {
+            x0 = max(cqx - rho, 0);
+            x1 = min(cqx + rho, dx - 1);
+            if (dyz2 < tau) {
+              a0 = start[rowbase + x0];
+              a1 = start[rowbase + x1 + 1];
+              const float gx = axis_gap(qx, mnx + x0 * cell, mnx + (x1 + 1) * cell);
+              if (a1 > a0) keya = dyz2 + gx * gx;
+            }
+          } else {
+            if (cqx - rho >= 0) {
+              x0 = x1 = cqx - rho;
+              a0 = start[rowbase + x0];
+              a1 = start[rowbase + x0 + 1];
+              const float gx = axis_gap(qx, mnx + x0 * cell, mnx + (x0 + 1) * cell);
+              if (a1 > a0) keya = dyz2 + gx * gx;
+            }
+            if (cqx + rho < dx) {
+              const int xb = cqx + rho;
+              b0 = start[rowbase + xb];
+              b1 = start[rowbase + xb + 1];
+              const float gx = axis_gap(qx, mnx + xb * cell, mnx + (xb + 1) * cell);
+              if (b1 > b0) keyb = dyz2 + gx * gx;
+            }
+          }
+        }
+      }
+      // nearest box first; stop as soon as the nearest remaining box cannot hold a better neighbour
+      for (;;) {
+        float kmin = fminf(keya, keyb);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) kmin = fminf(kmin, __shfl_xor(kmin, o, 64));
+        if (!(kmin < tau)) break;
+        const unsigned long long ma = __ballot(keya == kmin);
+        int p0, p1;
+        if (ma) {
+          const int l = __ffsll((long long)ma) - 1;
+          p0 = __shfl(a0, l, 64);
+          p1 = __shfl(a1, l, 64);
+          const int lx0 = __shfl(x0, l, 64), lx1 = __shfl(x1, l, 64);
+          if (lx1 > lx0 + 1 && tau < INFINITY) {       // long run: clip to the x interval the ball can reach
+            const float w = sqrtf(fmaxf(tau - __shfl(dyz2, l, 64), 0.f));
+            const int nx0 = max(lx0, (int)floorf((qx - w - mnx) / cell)), nx1 = min(lx1, (int)floorf((qx + w - mnx) / cell));
+            if (nx0 > nx1) p1 = p0;
+            else if (nx0 != lx0 || nx1 != lx1) {
+              const int rb = __shfl(rowbase, l, 64);
+              p0 = start[rb + nx0];
+              p1 = start[rb + nx1 + 1];
+            }
+          }
+          if (lane == l) keya = INFINITY;
+        } else {
+          const unsigned long long mb = __ballot(keyb == kmin);
+          const int l = __ffsll((long long)mb) - 1;
+          p0 = __shfl(b0, l, 64);
+          p1 = __shfl(b1, l, 64);
+          if (lane == l) keyb = INFINITY;
+        }
+        const bool had = found >= kk;
+        scan(p0, p1);
+        if (found >= kk && (!had || fill >= K + 8)) tighten();
+      }
+    }
+    if (found >= kk && fill > K) tighten();
+  }
+  knn_sort128(sd, sy, lane);
+  float s = (lane < kk) ? sy[lane] : 0.f;
+  s = mh_wave_sum(s);
+  if (lane == 0) dy[b] = s / (float)kk - qy;
+}
+
+extern "C" int mh_contact_knn_grid(const void* grid_ws, int M, const float* low_xyz, int B, int k, float* dy, void* stream) {
+  MH_CHECK(grid_ws && low_xyz && dy, "null argument");
+  MH_CHECK(M > 0 && B > 0, "empty input");
+  MH_CHECK(k >= 1 && k <= 32, "k must be in 1..32");
+  GridWs g = grid_carve((void*)grid_ws, M);
+  hipLaunchKernelGGL(k_contact_knn_grid, dim3(B), dim3(64), 0, (hipStream_t)stream, (const GridHdr*)g.hdr, (const int*)g.start,
+                     (const float*)g.sorted, M, low_xyz, k, dy);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}

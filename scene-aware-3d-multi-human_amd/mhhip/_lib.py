@@ -79,6 +79,10 @@ def lib():
         L.mh_reduce_sum.argtypes = [vp, ctypes.c_size_t, ctypes.c_float, vp, vp]
         L.mh_lowest_vertex.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp]
         L.mh_contact_knn.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp]
+        L.mh_scene_grid_bytes.restype = ctypes.c_size_t
+        L.mh_scene_grid_bytes.argtypes = [ctypes.c_int]
+        L.mh_scene_grid_build.argtypes = [vp, ctypes.c_int, vp, vp]
+        L.mh_contact_knn_grid.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp]
         L.mh_contact_foot_terms.argtypes = [ctypes.c_int] * 4 + [vp] * 4 + [ctypes.c_float] * 2 + [vp] * 5
         L.mh_scene_unproject.argtypes = [vp, ctypes.c_int, ctypes.c_int, c_float_p, vp, vp]
         L.mh_raster_workspace_bytes.restype = ctypes.c_size_t

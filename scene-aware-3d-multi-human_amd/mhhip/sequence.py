@@ -172,6 +172,16 @@ class SequenceEngine(object):
     def set_scene_points(self, pts):
         """pts (M,3) camera-space scene points or None (optimizer.py:605-616)."""
         self.scene_pts = None if pts is None else _dev(pts, self.dev).view(-1, 3)
+        self._build_scene_grid()
+
+    def _build_scene_grid(self):
+        self.scene_grid = None
+        if self.scene_pts is None or self.scene_pts.shape[0] == 0:
+            return
+        L = _lib.lib()
+        M = self.scene_pts.shape[0]
+        self.scene_grid = torch.empty(L.mh_scene_grid_bytes(M), dtype=torch.uint8, device=self.dev)
+        check(L.mh_scene_grid_build(ptr(self.scene_pts), M, ptr(self.scene_grid), _lib.stream_ptr(self.dev)))
 
     def scene_from_depth(self, depth, mask):
         d = _dev(depth, self.dev).view(self.H, self.W)
@@ -180,6 +190,7 @@ class SequenceEngine(object):
                                             _lib.stream_ptr(self.dev)))
         keep = _dev(np.asarray(mask, np.float32) if not isinstance(mask, torch.Tensor) else mask.float(), self.dev).view(-1) > 0.5
         self.scene_pts = pts[keep].contiguous()      # compaction only: plumbing
+        self._build_scene_grid()
         return self.scene_pts
 
     # -- forward of all local frames ---------------------------------------------------------------
@@ -251,7 +262,7 @@ class SequenceEngine(object):
         if scene:
             ev = self._tic('scene_terms')
             check(L.mh_lowest_vertex(ptr(self.verts), B, self.V, ptr(self.low_idx), ptr(self.low_xyz), st))
-            check(L.mh_contact_knn(ptr(self.scene_pts), self.scene_pts.shape[0], ptr(self.low_xyz), B, 32, ptr(self.dy), st))
+            check(L.mh_contact_knn_grid(ptr(self.scene_grid), self.scene_pts.shape[0], ptr(self.low_xyz), B, 32, ptr(self.dy), st))
             check(L.mh_contact_foot_terms(T, N, self.V, self.batch, ptr(self.verts), ptr(self.low_idx), ptr(self.low_xyz),
                                           ptr(self.dy), float(c['reg_contact']), float(c['reg_foot_sliding']), ptr(gpT),
                                           ptr(gv), ptr(self.batch_contact), ptr(self.batch_foot), st))

@@ -54,6 +54,14 @@ def main():
     L = _lib.lib(); st = _lib.stream_ptr(e.dev)
     print('lowest ms', timeit(lambda: check(L.mh_lowest_vertex(ptr(e.verts), e.B, e.V, ptr(e.low_idx), ptr(e.low_xyz), st))))
     print('knn ms (M=%d)' % e.scene_pts.shape[0], timeit(lambda: check(L.mh_contact_knn(ptr(e.scene_pts), e.scene_pts.shape[0], ptr(e.low_xyz), e.B, 32, ptr(e.dy), st))))
+    print('knn grid ms', timeit(lambda: check(L.mh_contact_knn_grid(ptr(e.scene_grid), e.scene_pts.shape[0], ptr(e.low_xyz), e.B, 32, ptr(e.dy), st))))
+    print('grid build ms', timeit(lambda: e._build_scene_grid()))
+    hdr = e.scene_grid[:32].cpu().numpy()
+    print('grid mn', hdr[:12].view(np.float32), 'cell', hdr[12:16].view(np.float32), 'dim', hdr[16:28].view(np.int32), 'ncells', hdr[28:32].view(np.int32))
+    d = torch.cdist(e.low_xyz.view(-1, 3), e.scene_pts)
+    kd = d.topk(32, largest=False).values
+    print('query->nearest: mean %.3f max %.3f; 32nd: mean %.3f max %.3f' % (kd[:, 0].mean(), kd[:, 0].max(), kd[:, 31].mean(), kd[:, 31].max()))
+    print('points within 32nd radius+cell', float((d < (kd[:, 31:32] + float(hdr[12:16].view(np.float32)[0]))).sum(1).float().mean()))
 
 
 if __name__ == '__main__':

@@ -64,14 +64,19 @@ struct RasterP {
   int* body_ns;              // [B] strips of the body
   int* total;                // [1] number of strips
   int* strip_body;           // [max_strips]
-  int* strip_row0;           // [max_strips]
+  int* strip_row0;           // [max_strips] first image row of the tile
   int* strip_rows;           // [max_strips]
-  long long* strip_koff;     // [max_strips] first window pixel of the strip in gkeys
+  int* strip_col0;           // [max_strips] first image column of the tile
+  int* strip_cols;           // [max_strips]
+  long long* body_koff;      // [B] first window pixel of the body in gkeys (window row-major)
   float* partial;            // [max_strips][6]
   float* dinv;               // [B][2]
   unsigned long long* gkeys; // [sum of window pixels][5]
   float* ndc;                // [B][V][3] projected vertices (NDC x, y, view z)
   unsigned* frows;           // [B][F] conservative pixel-row range of every face: lo | hi << 16 (lo > hi: skip)
+  unsigned* fsort;           // [B][F] faces ordered by their first row: hi << 20 | face
+  int* row_start;            // [B][H+1] first entry of fsort with lo >= row; [H] = number of visible faces
+  int* maxh;                 // [B] tallest face (rows) of the body
 };
 
 __device__ __forceinline__ float r_pix_to_ndc(int i, int S1, int S2) {
@@ -255,6 +260,21 @@ __global__ __launch_bounds__(256) void k_raster_windows(RasterP p) {
   }
 }
 
+#define R_TILE_W 64          // tile width for windows wider than one LDS strip
+
+// tile geometry of a window: full-width row strips while a row fits into LDS, column tiles otherwise
+__device__ __forceinline__ void r_tiling(int ww, int wh, int* tw, int* th, int* ncol, int* nrow) {
+  if (ww <= R_CAP) {
+    *tw = ww;
+    *th = max(1, R_CAP / ww);
+  } else {
+    *tw = R_TILE_W;
+    *th = R_CAP / R_TILE_W;
+  }
+  *ncol = (ww + *tw - 1) / *tw;
+  *nrow = (wh + *th - 1) / *th;
+}
+
 __global__ __launch_bounds__(1024) void k_raster_strip_table(RasterP p) {
   __shared__ int s_ns[1024];
   __shared__ long long s_px[1024];
@@ -267,13 +287,13 @@ __global__ __launch_bounds__(1024) void k_raster_strip_table(RasterP p) {
   __syncthreads();
   for (int base = 0; base < p.B; base += 1024) {
     const int b = base + threadIdx.x;
-    int ww = 0, wh = 0, rows = 1, ns = 0;
+    int ww = 0, wh = 0, tw = 1, th = 1, ncol = 0, nrow = 0, ns = 0;
     if (b < p.B) {
       ww = p.win[b * 4 + 2];
       wh = p.win[b * 4 + 3];
       if (ww > 0 && wh > 0) {
-        rows = max(1, R_CAP / ww);
-        ns = (wh + rows - 1) / rows;
+        r_tiling(ww, wh, &tw, &th, &ncol, &nrow);
+        ns = ncol * nrow;
       } else {
         ww = wh = 0;
       }
@@ -299,13 +319,15 @@ __global__ __launch_bounds__(1024) void k_raster_strip_table(RasterP p) {
     if (b < p.B) {
       p.body_first[b] = first;
       p.body_ns[b] = ns;
-      const int y0 = p.win[b * 4 + 1];
+      p.body_koff[b] = koff;
+      const int x0 = p.win[b * 4], y0 = p.win[b * 4 + 1];
       for (int k = 0; k < ns; ++k) {
-        const int r0 = k * rows, nr = min(rows, wh - r0);
+        const int tr = k / ncol, tc = k - tr * ncol;
         p.strip_body[first + k] = b;
-        p.strip_row0[first + k] = y0 + r0;
-        p.strip_rows[first + k] = nr;
-        p.strip_koff[first + k] = koff + (long long)r0 * ww;
+        p.strip_row0[first + k] = y0 + tr * th;
+        p.strip_rows[first + k] = min(th, wh - tr * th);
+        p.strip_col0[first + k] = x0 + tc * tw;
+        p.strip_cols[first + k] = min(tw, ww - tc * tw);
       }
     }
     __syncthreads();
@@ -379,70 +401,145 @@ __global__ __launch_bounds__(256) void k_raster_face_rows(RasterP p) {
   p.frows[i] = out;
 }
 
-#define RCH 1024             // faces tested per chunk (4 per thread)
+// counting sort of a body's visible faces by their first pixel row: a tile's candidate faces are then one
+// contiguous range of fsort (first row in [tile_row0 - tallest_face, tile_last_row]).
+#define RFS 512
+__global__ __launch_bounds__(RFS) void k_raster_face_sort(RasterP p) {
+  extern __shared__ int hist[];                     // [H + 1]
+  __shared__ int s_scan[RFS];
+  __shared__ int s_carry, s_maxh;
+  const int b = blockIdx.x, tid = threadIdx.x, H = p.H;
+  const unsigned* fr = p.frows + (size_t)b * p.F;
+  unsigned* fs = p.fsort + (size_t)b * p.F;
+  int* rs = p.row_start + (size_t)b * (H + 1);
+  for (int i = tid; i <= H; i += RFS) hist[i] = 0;
+  if (tid == 0) { s_carry = 0; s_maxh = 0; }
+  __syncthreads();
+  int mh = 0;
+  for (int f = tid; f < p.F; f += RFS) {
+    const unsigned r = fr[f];
+    const int lo = (int)(r & 0xffffu), hi = (int)(r >> 16);
+    if (lo <= hi) {
+      atomicAdd(&hist[lo], 1);
+      mh = max(mh, hi - lo);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mh = max(mh, __shfl_xor(mh, o, 64));
+  if ((tid & 63) == 0) atomicMax(&s_maxh, mh);
+  __syncthreads();
+  for (int base = 0; base <= H; base += RFS) {
+    const int i = base + tid;
+    const int v = i <= H ? hist[i] : 0;
+    s_scan[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < RFS; o <<= 1) {
+      int a = 0;
+      if (tid >= o) a = s_scan[tid - o];
+      __syncthreads();
+      s_scan[tid] += a;
+      __syncthreads();
+    }
+    if (i <= H) {
+      const int st = s_carry + s_scan[tid] - v;
+      hist[i] = st;
+      rs[i] = st;
+    }
+    __syncthreads();
+    if (tid == RFS - 1) s_carry += s_scan[RFS - 1];
+    __syncthreads();
+  }
+  if (tid == 0) p.maxh[b] = s_maxh;
+  for (int f = tid; f < p.F; f += RFS) {
+    const unsigned r = fr[f];
+    const int lo = (int)(r & 0xffffu), hi = (int)(r >> 16);
+    if (lo <= hi) fs[atomicAdd(&hist[lo], 1)] = ((unsigned)hi << 20) | (unsigned)f;
+  }
+}
 
+#ifdef ABL_COUNT
+__device__ unsigned long long g_cnt[8];
+extern "C" int mh_debug_counters(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cnt), sizeof(g_cnt)); }
+#endif
+#define RW (RB / 64)         // waves per tile workgroup
+#define RPL 512              // pair descriptors per wave and round (sub-pixel face path)
+
+// One workgroup per tile.  Every wave runs its own rounds of 64 candidate faces with no workgroup barrier in
+// between: gather (software-pipelined three rounds deep: sort entry -> vertex ids -> projected vertices), blurred
+// bbox against the tile, candidate counts, wave prefix sum, then all (face, pixel-centre) pairs of the round are
+// split evenly over the 64 lanes (every lane walks a contiguous run of pairs, the staged face stays in registers
+// while the run stays inside one face).  The run start -> face lookup is a scatter + prefix-max instead of a
+// search.  Only the key window is shared by the waves (LDS atomics).
 __global__ __launch_bounds__(RB) void k_raster_strip(RasterP p) {
   __shared__ unsigned long long keys[R_CAP * 5];
-  __shared__ float sTri[RB * RT];           // staged faces of the current round
-  __shared__ int sPre[RB + 1];              // exclusive prefix of the candidate counts
-  __shared__ int sXa[RB], sYa[RB], sNx[RB];
-  __shared__ unsigned short okl[RCH];       // faces of the chunk that overlap the strip rows
-  __shared__ float sXf[R_CAP];              // NDC x of the window columns
-  __shared__ float sYf[R_CAP];              // NDC y of the strip rows
-  __shared__ unsigned okn;
-  __shared__ int swave[RB / 64];
+  __shared__ float wT[RW][64 * RT];         // staged faces of the wave's current round
+  __shared__ int wPre[RW][65];              // exclusive prefix of the candidate counts
+  __shared__ int wDesc[RW][64];             // xa | ya << 10 | nx << 20 (tile-relative)
+  __shared__ int wFid[RW][64];
+  __shared__ int wMark[RW][64];
+  __shared__ unsigned short wPl[RW][RPL];   // pair list of the sub-pixel path: face slot | pair index << 6
+  __shared__ float sXf[R_CAP];              // NDC x of the tile columns
+  __shared__ float sYf[R_CAP];              // NDC y of the tile rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = p.H, W = p.W;
   const float blur_d = sqrtf(BLUR_D);
   const int total = p.total[0];
   const float rx = W > H ? 2.f * (float)W / (float)H : 2.f, ry = H > W ? 2.f * (float)H / (float)W : 2.f;
   const float kx = (float)W / rx, ky = (float)H / ry;      // pixels per NDC unit (approximate index only)
+  // wave-private staging.  __builtin_amdgcn_wave_barrier() is the only ordering needed: it keeps the compiler from
+  // moving LDS accesses across it, and LDS executes one wave's accesses in order (a fence would also wait for the
+  // prefetched global loads and serialise the gather pipeline)
+  float* T_ = wT[wave];
+  int* pre = wPre[wave];
+  int* desc = wDesc[wave];
+  int* fid = wFid[wave];
+  int* mark = wMark[wave];
+  unsigned short* pl = wPl[wave];
   for (int s = blockIdx.x; s < total; s += gridDim.x) {
     const int b = p.strip_body[s];
-    const int x0 = p.win[b * 4], ww = p.win[b * 4 + 2];
+    const int x0 = p.strip_col0[s], tw = p.strip_cols[s], x1 = x0 + tw - 1;
     const int sy0 = p.strip_row0[s], nrows = p.strip_rows[s], sy1 = sy0 + nrows - 1;
-    const int x1 = x0 + ww - 1;
-    const int npx = nrows * ww;
+    const int npx = nrows * tw;
     const float* nb = p.ndc + (size_t)b * p.V * 3;
-    const unsigned* fr = p.frows + (size_t)b * p.F;
+    const unsigned* fs = p.fsort + (size_t)b * p.F;
+    const int* rs = p.row_start + (size_t)b * (H + 1);
     __syncthreads();
     for (int i = tid; i < npx * 5; i += RB) keys[i] = RS_EMPTY;
-    for (int i = tid; i < ww; i += RB) sXf[i] = r_pix_to_ndc(W - 1 - (x0 + i), W, H);
+    for (int i = tid; i < tw; i += RB) sXf[i] = r_pix_to_ndc(W - 1 - (x0 + i), W, H);
     for (int i = tid; i < nrows; i += RB) sYf[i] = r_pix_to_ndc(H - 1 - (sy0 + i), H, W);
-    for (int chunk = 0; chunk < p.F; chunk += RCH) {
-      if (tid == 0) okn = 0u;
-      __syncthreads();
-      // ---- phase A: which faces of the chunk touch the strip rows (one 4-byte load per face) --------
+    const int i0 = rs[max(0, sy0 - p.maxh[b])], i1 = rs[min(sy1 + 1, H)];
+    __syncthreads();
+    if (i0 < i1) {
+      const int last = i1 - 1, stride = RW * 64;
+      int idx = i0 + wave * 64 + lane;
+      // pipeline registers: entry of round r+2, vertex ids of round r+1, coordinates of round r
+      unsigned e_a = fs[min(idx, last)], e_b = fs[min(idx + stride, last)], e_c = fs[min(idx + 2 * stride, last)];
+      int va[3], vb_[3];
+      float ca[9];
 #pragma unroll
-      for (int u = 0; u < RCH / RB; ++u) {
-        const int lf = u * RB + tid, f = chunk + lf;
-        bool ok = false;
-        if (f < p.F) {
-          const unsigned r = fr[f];
-          const int lo = (int)(r & 0xffffu), hi = (int)(r >> 16);
-          ok = lo <= hi && lo <= sy1 && hi >= sy0;
-        }
-        const unsigned long long m = __ballot(ok);
-        unsigned base = 0;
-        if (lane == 0 && m) base = atomicAdd(&okn, (unsigned)__popcll(m));
-        base = __shfl(base, 0, 64);
-        if (ok) okl[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)lf;
+      for (int k = 0; k < 3; ++k) va[k] = p.faces[3 * (int)(e_a & 0xfffffu) + k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) vb_[k] = p.faces[3 * (int)(e_b & 0xfffffu) + k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        ca[3 * k] = nb[(size_t)va[k] * 3]; ca[3 * k + 1] = nb[(size_t)va[k] * 3 + 1]; ca[3 * k + 2] = nb[(size_t)va[k] * 3 + 2];
       }
-      __syncthreads();
-      const int n_ok = (int)okn;
-      for (int seg = 0; seg < n_ok; seg += RB) {
-        // ---- phase B: stage up to RB overlapping faces, count their candidate pixel centres ----------
-        int cnt = 0;
-        if (seg + tid < n_ok) {
-          const int f = chunk + (int)okl[seg + tid];
-          float tx[3], ty[3], tz[3];
+      for (; idx - lane < i1; idx += stride) {
+        // ---- issue the next rounds' gathers before working on this one ------------------------------------
+        const unsigned e_n = fs[min(idx + 3 * stride, last)];
+        int vn[3];
+        float cn[9];
 #pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const int vi = p.faces[3 * f + k];
-            tx[k] = nb[(size_t)vi * 3]; ty[k] = nb[(size_t)vi * 3 + 1]; tz[k] = nb[(size_t)vi * 3 + 2];
-          }
-          const float bxmin = fminf(tx[0], fminf(tx[1], tx[2])) - blur_d, bxmax = fmaxf(tx[0], fmaxf(tx[1], tx[2])) + blur_d;
-          const float bymin = fminf(ty[0], fminf(ty[1], ty[2])) - blur_d, bymax = fmaxf(ty[0], fmaxf(ty[1], ty[2])) + blur_d;
+        for (int k = 0; k < 3; ++k) vn[k] = p.faces[3 * (int)(e_c & 0xfffffu) + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          cn[3 * k] = nb[(size_t)vb_[k] * 3]; cn[3 * k + 1] = nb[(size_t)vb_[k] * 3 + 1]; cn[3 * k + 2] = nb[(size_t)vb_[k] * 3 + 2];
+        }
+        // ---- this round: bbox against the tile, candidate count, staging -----------------------------------
+        int cnt = 0;
+        if (idx < i1 && (int)(e_a >> 20) >= sy0) {
+          const float bxmin = fminf(ca[0], fminf(ca[3], ca[6])) - blur_d, bxmax = fmaxf(ca[0], fmaxf(ca[3], ca[6])) + blur_d;
+          const float bymin = fminf(ca[1], fminf(ca[4], ca[7])) - blur_d, bymax = fmaxf(ca[1], fmaxf(ca[4], ca[7])) + blur_d;
           // approximate pixel range, then the exact test on the tabulated pixel-centre NDC values
           int xa = max(x0, (int)floorf((float)W - 0.5f - (bxmax + 0.5f * rx) * kx) - 1);
           int xb = min(x1, (int)ceilf((float)W - 0.5f - (bxmin + 0.5f * rx) * kx) + 1);
@@ -454,73 +551,131 @@ __global__ __launch_bounds__(RB) void k_raster_strip(RasterP p) {
           while (yb >= ya && sYf[yb - sy0] < bymin) --yb;
           cnt = max(0, xb - xa + 1) * max(0, yb - ya + 1);
           if (cnt > 0) {
-            float* T = sTri + tid * RT;
+            float* T = T_ + lane * RT;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { T[3 * k] = tx[k]; T[3 * k + 1] = ty[k]; T[3 * k + 2] = tz[k]; }
-            T[9] = 1.f / (r_edge(tx[2], ty[2], tx[0], ty[0], tx[1], ty[1]) + R_KEPS);
-            const float l01 = (tx[1] - tx[0]) * (tx[1] - tx[0]) + (ty[1] - ty[0]) * (ty[1] - ty[0]);
-            const float l02 = (tx[2] - tx[0]) * (tx[2] - tx[0]) + (ty[2] - ty[0]) * (ty[2] - ty[0]);
-            const float l12 = (tx[2] - tx[1]) * (tx[2] - tx[1]) + (ty[2] - ty[1]) * (ty[2] - ty[1]);
+            for (int k = 0; k < 9; ++k) T[k] = ca[k];
+            T[9] = 1.f / (r_edge(ca[6], ca[7], ca[0], ca[1], ca[3], ca[4]) + R_KEPS);
+            const float l01 = (ca[3] - ca[0]) * (ca[3] - ca[0]) + (ca[4] - ca[1]) * (ca[4] - ca[1]);
+            const float l02 = (ca[6] - ca[0]) * (ca[6] - ca[0]) + (ca[7] - ca[1]) * (ca[7] - ca[1]);
+            const float l12 = (ca[6] - ca[3]) * (ca[6] - ca[3]) + (ca[7] - ca[4]) * (ca[7] - ca[4]);
             T[10] = l01 <= R_KEPS ? -1.f : 1.f / l01;
             T[11] = l02 <= R_KEPS ? -1.f : 1.f / l02;
             T[12] = l12 <= R_KEPS ? -1.f : 1.f / l12;
-            sXa[tid] = xa; sYa[tid] = ya; sNx[tid] = xb - xa + 1;
+            desc[lane] = (xa - x0) | ((ya - sy0) << 10) | ((xb - xa + 1) << 20);
+            fid[lane] = (int)(e_a & 0xfffffu);
           }
         }
-        // block-wide exclusive scan of the counts
         int incl = cnt;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
           const int v = __shfl_up(incl, o, 64);
           if (lane >= o) incl += v;
         }
-        if (lane == 63) swave[wave] = incl;
-        __syncthreads();
-        int woff = 0;
+#ifdef ABL_NOC
+        const int npairs = 0;
+#else
+        const int npairs = __shfl(incl, 63, 64);
+#endif
+        const int excl = incl - cnt;
+#ifdef ABL_COUNT
+        if (lane == 0) { atomicAdd(&g_cnt[0], 1ull); atomicAdd(&g_cnt[1], (unsigned long long)npairs); if (!(npairs > 0 && npairs <= RPL && __ballot(cnt > 16) == 0ull) && npairs > 0) atomicAdd(&g_cnt[2], 1ull); }
+        { const unsigned long long mm = __ballot(cnt > 0); if (lane == 0) atomicAdd(&g_cnt[3], (unsigned long long)__popcll(mm)); }
+#endif
+        if (npairs > 0 && npairs <= RPL && __ballot(cnt > 16) == 0ull) {
+          // ---- sub-pixel faces (a few candidates each): every face writes its pair descriptors, then the pairs are
+          // evaluated with full lanes straight from the list
+          for (int i = 0; i < cnt; ++i) pl[excl + i] = (unsigned short)(lane | (i << 6));
+          __builtin_amdgcn_wave_barrier();
+          for (int i = lane; i < npairs; i += 64) {
+            const int e = (int)pl[i], lo = e & 63, k = e >> 6;
+            const int d = desc[lo];
+            const int nx = d >> 20;
+            const int ky_ = (int)(((float)k + 0.5f) * __builtin_amdgcn_rcpf((float)nx)), kx_ = k - ky_ * nx;
+            const int xi = (d & 1023) + kx_, yi = ((d >> 10) & 1023) + ky_;
+            float T[RT];
 #pragma unroll
-        for (int w = 0; w < RB / 64; ++w) woff += (w < wave) ? swave[w] : 0;
-        sPre[tid] = woff + incl - cnt;
-        if (tid == RB - 1) sPre[RB] = woff + incl;
-        __syncthreads();
-        // ---- phase C: all (face, pixel) pairs of the round, split evenly over the workgroup: every
-        // thread walks a contiguous run of pairs, so the staged face stays in registers while the run
-        // stays inside one face, and neighbouring lanes work on different faces (few LDS collisions)
-        const int npairs = sPre[RB];
-        const int per = (npairs + RB - 1) / RB;
-        const int j0 = tid * per, j1 = min(j0 + per, npairs);
-        if (j0 < j1) {
-          int lo = 0, hi = RB;                           // largest o with sPre[o] <= j0
-#pragma unroll
-          for (int it = 0; it < RB_LOG2; ++it) {
-            const int mid = (lo + hi) >> 1;
-            if (sPre[mid] <= j0) lo = mid; else hi = mid;
-          }
-          float T[RT];
-          int nx = 1, kx_ = 0, ky_ = 0, xa = 0, ya = 0, nextp = -1;
-          for (int j = j0; j < j1; ++j) {
-            if (j >= nextp) {                            // first pair of the run, or the face changed
-              while (sPre[lo + 1] <= j) ++lo;
-#pragma unroll
-              for (int q = 0; q < RT; ++q) T[q] = sTri[lo * RT + q];
-              nx = sNx[lo]; xa = sXa[lo] - x0; ya = sYa[lo] - sy0;
-              const int k = j - sPre[lo];
-              ky_ = k / nx; kx_ = k - ky_ * nx;
-              nextp = sPre[lo + 1];
-            }
-            const int xi = xa + kx_, yi = ya + ky_;
-            float pz, d;
+            for (int q = 0; q < RT; ++q) T[q] = T_[lo * RT + q];
+            float pz, dd;
             bool inside;
-            if (r_eval_fast(T, sXf[xi], sYf[yi], &pz, &inside, &d))
-              r_insert(keys + (size_t)(yi * ww + xi) * 5, pz, inside, d, chunk + (int)okl[seg + lo]);
-            if (++kx_ == nx) { kx_ = 0; ++ky_; }
+#ifdef ABL_NOEVAL
+            if (T[0] == 1234.5f && xi == 77777) keys[0] = 0;
+#elif defined(ABL_NOINSERT)
+            r_eval_fast(T, sXf[xi], sYf[yi], &pz, &inside, &dd);
+            if (pz == 1234.5f && dd == 3.f) keys[0] = 0;
+#else
+            r_eval_fast(T, sXf[xi], sYf[yi], &pz, &inside, &dd);
+            r_insert(keys + (size_t)(yi * tw + xi) * 5, pz, inside, dd, fid[lo]);
+#endif
           }
+          __builtin_amdgcn_wave_barrier();
+        } else if (npairs > 0) {
+          // ---- larger faces: the pairs are split evenly over the lanes, every lane walks a contiguous run ----------
+          pre[lane] = excl;
+          if (lane == 63) pre[64] = npairs;
+          mark[lane] = -1;
+          __builtin_amdgcn_wave_barrier();
+          // run start -> face: face o opens at the first lane whose run starts at or after pre[o]
+          const int per = (npairs + 63) >> 6;
+          if (cnt > 0) {
+            const int tf = (excl + per - 1) / per;
+            if (tf < 64) atomicMax(&mark[tf], lane);
+          }
+          __builtin_amdgcn_wave_barrier();
+          int lo = mark[lane];
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(lo, o, 64);
+            if (lane >= o) lo = max(lo, v);
+          }
+          const int j0 = lane * per, j1 = min(j0 + per, npairs);
+          if (j0 < j1) {
+            float T[RT];
+#pragma unroll
+            for (int q = 0; q < RT; ++q) T[q] = T_[lo * RT + q];
+            int d = desc[lo], f = fid[lo];
+            int nx = d >> 20, xa = d & 1023, ya = (d >> 10) & 1023;
+            const int k = j0 - pre[lo];
+            int ky_ = k / nx, kx_ = k - ky_ * nx;
+            int nextp = pre[lo + 1];
+            for (int j = j0;;) {
+              const int xi = xa + kx_, yi = ya + ky_;
+              float pz, dd;
+              bool inside;
+              r_eval_fast(T, sXf[xi], sYf[yi], &pz, &inside, &dd);
+              r_insert(keys + (size_t)(yi * tw + xi) * 5, pz, inside, dd, f);
+              if (++j >= j1) break;
+              if (++kx_ == nx) { kx_ = 0; ++ky_; }
+              if (j >= nextp) {                          // the run moves on to the next face with candidates
+                ++lo;
+                while (pre[lo + 1] <= j) ++lo;
+#pragma unroll
+                for (int q = 0; q < RT; ++q) T[q] = T_[lo * RT + q];
+                d = desc[lo]; f = fid[lo];
+                nx = d >> 20; xa = d & 1023; ya = (d >> 10) & 1023;
+                kx_ = 0; ky_ = 0;
+                nextp = pre[lo + 1];
+              }
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
         }
-        __syncthreads();
+        // ---- rotate the pipeline ----------------------------------------------------------------------------------
+        e_a = e_b; e_b = e_c; e_c = e_n;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) vb_[k] = vn[k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) ca[k] = cn[k];
       }
     }
-    // finished window -> HBM (40 B per pixel, coalesced)
-    unsigned long long* gk = p.gkeys + (size_t)p.strip_koff[s] * 5;
-    for (int i = tid; i < npx * 5; i += RB) gk[i] = keys[i];
+    __syncthreads();
+    // finished tile -> HBM (40 B per pixel), window row-major
+    const int wx0 = p.win[b * 4], wy0 = p.win[b * 4 + 1], ww = p.win[b * 4 + 2];
+    unsigned long long* gk = p.gkeys + (size_t)p.body_koff[b] * 5;
+    for (int i = tid; i < npx * 5; i += RB) {
+      const int px = i / 5, c = i - px * 5;
+      const int r = px / tw, cc = px - r * tw;
+      gk[((size_t)(sy0 - wy0 + r) * ww + (x0 - wx0 + cc)) * 5 + c] = keys[i];
+    }
   }
 }
 
@@ -551,10 +706,11 @@ __global__ __launch_bounds__(RB) void k_raster_sums(RasterP p) {
   const int total = p.total[0];
   for (int s = blockIdx.x; s < total; s += gridDim.x) {
     const int b = p.strip_body[s], t = b / p.N, n = b % p.N;
-    const int x0 = p.win[b * 4], ww = p.win[b * 4 + 2];
-    const int sy0 = p.strip_row0[s], npx = p.strip_rows[s] * ww;
+    const int x0 = p.strip_col0[s], tw = p.strip_cols[s];
+    const int sy0 = p.strip_row0[s], npx = p.strip_rows[s] * tw;
+    const int wx0 = p.win[b * 4], wy0 = p.win[b * 4 + 1], ww = p.win[b * 4 + 2];
     const float* vb = p.ndc + (size_t)b * p.V * 3;
-    const unsigned long long* gk = p.gkeys + (size_t)p.strip_koff[s] * 5;
+    const unsigned long long* gk = p.gkeys + (size_t)p.body_koff[b] * 5;
     const float min_z = logf(1.f + expf(p.zmin_lin[t]));                    // optimizer.py:683-688
     const float max_z = min_z + 1.f + logf(1.f + expf(p.zmax_lin[t]));
     const float inv_min = 1.f / min_z, inv_max = 1.f / max_z, dspan = inv_min - inv_max;
@@ -562,9 +718,9 @@ __global__ __launch_bounds__(RB) void k_raster_sums(RasterP p) {
     const uint32_t fr = p.front[b];
     float lA = 0.f, lB = 0.f, lC = 0.f, lS1 = 0.f, lS2 = 0.f, lCorr = 0.f;
     for (int i = tid; i < npx; i += RB) {
-      const int yi = sy0 + i / ww, xi = x0 + i % ww;
+      const int yi = sy0 + i / tw, xi = x0 + i % tw;
       const size_t gp = (size_t)t * P + (size_t)yi * W + xi;
-      const unsigned long long* q = gk + (size_t)i * 5;
+      const unsigned long long* q = gk + ((size_t)(yi - wy0) * ww + (xi - wx0)) * 5;
       const unsigned long long k0 = q[0];
       if (k0 != RS_EMPTY) {
         const float z = __uint_as_float((unsigned)(k0 >> 32));
@@ -651,7 +807,7 @@ __global__ __launch_bounds__(RB) void k_raster_grads(RasterP p) {
     GradAcc acc;
     acc.tab = use_tab ? gtab : nullptr; acc.gvb = gvb;
     // the strips of a body are consecutive in the work list, so its window is one contiguous key range
-    const unsigned long long* gk = p.gkeys + (size_t)p.strip_koff[p.body_first[b]] * 5;
+    const unsigned long long* gk = p.gkeys + (size_t)p.body_koff[b] * 5;
     float S[6];
     r_body_sums(p, b, S);
     const float cnt = S[2] + 1.f;
@@ -818,15 +974,20 @@ __global__ void k_fill(float* x, size_t n, float v) {
 }
 
 static size_t r_align(size_t x) { return (x + 255) & ~(size_t)255; }
-static size_t r_ws_extra(size_t B, int V, int F) { return r_align(B * V * 3 * 4) + r_align(B * F * 4); }
+static size_t r_ws_extra(size_t B, int V, int F, int H) {
+  return r_align(B * V * 3 * 4) + 2 * r_align(B * F * 4) + r_align(B * (size_t)(H + 1) * 4) + r_align(B * 4) + r_align(B * 8);
+}
 static int r_max_strips(int B, int H, int W) {
-  const int rows = R_CAP / W > 0 ? R_CAP / W : 1;      // narrowest strips happen for full-width windows
-  return B * ((H + rows - 1) / rows);
+  // full-width windows give the most tiles per body
+  const int th = W <= R_CAP ? (R_CAP / W > 0 ? R_CAP / W : 1) : R_CAP / R_TILE_W;
+  const int tw = W <= R_CAP ? W : R_TILE_W;
+  const int per_body = ((W + tw - 1) / tw) * ((H + th - 1) / th);
+  return B * (per_body > H ? per_body : H);
 }
 
 extern "C" size_t mh_raster_workspace_bytes(int T, int N, int V, int F, int H, int W) {
   const size_t B = (size_t)T * N, ms = (size_t)r_max_strips((int)B, H, W);
-  return r_ws_extra(B, V, F) + r_align(B * 4 * 4) + 2 * r_align(B * 4) + r_align(4) + 3 * r_align(ms * 4) + r_align(ms * 8) + r_align(ms * 6 * 4) +
+  return r_ws_extra(B, V, F, H) + r_align(B * 4 * 4) + 2 * r_align(B * 4) + r_align(4) + 5 * r_align(ms * 4) + r_align(ms * 6 * 4) +
          r_align(B * 2 * 4) + r_align(B * (size_t)H * W * 5 * 8);
 }
 
@@ -842,8 +1003,7 @@ extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const f
                sil_apply && sil_D && sil_S && depth_body && sil_body && ws,
            "null argument");
   MH_CHECK(T > 0 && N > 0 && N <= 32 && V > 0 && F > 0 && H > 0 && W > 0, "empty input");
-  MH_CHECK(W <= R_CAP, "image wider than one LDS strip");
-  MH_CHECK(H <= 65535 && F <= 65535, "face row ranges and staged face ids are 16 bits");
+  MH_CHECK(H <= 4095 && W <= 65535 && F < (1 << 20), "sorted face entries hold 12-bit rows and 20-bit face ids");
   RasterP p;
   p.B = T * N; p.N = N; p.V = V; p.F = F; p.H = H; p.W = W;
   // transforms.py:222-255 with image_size = (W, H)
@@ -881,11 +1041,16 @@ extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const f
   p.strip_body = (int*)c; c += r_align(ms * 4);
   p.strip_row0 = (int*)c; c += r_align(ms * 4);
   p.strip_rows = (int*)c; c += r_align(ms * 4);
-  p.strip_koff = (long long*)c; c += r_align(ms * 8);
+  p.strip_col0 = (int*)c; c += r_align(ms * 4);
+  p.strip_cols = (int*)c; c += r_align(ms * 4);
   p.partial = (float*)c; c += r_align(ms * 6 * 4);
   p.dinv = (float*)c; c += r_align(B * 2 * 4);
   p.ndc = (float*)c; c += r_align(B * V * 3 * 4);
   p.frows = (unsigned*)c; c += r_align(B * F * 4);
+  p.fsort = (unsigned*)c; c += r_align(B * F * 4);
+  p.row_start = (int*)c; c += r_align(B * (size_t)(H + 1) * 4);
+  p.maxh = (int*)c; c += r_align(B * 4);
+  p.body_koff = (long long*)c; c += r_align(B * 8);
   p.gkeys = (unsigned long long*)c;
   hipStream_t st = (hipStream_t)stream;
   if (zbuf_out) {   // -1 = empty, like fragments.zbuf
@@ -898,6 +1063,8 @@ extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const f
   hipLaunchKernelGGL(k_raster_strip_table, dim3(1), dim3(1024), 0, st, p);
   MH_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_raster_face_rows, dim3((unsigned)((B * F + 255) / 256)), dim3(256), 0, st, p);
+  MH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_raster_face_sort, dim3(p.B), dim3(RFS), (size_t)(H + 1) * sizeof(int), st, p);
   MH_LAUNCH_CHECK();
   // persistent grids over the device-side work list (the strip count is only known on the device)
   const int grid = 256 * 3 * 4;

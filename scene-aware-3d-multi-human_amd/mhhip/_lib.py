@@ -7,7 +7,7 @@ import re
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libmhmocap_hip.so')
+LIB_PATH = os.environ.get('MHHIP_LIB') or os.path.join(HERE, 'libmhmocap_hip.so')   # override: kernel experiments
 HEADER = os.path.join(os.path.dirname(os.path.dirname(HERE)), 'include', 'mhmocap_hip.h')
 
 c_float_p = ctypes.POINTER(ctypes.c_float)

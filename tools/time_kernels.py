@@ -42,6 +42,14 @@ def main():
     print('seg coverage px/body', seq['seg_mask'].sum() / (T * 4))
     print('raster fwd+bwd  ms', timeit(lambda: r(e, gv, log)))
     print('raster fwd only ms', timeit(lambda: r(e, gv, log, with_grads=False)))
+    import ctypes
+    from mhhip import _lib as _ll
+    if hasattr(_ll.lib(), 'mh_debug_counters'):
+        buf = (ctypes.c_ulonglong * 8)()
+        _ll.lib().mh_debug_counters(buf); c0 = list(buf)
+        r(e, gv, log, with_grads=False); torch.cuda.synchronize()
+        _ll.lib().mh_debug_counters(buf); c1 = list(buf)
+        print('counters per call: rounds %d pairs %d runpath-rounds %d faces-with-cands %d' % tuple(c1[i] - c0[i] for i in range(4)))
     print('lbs fwd ms', timeit(lambda: e.forward()))
     from mhhip import _lib as _l
     from mhhip._lib import ptr as _p, check as _c

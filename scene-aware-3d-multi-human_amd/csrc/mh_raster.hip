@@ -343,12 +343,12 @@ __global__ __launch_bounds__(1024) void k_raster_strip_table(RasterP p) {
 // =============================================================================================
 // rasterisation of one strip into LDS
 // =============================================================================================
-// squared distance to segment ab with the staged 1/|ab|^2 (il < 0 marks a degenerate segment)
+// squared distance to segment ab with the staged 1/|ab|^2, parametrised from b: il = 0 marks a degenerate segment and
+// then yields |p - b|^2, the reference's answer for that case, without a branch
 __device__ __forceinline__ float r_seg_fast(float px, float py, float ax, float ay, float bx, float by, float il) {
-  if (il < 0.f) return (px - bx) * (px - bx) + (py - by) * (py - by);
-  const float bax = bx - ax, bay = by - ay;
-  const float tt = fminf(fmaxf((bax * (px - ax) + bay * (py - ay)) * il, 0.f), 1.f);
-  const float qx = ax + tt * bax - px, qy = ay + tt * bay - py;
+  const float abx = ax - bx, aby = ay - by, dx = px - bx, dy = py - by;
+  const float tt = fminf(fmaxf((abx * dx + aby * dy) * il, 0.f), 1.f);
+  const float qx = tt * abx - dx, qy = tt * aby - dy;
   return qx * qx + qy * qy;
 }
 
@@ -554,13 +554,13 @@ __global__ __launch_bounds__(RB) void k_raster_strip(RasterP p) {
             float* T = T_ + lane * RT;
 #pragma unroll
             for (int k = 0; k < 9; ++k) T[k] = ca[k];
-            T[9] = 1.f / (r_edge(ca[6], ca[7], ca[0], ca[1], ca[3], ca[4]) + R_KEPS);
+            T[9] = __builtin_amdgcn_rcpf(r_edge(ca[6], ca[7], ca[0], ca[1], ca[3], ca[4]) + R_KEPS);
             const float l01 = (ca[3] - ca[0]) * (ca[3] - ca[0]) + (ca[4] - ca[1]) * (ca[4] - ca[1]);
             const float l02 = (ca[6] - ca[0]) * (ca[6] - ca[0]) + (ca[7] - ca[1]) * (ca[7] - ca[1]);
             const float l12 = (ca[6] - ca[3]) * (ca[6] - ca[3]) + (ca[7] - ca[4]) * (ca[7] - ca[4]);
-            T[10] = l01 <= R_KEPS ? -1.f : 1.f / l01;
-            T[11] = l02 <= R_KEPS ? -1.f : 1.f / l02;
-            T[12] = l12 <= R_KEPS ? -1.f : 1.f / l12;
+            T[10] = l01 <= R_KEPS ? 0.f : __builtin_amdgcn_rcpf(l01);
+            T[11] = l02 <= R_KEPS ? 0.f : __builtin_amdgcn_rcpf(l02);
+            T[12] = l12 <= R_KEPS ? 0.f : __builtin_amdgcn_rcpf(l12);
             desc[lane] = (xa - x0) | ((ya - sy0) << 10) | ((xb - xa + 1) << 20);
             fid[lane] = (int)(e_a & 0xfffffu);
           }
@@ -786,7 +786,8 @@ __global__ void k_raster_body_out(RasterP p) {
 // =============================================================================================
 // gradients per strip
 // =============================================================================================
-__global__ __launch_bounds__(RB) void k_raster_grads(RasterP p) {
+#define RGB 1024             // threads per body workgroup of the gradient kernel (one workgroup per CU: LDS table)
+__global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
   extern __shared__ __attribute__((aligned(16))) float gtab[];     // [V][3] when it fits
   const int tid = threadIdx.x;
   const int H = p.H, W = p.W, P = H * W;
@@ -802,7 +803,7 @@ __global__ __launch_bounds__(RB) void k_raster_grads(RasterP p) {
     float* gvb = p.gverts + (size_t)b * p.V * 3;
     __syncthreads();
     if (use_tab)
-      for (int i = tid; i < p.V * 3; i += RB) gtab[i] = 0.f;
+      for (int i = tid; i < p.V * 3; i += RGB) gtab[i] = 0.f;
     __syncthreads();
     GradAcc acc;
     acc.tab = use_tab ? gtab : nullptr; acc.gvb = gvb;
@@ -816,7 +817,7 @@ __global__ __launch_bounds__(RB) void k_raster_grads(RasterP p) {
     const float gAlphaScale = p.coef_sil * p.sil_apply[b] * 2.f / (p.sil_D[b] + 1.f);
     const float pvalid = p.p2d_valid[b];
     const uint32_t fr = p.front[b];
-    for (int i = tid; i < npx; i += RB) {
+    for (int i = tid; i < npx; i += RGB) {
       const int yi = sy0 + i / ww, xi = x0 + i % ww;
       const size_t gp = (size_t)t * P + (size_t)yi * W + xi;
       const float yf = r_pix_to_ndc(H - 1 - yi, H, W), xf = r_pix_to_ndc(W - 1 - xi, W, H);
@@ -944,7 +945,7 @@ __global__ __launch_bounds__(RB) void k_raster_grads(RasterP p) {
     }
     __syncthreads();
     if (use_tab)
-      for (int i = tid; i < p.V * 3; i += RB) {
+      for (int i = tid; i < p.V * 3; i += RGB) {
         const float g = gtab[i];
         if (g != 0.f) gvb[i] += g;
       }
@@ -1081,7 +1082,7 @@ extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const f
       MH_HIP(hipFuncSetAttribute((const void*)k_raster_grads, hipFuncAttributeMaxDynamicSharedMemorySize, RG_MAXV * 3 * 4));
       attr_set = true;
     }
-    hipLaunchKernelGGL(k_raster_grads, dim3(p.B < 4096 ? p.B : 4096), dim3(RB), tab, st, p);
+    hipLaunchKernelGGL(k_raster_grads, dim3(p.B < 4096 ? p.B : 4096), dim3(RGB), tab, st, p);
     MH_LAUNCH_CHECK();
   }
   if (gzmin && gzmax) {

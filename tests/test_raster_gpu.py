@@ -25,11 +25,11 @@ def _scene(T, N, W, H, seed, zlo, zhi):
     return sp, pT.astype(np.float32), rng
 
 
-def _run_case(smpl_struct, smpl_regs, T, N, W, H, seed, zlo=3.0, zhi=6.0):
+def _run_case(smpl_struct, smpl_regs, T, N, W, H, seed, zlo=3.0, zhi=6.0, fov=60.0):
     from mhhip import engine
     from mhhip.sequence import SequenceEngine
     from mhhip.raster import RasterTerms
-    K = synthetic.default_cam_K((W, H), 60.0)
+    K = synthetic.default_cam_K((W, H), fov)
     sp, pT, rng = _scene(T, N, W, H, seed, zlo, zhi)
     model = engine.BodyModel(smpl_struct, smpl_regs)
     omodel = lo.BodyModel(smpl_struct, smpl_regs)
@@ -138,4 +138,12 @@ def test_raster_terms_strips(smpl_struct, smpl_regs):
     """bodies close to the camera: the screen window exceeds the LDS capacity -> row strips, two sweeps"""
     r = _run_case(smpl_struct, smpl_regs, T=1, N=2, W=160, H=96, seed=8, zlo=1.6, zhi=2.0)
     assert (r['zbuf'] > 0).sum() > 1920
+    _check(r)
+
+
+def test_raster_terms_wide_window_column_tiles(smpl_struct, smpl_regs):
+    """a body whose screen window is wider than one LDS strip (640 px): the window is cut into column tiles"""
+    r = _run_case(smpl_struct, smpl_regs, T=1, N=2, W=1000, H=40, seed=9, zlo=0.85, zhi=1.0, fov=1.6)
+    span = [int(np.ptp(np.nonzero(c)[0])) if c.any() else 0 for c in (r['zbuf'][0] > 0).any(axis=1)]
+    assert max(span) > 640, span
     _check(r)

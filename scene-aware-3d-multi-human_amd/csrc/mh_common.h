@@ -62,7 +62,7 @@ struct mh_regressor {
 struct mh_model {
   int V, VP, F, nw;
   float* vt;       // [VP][3]   template, zero padded
-  float* D;        // [3][MH_KD][VP] basis planes (x,y,z), k-major: rows 0..9 shape, 10..216 pose
+  float* D;        // [VP/32][MH_KD/16][3][64][8] basis tiled for the forward MFMA B operand (see mh_model.hip)
   float* Dt;       // [3][VP][MH_FS] the same, vertex-major (backward operand)
   int* skidx;      // [VP][nw] bones of the <= nw non-zero skinning weights per vertex
   float* skw;      // [VP][nw]

@@ -105,18 +105,25 @@ extern "C" int mh_model_create(mh_model** out, const mh_model_host* h) {
     if ((rc = upload(&m->vt, vt))) return rc;
   }
   {
-    // basis planes: D[c][k][v]; k<10: shapedirs[v][c][k]; 10<=k<217: posedirs[v][c][k-10]
+    // basis, k<10: shapedirs[v][c][k]; 10<=k<217: posedirs[v][c][k-10], in two layouts:
+    //   D  (forward MFMA B operand)  [tile = v/32][kg = k/16][c][lane = (k%2)*32 + v%32][u = (k%16)/2]: the eight
+    //      values one lane feeds into the eight two-k MFMA steps of a k-group are 32 contiguous bytes
+    //   Dt (backward operand)        [c][v][k]
     std::vector<float> D((size_t)3 * MH_KD * VP, 0.f), Dt((size_t)3 * VP * MH_FS, 0.f);
+    auto didx = [&](int c, int k, int v) {
+      const int tile = v >> 5, li = v & 31, kg = k >> 4, lh = k & 1, u = (k & 15) >> 1;
+      return ((((size_t)tile * (MH_KD / 16) + kg) * 3 + c) * 64 + (lh * 32 + li)) * 8 + u;
+    };
     for (int v = 0; v < V; ++v)
       for (int c = 0; c < 3; ++c) {
         for (int k = 0; k < MH_NUM_BETAS; ++k) {
           float x = h->shapedirs[((size_t)v * 3 + c) * MH_NUM_BETAS + k];
-          D[((size_t)c * MH_KD + k) * VP + v] = x;
+          D[didx(c, k, v)] = x;
           Dt[((size_t)c * VP + v) * MH_FS + k] = x;
         }
         for (int k = 0; k < MH_NUM_POSE_BASIS; ++k) {
           float x = h->posedirs[((size_t)v * 3 + c) * MH_NUM_POSE_BASIS + k];
-          D[((size_t)c * MH_KD + 10 + k) * VP + v] = x;
+          D[didx(c, 10 + k, v)] = x;
           Dt[((size_t)c * VP + v) * MH_FS + 10 + k] = x;
         }
       }

@@ -374,13 +374,34 @@ __device__ __forceinline__ bool r_eval_fast(const float* T, float xf, float yf, 
   return true;
 }
 
-// conservative pixel-row range of every face (one pass per body instead of one per strip): a strip
-// then rejects a face with one 4-byte load.
-__global__ __launch_bounds__(256) void k_raster_face_rows(RasterP p) {
-  const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
-  if (i >= (size_t)p.B * p.F) return;
-  const int b = (int)(i / p.F), f = (int)(i - (size_t)b * p.F);
-  const float* nb = p.ndc + (size_t)b * p.V * 3;
+// wave64 inclusive scans on the DPP network (row shifts inside the rows of 16, then the two row broadcasts):
+// six VALU ops, no LDS round trips (a __shfl_up scan is six ds_bpermute each followed by a wait)
+__device__ __forceinline__ int r_wave_scan_add(int x) {
+  int v = x;
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
+__device__ __forceinline__ int r_wave_scan_max(int x) {              // values >= -1
+  int v = x;
+  v = max(v, __builtin_amdgcn_update_dpp(-1, v, 0x111, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(-1, v, 0x112, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(-1, v, 0x114, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(-1, v, 0x118, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(-1, v, 0x142, 0xa, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(-1, v, 0x143, 0xc, 0xf, false));
+  return v;
+}
+
+// conservative pixel-row range of every face + counting sort of the body's visible faces by their first row (one
+// workgroup per body): a tile's candidate faces are then one contiguous range of fsort (first row in
+// [tile_row0 - tallest_face, tile_last_row]); entries are hi << 20 | face.
+#define RFS 512
+__device__ __forceinline__ unsigned r_face_rows(const RasterP& p, const float* nb, int f) {
   float x[3], y[3], z[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -398,26 +419,24 @@ __global__ __launch_bounds__(256) void k_raster_face_rows(RasterP p) {
       out = ulo | (uhi << 16);
     }
   }
-  p.frows[i] = out;
+  return out;
 }
 
-// counting sort of a body's visible faces by their first pixel row: a tile's candidate faces are then one
-// contiguous range of fsort (first row in [tile_row0 - tallest_face, tile_last_row]).
-#define RFS 512
 __global__ __launch_bounds__(RFS) void k_raster_face_sort(RasterP p) {
   extern __shared__ int hist[];                     // [H + 1]
-  __shared__ int s_scan[RFS];
-  __shared__ int s_carry, s_maxh;
+  __shared__ int s_maxh;
   const int b = blockIdx.x, tid = threadIdx.x, H = p.H;
-  const unsigned* fr = p.frows + (size_t)b * p.F;
+  const float* nb = p.ndc + (size_t)b * p.V * 3;
+  unsigned* fr = p.frows + (size_t)b * p.F;
   unsigned* fs = p.fsort + (size_t)b * p.F;
   int* rs = p.row_start + (size_t)b * (H + 1);
   for (int i = tid; i <= H; i += RFS) hist[i] = 0;
-  if (tid == 0) { s_carry = 0; s_maxh = 0; }
+  if (tid == 0) s_maxh = 0;
   __syncthreads();
   int mh = 0;
   for (int f = tid; f < p.F; f += RFS) {
-    const unsigned r = fr[f];
+    const unsigned r = r_face_rows(p, nb, f);
+    fr[f] = r;
     const int lo = (int)(r & 0xffffu), hi = (int)(r >> 16);
     if (lo <= hi) {
       atomicAdd(&hist[lo], 1);
@@ -428,28 +447,21 @@ __global__ __launch_bounds__(RFS) void k_raster_face_sort(RasterP p) {
   for (int o = 32; o > 0; o >>= 1) mh = max(mh, __shfl_xor(mh, o, 64));
   if ((tid & 63) == 0) atomicMax(&s_maxh, mh);
   __syncthreads();
-  for (int base = 0; base <= H; base += RFS) {
-    const int i = base + tid;
-    const int v = i <= H ? hist[i] : 0;
-    s_scan[tid] = v;
-    __syncthreads();
-    for (int o = 1; o < RFS; o <<= 1) {
-      int a = 0;
-      if (tid >= o) a = s_scan[tid - o];
-      __syncthreads();
-      s_scan[tid] += a;
-      __syncthreads();
+  if (tid < 64) {                                   // exclusive scan of the row histogram by one wave
+    int carry = 0;
+    for (int base = 0; base <= H; base += 64) {
+      const int i = base + tid;
+      const int v = i <= H ? hist[i] : 0;
+      const int incl = r_wave_scan_add(v);
+      if (i <= H) {
+        hist[i] = carry + incl - v;
+        rs[i] = carry + incl - v;
+      }
+      carry += __builtin_amdgcn_readlane(incl, 63);
     }
-    if (i <= H) {
-      const int st = s_carry + s_scan[tid] - v;
-      hist[i] = st;
-      rs[i] = st;
-    }
-    __syncthreads();
-    if (tid == RFS - 1) s_carry += s_scan[RFS - 1];
-    __syncthreads();
+    if (tid == 0) p.maxh[b] = s_maxh;
   }
-  if (tid == 0) p.maxh[b] = s_maxh;
+  __syncthreads();
   for (int f = tid; f < p.F; f += RFS) {
     const unsigned r = fr[f];
     const int lo = (int)(r & 0xffffu), hi = (int)(r >> 16);
@@ -477,6 +489,7 @@ __global__ __launch_bounds__(RB) void k_raster_strip(RasterP p) {
   __shared__ int wDesc[RW][64];             // xa | ya << 10 | nx << 20 (tile-relative)
   __shared__ int wFid[RW][64];
   __shared__ int wMark[RW][64];
+  __shared__ unsigned wZb[RW][64];          // bits of the nearest vertex depth of the staged faces
   __shared__ unsigned short wPl[RW][RPL];   // pair list of the sub-pixel path: face slot | pair index << 6
   __shared__ float sXf[R_CAP];              // NDC x of the tile columns
   __shared__ float sYf[R_CAP];              // NDC y of the tile rows
@@ -494,6 +507,7 @@ __global__ __launch_bounds__(RB) void k_raster_strip(RasterP p) {
   int* desc = wDesc[wave];
   int* fid = wFid[wave];
   int* mark = wMark[wave];
+  unsigned* zbs = wZb[wave];
   unsigned short* pl = wPl[wave];
   for (int s = blockIdx.x; s < total; s += gridDim.x) {
     const int b = p.strip_body[s];
@@ -563,19 +577,11 @@ __global__ __launch_bounds__(RB) void k_raster_strip(RasterP p) {
             T[12] = l12 <= R_KEPS ? 0.f : __builtin_amdgcn_rcpf(l12);
             desc[lane] = (xa - x0) | ((ya - sy0) << 10) | ((xb - xa + 1) << 20);
             fid[lane] = (int)(e_a & 0xfffffu);
+            zbs[lane] = __float_as_uint(fminf(ca[2], fminf(ca[5], ca[8])));
           }
         }
-        int incl = cnt;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const int v = __shfl_up(incl, o, 64);
-          if (lane >= o) incl += v;
-        }
-#ifdef ABL_NOC
-        const int npairs = 0;
-#else
-        const int npairs = __shfl(incl, 63, 64);
-#endif
+        const int incl = r_wave_scan_add(cnt);
+        const int npairs = __builtin_amdgcn_readlane(incl, 63);
         const int excl = incl - cnt;
 #ifdef ABL_COUNT
         if (lane == 0) { atomicAdd(&g_cnt[0], 1ull); atomicAdd(&g_cnt[1], (unsigned long long)npairs); if (!(npairs > 0 && npairs <= RPL && __ballot(cnt > 16) == 0ull) && npairs > 0) atomicAdd(&g_cnt[2], 1ull); }
@@ -586,7 +592,35 @@ __global__ __launch_bounds__(RB) void k_raster_strip(RasterP p) {
           // evaluated with full lanes straight from the list
           for (int i = 0; i < cnt; ++i) pl[excl + i] = (unsigned short)(lane | (i << 6));
           __builtin_amdgcn_wave_barrier();
-          for (int i = lane; i < npairs; i += 64) {
+          // depth cull, compacting the list in place: the clipped-barycentric depth of a face is never below its
+          // nearest vertex, so a pair whose face lies entirely behind both the pixel's current nearest key and its
+          // current 4th silhouette key cannot change the window (the keys only ever decrease)
+          int nkeep = 0;
+          for (int base = 0; base < npairs; base += 64) {
+            const int i = base + lane;
+            bool keep = false;
+            unsigned short e16 = 0;
+            if (i < npairs) {
+              e16 = pl[i];
+              const int lo = e16 & 63, k = e16 >> 6;
+              const int d = desc[lo];
+              const int nx = d >> 20;
+              const int ky_ = (int)(((float)k + 0.5f) * __builtin_amdgcn_rcpf((float)nx)), kx_ = k - ky_ * nx;
+              const int xi = (d & 1023) + kx_, yi = ((d >> 10) & 1023) + ky_;
+              const unsigned* qh = (const unsigned*)(keys + (size_t)(yi * tw + xi) * 5);
+              const unsigned zb = zbs[lo];
+              keep = !(zb > qh[1] && zb > qh[9]);
+            }
+            const unsigned long long m = __ballot(keep);
+            __builtin_amdgcn_wave_barrier();
+            if (keep) pl[nkeep + __popcll(m & ((1ull << lane) - 1ull))] = e16;
+            nkeep += __popcll(m);
+          }
+          __builtin_amdgcn_wave_barrier();
+#ifdef ABL_COUNT
+          if (lane == 0) atomicAdd(&g_cnt[4], (unsigned long long)nkeep);
+#endif
+          for (int i = lane; i < nkeep; i += 64) {
             const int e = (int)pl[i], lo = e & 63, k = e >> 6;
             const int d = desc[lo];
             const int nx = d >> 20;
@@ -621,12 +655,7 @@ __global__ __launch_bounds__(RB) void k_raster_strip(RasterP p) {
             if (tf < 64) atomicMax(&mark[tf], lane);
           }
           __builtin_amdgcn_wave_barrier();
-          int lo = mark[lane];
-#pragma unroll
-          for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(lo, o, 64);
-            if (lane >= o) lo = max(lo, v);
-          }
+          int lo = r_wave_scan_max(mark[lane]);
           const int j0 = lane * per, j1 = min(j0 + per, npairs);
           if (j0 < j1) {
             float T[RT];
@@ -1062,8 +1091,6 @@ extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const f
   hipLaunchKernelGGL(k_raster_windows, dim3(p.B), dim3(256), 0, st, p);
   MH_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_raster_strip_table, dim3(1), dim3(1024), 0, st, p);
-  MH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_raster_face_rows, dim3((unsigned)((B * F + 255) / 256)), dim3(256), 0, st, p);
   MH_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_raster_face_sort, dim3(p.B), dim3(RFS), (size_t)(H + 1) * sizeof(int), st, p);
   MH_LAUNCH_CHECK();

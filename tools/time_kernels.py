@@ -49,7 +49,7 @@ def main():
         _ll.lib().mh_debug_counters(buf); c0 = list(buf)
         r(e, gv, log, with_grads=False); torch.cuda.synchronize()
         _ll.lib().mh_debug_counters(buf); c1 = list(buf)
-        print('counters per call: rounds %d pairs %d runpath-rounds %d faces-with-cands %d' % tuple(c1[i] - c0[i] for i in range(4)))
+        print('counters per call: rounds %d pairs %d runpath-rounds %d faces-with-cands %d kept-after-cull %d' % tuple(c1[i] - c0[i] for i in range(5)))
     print('lbs fwd ms', timeit(lambda: e.forward()))
     from mhhip import _lib as _l
     from mhhip._lib import ptr as _p, check as _c

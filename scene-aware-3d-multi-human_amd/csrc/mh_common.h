@@ -63,7 +63,7 @@ struct mh_model {
   int V, VP, F, nw;
   float* vt;       // [VP][3]   template, zero padded
   float* D;        // [VP/32][MH_KD/16][3][64][8] basis tiled for the forward MFMA B operand (see mh_model.hip)
-  float* Dt;       // [3][VP][MH_FS] the same, vertex-major (backward operand)
+  float* Dt;       // [3][VP][16][16] the same, tiled for the backward MFMA B operand (see mh_model.hip)
   int* skidx;      // [VP][nw] bones of the <= nw non-zero skinning weights per vertex
   float* skw;      // [VP][nw]
   float* Jt;       // [24][3]     J_regressor . v_template

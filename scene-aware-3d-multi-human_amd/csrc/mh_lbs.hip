@@ -440,17 +440,60 @@ __global__ __launch_bounds__(256, 2) void k_skin_bwd(SkinBwdP p) {
   float sT0 = 0, sT1 = 0, sT2 = 0, sS = 0;
   const int qend = min((ch + 1) * p.PQ, p.VP / 4);
   const float* sAb = sA + li * BWD_AS;
-  const size_t plane = (size_t)p.VP * MH_FS;
-  for (int qd = ch * p.PQ + wave; qd < qend; qd += 4) {
+  // Dt tile of (vertex, body column li): [c][v][li][16] -> four 16-byte loads per component
+  const f32x4* dtb = (const f32x4*)p.Dt + ((size_t)lq * 16 + li) * 4;
+  const size_t cplane = (size_t)p.VP * 64;               // f32x4 units per component
+  int qd = ch * p.PQ + wave;
+  f32x4 d0[4], d1[4], d2[4];
+  float ng[3] = {0, 0, 0}, nq[3] = {0, 0, 0};
+  int nsj[4] = {0, 0, 0, 0}, nke0 = 0, nke1 = 0;
+  float nsw[4] = {0, 0, 0, 0};
+  const bool has_g = p.gverts != nullptr;
+  const int nw4 = p.nw < 4 ? p.nw : 4;
+  auto load_vertex_tables = [&](int vv) {   // skinning row + regressor row bounds of vertex vv (padded rows exist up to VP)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      nsj[k] = k < nw4 ? p.skidx[(size_t)vv * p.nw + k] : 0;
+      nsw[k] = k < nw4 ? p.skw[(size_t)vv * p.nw + k] : 0.f;
+    }
+    nke0 = p.kpv_ptr[vv];
+    nke1 = p.kpv_ptr[vv + 1];
+  };
+  if (qd < qend) {
+    load_vertex_tables(4 * qd + lq);
+    const f32x4* d = dtb + (size_t)(4 * qd) * 64;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { d0[k] = d[k]; d1[k] = d[cplane + k]; d2[k] = d[2 * cplane + k]; }
     const int v = 4 * qd + lq;
-    float g0 = 0, g1 = 0, g2 = 0, q0 = 0, q1 = 0, q2 = 0;
     if (bvalid && v < p.V) {
       const size_t o = ((size_t)b * p.V + v) * 3;
-      if (p.gverts) { g0 = p.gverts[o]; g1 = p.gverts[o + 1]; g2 = p.gverts[o + 2]; }
-      q0 = p.vposed[o]; q1 = p.vposed[o + 1]; q2 = p.vposed[o + 2];
+      if (has_g) { ng[0] = p.gverts[o]; ng[1] = p.gverts[o + 1]; ng[2] = p.gverts[o + 2]; }
+      nq[0] = p.vposed[o]; nq[1] = p.vposed[o + 1]; nq[2] = p.vposed[o + 2];
+    }
+  }
+  for (; qd < qend; qd += 4) {
+    const int v = 4 * qd + lq;
+    float g0 = ng[0], g1 = ng[1], g2 = ng[2];
+    const float q0 = nq[0], q1 = nq[1], q2 = nq[2];
+    // the next quad's adjoints and posed vertices stream from HBM: issue them a whole iteration ahead
+    int sj4[4];
+    float sw4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sj4[k] = nsj[k]; sw4[k] = nsw[k]; }
+    const int ke0 = nke0, ke1 = nke1;
+    const int qn = qd + 4 < qend ? qd + 4 : qd;
+    load_vertex_tables(4 * qn + lq);
+    {
+      const int vn = 4 * qn + lq;
+      ng[0] = ng[1] = ng[2] = nq[0] = nq[1] = nq[2] = 0.f;
+      if (bvalid && vn < p.V) {
+        const size_t o = ((size_t)b * p.V + vn) * 3;
+        if (has_g) { ng[0] = p.gverts[o]; ng[1] = p.gverts[o + 1]; ng[2] = p.gverts[o + 2]; }
+        nq[0] = p.vposed[o]; nq[1] = p.vposed[o + 1]; nq[2] = p.vposed[o + 2];
+      }
     }
     // key-point regressor adjoint: dL/dverts += R^T dL/djoints
-    for (int e = p.kpv_ptr[v]; e < p.kpv_ptr[v + 1]; ++e) {
+    for (int e = ke0; e < ke1; ++e) {
       const float w = p.kpv_w[e];
       const float* gj = sGj + li * 52 + p.kpv_j[e] * 3;
       g0 = fmaf(w, gj[0], g0);
@@ -462,9 +505,9 @@ __global__ __launch_bounds__(256, 2) void k_skin_bwd(SkinBwdP p) {
 #pragma unroll
     for (int e = 0; e < 12; ++e) T[e] = 0.f;
     float wd0 = 0.f, wd1 = 0.f;   // dense skinning weights W[v][li], W[v][16+li] (MFMA B operands)
-    for (int k = 0; k < p.nw; ++k) {
-      const int j = p.skidx[(size_t)v * p.nw + k];
-      const float w = p.skw[(size_t)v * p.nw + k];
+    for (int k = 0; k < p.nw; ++k) {       // (kept as a loop: unrolling it costs more in spills than it saves)
+      const int j = k < 4 ? sj4[k] : p.skidx[(size_t)v * p.nw + k];
+      const float w = k < 4 ? sw4[k] : p.skw[(size_t)v * p.nw + k];
       const f32x4* Aj = (const f32x4*)(sAb + j * 12);
       const f32x4 a0 = Aj[0], a1 = Aj[1], a2 = Aj[2];
 #pragma unroll
@@ -485,12 +528,20 @@ __global__ __launch_bounds__(256, 2) void k_skin_bwd(SkinBwdP p) {
     // d/d v_posed = T.R^T gx  -> rows of the [shape | pose] basis
     const float gv[3] = {fmaf(T[8], gx2, fmaf(T[4], gx1, T[0] * gx0)), fmaf(T[9], gx2, fmaf(T[5], gx1, T[1] * gx0)),
                          fmaf(T[10], gx2, fmaf(T[6], gx1, T[2] * gx0))};
-    const float* dt = p.Dt + (size_t)v * MH_FS + li;
+    // each component's basis registers are refilled for the next quad as soon as its 14 MFMAs have issued
+    const f32x4* dn = dtb + (size_t)(4 * qn) * 64;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int t = 0; t < 14; ++t) accF[t] = MFMA16(gv[0], d0[t >> 2][t & 3], accF[t]);
 #pragma unroll
-      for (int t = 0; t < 14; ++t) accF[t] = MFMA16(gv[c], dt[c * plane + t * 16], accF[t]);
-    }
+    for (int k = 0; k < 4; ++k) d0[k] = dn[k];
+#pragma unroll
+    for (int t = 0; t < 14; ++t) accF[t] = MFMA16(gv[1], d1[t >> 2][t & 3], accF[t]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d1[k] = dn[cplane + k];
+#pragma unroll
+    for (int t = 0; t < 14; ++t) accF[t] = MFMA16(gv[2], d2[t >> 2][t & 3], accF[t]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d2[k] = dn[2 * cplane + k];
     // d/dA_j = sum_v w_vj gx (x) [v_posed;1]
     const float gxs[3] = {gx0, gx1, gx2};
     const float qh[4] = {q0, q1, q2, 1.f};

@@ -108,8 +108,10 @@ extern "C" int mh_model_create(mh_model** out, const mh_model_host* h) {
     // basis, k<10: shapedirs[v][c][k]; 10<=k<217: posedirs[v][c][k-10], in two layouts:
     //   D  (forward MFMA B operand)  [tile = v/32][kg = k/16][c][lane = (k%2)*32 + v%32][u = (k%16)/2]: the eight
     //      values one lane feeds into the eight two-k MFMA steps of a k-group are 32 contiguous bytes
-    //   Dt (backward operand)        [c][v][k]
-    std::vector<float> D((size_t)3 * MH_KD * VP, 0.f), Dt((size_t)3 * VP * MH_FS, 0.f);
+    //   Dt (backward MFMA B operand) [c][v][li = k%16][t = k/16, padded to 16]: the 14 column-tile values one lane
+    //      (body li, vertex) feeds into the feature-gradient MFMAs are 64 contiguous bytes
+    std::vector<float> D((size_t)3 * MH_KD * VP, 0.f), Dt((size_t)3 * VP * 256, 0.f);
+    auto tidx = [&](int c, int k, int v) { return (((size_t)c * VP + v) * 16 + (k & 15)) * 16 + (k >> 4); };
     auto didx = [&](int c, int k, int v) {
       const int tile = v >> 5, li = v & 31, kg = k >> 4, lh = k & 1, u = (k & 15) >> 1;
       return ((((size_t)tile * (MH_KD / 16) + kg) * 3 + c) * 64 + (lh * 32 + li)) * 8 + u;
@@ -119,12 +121,12 @@ extern "C" int mh_model_create(mh_model** out, const mh_model_host* h) {
         for (int k = 0; k < MH_NUM_BETAS; ++k) {
           float x = h->shapedirs[((size_t)v * 3 + c) * MH_NUM_BETAS + k];
           D[didx(c, k, v)] = x;
-          Dt[((size_t)c * VP + v) * MH_FS + k] = x;
+          Dt[tidx(c, k, v)] = x;
         }
         for (int k = 0; k < MH_NUM_POSE_BASIS; ++k) {
           float x = h->posedirs[((size_t)v * 3 + c) * MH_NUM_POSE_BASIS + k];
           D[didx(c, 10 + k, v)] = x;
-          Dt[((size_t)c * VP + v) * MH_FS + 10 + k] = x;
+          Dt[tidx(c, 10 + k, v)] = x;
         }
       }
     if ((rc = upload(&m->D, D))) return rc;

@@ -32,9 +32,6 @@ COEFS = dict(proj2d=1.0, depth=0.05, silhouette=0.1, reg_poses=0.002, reg_scales
              reg_verts_filter=0.002, reg_contact=0.001, reg_foot_sliding=0.01)   # configs/predict_mupots.yml:17-25
 N_PEOPLE, T_LOCAL, IMG, BATCH = 4, 200, (240, 135), 10
 # algorithmic bytes / flops of the LBS+projection kernels per human.frame.iteration (fwd+bwd)
-LBS_BYTES_PER_BODY = 167028.0
-LBS_FLOPS_PER_BODY = 38.0e6
-LBS_CONST_BYTES = 19.35e6          # model constants, once per launch
 PEAK_HBM_GBS = 8000.0
 PEAK_F32_MFMA_TFLOPS = 157.3
 
@@ -57,6 +54,16 @@ def ground_scene(K, W, H):
     ys = (np.arange(H, dtype=np.float32) + 0.5 - K[1, 2]) / K[1, 1]
     d = np.minimum(np.where(ys[:, None] > 1e-3, 1.15 / np.maximum(ys[:, None], 1e-3), 10.0), 10.0)
     return np.tile(d, (1, W)).astype(np.float32)
+
+
+def load_pmc_traffic():
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE and
+    WRITE_SIZE need separate passes, profiles/README.md); None when the file is absent."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return json.load(f)
 
 
 def cpu_baseline(struct, regs, K, seq, pT0, frames, cycles):
@@ -160,33 +167,60 @@ def main():
     # launch sequence runs once more eagerly with events around the kernel groups (same kernels, same
     # stream, same data; only the launch mechanism differs)
     e.enable_timing(True)
+    import ctypes
+    from mhhip import _lib
+    L = _lib.lib()
+    L.mh_profile_enable(1)
+    prof_names = ['k_raster_strip', 'k_raster_grads', 'k_skin_fwd', 'k_skin_bwd', 'k_contact_knn_grid', 'k_raster_sums']
+    prof = {k: [] for k in prof_names}
     for c in range(args.steps):
         one_cycle(args.warmup + args.steps + c, False)
+        torch.cuda.synchronize()
+        for i, k in enumerate(prof_names):      # duration of this cycle's launch (HIP events on the launch stream)
+            ms1 = ctypes.c_float(0)
+            if L.mh_profile_read(i, ctypes.byref(ms1)) == 0:
+                prof[k].append(float(ms1.value))
+    L.mh_profile_enable(0)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     kern = e.timing_summary()
     e.enable_timing(False)
+    kernel_us = {k: 1e3 * float(np.mean(v)) for k, v in prof.items() if v}
+    win = raster.ws[:e.B * 16].view(torch.int32).view(e.B, 4).cpu().numpy()
+    window_px = int((np.maximum(win[:, 2], 0).astype(np.int64) * np.maximum(win[:, 3], 0)).sum())
     log = sh.read_log(1)
 
     if rank == 0:
         ms = 1e3 * dt / args.steps
         its = args.steps / dt
         bodies = N_PEOPLE * T_LOCAL
-        lbs_ms = kern.get('lbs_forward', 0.0) + kern.get('lbs_backward', 0.0)
-        dom = max(kern, key=kern.get) if kern else None
-        lbs_bytes = LBS_BYTES_PER_BODY * bodies + 2 * LBS_CONST_BYTES
-        lbs_flops = LBS_FLOPS_PER_BODY * bodies
+        V, F = int(e.V), int(raster.faces.shape[0])
+        dom = max(kernel_us, key=kernel_us.get) if kernel_us else None
+        traffic = load_pmc_traffic()
+        # dominant kernel: k_raster_strip.  Algorithmic bytes per launch: every body's projected
+        # vertices (12 B x V) and row-sorted face list (4 B x F) in, the 40-byte key record of every window pixel out,
+        # plus the face table once.  The kernel is VALU-issue bound, not HBM bound (profiles/: SQ_ACTIVE_INST_VALU is
+        # ~80 % of the wave-resident cycles); the HBM fraction is reported because the contract asks for one.
         roof = None
-        if lbs_ms > 0:
-            tf = lbs_flops / (lbs_ms * 1e-3) / 1e12
-            roof = {'kernel': 'LBS+projection (k_pose_fwd,k_skin_fwd,k_skin_bwd,k_pose_bwd)', 'bound': 'mfma',
-                    'achieved': round(tf, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(tf / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
-                    'launch_ms': round(lbs_ms, 4), 'algorithmic_bytes': lbs_bytes, 'algorithmic_flops': lbs_flops,
-                    'hbm_achieved_GBs': round(lbs_bytes / (lbs_ms * 1e-3) / 1e9, 1),
-                    'hbm_frac': round(lbs_bytes / (lbs_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                    'dominant_group': dom}
+        if 'k_raster_strip' in kernel_us:
+            us = kernel_us['k_raster_strip']
+            algo = bodies * (12.0 * V + 4.0 * F) + 40.0 * window_px + 12.0 * F
+            gbs = algo / (us * 1e-6) / 1e9
+            roof = {'kernel': 'k_raster_strip', 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS,
+                    'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4), 'traffic': traffic.get('k_raster_strip'),
+                    'launch_us': round(us, 1), 'algorithmic_bytes': algo, 'window_pixels': window_px,
+                    'note': 'dominant kernel by time; integer/LDS-atomic z-buffer selection, VALU-issue bound '
+                            '(see DESIGN.md section 4 and profiles/)', 'dominant_by_events': dom}
+        # the GEMM-shaped kernels against the dense f32 MFMA peak: flops = 2 x 3 x 217 x V per body forward, plus the
+        # 12 x 24 bone-transform adjoint per vertex backward
+        roof_mfma = {}
+        for k, fl in (('k_skin_fwd', bodies * V * 217.0 * 6.0), ('k_skin_bwd', bodies * V * (217.0 * 6.0 + 12.0 * 24.0 * 2.0))):
+            if k in kernel_us:
+                tf = fl / (kernel_us[k] * 1e-6) / 1e12
+                roof_mfma[k] = {'bound': 'mfma', 'achieved': round(tf, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                'frac': round(tf / PEAK_F32_MFMA_TFLOPS, 4), 'launch_us': round(kernel_us[k], 1),
+                                'algorithmic_flops': fl, 'traffic': traffic.get(k)}
         out = {
             'metric': 'optimizer iterations/sec (N humans x T frames)', 'value': round(its * world, 3),
             'unit': 'iterations/s (4 humans x 200 frames per iteration unit)', 'n_gpus': world, 'steps': args.steps,
@@ -198,7 +232,8 @@ def main():
                                    % (T_LOCAL * world),
                        'humans': N_PEOPLE, 'frames': T_LOCAL * world, 'frames_per_gpu': T_LOCAL, 'image': list(IMG),
                        'parallelism': 'frames sharded x%d, RCCL all-reduce on betas/scale grads' % world},
-            'roofline': roof, 'kernel_ms': {k: round(v, 4) for k, v in kern.items()},
+            'roofline': roof, 'roofline_mfma': roof_mfma, 'kernel_us': {k: round(v, 1) for k, v in kernel_us.items()},
+            'kernel_group_ms': {k: round(v, 4) for k, v in kern.items()},
             'loss_first_cycle': {k: float(v) for k, v in log[0].items()},
         }
         if not args.no_cpu_baseline and world == 1:

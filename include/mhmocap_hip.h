@@ -68,6 +68,16 @@ enum { MH_REG_ALPHAPOSE = 0, MH_REG_H36M17 = 1, MH_REG_MUPOTS = 2, MH_REG_EXTRA9
 
 const char* mh_last_error(void);
 int mh_version(void);
+
+/* Measurement aid (bench.py, DESIGN.md "measurement"): when enabled, the library brackets the launches of its
+ * dominant kernels with HIP events on the caller's stream; mh_profile_read synchronises on the pair of the most recent
+ * launch and returns its duration.  Off by default; not meant to be on during stream capture. */
+enum mh_profile_kernel {
+  MH_PROF_RASTER_STRIP = 0, MH_PROF_RASTER_GRADS = 1, MH_PROF_SKIN_FWD = 2, MH_PROF_SKIN_BWD = 3,
+  MH_PROF_CONTACT_KNN = 4, MH_PROF_RASTER_SUMS = 5, MH_PROF_COUNT = 6
+};
+int mh_profile_enable(int on);
+int mh_profile_read(int which, float* ms);
 /* number of visible HIP devices (0 on a CPU-only host; never fails) */
 int mh_device_count(void);
 

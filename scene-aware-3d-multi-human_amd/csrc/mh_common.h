@@ -16,6 +16,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 void mh_set_error(const char* fmt, ...);
+// event brackets around the named kernels (no-ops unless mh_profile_enable(1)); edge 0 = before, 1 = after
+void mh_prof_mark(int which, int edge, hipStream_t st);
 
 #define MH_HIP(call)                                                                   \
   do {                                                                                 \

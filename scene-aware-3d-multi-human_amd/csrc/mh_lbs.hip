@@ -322,8 +322,10 @@ extern "C" int mh_lbs_forward(const mh_model* m, int B, int NB, const float* bet
   sp.featT = w.featT; sp.A = w.A; sp.scale = w.scale; sp.transl = transl;
   sp.D = m->D; sp.vt = m->vt; sp.skidx = m->skidx; sp.skw = m->skw;
   sp.verts = verts; sp.vposed = vposed;
+  mh_prof_mark(MH_PROF_SKIN_FWD, 0, st);
   hipLaunchKernelGGL(k_skin_fwd, dim3(((m->VP / 32 + 3) / 4 + 7) / 8 * 8, G), dim3(256), 0, st, sp);
   MH_LAUNCH_CHECK();
+  mh_prof_mark(MH_PROF_SKIN_FWD, 1, st);
   return MH_OK;
 }
 
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void k_skin_bwd(SkinBwdP p) {
   const f32x4* dtb = (const f32x4*)p.Dt + ((size_t)lq * 16 + li) * 4;
   const size_t cplane = (size_t)p.VP * 64;               // f32x4 units per component
   int qd = ch * p.PQ + wave;
-  f32x4 d0[4], d1[4], d2[4];
+  f32x4 dbuf[3][2];      // three half-components (8 column tiles each) in flight: 24 registers instead of 48
   float ng[3] = {0, 0, 0}, nq[3] = {0, 0, 0};
   int nsj[4] = {0, 0, 0, 0}, nke0 = 0, nke1 = 0;
   float nsw[4] = {0, 0, 0, 0};
@@ -462,8 +464,9 @@ __global__ __launch_bounds__(256, 2) void k_skin_bwd(SkinBwdP p) {
   if (qd < qend) {
     load_vertex_tables(4 * qd + lq);
     const f32x4* d = dtb + (size_t)(4 * qd) * 64;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { d0[k] = d[k]; d1[k] = d[cplane + k]; d2[k] = d[2 * cplane + k]; }
+    dbuf[0][0] = d[0]; dbuf[0][1] = d[1];                       // component 0, tiles 0..7
+    dbuf[1][0] = d[2]; dbuf[1][1] = d[3];                       // component 0, tiles 8..13
+    dbuf[2][0] = d[cplane]; dbuf[2][1] = d[cplane + 1];         // component 1, tiles 0..7
     const int v = 4 * qd + lq;
     if (bvalid && v < p.V) {
       const size_t o = ((size_t)b * p.V + v) * 3;
@@ -506,8 +509,10 @@ __global__ __launch_bounds__(256, 2) void k_skin_bwd(SkinBwdP p) {
     for (int e = 0; e < 12; ++e) T[e] = 0.f;
     float wd0 = 0.f, wd1 = 0.f;   // dense skinning weights W[v][li], W[v][16+li] (MFMA B operands)
     for (int k = 0; k < p.nw; ++k) {       // (kept as a loop: unrolling it costs more in spills than it saves)
-      const int j = k < 4 ? sj4[k] : p.skidx[(size_t)v * p.nw + k];
-      const float w = k < 4 ? sw4[k] : p.skw[(size_t)v * p.nw + k];
+      // selects instead of sj4[k]: a dynamically indexed register array would live in scratch memory
+      int j = k == 0 ? sj4[0] : k == 1 ? sj4[1] : k == 2 ? sj4[2] : sj4[3];
+      float w = k == 0 ? sw4[0] : k == 1 ? sw4[1] : k == 2 ? sw4[2] : sw4[3];
+      if (k >= 4) { j = p.skidx[(size_t)v * p.nw + k]; w = p.skw[(size_t)v * p.nw + k]; }
       const f32x4* Aj = (const f32x4*)(sAb + j * 12);
       const f32x4 a0 = Aj[0], a1 = Aj[1], a2 = Aj[2];
 #pragma unroll
@@ -528,20 +533,20 @@ __global__ __launch_bounds__(256, 2) void k_skin_bwd(SkinBwdP p) {
     // d/d v_posed = T.R^T gx  -> rows of the [shape | pose] basis
     const float gv[3] = {fmaf(T[8], gx2, fmaf(T[4], gx1, T[0] * gx0)), fmaf(T[9], gx2, fmaf(T[5], gx1, T[1] * gx0)),
                          fmaf(T[10], gx2, fmaf(T[6], gx1, T[2] * gx0))};
-    // each component's basis registers are refilled for the next quad as soon as its 14 MFMAs have issued
+    // six half-components per quad; the buffer a half has just used is refilled with the half three steps ahead
+    // (same quad, or the next quad's first halves)
+    const f32x4* dc = dtb + (size_t)(4 * qd) * 64;
     const f32x4* dn = dtb + (size_t)(4 * qn) * 64;
 #pragma unroll
-    for (int t = 0; t < 14; ++t) accF[t] = MFMA16(gv[0], d0[t >> 2][t & 3], accF[t]);
+    for (int st = 0; st < 6; ++st) {
+      const int c = st >> 1, h = st & 1, bi = st % 3;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) d0[k] = dn[k];
-#pragma unroll
-    for (int t = 0; t < 14; ++t) accF[t] = MFMA16(gv[1], d1[t >> 2][t & 3], accF[t]);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) d1[k] = dn[cplane + k];
-#pragma unroll
-    for (int t = 0; t < 14; ++t) accF[t] = MFMA16(gv[2], d2[t >> 2][t & 3], accF[t]);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) d2[k] = dn[2 * cplane + k];
+      for (int t = 8 * h; t < (h ? 14 : 8); ++t) accF[t] = MFMA16(gv[c], dbuf[bi][(t >> 2) & 1][t & 3], accF[t]);
+      const int s3 = st + 3;
+      const f32x4* src = (s3 < 6 ? dc : dn) + (size_t)((s3 % 6) >> 1) * cplane + 2 * (s3 & 1);
+      dbuf[bi][0] = src[0];
+      dbuf[bi][1] = src[1];
+    }
     // d/dA_j = sum_v w_vj gx (x) [v_posed;1]
     const float gxs[3] = {gx0, gx1, gx2};
     const float qh[4] = {q0, q1, q2, 1.f};
@@ -888,8 +893,10 @@ extern "C" int mh_lbs_backward(const mh_model* m, int B, int NB, const float* be
   sp.Dt = m->Dt; sp.skidx = m->skidx; sp.skw = m->skw;
   sp.kpv_ptr = m->kpv_ptr; sp.kpv_j = m->kpv_j; sp.kpv_w = m->kpv_w;
   sp.pF = bw.pF; sp.pA = bw.pA; sp.pS = bw.pS;
+  mh_prof_mark(MH_PROF_SKIN_BWD, 0, st);
   hipLaunchKernelGGL(k_skin_bwd, dim3(G16, CH), dim3(256), lds, st, sp);
   MH_LAUNCH_CHECK();
+  mh_prof_mark(MH_PROF_SKIN_BWD, 1, st);
   PoseBwdP pp;
   pp.B = B; pp.NB = NB; pp.G = G; pp.CH = CH;
   pp.betas = betas; pp.poses = poses; pp.gjoints = gjoints;

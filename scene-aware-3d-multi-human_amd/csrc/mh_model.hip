@@ -16,6 +16,37 @@ void mh_set_error(const char* fmt, ...) {
 
 extern "C" const char* mh_last_error(void) { return g_err; }
 extern "C" int mh_version(void) { return 1; }
+
+// ---- measurement aid --------------------------------------------------------------------------------------
+static bool g_prof_on = false;
+static hipEvent_t g_prof_ev[MH_PROF_COUNT][2];
+static bool g_prof_have[MH_PROF_COUNT];
+static bool g_prof_init = false;
+
+extern "C" int mh_profile_enable(int on) {
+  if (on && !g_prof_init) {
+    for (int i = 0; i < MH_PROF_COUNT; ++i)
+      for (int e = 0; e < 2; ++e) MH_HIP(hipEventCreate(&g_prof_ev[i][e]));
+    g_prof_init = true;
+  }
+  for (int i = 0; i < MH_PROF_COUNT; ++i) g_prof_have[i] = false;
+  g_prof_on = on != 0;
+  return MH_OK;
+}
+
+void mh_prof_mark(int which, int edge, hipStream_t st) {
+  if (!g_prof_on || which < 0 || which >= MH_PROF_COUNT) return;
+  (void)hipEventRecord(g_prof_ev[which][edge], st);
+  if (edge == 1) g_prof_have[which] = true;
+}
+
+extern "C" int mh_profile_read(int which, float* ms) {
+  MH_CHECK(ms && which >= 0 && which < MH_PROF_COUNT, "bad profile slot");
+  MH_CHECK(g_prof_init && g_prof_have[which], "no launch recorded for this slot");
+  MH_HIP(hipEventSynchronize(g_prof_ev[which][1]));
+  MH_HIP(hipEventElapsedTime(ms, g_prof_ev[which][0], g_prof_ev[which][1]));
+  return MH_OK;
+}
 extern "C" int mh_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) {

@@ -1096,10 +1096,14 @@ extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const f
   MH_LAUNCH_CHECK();
   // persistent grids over the device-side work list (the strip count is only known on the device)
   const int grid = 256 * 3 * 4;
+  mh_prof_mark(MH_PROF_RASTER_STRIP, 0, st);
   hipLaunchKernelGGL(k_raster_strip, dim3(grid), dim3(RB), 0, st, p);
   MH_LAUNCH_CHECK();
+  mh_prof_mark(MH_PROF_RASTER_STRIP, 1, st);
+  mh_prof_mark(MH_PROF_RASTER_SUMS, 0, st);
   hipLaunchKernelGGL(k_raster_sums, dim3(grid), dim3(RB), 0, st, p);
   MH_LAUNCH_CHECK();
+  mh_prof_mark(MH_PROF_RASTER_SUMS, 1, st);
   hipLaunchKernelGGL(k_raster_body_out, dim3((p.B + 255) / 256), dim3(256), 0, st, p);
   MH_LAUNCH_CHECK();
   if (gverts) {
@@ -1109,8 +1113,10 @@ extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const f
       MH_HIP(hipFuncSetAttribute((const void*)k_raster_grads, hipFuncAttributeMaxDynamicSharedMemorySize, RG_MAXV * 3 * 4));
       attr_set = true;
     }
+    mh_prof_mark(MH_PROF_RASTER_GRADS, 0, st);
     hipLaunchKernelGGL(k_raster_grads, dim3(p.B < 4096 ? p.B : 4096), dim3(RGB), tab, st, p);
     MH_LAUNCH_CHECK();
+    mh_prof_mark(MH_PROF_RASTER_GRADS, 1, st);
   }
   if (gzmin && gzmax) {
     hipLaunchKernelGGL(k_depth_range_grads, dim3((T + 127) / 128), dim3(128), 0, st, T, N, (const float*)p.dinv, zmin_lin,

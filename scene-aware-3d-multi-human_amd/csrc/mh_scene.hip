@@ -615,8 +615,10 @@ extern "C" int mh_contact_knn_grid(const void* grid_ws, int M, const float* low_
   MH_CHECK(M > 0 && B > 0, "empty input");
   MH_CHECK(k >= 1 && k <= 32, "k must be in 1..32");
   GridWs g = grid_carve((void*)grid_ws, M);
+  mh_prof_mark(MH_PROF_CONTACT_KNN, 0, (hipStream_t)stream);
   hipLaunchKernelGGL(k_contact_knn_grid, dim3(B), dim3(64), 0, (hipStream_t)stream, (const GridHdr*)g.hdr, (const int*)g.start,
                      (const float*)g.sorted, M, low_xyz, k, dy);
   MH_LAUNCH_CHECK();
+  mh_prof_mark(MH_PROF_CONTACT_KNN, 1, (hipStream_t)stream);
   return MH_OK;
 }

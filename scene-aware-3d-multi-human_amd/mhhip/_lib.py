@@ -79,6 +79,8 @@ def lib():
         L.mh_reduce_sum.argtypes = [vp, ctypes.c_size_t, ctypes.c_float, vp, vp]
         L.mh_lowest_vertex.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp]
         L.mh_contact_knn.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp]
+        L.mh_profile_enable.argtypes = [ctypes.c_int]
+        L.mh_profile_read.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
         L.mh_scene_grid_bytes.restype = ctypes.c_size_t
         L.mh_scene_grid_bytes.argtypes = [ctypes.c_int]
         L.mh_scene_grid_build.argtypes = [vp, ctypes.c_int, vp, vp]

@@ -77,6 +77,10 @@ struct RasterP {
   unsigned* fsort;           // [B][F] faces ordered by their first row: hi << 20 | face
   int* row_start;            // [B][H+1] first entry of fsort with lo >= row; [H] = number of visible faces
   int* maxh;                 // [B] tallest face (rows) of the body
+  int* gunit_body;           // [max_units] gradient work units: RG_UNIT window pixels of one body, full units first
+  int* gunit_p0;             // [max_units] first window pixel of the unit
+  int* gunit_total;          // [1]
+  int* strip_order;          // [max_strips] tiles by decreasing candidate-face count (longest first)
 };
 
 __device__ __forceinline__ float r_pix_to_ndc(int i, int S1, int S2) {
@@ -149,23 +153,33 @@ __device__ __forceinline__ void r_load_tri_ndc(const RasterP& p, const float* nb
 // summed into an LDS table indexed directly by the vertex (V x 3 floats = 82 KB for SMPL, LDS float
 // atomics), then added to dL/dverts with plain coalesced read-modify-writes -- no global atomics.
 // Bodies whose table does not fit in LDS (V > RG_MAXV) scatter with global atomics instead.
-#define RG_MAXV 13000
-struct GradAcc {
-  float* tab;     // LDS [V][3] or null
-  float* gvb;     // global dL/dverts of this body
-};
-__device__ __forceinline__ void r_acc_add(const GradAcc& a, int vid, float gx, float gy, float gz) {
-  float* o = (a.tab ? a.tab : a.gvb) + (size_t)vid * 3;
-  atomicAdd(o, gx);
-  atomicAdd(o + 1, gy);
-  atomicAdd(o + 2, gz);
+#define RG_MAXV 11500
+#define RG_UNIT 2048           // window pixels per work unit of the gradient kernel (one classification pass)
+#define RG_LIST RG_UNIT
+// dynamic LDS of the gradient kernel: [V][3] gradient table when it fits, then the live-pixel list.  The scatter
+// goes through this symbol (not through a pointer chosen at run time) so that the compiler emits ds_add_f32 rather
+// than flat atomics.
+extern __shared__ __attribute__((aligned(16))) float rg_tab[];
+template <bool TAB>
+__device__ __forceinline__ void r_acc_add(float* gvb, int vid, float gx, float gy, float gz) {
+  if (TAB) {
+    atomicAdd(&rg_tab[vid * 3], gx);
+    atomicAdd(&rg_tab[vid * 3 + 1], gy);
+    atomicAdd(&rg_tab[vid * 3 + 2], gz);
+  } else {
+    float* o = gvb + (size_t)vid * 3;
+    atomicAdd(o, gx);
+    atomicAdd(o + 1, gy);
+    atomicAdd(o + 2, gz);
+  }
 }
 // scatter d/d(ndc x, ndc y, z) of one vertex to camera space
-__device__ __forceinline__ void r_scatter(const RasterP& p, const GradAcc& a, const Tri& t, int k, float gxn, float gyn, float gz) {
+template <bool TAB>
+__device__ __forceinline__ void r_scatter(const RasterP& p, float* gvb, const Tri& t, int k, float gxn, float gyn, float gz) {
   const float Z = t.z[k];
   const float gx = -p.s / Z * gxn, gy = -p.s / Z * gyn;
   const float gzz = gz + p.s * (t.cx[k] * gxn + t.cy[k] * gyn) / (Z * Z);
-  r_acc_add(a, t.idx[k], gx, gy, gzz);
+  r_acc_add<TAB>(gvb, t.idx[k], gx, gy, gzz);
 }
 
 __device__ __forceinline__ float r_block_sum(float v, float* sh) {
@@ -338,6 +352,34 @@ __global__ __launch_bounds__(1024) void k_raster_strip_table(RasterP p) {
     __syncthreads();
   }
   if (threadIdx.x == 0) p.total[0] = carry_ns;
+  // work units of the gradient kernel: a body's window in pieces of RG_UNIT pixels, the full pieces first so that
+  // the long units start early and the partial ones fill the tail (the per-body version finished 2x later than
+  // its work divided by the CU count: the largest bodies happened to start last)
+  __shared__ int c_full, c_part;
+  if (threadIdx.x == 0) c_full = c_part = 0;
+  __syncthreads();
+  for (int b = threadIdx.x; b < p.B; b += 1024) {
+    const int ww = p.win[b * 4 + 2], wh = p.win[b * 4 + 3];
+    const int npx = (ww > 0 && wh > 0) ? ww * wh : 0;
+    const int nfull = npx / RG_UNIT;
+    if (nfull) {
+      const int pos = atomicAdd(&c_full, nfull);
+      for (int k = 0; k < nfull; ++k) { p.gunit_body[pos + k] = b; p.gunit_p0[pos + k] = k * RG_UNIT; }
+    }
+  }
+  __syncthreads();
+  const int nf = c_full;
+  for (int b = threadIdx.x; b < p.B; b += 1024) {
+    const int ww = p.win[b * 4 + 2], wh = p.win[b * 4 + 3];
+    const int npx = (ww > 0 && wh > 0) ? ww * wh : 0;
+    if (npx % RG_UNIT) {
+      const int pos = nf + atomicAdd(&c_part, 1);
+      p.gunit_body[pos] = b;
+      p.gunit_p0[pos] = (npx / RG_UNIT) * RG_UNIT;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) p.gunit_total[0] = c_full + c_part;
 }
 
 // =============================================================================================
@@ -469,10 +511,48 @@ __global__ __launch_bounds__(RFS) void k_raster_face_sort(RasterP p) {
   }
 }
 
+#ifdef ABL_TIME
+__device__ unsigned long long g_ts[16];
+__device__ unsigned long long g_tb[8192];
+extern "C" int mh_debug_ts(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ts), sizeof(g_ts)); }
+extern "C" int mh_debug_tb(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tb), sizeof(g_tb)); }
+#define TB(i) do { if (threadIdx.x == 0 && u < 4096) g_tb[2 * u + (i)] = wall_clock64(); } while (0)
+#define TBS(i) do { if (threadIdx.x == 0 && s < 4096) g_tb[2 * s + (i)] = wall_clock64(); } while (0)
+#define TS(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_ts[i] = wall_clock64(); } while (0)
+#else
+#define TS(i)
+#define TB(i)
+#define TBS(i)
+#endif
 #ifdef ABL_COUNT
 __device__ unsigned long long g_cnt[8];
 extern "C" int mh_debug_counters(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cnt), sizeof(g_cnt)); }
 #endif
+// Longest-processing-time-first order of the tiles: a tile's cost is its candidate-face count (known once the faces
+// are sorted by row).  Counting sort into 64 cost classes, most expensive first; without it the last tiles to start
+// were often among the most expensive and the kernel ended ~40 % later than its work divided by the CU count.
+__global__ __launch_bounds__(1024) void k_raster_strip_order(RasterP p) {
+  __shared__ int hist[64], cursor[64];
+  const int tid = threadIdx.x, total = p.total[0], H = p.H;
+  if (tid < 64) hist[tid] = 0;
+  __syncthreads();
+  auto cost_class = [&](int s) {
+    const int b = p.strip_body[s];
+    const int sy0 = p.strip_row0[s], sy1 = sy0 + p.strip_rows[s] - 1;
+    const int* rs = p.row_start + (size_t)b * (H + 1);
+    const int n = rs[min(sy1 + 1, H)] - rs[max(0, sy0 - p.maxh[b])];
+    return 63 - min(63, (int)((long long)n * 64 / (p.F + 1)));       // class 0 = most faces
+  };
+  for (int s = tid; s < total; s += 1024) atomicAdd(&hist[cost_class(s)], 1);
+  __syncthreads();
+  if (tid == 0) {
+    int a = 0;
+    for (int k = 0; k < 64; ++k) { cursor[k] = a; a += hist[k]; }
+  }
+  __syncthreads();
+  for (int s = tid; s < total; s += 1024) p.strip_order[atomicAdd(&cursor[cost_class(s)], 1)] = s;
+}
+
 #define RW (RB / 64)         // waves per tile workgroup
 #define RPL 512              // pair descriptors per wave and round (sub-pixel face path)
 
@@ -509,7 +589,11 @@ __global__ __launch_bounds__(RB) void k_raster_strip(RasterP p) {
   int* mark = wMark[wave];
   unsigned* zbs = wZb[wave];
   unsigned short* pl = wPl[wave];
-  for (int s = blockIdx.x; s < total; s += gridDim.x) {
+  for (int si = blockIdx.x; si < total; si += gridDim.x) {
+    const int s = p.strip_order[si];
+#ifdef ABL_TIMES
+    TBS(0);
+#endif
     const int b = p.strip_body[s];
     const int x0 = p.strip_col0[s], tw = p.strip_cols[s], x1 = x0 + tw - 1;
     const int sy0 = p.strip_row0[s], nrows = p.strip_rows[s], sy1 = sy0 + nrows - 1;
@@ -705,6 +789,9 @@ __global__ __launch_bounds__(RB) void k_raster_strip(RasterP p) {
       const int r = px / tw, cc = px - r * tw;
       gk[((size_t)(sy0 - wy0 + r) * ww + (x0 - wx0 + cc)) * 5 + c] = keys[i];
     }
+#ifdef ABL_TIMES
+    TBS(1);
+#endif
   }
 }
 
@@ -816,26 +903,32 @@ __global__ void k_raster_body_out(RasterP p) {
 // gradients per strip
 // =============================================================================================
 #define RGB 1024             // threads per body workgroup of the gradient kernel (one workgroup per CU: LDS table)
+template <bool TAB>
 __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
-  extern __shared__ __attribute__((aligned(16))) float gtab[];     // [V][3] when it fits
+  float* gtab = rg_tab;
   const int tid = threadIdx.x;
   const int H = p.H, W = p.W, P = H * W;
-  const bool use_tab = p.V <= RG_MAXV;
-  for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
-    const int ns = p.body_ns[b];
-    if (ns == 0) continue;
+  const bool use_tab = TAB;
+  int* plist = (int*)(gtab + (use_tab ? p.V * 3 : 0));
+  int* s_n = plist + RG_LIST;
+  const int nunits = p.gunit_total[0];
+  for (int u = blockIdx.x; u < nunits; u += gridDim.x) {
+    const int b = p.gunit_body[u], up0 = p.gunit_p0[u];
     const int t = b / p.N, n = b % p.N;
     const int x0 = p.win[b * 4], ww = p.win[b * 4 + 2], y0 = p.win[b * 4 + 1], wh = p.win[b * 4 + 3];
-    const int npx = ww * wh;
+    const int npx = min(ww * wh, up0 + RG_UNIT);
     const int sy0 = y0;
     const float* vb = p.ndc + (size_t)b * p.V * 3;
     float* gvb = p.gverts + (size_t)b * p.V * 3;
+    TS(0);
+#ifndef ABL_TIMES
+    TB(0);
+#endif
     __syncthreads();
     if (use_tab)
       for (int i = tid; i < p.V * 3; i += RGB) gtab[i] = 0.f;
     __syncthreads();
-    GradAcc acc;
-    acc.tab = use_tab ? gtab : nullptr; acc.gvb = gvb;
+    TS(1);
     // the strips of a body are consecutive in the work list, so its window is one contiguous key range
     const unsigned long long* gk = p.gkeys + (size_t)p.body_koff[b] * 5;
     float S[6];
@@ -846,13 +939,43 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
     const float gAlphaScale = p.coef_sil * p.sil_apply[b] * 2.f / (p.sil_D[b] + 1.f);
     const float pvalid = p.p2d_valid[b];
     const uint32_t fr = p.front[b];
-    for (int i = tid; i < npx; i += RGB) {
+    TS(2);
+    // most window pixels carry no gradient (outside the blur band, masked out, occluded by a nearer person's mask):
+    // classify RG_LIST pixels at a time, compact the live ones into an LDS list and evaluate those with full waves
+    for (int cbase = up0; cbase < npx; cbase += RG_LIST) {
+    if (tid == 0) *s_n = 0;
+    __syncthreads();
+    for (int i = cbase + tid; i < min(cbase + RG_LIST, npx); i += RGB) {
+      const int yi = sy0 + i / ww, xi = x0 + i % ww;
+      const size_t gp = (size_t)t * P + (size_t)yi * W + xi;
+      const unsigned long long* q = gk + (size_t)i * 5;
+      const bool dep = gA != 0.f && pvalid != 0.f && q[0] != RS_EMPTY && ((p.ebits[gp] >> n) & 1u);
+      const bool sil = gAlphaScale != 0.f && q[1] != RS_EMPTY && (p.bits[gp] & fr) == 0u;
+      const bool live = dep || sil;
+      const unsigned long long m = __ballot(live);
+      if (m) {
+        int base = 0;
+        const int lane = tid & 63;
+        if (lane == 0) base = atomicAdd(s_n, __popcll(m));
+        base = __shfl(base, 0, 64);
+        if (live) plist[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+      }
+    }
+    __syncthreads();
+    TS(3);
+    const int nlive = *s_n;
+    for (int li_ = tid; li_ < nlive; li_ += RGB) {
+      const int i = plist[li_];
       const int yi = sy0 + i / ww, xi = x0 + i % ww;
       const size_t gp = (size_t)t * P + (size_t)yi * W + xi;
       const float yf = r_pix_to_ndc(H - 1 - yi, H, W), xf = r_pix_to_ndc(W - 1 - xi, W, H);
       const unsigned long long* q = gk + (size_t)i * 5;
       const unsigned long long k0 = q[0];
+#ifdef ABL_NODEP
+      if (false) {
+#else
       if (k0 != RS_EMPTY && gA != 0.f) {
+#endif
         const float z = __uint_as_float((unsigned)(k0 >> 32));
         const float m = (z > 0.f ? 1.f : 0.f) * (float)((p.ebits[gp] >> n) & 1u) * pvalid;
         const float zc = z + 0.2f;
@@ -899,13 +1022,17 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
           gx[0] += garea * (tr.y[2] - tr.y[1]);  gy[0] += garea * (tr.x[1] - tr.x[2]);
           gx[1] += garea * (-(tr.y[2] - tr.y[0])); gy[1] += garea * (tr.x[2] - tr.x[0]);
 #pragma unroll
-          for (int k = 0; k < 3; ++k) r_scatter(p, acc, tr, k, gx[k], gy[k], gz[k]);
+          for (int k = 0; k < 3; ++k) r_scatter<TAB>(p, gvb, tr, k, gx[k], gy[k], gz[k]);
         }
       }
       // silhouette: the (up to) four selected faces are fetched together (independent gathers in
       // flight), evaluated, and scattered from registers
       const uint32_t wb = p.bits[gp];
+#ifdef ABL_NOSIL
+      if (false) {
+#else
       if (gAlphaScale != 0.f && (wb & fr) == 0u && q[1] != RS_EMPTY) {
+#endif
         Tri trs[4];
         bool have[4];
 #pragma unroll
@@ -966,18 +1093,24 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
 #pragma unroll
             for (int v = 0; v < 3; ++v) {
               const float w = (v == ea[k] ? wa[k] : 0.f) + (v == eb[k] ? wb_[k] : 0.f);
-              if (w != 0.f) r_scatter(p, acc, tr, v, gd * w * 2.f * gqx[k], gd * w * 2.f * gqy[k], 0.f);
+              if (w != 0.f) r_scatter<TAB>(p, gvb, tr, v, gd * w * 2.f * gqx[k], gd * w * 2.f * gqy[k], 0.f);
             }
           }
         }
       }
     }
     __syncthreads();
+    TS(4);
+    }   // classification pass
     if (use_tab)
       for (int i = tid; i < p.V * 3; i += RGB) {
         const float g = gtab[i];
-        if (g != 0.f) gvb[i] += g;
+        if (g != 0.f) atomicAdd(&gvb[i], g);      // several units of one body may flush concurrently
       }
+    TS(5);
+#ifndef ABL_TIMES
+    TB(1);
+#endif
   }
 }
 
@@ -1004,6 +1137,7 @@ __global__ void k_fill(float* x, size_t n, float v) {
 }
 
 static size_t r_align(size_t x) { return (x + 255) & ~(size_t)255; }
+static size_t r_max_units(size_t B, int H, int W) { return B + B * (size_t)H * W / RG_UNIT + 1; }
 static size_t r_ws_extra(size_t B, int V, int F, int H) {
   return r_align(B * V * 3 * 4) + 2 * r_align(B * F * 4) + r_align(B * (size_t)(H + 1) * 4) + r_align(B * 4) + r_align(B * 8);
 }
@@ -1017,7 +1151,7 @@ static int r_max_strips(int B, int H, int W) {
 
 extern "C" size_t mh_raster_workspace_bytes(int T, int N, int V, int F, int H, int W) {
   const size_t B = (size_t)T * N, ms = (size_t)r_max_strips((int)B, H, W);
-  return r_ws_extra(B, V, F, H) + r_align(B * 4 * 4) + 2 * r_align(B * 4) + r_align(4) + 5 * r_align(ms * 4) + r_align(ms * 6 * 4) +
+  return r_ws_extra(B, V, F, H) + 2 * r_align(r_max_units(B, H, W) * 4) + r_align(4) + r_align(B * 4 * 4) + 2 * r_align(B * 4) + r_align(4) + 6 * r_align(ms * 4) + r_align(ms * 6 * 4) +
          r_align(B * 2 * 4) + r_align(B * (size_t)H * W * 5 * 8);
 }
 
@@ -1073,6 +1207,7 @@ extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const f
   p.strip_rows = (int*)c; c += r_align(ms * 4);
   p.strip_col0 = (int*)c; c += r_align(ms * 4);
   p.strip_cols = (int*)c; c += r_align(ms * 4);
+  p.strip_order = (int*)c; c += r_align(ms * 4);
   p.partial = (float*)c; c += r_align(ms * 6 * 4);
   p.dinv = (float*)c; c += r_align(B * 2 * 4);
   p.ndc = (float*)c; c += r_align(B * V * 3 * 4);
@@ -1081,6 +1216,9 @@ extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const f
   p.row_start = (int*)c; c += r_align(B * (size_t)(H + 1) * 4);
   p.maxh = (int*)c; c += r_align(B * 4);
   p.body_koff = (long long*)c; c += r_align(B * 8);
+  p.gunit_body = (int*)c; c += r_align(r_max_units(B, H, W) * 4);
+  p.gunit_p0 = (int*)c; c += r_align(r_max_units(B, H, W) * 4);
+  p.gunit_total = (int*)c; c += r_align(4);
   p.gkeys = (unsigned long long*)c;
   hipStream_t st = (hipStream_t)stream;
   if (zbuf_out) {   // -1 = empty, like fragments.zbuf
@@ -1093,6 +1231,8 @@ extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const f
   hipLaunchKernelGGL(k_raster_strip_table, dim3(1), dim3(1024), 0, st, p);
   MH_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_raster_face_sort, dim3(p.B), dim3(RFS), (size_t)(H + 1) * sizeof(int), st, p);
+  MH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_raster_strip_order, dim3(1), dim3(1024), 0, st, p);
   MH_LAUNCH_CHECK();
   // persistent grids over the device-side work list (the strip count is only known on the device)
   const int grid = 256 * 3 * 4;
@@ -1107,14 +1247,18 @@ extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const f
   hipLaunchKernelGGL(k_raster_body_out, dim3((p.B + 255) / 256), dim3(256), 0, st, p);
   MH_LAUNCH_CHECK();
   if (gverts) {
-    const size_t tab = V <= RG_MAXV ? (size_t)V * 3 * sizeof(float) : 0;
+    const bool use_tab = V <= RG_MAXV;
+    const size_t tab = (use_tab ? (size_t)V * 3 * sizeof(float) : 0) + (RG_LIST + 1) * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
-      MH_HIP(hipFuncSetAttribute((const void*)k_raster_grads, hipFuncAttributeMaxDynamicSharedMemorySize, RG_MAXV * 3 * 4));
+      MH_HIP(hipFuncSetAttribute((const void*)k_raster_grads<true>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_MAXV * 3 * 4 + (RG_LIST + 1) * 4));
       attr_set = true;
     }
     mh_prof_mark(MH_PROF_RASTER_GRADS, 0, st);
-    hipLaunchKernelGGL(k_raster_grads, dim3(p.B < 4096 ? p.B : 4096), dim3(RGB), tab, st, p);
+    // one workgroup per CU is resident (LDS table); the work-unit count is only known on the device
+    const int ggrid = 256 * 6;
+    if (use_tab) hipLaunchKernelGGL(k_raster_grads<true>, dim3(ggrid), dim3(RGB), tab, st, p);
+    else hipLaunchKernelGGL(k_raster_grads<false>, dim3(ggrid), dim3(RGB), tab, st, p);
     MH_LAUNCH_CHECK();
     mh_prof_mark(MH_PROF_RASTER_GRADS, 1, st);
   }

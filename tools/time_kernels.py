@@ -42,6 +42,16 @@ def main():
     print('seg coverage px/body', seq['seg_mask'].sum() / (T * 4))
     print('raster fwd+bwd  ms', timeit(lambda: r(e, gv, log)))
     print('raster fwd only ms', timeit(lambda: r(e, gv, log, with_grads=False)))
+    import ctypes as _ct
+    from mhhip import _lib as _l3
+    if hasattr(_l3.lib(), 'mh_debug_ts'):
+        r(e, gv, log); torch.cuda.synchronize()
+        buf = (_ct.c_ulonglong * 16)(); _l3.lib().mh_debug_ts(buf); ts = list(buf)
+        print('grads block 0 phases (100 MHz ticks -> us):', [round((ts[i + 1] - ts[i]) / 100.0, 2) for i in range(5)])
+        buf2 = (_ct.c_ulonglong * 8192)(); _l3.lib().mh_debug_tb(buf2); tb = np.array(list(buf2), dtype=np.float64).reshape(4096, 2); tb = tb[tb[:, 1] > 0]
+        t0 = tb[:, 0].min(); dur = (tb[:, 1] - tb[:, 0]) / 100.0; st = (tb[:, 0] - t0) / 100.0
+        print('blocks %d: dur us mean %.1f p50 %.1f p90 %.1f max %.1f; sum/256 = %.1f us; last end %.1f us' % (len(dur), dur.mean(), np.median(dur), np.percentile(dur, 90), dur.max(), dur.sum() / 256, ((tb[:, 1] - t0) / 100.0).max()))
+        print('start times us (every 64th block):', [round(x, 1) for x in st[::64]])
     import ctypes
     from mhhip import _lib as _ll
     if hasattr(_ll.lib(), 'mh_debug_counters'):

@@ -3,25 +3,24 @@
 // itself is PyTorch3D's MeshRasterizer / SoftSilhouetteShader, restated from its published
 // semantics -- see oracle/raster_select.c for the provenance note).
 //
-// MI355X design.  SMPL triangles are sub-pixel at MuPoTs resolution (13776 faces on a few hundred
-// pixels), so rasterisation is FACE-parallel with the per-pixel K-nearest lists kept in LDS:
-//   k_raster_windows     one wave per body: screen window of the body (bbox of projected vertices)
-//   k_raster_strip_table one block: cuts every window into row strips of <= R_CAP pixels and
-//                        prefix-sums them into a work list (device-side: no host sync); a close-up
-//                        body becomes many strips, so the work per workgroup is bounded and the
-//                        launch load-balances (the first version, one body per workgroup, was
-//                        tail-bound by the nearest body)
-//   k_raster_strip       one workgroup per strip: faces are staged in chunks (projection + bbox
-//                        rejection per face), the (face, pixel-centre) pairs inside the blurred bbox
-//                        are compacted into an LDS queue (wave-aggregated append) and evaluated with
-//                        full lanes; 64-bit (z, face) keys go into the strip's LDS window with
-//                        ds_min_rtn_u64: slot 0 = nearest face of the blur 1e-4 pass (all the
-//                        reference reads of its K=8 rasterisation, optimizer.py:430), slots 1..4 =
-//                        the K=4 nearest of the blur 2e-5 silhouette pass (atomic-min cascade: the
-//                        displaced key moves on to the next slot).  The finished window is written
-//                        to HBM once (40 B per window pixel).
-//   k_raster_sums        per strip: residual sums of the depth and silhouette terms
-//   k_raster_grads       per strip: per-pixel gradients scattered to the vertices (float atomics)
+// MI355X design.  SMPL triangles are sub-pixel at MuPoTs resolution (13776 faces on a few
+// hundred pixels, blur radius larger than a face), so rasterisation is FACE-parallel with the per-pixel K-nearest
+// lists kept in LDS:
+//   k_raster_windows      one workgroup per body: NDC projection of the vertices + screen window
+//   k_raster_face_sort    one workgroup per body: pixel-row range of every face, counting sort by first row
+//                         (a tile's candidate faces become one contiguous range)
+//   k_raster_strip_table  one workgroup: windows cut into tiles of <= R_CAP pixels, prefix-summed into a device-side
+//                         work list (no host sync); also the work units of the gradient kernel
+//   k_raster_strip_order  one workgroup: tiles by decreasing candidate-face count (longest first)
+//   k_raster_strip        one workgroup per tile; every wave runs barrier-free rounds of 64 faces (3-deep gather
+//                         pipeline, bbox, pair list / even split, depth cull) and inserts 64-bit (z, face) keys into
+//                         the tile's LDS window with ds_min_u64: slot 0 = nearest face of the blur 1e-4 pass (all
+//                         the reference reads of its K=8 rasterisation, optimizer.py:430), slots 1..4 = the K=4
+//                         nearest of the blur 2e-5 silhouette pass (atomic-min cascade: the displaced key moves on).
+//                         The finished window is written to HBM once (40 B per window pixel).
+//   k_raster_sums         per tile: residual sums of the depth and silhouette terms
+//   k_raster_grads        per work unit (2048 window pixels of one body): live-pixel compaction, exact re-evaluation
+//                         of the selected faces, gradients scattered to an LDS vertex table, flushed with atomics
 // No (b,N,H,W,K) fragment tensor, z-buffer or alpha image is materialised (the reference builds
 // two of them per batch).
 #include "mh_common.h"
@@ -32,8 +31,7 @@
 #define BLUR_S 2e-5f         // optimizer.py:223
 #define SIGMA_S 1e-4f        // BlendParams.sigma default used by SoftSilhouetteShader
 #define RB 512               // threads per strip workgroup
-#define RB_LOG2 9
-#define R_CAP 640            // window pixels per strip (5 x u64 each = 25.6 KB of LDS; 3 workgroups per CU)
+#define R_CAP 640            // window pixels per tile (5 x u64 each = 25.6 KB of LDS; 2 workgroups per CU)
 #define RT 13                // floats staged per face: 9 NDC coordinates, 1/area, 1/|edge|^2 x 3
 
 struct RasterP {

@@ -79,7 +79,8 @@ class ShardedSequence(object):
             if graphs:
                 e.cycle_graphed(row, raster=raster)
             else:
-                e.cycle(row, raster=raster)
+                e.cycle_begin()
+                e.cycle_finish(row, raster=raster)
             return
         halo = {}
         pp, pn = self._gather_boundaries(e.leaf('poses_T'))

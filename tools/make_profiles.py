@@ -16,7 +16,7 @@ def per_kernel(d, counter):
     for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
         for r in csv.DictReader(open(f)):
             if r['Counter_Name'] == counter:
-                k = r['Kernel_Name'].split('(')[0]
+                k = r['Kernel_Name'].split('(')[0].replace('void ', '').split('<')[0]
                 acc[k] += float(r['Counter_Value']); n[k].add(r['Dispatch_Id'])
     return {k: acc[k] / len(n[k]) for k in acc}
 

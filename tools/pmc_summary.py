@@ -4,7 +4,7 @@ d = sys.argv[1]; pat = sys.argv[2] if len(sys.argv) > 2 else ''
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(set)
 for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name'].split('(')[0]
+        k = r['Kernel_Name'].split('(')[0].replace('void ', '').split('<')[0]
         if pat in k:
             acc[k][r['Counter_Name']] += float(r['Counter_Value']); n[k].add(r['Dispatch_Id'])
 for k in acc:

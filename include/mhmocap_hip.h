@@ -229,6 +229,9 @@ int mh_contact_knn(const float* points /*(M,3)*/, int M, const float* low_xyz, i
  * shells until its k-th distance is final.  grid_ws: mh_scene_grid_bytes(M) bytes owned by the caller. */
 size_t mh_scene_grid_bytes(int M);
 int mh_scene_grid_build(const float* points /*(M,3)*/, int M, void* grid_ws, void* stream);
+/* the same with the point count in device memory (written by mh_scene_points): grid_ws sized for M_cap, which is also
+ * the M to pass to mh_contact_knn_grid */
+int mh_scene_grid_build_dev(const float* points, const int* M_dev, int M_cap, void* grid_ws, void* stream);
 int mh_contact_knn_grid(const void* grid_ws, int M, const float* low_xyz, int B, int k,
                         float* dy /*(B)*/, void* stream);
 /* contact: sum |dy+0.02| per batch, gpT.y += coef * (-sign(dy+0.02)); foot sliding between
@@ -242,6 +245,25 @@ int mh_contact_foot_terms(int T, int N, int V, int batch, const float* verts, co
  * transforms.py:114-130).  K_host: HOST 3x3 intrinsics.                                       */
 int mh_scene_unproject(const float* depth /*(H,W)*/, int H, int W, const float* K_host,
                        float* points /*(H*W,3)*/, void* stream);
+
+/* ---- a24: scene aggregation on the device (optimizer.py:578-584; fhsog.py:180-202 aggegrate_scene_geometry_median;
+ * utils.py:174-209 postprocess_depthmap, :91-135 fillin_values).  ws: mh_scene_workspace_bytes(T,H,W) bytes.
+ * mh_scene_median: per-pixel masked median over the T frames of 1/target_disp (target_disp from the normalised
+ *   disparity `depths` and the depth-range leaves, optimizer.py:425-426), backmask (T,H,W) bytes, non-zero = background;
+ *   np.ma.median semantics (mean of the two middle values; 0 and mask 0 where no frame is valid).
+ * mh_scene_postprocess: bilateral(1/clip(depth)) d=9 sigmaColor .05 sigmaSpace 25 (optional), Sobel edge mask of
+ *   disparity and depth (> 3 x mean of the std-normalised sum), eroded twice, times ma_mask (may be NULL), then the
+ *   fillin_ksize x fillin_ksize median fill looped until no masked pixel is left.
+ * mh_scene_points: un-projection of the pixels with mask > 0.5 (row-major order) into points (<= H*W rows); the number
+ *   of points is written to count_dev (device memory: no host synchronisation). */
+size_t mh_scene_workspace_bytes(int T, int H, int W);
+int mh_scene_median(int T, int H, int W, const float* depths /*(T,H,W)*/, const uint8_t* backmask /*(T,H,W)*/,
+                    const float* zmin_lin /*(T)*/, const float* zmax_lin /*(T)*/, float* ma_depth /*(H,W)*/,
+                    float* ma_mask /*(H,W) 0/1*/, void* ws, void* stream);
+int mh_scene_postprocess(int H, int W, const float* ma_depth, const float* ma_mask, int use_bilateral, int fillin_ksize,
+                         float* scene_depth /*(H,W)*/, void* ws, void* stream);
+int mh_scene_points(int H, int W, const float* K_host, const float* scene_depth, const float* mask, float* points,
+                    int* count_dev, void* stream);
 
 /* ---- a13/a14: differentiable z-buffer + soft silhouette fused with their residuals ------------
  * Replaces, per cycle, for all T*N bodies at once: Meshes -> MeshRasterizer(K=8, blur 1e-4) ->

@@ -313,10 +313,12 @@ struct GridHdr {        // device-resident header (written by k_grid_setup)
   float cell;
   int dim[3];
   int ncells;
+  int npts;          // points in the cloud (<= the capacity the workspace was sized for)
 };
 
-__global__ __launch_bounds__(1024) void k_grid_setup(const float* pts, int M, GridHdr* hdr, int* counts, int max_cells) {
+__global__ __launch_bounds__(1024) void k_grid_setup(const float* pts, int M_host, const int* M_dev, GridHdr* hdr, int* counts, int max_cells) {
   __shared__ float smn[3][16], smx[3][16];
+  const int M = M_dev ? *M_dev : M_host;
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (int i = threadIdx.x; i < M; i += 1024)
 #pragma unroll
@@ -343,7 +345,8 @@ __global__ __launch_bounds__(1024) void k_grid_setup(const float* pts, int M, Gr
     }
     // the clouds are surfaces: aim at ~16 points per occupied cell of the largest face of the bbox
     const float area = fmaxf(ext[0] * ext[1], fmaxf(ext[1] * ext[2], ext[0] * ext[2]));
-    float cell = fminf(fmaxf(sqrtf(area * 16.f / (float)M), 0.02f), 4.f);
+    float cell = fminf(fmaxf(sqrtf(area * 16.f / (float)max(M, 1)), 0.02f), 4.f);
+    if (M == 0) { for (int c = 0; c < 3; ++c) { mn[c] = 0.f; ext[c] = 1e-3f; } cell = 1.f; }
     int d[3];
     for (;;) {
       long long n = 1;
@@ -354,6 +357,7 @@ __global__ __launch_bounds__(1024) void k_grid_setup(const float* pts, int M, Gr
     hdr->cell = cell;
     for (int c = 0; c < 3; ++c) { hdr->mn[c] = mn[c]; hdr->dim[c] = d[c]; }
     hdr->ncells = d[0] * d[1] * d[2];
+    hdr->npts = M;
   }
   __syncthreads();
   const int nc = hdr->ncells;
@@ -367,9 +371,9 @@ __device__ __forceinline__ int grid_cell(const GridHdr* h, float x, float y, flo
   return (cz * h->dim[1] + cy) * h->dim[0] + cx;
 }
 
-__global__ void k_grid_count(const float* pts, int M, const GridHdr* hdr, int* counts, int* pcell) {
+__global__ void k_grid_count(const float* pts, const GridHdr* hdr, int* counts, int* pcell) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= M) return;
+  if (i >= hdr->npts) return;
   const int c = grid_cell(hdr, pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2]);
   pcell[i] = c;
   atomicAdd(&counts[c], 1);
@@ -406,9 +410,9 @@ __global__ __launch_bounds__(1024) void k_grid_scan(const GridHdr* hdr, int* cou
   if (threadIdx.x == 0) counts[nc] = carry;
 }
 
-__global__ void k_grid_scatter(const float* pts, int M, const int* pcell, int* cursor, float* sorted) {
+__global__ void k_grid_scatter(const float* pts, const GridHdr* hdr, const int* pcell, int* cursor, float* sorted) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= M) return;
+  if (i >= hdr->npts) return;
   const int pos = atomicAdd(&cursor[pcell[i]], 1);
   sorted[(size_t)pos * 3] = pts[(size_t)i * 3];
   sorted[(size_t)pos * 3 + 1] = pts[(size_t)i * 3 + 1];
@@ -439,20 +443,30 @@ extern "C" size_t mh_scene_grid_bytes(int M) {
          g_align((size_t)(M > 0 ? M : 1) * 4) + g_align((size_t)(M > 0 ? M : 1) * 12);
 }
 
-extern "C" int mh_scene_grid_build(const float* points, int M, void* grid_ws, void* stream) {
-  MH_CHECK(points && grid_ws, "null argument");
-  MH_CHECK(M > 0, "empty scene");
+static int grid_build(const float* points, int M, const int* M_dev, void* grid_ws, hipStream_t st) {
   GridWs g = grid_carve(grid_ws, M);
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(1024), 0, st, points, M, g.hdr, g.start, GRID_MAX_CELLS);
+  hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(1024), 0, st, points, M, M_dev, g.hdr, g.start, GRID_MAX_CELLS);
   MH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_grid_count, dim3((M + 255) / 256), dim3(256), 0, st, points, M, (const GridHdr*)g.hdr, g.start, g.pcell);
+  hipLaunchKernelGGL(k_grid_count, dim3((M + 255) / 256), dim3(256), 0, st, points, (const GridHdr*)g.hdr, g.start, g.pcell);
   MH_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_grid_scan, dim3(1), dim3(1024), 0, st, (const GridHdr*)g.hdr, g.start, g.cursor);
   MH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_grid_scatter, dim3((M + 255) / 256), dim3(256), 0, st, points, M, (const int*)g.pcell, g.cursor, g.sorted);
+  hipLaunchKernelGGL(k_grid_scatter, dim3((M + 255) / 256), dim3(256), 0, st, points, (const GridHdr*)g.hdr, (const int*)g.pcell, g.cursor,
+                     g.sorted);
   MH_LAUNCH_CHECK();
   return MH_OK;
+}
+
+extern "C" int mh_scene_grid_build(const float* points, int M, void* grid_ws, void* stream) {
+  MH_CHECK(points && grid_ws, "null argument");
+  MH_CHECK(M > 0, "empty scene");
+  return grid_build(points, M, nullptr, grid_ws, (hipStream_t)stream);
+}
+
+extern "C" int mh_scene_grid_build_dev(const float* points, const int* M_dev, int M_cap, void* grid_ws, void* stream) {
+  MH_CHECK(points && M_dev && grid_ws, "null argument");
+  MH_CHECK(M_cap > 0, "empty capacity");
+  return grid_build(points, M_cap, M_dev, grid_ws, (hipStream_t)stream);
 }
 
 // one wave per query
@@ -476,7 +490,9 @@ __global__ __launch_bounds__(64) void k_contact_knn_grid(const GridHdr* hdr, con
             cqz = min(max((int)floorf((qz - hdr->mn[2]) / cell), 0), dz - 1);
   float tau = INFINITY;
   int fill = K, found = 0;
-  const int kk = M < K ? M : K;
+  const int npts = hdr->npts;
+  if (npts == 0) { if (lane == 0) dy[b] = 0.f; return; }
+  const int kk = npts < K ? npts : K;
   // enough shells to cover the whole grid from wherever the query is
   const int rmax = max(max(max(cqx, dx - 1 - cqx), max(cqy, dyy - 1 - cqy)), max(cqz, dz - 1 - cqz));
   // the points of a run of x-adjacent cells are contiguous in the sorted cloud

@@ -1,0 +1,365 @@
+// Scene aggregation on the device: what the reference does on the host with numpy / OpenCV once
+// per cycle >= 30 (optimizer.py:578-584; fhsog.py:180-202; utils.py:91-135, 174-209):
+//   per-pixel masked median over time of the metric depth 1/target_disp  ->  bilateral filter of the disparity  ->
+//   Sobel edge mask of disparity and depth (global std / mean thresholds), eroded twice, times the median's validity
+//   ->  iterative 7x7 median fill of the masked pixels  ->  un-projection of the valid pixels (compacted on the device,
+//   the count stays in device memory so nothing synchronises with the host).
+// OpenCV is not available offline; bilateral / Sobel / erode follow its documented semantics (BORDER_REFLECT_101,
+// circular bilateral support, constant +inf border for erode) exactly as mhmocap/scene_host.py restates them.
+#include "mh_common.h"
+
+// ---- per-frame depth range (optimizer.py:683-688): inv_min = 1/min_z, inv_max = 1/max_z ------------------------------
+__global__ void k_scene_ranges(int T, const float* zmin_lin, const float* zmax_lin, float* invz) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const float min_z = logf(1.f + expf(zmin_lin[t]));
+  const float max_z = min_z + 1.f + logf(1.f + expf(zmax_lin[t]));
+  invz[2 * t] = 1.f / min_z;
+  invz[2 * t + 1] = 1.f / max_z;
+}
+
+// ---- masked median over time ---------------------------------------------------------------------------------------------
+// One wave per 64 consecutive pixels (coalesced frame reads); every lane keeps its pixel's T depth values as raw bits in
+// an LDS column [t][lane] (conflict-free) and radix-selects the upper median bit by bit (positive floats order like
+// unsigned integers), then one more pass finds the lower median for an even count.  np.ma.median semantics: mean of
+// the two middle values, 0 for an all-masked pixel.
+#define SM_INVALID 0xffffffffu
+template <bool IN_LDS>
+__global__ __launch_bounds__(64) void k_scene_median(int T, int P, const float* depths, const unsigned char* backmask,
+                                                     const float* invz, float* ma_depth, float* ma_mask) {
+  extern __shared__ unsigned col[];                       // [T][64] when IN_LDS
+  const int lane = threadIdx.x, p = blockIdx.x * 64 + lane;
+  const bool live = p < P;
+  auto value = [&](int t) -> unsigned {
+    if (!live || backmask[(size_t)t * P + p] == 0) return SM_INVALID;
+    const float inv_min = invz[2 * t], inv_max = invz[2 * t + 1];
+    const float disp = depths[(size_t)t * P + p] * (inv_min - inv_max) + inv_max;      // optimizer.py:425
+    return __float_as_uint(1.0f / disp);                                               // :426
+  };
+  int n = 0;
+  for (int t = 0; t < T; ++t) {
+    const unsigned v = value(t);
+    if (IN_LDS) col[t * 64 + lane] = v;
+    n += v != SM_INVALID;
+  }
+  if (!live) return;
+  if (n == 0) { ma_depth[p] = 0.f; ma_mask[p] = 0.f; return; }
+  auto get = [&](int t) -> unsigned { return IN_LDS ? col[t * 64 + lane] : value(t); };
+  // k-th smallest (0-based) by bitwise descent
+  int k = n >> 1;
+  unsigned prefix = 0u;
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned hi = bit == 31 ? 0u : (0xffffffffu << (bit + 1));
+    int c0 = 0;
+    for (int t = 0; t < T; ++t) {
+      const unsigned v = get(t);
+      c0 += ((v & (hi | (1u << bit))) == prefix) ? 1 : 0;
+    }
+    if (k >= c0) { k -= c0; prefix |= 1u << bit; }
+  }
+  float med = __uint_as_float(prefix);
+  if ((n & 1) == 0) {
+    // lower middle: equal to the upper one unless exactly n/2 values are strictly smaller
+    int less = 0;
+    unsigned best = 0u;
+    for (int t = 0; t < T; ++t) {
+      const unsigned v = get(t);
+      if (v < prefix) { ++less; best = v > best ? v : best; }
+    }
+    const float lo = (less == (n >> 1)) ? __uint_as_float(best) : med;
+    med = (lo + med) / 2.f;
+  }
+  ma_depth[p] = med;
+  ma_mask[p] = 1.f;
+}
+
+__device__ __forceinline__ int r101(int i, int n) {       // BORDER_REFLECT_101, |offset| < n
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * n - 2 - i;
+  return i;
+}
+
+// ---- bilateral filter of 1/clip(depth): d = 9 (radius 4, circular support), sigmaColor 0.05, sigmaSpace 25 -------------------
+__global__ void k_scene_bilateral(int H, int W, const float* depth, float* depth_out) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= H * W) return;
+  const int y = p / W, x = p - y * W;
+  auto src = [&](int yy, int xx) { return 1.0f / fminf(fmaxf(depth[r101(yy, H) * W + r101(xx, W)], 0.01f), 100.f); };
+  const float c = src(y, x);
+  double num = 0.0, den = 0.0;
+  for (int dy = -4; dy <= 4; ++dy)
+    for (int dx = -4; dx <= 4; ++dx) {
+      if (dy * dy + dx * dx > 16) continue;
+      const float q = src(y + dy, x + dx);
+      const float dq = q - c;
+      const float w = expf((float)(-(double)(dy * dy + dx * dx) / (2.0 * 25.0 * 25.0)) - (dq * dq) / (float)(2.0 * 0.05 * 0.05));
+      num += (double)(w * q);
+      den += (double)w;
+    }
+  const float disp = (float)(num / den);
+  depth_out[p] = 1.0f / fminf(fmaxf(disp, 0.01f), 100.f);
+}
+
+// ---- Sobel magnitudes of disparity and depth + their global sums --------------------------------------------------------------
+__device__ __forceinline__ double blk_sum(double v, double* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sh[w];
+  return s;
+}
+
+__global__ __launch_bounds__(256) void k_scene_sobel(int H, int W, const float* depth, float* g_disp, float* g_depth, double* stats) {
+  __shared__ double sh[4];
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  double a = 0.0, a2 = 0.0, b = 0.0, b2 = 0.0;
+  if (p < H * W) {
+    const int y = p / W, x = p - y * W;
+    const float ks[3] = {1.f, 2.f, 1.f}, kd[3] = {-1.f, 0.f, 1.f};
+    float gxd = 0.f, gyd = 0.f, gxz = 0.f, gyz = 0.f;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        const float z = depth[r101(y + i - 1, H) * W + r101(x + j - 1, W)];
+        const float d = 1.0f / fminf(fmaxf(z, 0.1f), 100.f);
+        gxd += ks[i] * kd[j] * d; gyd += kd[i] * ks[j] * d;
+        gxz += ks[i] * kd[j] * z; gyz += kd[i] * ks[j] * z;
+      }
+    const float gd = fabsf(gxd) + fabsf(gyd), gz = fabsf(gxz) + fabsf(gyz);
+    g_disp[p] = gd; g_depth[p] = gz;
+    a = gd; a2 = (double)gd * gd; b = gz; b2 = (double)gz * gz;
+  }
+  a = blk_sum(a, sh); a2 = blk_sum(a2, sh); b = blk_sum(b, sh); b2 = blk_sum(b2, sh);
+  if (threadIdx.x == 0) { atomicAdd(&stats[0], a); atomicAdd(&stats[1], a2); atomicAdd(&stats[2], b); atomicAdd(&stats[3], b2); }
+}
+
+// grad = g_disp / std(g_disp) + g_depth / std(g_depth), and its global sum
+__global__ __launch_bounds__(256) void k_scene_grad(int P, const float* g_disp, const float* g_depth, double* stats, float* grad) {
+  __shared__ double sh[4];
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const double n = (double)P;
+  const double ma = stats[0] / n, mb = stats[2] / n;
+  const float sa = (float)sqrt(fmax(stats[1] / n - ma * ma, 0.0)), sb = (float)sqrt(fmax(stats[3] / n - mb * mb, 0.0));
+  double g = 0.0;
+  if (p < P) {
+    const float v = g_disp[p] / sa + g_depth[p] / sb;
+    grad[p] = v;
+    g = v;
+  }
+  g = blk_sum(g, sh);
+  if (threadIdx.x == 0) atomicAdd(&stats[4], g);
+}
+
+// dmask = erode^2(1 - [grad > 3 mean]) * mask ; two 3x3 erosions with an ignoring border = one 5x5 erosion
+__global__ void k_scene_edges(int H, int W, const float* grad, const float* ma_mask, const double* stats, float* dmask) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= H * W) return;
+  const int y = p / W, x = p - y * W;
+  const float thr = 3.f * (float)(stats[4] / (double)(H * W));
+  float keep = 1.f;
+  for (int dy = -2; dy <= 2; ++dy)
+    for (int dx = -2; dx <= 2; ++dx) {
+      const int yy = y + dy, xx = x + dx;
+      if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+      if (grad[yy * W + xx] > thr) keep = 0.f;
+    }
+  dmask[p] = ma_mask ? keep * ma_mask[p] : keep;
+}
+
+// ---- iterative median fill (utils.py:91-135 looped by :206-207) ---------------------------------------------------------------
+// One workgroup: the masked pixels form a shrinking list; a sweep fills every listed pixel that sees a valid pixel in its
+// window from the values of the valid pixels only (so a sweep is a pure function of the previous state), then the
+// updates are applied together.  Ends when the list is empty (or nothing can be filled any more).
+#define FILL_TH 1024
+__global__ __launch_bounds__(FILL_TH) void k_scene_fill(int H, int W, int ksize, float* depth, float* mask, int* list_a, int* list_b,
+                                                        float* upd) {
+  __shared__ int s_cnt, s_next, s_filled;
+  const int tid = threadIdx.x, P = H * W, k = ksize / 2;
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  for (int p = tid; p < P; p += FILL_TH)
+    if (!(mask[p] > 0.f)) list_a[atomicAdd(&s_cnt, 1)] = p;
+  __syncthreads();
+  int* cur = list_a;
+  int* nxt = list_b;
+  for (;;) {
+    const int n = s_cnt;
+    if (n == 0) break;
+    __syncthreads();
+    if (tid == 0) { s_next = 0; s_filled = 0; }
+    __syncthreads();
+    for (int i = tid; i < n; i += FILL_TH) {
+      const int p = cur[i];
+      const int y = p / W, x = p - y * W;
+      float v[121];                                   // ksize <= 11
+      int c = 0;
+      for (int yy = max(0, y - k); yy < min(H, y + k + 1); ++yy)
+        for (int xx = max(0, x - k); xx < min(W, x + k + 1); ++xx)
+          if (mask[yy * W + xx] > 0.f) {
+            // insertion sort
+            const float val = depth[yy * W + xx];
+            int j = c++;
+            while (j > 0 && v[j - 1] > val) { v[j] = v[j - 1]; --j; }
+            v[j] = val;
+          }
+      if (c > 0) {
+        upd[i] = (c & 1) ? v[c >> 1] : (v[(c >> 1) - 1] + v[c >> 1]) / 2.f;
+        atomicAdd(&s_filled, 1);
+      } else {
+        upd[i] = -1.f;
+        nxt[atomicAdd(&s_next, 1)] = p;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += FILL_TH)
+      if (upd[i] >= 0.f) { depth[cur[i]] = upd[i]; mask[cur[i]] = 1.f; }
+    __threadfence_block();
+    __syncthreads();
+    const int filled = s_filled, rest = s_next;
+    __syncthreads();
+    if (tid == 0) s_cnt = filled > 0 ? rest : 0;       // nothing reachable: stop (the reference would loop forever)
+    __syncthreads();
+    int* t = cur; cur = nxt; nxt = t;
+  }
+}
+
+// ---- un-projection of the valid pixels, compacted in row-major order (optimizer.py:605-613) ------------------------------------
+__global__ __launch_bounds__(1024) void k_scene_points(int H, int W, const float* depth, const float* mask, float i00, float i01, float i10,
+                                                       float i11, float cx, float cy, float* pts, int* count) {
+  __shared__ int swave[16];
+  __shared__ int s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, P = H * W;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int base = 0; base < P; base += 1024) {
+    const int p = base + tid;
+    const bool keep = p < P && mask[p] > 0.5f;
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) swave[wave] = __popcll(m);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; ++w) off += swave[w];
+    if (keep) {
+      const int o = off + __popcll(m & ((1ull << lane) - 1ull));
+      const float u = (float)(p % W) + 0.5f - cx, v = (float)(p / W) + 0.5f - cy;
+      const float d = depth[p];
+      pts[(size_t)o * 3] = d * (u * i00 + v * i10);
+      pts[(size_t)o * 3 + 1] = d * (u * i01 + v * i11);
+      pts[(size_t)o * 3 + 2] = d;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int s = 0;
+      for (int w = 0; w < 16; ++w) s += swave[w];
+      s_base += s;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) *count = s_base;
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------------
+static size_t sa_align(size_t x) { return (x + 255) & ~(size_t)255; }
+struct SceneWs {
+  float* invz;      // [T][2]
+  float* depth1;    // [P] bilateral-filtered depth, then filled in place
+  float* g_disp;    // [P]
+  float* g_depth;   // [P]
+  float* grad;      // [P]
+  float* dmask;     // [P]
+  float* upd;       // [P]
+  int* list_a;      // [P]
+  int* list_b;      // [P]
+  double* stats;    // [8]
+};
+static SceneWs scene_carve(void* ws, int P) {
+  char* c = (char*)ws;
+  SceneWs s;
+  s.depth1 = (float*)c; c += sa_align((size_t)P * 4);
+  s.g_disp = (float*)c; c += sa_align((size_t)P * 4);
+  s.g_depth = (float*)c; c += sa_align((size_t)P * 4);
+  s.grad = (float*)c; c += sa_align((size_t)P * 4);
+  s.dmask = (float*)c; c += sa_align((size_t)P * 4);
+  s.upd = (float*)c; c += sa_align((size_t)P * 4);
+  s.list_a = (int*)c; c += sa_align((size_t)P * 4);
+  s.list_b = (int*)c; c += sa_align((size_t)P * 4);
+  s.stats = (double*)c; c += sa_align(64);
+  s.invz = (float*)c;                                   // [T][2], last: the only T-dependent part
+  return s;
+}
+
+extern "C" size_t mh_scene_workspace_bytes(int T, int H, int W) {
+  const size_t P = (size_t)H * W;
+  return 8 * sa_align(P * 4) + sa_align(64) + sa_align((size_t)(T > 0 ? T : 1) * 8);
+}
+
+extern "C" int mh_scene_median(int T, int H, int W, const float* depths, const uint8_t* backmask, const float* zmin_lin,
+                               const float* zmax_lin, float* ma_depth, float* ma_mask, void* ws, void* stream) {
+  MH_CHECK(depths && backmask && zmin_lin && zmax_lin && ma_depth && ma_mask && ws, "null argument");
+  MH_CHECK(T > 0 && H > 0 && W > 0, "empty input");
+  const int P = H * W;
+  SceneWs s = scene_carve(ws, P);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_scene_ranges, dim3((T + 127) / 128), dim3(128), 0, st, T, zmin_lin, zmax_lin, s.invz);
+  MH_LAUNCH_CHECK();
+  const size_t lds = (size_t)T * 64 * sizeof(unsigned);
+  if (lds <= 150 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      MH_HIP(hipFuncSetAttribute((const void*)k_scene_median<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(k_scene_median<true>, dim3((P + 63) / 64), dim3(64), lds, st, T, P, depths, backmask, (const float*)s.invz,
+                       ma_depth, ma_mask);
+  } else {     // very long sequences: the values are recomputed from HBM/L2 in every pass
+    hipLaunchKernelGGL(k_scene_median<false>, dim3((P + 63) / 64), dim3(64), 0, st, T, P, depths, backmask, (const float*)s.invz,
+                       ma_depth, ma_mask);
+  }
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+extern "C" int mh_scene_postprocess(int H, int W, const float* ma_depth, const float* ma_mask, int use_bilateral, int fillin_ksize,
+                                    float* scene_depth, void* ws, void* stream) {
+  MH_CHECK(ma_depth && scene_depth && ws, "null argument");
+  MH_CHECK(H > 0 && W > 0, "empty image");
+  MH_CHECK(H > 4 && W > 4, "image smaller than the bilateral support");
+  MH_CHECK(fillin_ksize > 1 && fillin_ksize <= 11, "fill-in window must be 2..11");
+  const int P = H * W;
+  SceneWs s = scene_carve(ws, P);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 g256((P + 255) / 256), b256(256);
+  if (use_bilateral) {
+    hipLaunchKernelGGL(k_scene_bilateral, g256, b256, 0, st, H, W, ma_depth, s.depth1);
+    MH_LAUNCH_CHECK();
+  } else {
+    MH_HIP(hipMemcpyAsync(s.depth1, ma_depth, (size_t)P * 4, hipMemcpyDeviceToDevice, st));
+  }
+  MH_HIP(hipMemsetAsync(s.stats, 0, 64, st));
+  hipLaunchKernelGGL(k_scene_sobel, g256, b256, 0, st, H, W, (const float*)s.depth1, s.g_disp, s.g_depth, s.stats);
+  MH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_scene_grad, g256, b256, 0, st, P, (const float*)s.g_disp, (const float*)s.g_depth, s.stats, s.grad);
+  MH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_scene_edges, g256, b256, 0, st, H, W, (const float*)s.grad, ma_mask, (const double*)s.stats, s.dmask);
+  MH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_scene_fill, dim3(1), dim3(FILL_TH), 0, st, H, W, fillin_ksize, s.depth1, s.dmask, s.list_a, s.list_b, s.upd);
+  MH_LAUNCH_CHECK();
+  MH_HIP(hipMemcpyAsync(scene_depth, s.depth1, (size_t)P * 4, hipMemcpyDeviceToDevice, st));
+  return MH_OK;
+}
+
+extern "C" int mh_scene_points(int H, int W, const float* K_host, const float* scene_depth, const float* mask, float* points,
+                               int* count_dev, void* stream) {
+  MH_CHECK(K_host && scene_depth && mask && points && count_dev, "null argument");
+  MH_CHECK(H > 0 && W > 0, "empty image");
+  const double a = K_host[0], b = K_host[3], c = K_host[1], d = K_host[4];   // M = K[:2,:2]^T = [[a,b],[c,d]]
+  const double det = a * d - b * c;
+  MH_CHECK(det != 0.0, "singular intrinsics");
+  const float i00 = (float)(d / det), i01 = (float)(-b / det), i10 = (float)(-c / det), i11 = (float)(a / det);
+  hipLaunchKernelGGL(k_scene_points, dim3(1), dim3(1024), 0, (hipStream_t)stream, H, W, scene_depth, mask, i00, i01, i10, i11,
+                     K_host[2], K_host[5], points, count_dev);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}

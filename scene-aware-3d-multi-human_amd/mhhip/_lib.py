@@ -79,11 +79,17 @@ def lib():
         L.mh_reduce_sum.argtypes = [vp, ctypes.c_size_t, ctypes.c_float, vp, vp]
         L.mh_lowest_vertex.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp]
         L.mh_contact_knn.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp]
+        L.mh_scene_workspace_bytes.restype = ctypes.c_size_t
+        L.mh_scene_workspace_bytes.argtypes = [ctypes.c_int] * 3
+        L.mh_scene_median.argtypes = [ctypes.c_int] * 3 + [vp] * 8
+        L.mh_scene_postprocess.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp]
+        L.mh_scene_points.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp]
         L.mh_profile_enable.argtypes = [ctypes.c_int]
         L.mh_profile_read.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
         L.mh_scene_grid_bytes.restype = ctypes.c_size_t
         L.mh_scene_grid_bytes.argtypes = [ctypes.c_int]
         L.mh_scene_grid_build.argtypes = [vp, ctypes.c_int, vp, vp]
+        L.mh_scene_grid_build_dev.argtypes = [vp, vp, ctypes.c_int, vp, vp]
         L.mh_contact_knn_grid.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp]
         L.mh_contact_foot_terms.argtypes = [ctypes.c_int] * 4 + [vp] * 4 + [ctypes.c_float] * 2 + [vp] * 5
         L.mh_scene_unproject.argtypes = [vp, ctypes.c_int, ctypes.c_int, c_float_p, vp, vp]

@@ -70,6 +70,10 @@ class SequenceEngine(object):
         self.log = z(max_cycles, 16)
         self.tmp_log = z(16)
         self.scene_pts = None
+        self.scene_grid = None
+        self.scene_M = 0                 # capacity the grid workspace was sized for
+        self._scene_dev = None           # device-side scene aggregation state (scene_device_setup)
+        self._scene_pending = False
         self.verts_filt = None
         self.pT_filt = None
         self.has_images = False
@@ -181,7 +185,61 @@ class SequenceEngine(object):
         L = _lib.lib()
         M = self.scene_pts.shape[0]
         self.scene_grid = torch.empty(L.mh_scene_grid_bytes(M), dtype=torch.uint8, device=self.dev)
+        self.scene_M = M
+        self._scene_pending = False
         check(L.mh_scene_grid_build(ptr(self.scene_pts), M, ptr(self.scene_grid), _lib.stream_ptr(self.dev)))
+
+    # -- scene aggregation on the device (optimizer.py:578-584 + fhsog.py:180-202 + utils.py:174-209) ---------
+    def scene_device_setup(self, backmasks):
+        """backmasks (T,H,W), non-zero = background.  Allocates the buffers of the per-cycle scene update, which runs
+        on its own stream: the contact term of the NEXT cycle waits for it with an event, nothing syncs the host."""
+        L = _lib.lib()
+        T, H, W = self.T, self.H, self.W
+        P = H * W
+        d = {}
+        d['back'] = torch.as_tensor(np.ascontiguousarray((np.asarray(backmasks) != 0).astype(np.uint8))).to(self.dev)
+        d['ws'] = torch.empty(L.mh_scene_workspace_bytes(T, H, W), dtype=torch.uint8, device=self.dev)
+        d['ma_depth'] = torch.zeros(H, W, device=self.dev)
+        d['ma_mask'] = torch.zeros(H, W, device=self.dev)
+        d['depth'] = torch.zeros(H, W, device=self.dev)
+        d['pts'] = torch.zeros(P, 3, device=self.dev)
+        d['count'] = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        d['zsnap'] = torch.zeros(2 * T, device=self.dev)
+        d['stream'] = torch.cuda.Stream(device=self.dev, priority=-1)     # short dependent kernels: schedule them first
+        d['ev_main'] = torch.cuda.Event()
+        d['ev_scene'] = torch.cuda.Event()
+        d['grid'] = torch.empty(L.mh_scene_grid_bytes(P), dtype=torch.uint8, device=self.dev)
+        self._scene_dev = d
+
+    def scene_device_update(self):
+        """One scene update from the current depth-range leaves (call after the cycle's kernels, before the step)."""
+        d, L = self._scene_dev, _lib.lib()
+        T, H, W = self.T, self.H, self.W
+        d['zsnap'][:T].copy_(self.leaf('zmin_lin').view(-1))
+        d['zsnap'][T:].copy_(self.leaf('zmax_lin').view(-1))
+        main = torch.cuda.current_stream(self.dev)
+        d['ev_main'].record(main)
+        side = d['stream']
+        side.wait_event(d['ev_main'])
+        st = side.cuda_stream
+        check(L.mh_scene_median(T, H, W, ptr(self.depths), ptr(d['back']), ptr(d['zsnap'][:T]), ptr(d['zsnap'][T:]),
+                                ptr(d['ma_depth']), ptr(d['ma_mask']), ptr(d['ws']), st))
+        check(L.mh_scene_postprocess(H, W, ptr(d['ma_depth']), ptr(d['ma_mask']), 1, 7, ptr(d['depth']), ptr(d['ws']), st))
+        check(L.mh_scene_points(H, W, self.K.ctypes.data_as(_lib.c_float_p), ptr(d['depth']), ptr(d['ma_mask']), ptr(d['pts']),
+                                ptr(d['count']), st))
+        check(L.mh_scene_grid_build_dev(ptr(d['pts']), ptr(d['count']), H * W, ptr(d['grid']), st))
+        d['ev_scene'].record(side)
+        self.scene_pts = d['pts']                 # capacity buffer; the live count is d['count'] (device)
+        self.scene_grid = d['grid']
+        self.scene_M = H * W
+        self._scene_pending = True
+
+    def scene_device_result(self):
+        """(scene_depth (H,W), ma_mask (H,W) bool, points (M,3)) of the last device update, on the host."""
+        d = self._scene_dev
+        d['stream'].synchronize()
+        n = int(d['count'].item())
+        return d['depth'].cpu().numpy(), d['ma_mask'].cpu().numpy() > 0.5, d['pts'][:n].clone()
 
     def scene_from_depth(self, depth, mask):
         d = _dev(depth, self.dev).view(self.H, self.W)
@@ -216,6 +274,11 @@ class SequenceEngine(object):
         self.forward()
 
     def cycle_finish(self, row, use_images=True, raster=None):
+        self._finish_a(use_images, raster)
+        self._finish_b(row, use_images, raster)
+
+    def _finish_a(self, use_images=True, raster=None):
+        """terms that do not read the scene: 2D joints, priors, velocity, rasterised depth / silhouette"""
         L = _lib.lib()
         st = _lib.stream_ptr(self.dev)
         c = self.c
@@ -259,10 +322,29 @@ class SequenceEngine(object):
                 # no rasteriser: alpha = 0, zbuf empty -> the mask-only silhouette term (tests only)
                 self.sil_body.copy_(self.sil_apply * self.sil_S / (self.sil_D + 1.0))
                 check(L.mh_reduce_sum(ptr(self.sil_body), B, 1.0, ptr(log[2:3]), st))
+        self._gv_cur = gv
+
+    def _finish_b(self, row, use_images=True, raster=None):
+        """contact / foot sliding (read the scene cloud), filtered-vertex term, LBS backward, log row"""
+        L = _lib.lib()
+        st = _lib.stream_ptr(self.dev)
+        c = self.c
+        T, N, B = self.T, self.N, self.B
+        g = self.grads
+        gpT, gposes = self.leaf('poses_T', g), self.leaf('poses_smpl', g)
+        gbetas, gxs = self.leaf('betas', g), self.leaf('xscale', g)
+        pT = self.leaf('poses_T')
+        h = self.halo or {}
+        scene = self.scene_pts is not None
+        filt = self.verts_filt is not None and self.pT_filt is not None
+        gv, log = self._gv_cur, self.tmp_log
         if scene:
             ev = self._tic('scene_terms')
             check(L.mh_lowest_vertex(ptr(self.verts), B, self.V, ptr(self.low_idx), ptr(self.low_xyz), st))
-            check(L.mh_contact_knn_grid(ptr(self.scene_grid), self.scene_pts.shape[0], ptr(self.low_xyz), B, 32, ptr(self.dy), st))
+            if self._scene_pending:              # the scene of the previous cycle is built on its own stream
+                torch.cuda.current_stream(self.dev).wait_event(self._scene_dev['ev_scene'])
+                self._scene_pending = False
+            check(L.mh_contact_knn_grid(ptr(self.scene_grid), self.scene_M, ptr(self.low_xyz), B, 32, ptr(self.dy), st))
             check(L.mh_contact_foot_terms(T, N, self.V, self.batch, ptr(self.verts), ptr(self.low_idx), ptr(self.low_xyz),
                                           ptr(self.dy), float(c['reg_contact']), float(c['reg_foot_sliding']), ptr(gpT),
                                           ptr(gv), ptr(self.batch_contact), ptr(self.batch_foot), st))
@@ -301,9 +383,12 @@ class SequenceEngine(object):
         return (raster is not None, self.scene_pts is not None and id(self.scene_pts),
                 self.verts_filt is not None and self.pT_filt is not None, self.halo is None)
 
-    def replay(self, key, fn):
+    def replay(self, key, fn, wait_scene=True):
         """Run ``fn`` (a fixed launch sequence on static buffers) through a captured graph; the first
         call runs it eagerly (lazy allocations, one-time attribute calls) and captures it."""
+        if wait_scene and self._scene_pending:   # cross-stream dependency stays outside the captured sequence
+            torch.cuda.current_stream(self.dev).wait_event(self._scene_dev['ev_scene'])
+            self._scene_pending = False
         if not hasattr(self, '_graphs'):
             self._graphs = {}
         g = self._graphs.get(key)
@@ -320,10 +405,20 @@ class SequenceEngine(object):
     def cycle_graphed(self, row, raster=None):
         """``cycle`` through a captured graph (single-process form; the sharded driver replays
         ``cycle_begin`` / ``cycle_finish`` separately around its exchanges)."""
-        def body():
-            self.cycle_begin()
-            self.cycle_finish(None, raster=raster)
-        self.replay(('full',) + self._graph_key(raster), body)
+        key = self._graph_key(raster)
+        if self._scene_dev is not None:
+            # the scene cloud is rebuilt every cycle on its own stream: everything up to the rasteriser replays
+            # without waiting for it, only the contact part does
+            def part_a():
+                self.cycle_begin()
+                self._finish_a(True, raster)
+            self.replay(('a',) + key, part_a, wait_scene=False)
+            self.replay(('b',) + key, lambda: self._finish_b(None, True, raster))
+        else:
+            def body():
+                self.cycle_begin()
+                self.cycle_finish(None, raster=raster)
+            self.replay(('full',) + key, body)
         self.log[row].copy_(self.tmp_log)
 
     def step_dev(self, alpha=0.5, momentum=0.9, eps=1e-8, gamma=0.99, lr0=0.01):

@@ -74,7 +74,7 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
                  reg_velocity_coef=1.0, reg_verts_filter_coef=1.0, reg_poses_coef=1.0, reg_scales_coef=1.0,
                  reg_contact_coef=1.0, reg_foot_sliding_coef=1.0, joint_confidence_thr=0.5, eps=1e-3, **kargs):
         self.use_rasteriser = kargs.pop('use_rasteriser', True)
-        self.scene_update = kargs.pop('scene_update', 'host')
+        self.scene_update = kargs.pop('scene_update', 'device')      # 'device' | 'host' (numpy, like the reference) | 'none'
         super().__init__(**kargs)
         if focal_length is None:
             focal_length = get_focal(min(image_size), fov)
@@ -252,8 +252,13 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
                 self.poses_T_filtered = e.pT_filt.view(self.num_frames, self.num_people, 1, 3)
                 self.verts_filtered = e.verts_filt
             e.cycle(cycle, raster=raster)
-            if cycle >= 30 and self.scene_update == 'host' and e.has_images and self._backmasks is not None:
-                self._host_scene_update()                                     # :578-584
+            if cycle >= 30 and e.has_images and self._backmasks is not None:     # :578-584
+                if self.scene_update == 'host':
+                    self._host_scene_update()
+                elif self.scene_update == 'device':
+                    if e._scene_dev is None:
+                        e.scene_device_setup(self._backmasks)
+                    e.scene_device_update()                                   # own stream; next cycle's contact term waits
             if not self.optim_scale_factor:
                 e.leaf('xscale', e.grads).zero_()
             e.step(lr)                                                        # RMSprop(lr=.01, alpha=.5, momentum=.9) :355
@@ -271,7 +276,16 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
         self.update_scene_pointcloud(self.scene_depth, ma_mask)
 
     def _finish_scene(self):
-        if getattr(self, '_ma', None) is None:
+        e = self.engine
+        if self.scene_update == 'device' and e._scene_dev is not None:
+            from . import scene_host
+            self.scene_depth, ma_mask, pts = e.scene_device_result()
+            self.scene_pcd = pts.unsqueeze(0).unsqueeze(0)
+            ma_image = None
+            if self._images is not None:          # the colour median does not depend on the optimised variables: once
+                ma_image = scene_host.aggregate_scene_median(None, self._images, self._backmasks, images_only=True)[0]
+            self._ma = (ma_image, ma_mask)
+        if getattr(self, '_ma', None) is None or self._ma[0] is None:
             return
         from . import scene_host
         scene_img, scene_mask = self._ma[0].copy(), self._ma[1].astype(np.float32).copy()

@@ -18,12 +18,14 @@ def target_depths(engine):
     return (1.0 / disp).cpu().numpy()
 
 
-def aggregate_scene_median(depths, images, backmasks, depth_metric='median'):
+def aggregate_scene_median(depths, images, backmasks, depth_metric='median', images_only=False):
     """fhsog.py:180-202: per-pixel masked median over time of depth (and colour)."""
     bkg_img = None
     if images is not None:
         m = np.ma.array(images, mask=np.tile(backmasks[..., np.newaxis] == 0, (1, 1, 1, 3)))
         bkg_img = np.ma.median(m, axis=0).data.astype(np.uint8)
+    if images_only:
+        return bkg_img, None, None
     md = getattr(np.ma, depth_metric)(np.ma.array(depths, mask=backmasks == 0), axis=0)
     return bkg_img, md.data.astype(np.float32), md.mask == 0
 

@@ -74,6 +74,16 @@ def main():
     print('knn ms (M=%d)' % e.scene_pts.shape[0], timeit(lambda: check(L.mh_contact_knn(ptr(e.scene_pts), e.scene_pts.shape[0], ptr(e.low_xyz), e.B, 32, ptr(e.dy), st))))
     print('knn grid ms', timeit(lambda: check(L.mh_contact_knn_grid(ptr(e.scene_grid), e.scene_pts.shape[0], ptr(e.low_xyz), e.B, 32, ptr(e.dy), st))))
     print('grid build ms', timeit(lambda: e._build_scene_grid()))
+    e.scene_device_setup(seq['backmasks'])
+    def scene_upd():
+        e.scene_device_update(); e._scene_dev['stream'].synchronize()
+    print('device scene update ms (median+postprocess+points+grid, own stream, synced)', timeit(scene_upd))
+    from mhhip._lib import check as _ck
+    d = e._scene_dev
+    Ls = _l.lib() if False else __import__('mhhip._lib', fromlist=['lib']).lib()
+    stp = __import__('mhhip._lib', fromlist=['lib']).stream_ptr(e.dev)
+    print('  median ms', timeit(lambda: _ck(Ls.mh_scene_median(e.T, e.H, e.W, ptr(e.depths), ptr(d['back']), ptr(d['zsnap'][:e.T]), ptr(d['zsnap'][e.T:]), ptr(d['ma_depth']), ptr(d['ma_mask']), ptr(d['ws']), stp))))
+    print('  postprocess ms', timeit(lambda: _ck(Ls.mh_scene_postprocess(e.H, e.W, ptr(d['ma_depth']), ptr(d['ma_mask']), 1, 7, ptr(d['depth']), ptr(d['ws']), stp))))
     hdr = e.scene_grid[:32].cpu().numpy()
     print('grid mn', hdr[:12].view(np.float32), 'cell', hdr[12:16].view(np.float32), 'dim', hdr[16:28].view(np.int32), 'ncells', hdr[28:32].view(np.int32))
     d = torch.cdist(e.low_xyz.view(-1, 3), e.scene_pts)

@@ -143,9 +143,11 @@ def main():
     def one_cycle(c, graphs, scene=False):
         if c % 25 == 0 and c > 0:
             sh.update_filters()
-        sh.cycle(c % e.log.shape[0], raster=raster, graphs=graphs)
         if scene:                     # the organic path of fit (cycle >= 30): scene rebuilt from the sequence every cycle
-            e.scene_device_update()   # own stream; the next cycle's contact term waits for it with an event
+            e.scene_device_update()   # own stream, from the leaves as they are before this cycle's step
+        sh.cycle(c % e.log.shape[0], raster=raster, graphs=graphs)
+        if scene:
+            e.scene_device_swap()     # read by the next cycle's contact term (which waits on the update's event)
         sh.step()                     # RMSprop with the device-resident lr (x0.99 per cycle)
 
     use_graphs = not args.eager

@@ -191,8 +191,11 @@ class SequenceEngine(object):
 
     # -- scene aggregation on the device (optimizer.py:578-584 + fhsog.py:180-202 + utils.py:174-209) ---------
     def scene_device_setup(self, backmasks):
-        """backmasks (T,H,W), non-zero = background.  Allocates the buffers of the per-cycle scene update, which runs
-        on its own stream: the contact term of the NEXT cycle waits for it with an event, nothing syncs the host."""
+        """backmasks (T,H,W), non-zero = background.  Allocates the buffers of the per-cycle scene update.  The update
+        of cycle c only depends on the depth-range leaves as they are at the START of cycle c and its result is first
+        read by the contact term of cycle c+1, so it is launched on its own stream at the start of the cycle into the
+        back set of (points, count, grid) and swapped in after the cycle: more than a full cycle of slack, nothing
+        waits for the host."""
         L = _lib.lib()
         T, H, W = self.T, self.H, self.W
         P = H * W
@@ -202,44 +205,60 @@ class SequenceEngine(object):
         d['ma_depth'] = torch.zeros(H, W, device=self.dev)
         d['ma_mask'] = torch.zeros(H, W, device=self.dev)
         d['depth'] = torch.zeros(H, W, device=self.dev)
-        d['pts'] = torch.zeros(P, 3, device=self.dev)
-        d['count'] = torch.zeros(1, dtype=torch.int32, device=self.dev)
-        d['zsnap'] = torch.zeros(2 * T, device=self.dev)
-        d['stream'] = torch.cuda.Stream(device=self.dev, priority=-1)     # short dependent kernels: schedule them first
+        d['stream'] = torch.cuda.Stream(device=self.dev)
         d['ev_main'] = torch.cuda.Event()
-        d['ev_scene'] = torch.cuda.Event()
-        d['grid'] = torch.empty(L.mh_scene_grid_bytes(P), dtype=torch.uint8, device=self.dev)
+        d['sets'] = [dict(pts=torch.zeros(P, 3, device=self.dev), count=torch.zeros(1, dtype=torch.int32, device=self.dev),
+                          grid=torch.empty(L.mh_scene_grid_bytes(P), dtype=torch.uint8, device=self.dev),
+                          zsnap=torch.zeros(2 * T, device=self.dev), ev=torch.cuda.Event()) for _ in range(2)]
+        d['next'] = 0                 # set the next update writes
+        d['ready'] = None             # set written by the last update, not yet swapped in
+        d['front'] = None
         self._scene_dev = d
 
     def scene_device_update(self):
-        """One scene update from the current depth-range leaves (call after the cycle's kernels, before the step)."""
+        """Launch one scene update from the current depth-range leaves into the back set (own stream)."""
         d, L = self._scene_dev, _lib.lib()
         T, H, W = self.T, self.H, self.W
-        d['zsnap'][:T].copy_(self.leaf('zmin_lin').view(-1))
-        d['zsnap'][T:].copy_(self.leaf('zmax_lin').view(-1))
+        k = d['next']
+        s = d['sets'][k]
+        s['zsnap'][:T].copy_(self.leaf('zmin_lin').view(-1))
+        s['zsnap'][T:].copy_(self.leaf('zmax_lin').view(-1))
         main = torch.cuda.current_stream(self.dev)
         d['ev_main'].record(main)
         side = d['stream']
         side.wait_event(d['ev_main'])
         st = side.cuda_stream
-        check(L.mh_scene_median(T, H, W, ptr(self.depths), ptr(d['back']), ptr(d['zsnap'][:T]), ptr(d['zsnap'][T:]),
+        check(L.mh_scene_median(T, H, W, ptr(self.depths), ptr(d['back']), ptr(s['zsnap'][:T]), ptr(s['zsnap'][T:]),
                                 ptr(d['ma_depth']), ptr(d['ma_mask']), ptr(d['ws']), st))
         check(L.mh_scene_postprocess(H, W, ptr(d['ma_depth']), ptr(d['ma_mask']), 1, 7, ptr(d['depth']), ptr(d['ws']), st))
-        check(L.mh_scene_points(H, W, self.K.ctypes.data_as(_lib.c_float_p), ptr(d['depth']), ptr(d['ma_mask']), ptr(d['pts']),
-                                ptr(d['count']), st))
-        check(L.mh_scene_grid_build_dev(ptr(d['pts']), ptr(d['count']), H * W, ptr(d['grid']), st))
-        d['ev_scene'].record(side)
-        self.scene_pts = d['pts']                 # capacity buffer; the live count is d['count'] (device)
-        self.scene_grid = d['grid']
-        self.scene_M = H * W
+        check(L.mh_scene_points(H, W, self.K.ctypes.data_as(_lib.c_float_p), ptr(d['depth']), ptr(d['ma_mask']), ptr(s['pts']),
+                                ptr(s['count']), st))
+        check(L.mh_scene_grid_build_dev(ptr(s['pts']), ptr(s['count']), H * W, ptr(s['grid']), st))
+        s['ev'].record(side)
+        d['ready'] = k
+        d['next'] = 1 - k
+
+    def scene_device_swap(self):
+        """Make the last update the scene the contact term reads from now on (pointer swap; its consumer waits on the
+        update's event)."""
+        d = self._scene_dev
+        if d['ready'] is None:
+            return
+        s = d['sets'][d['ready']]
+        d['front'], d['ready'] = s, None
+        self.scene_pts = s['pts']                 # capacity buffer; the live count is s['count'] (device)
+        self.scene_grid = s['grid']
+        self.scene_M = self.H * self.W
+        self._scene_event = s['ev']
         self._scene_pending = True
 
     def scene_device_result(self):
         """(scene_depth (H,W), ma_mask (H,W) bool, points (M,3)) of the last device update, on the host."""
         d = self._scene_dev
         d['stream'].synchronize()
-        n = int(d['count'].item())
-        return d['depth'].cpu().numpy(), d['ma_mask'].cpu().numpy() > 0.5, d['pts'][:n].clone()
+        s = d['front'] if d['ready'] is None else d['sets'][d['ready']]
+        n = int(s['count'].item())
+        return d['depth'].cpu().numpy(), d['ma_mask'].cpu().numpy() > 0.5, s['pts'][:n].clone()
 
     def scene_from_depth(self, depth, mask):
         d = _dev(depth, self.dev).view(self.H, self.W)
@@ -342,7 +361,7 @@ class SequenceEngine(object):
             ev = self._tic('scene_terms')
             check(L.mh_lowest_vertex(ptr(self.verts), B, self.V, ptr(self.low_idx), ptr(self.low_xyz), st))
             if self._scene_pending:              # the scene of the previous cycle is built on its own stream
-                torch.cuda.current_stream(self.dev).wait_event(self._scene_dev['ev_scene'])
+                torch.cuda.current_stream(self.dev).wait_event(self._scene_event)
                 self._scene_pending = False
             check(L.mh_contact_knn_grid(ptr(self.scene_grid), self.scene_M, ptr(self.low_xyz), B, 32, ptr(self.dy), st))
             check(L.mh_contact_foot_terms(T, N, self.V, self.batch, ptr(self.verts), ptr(self.low_idx), ptr(self.low_xyz),
@@ -387,7 +406,7 @@ class SequenceEngine(object):
         """Run ``fn`` (a fixed launch sequence on static buffers) through a captured graph; the first
         call runs it eagerly (lazy allocations, one-time attribute calls) and captures it."""
         if wait_scene and self._scene_pending:   # cross-stream dependency stays outside the captured sequence
-            torch.cuda.current_stream(self.dev).wait_event(self._scene_dev['ev_scene'])
+            torch.cuda.current_stream(self.dev).wait_event(self._scene_event)
             self._scene_pending = False
         if not hasattr(self, '_graphs'):
             self._graphs = {}

@@ -251,14 +251,18 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
                 e.update_filters(min_cutoff1, beta1, min_cutoff2, beta2)
                 self.poses_T_filtered = e.pT_filt.view(self.num_frames, self.num_people, 1, 3)
                 self.verts_filtered = e.verts_filt
+            scene_now = cycle >= 30 and e.has_images and self._backmasks is not None      # :578-584
+            if scene_now and self.scene_update == 'device':
+                # the update only reads the depth-range leaves as they are before this cycle's step and is first used by
+                # the NEXT cycle's contact term: launch it now on its own stream, swap it in after the cycle
+                if e._scene_dev is None:
+                    e.scene_device_setup(self._backmasks)
+                e.scene_device_update()
             e.cycle(cycle, raster=raster)
-            if cycle >= 30 and e.has_images and self._backmasks is not None:     # :578-584
-                if self.scene_update == 'host':
-                    self._host_scene_update()
-                elif self.scene_update == 'device':
-                    if e._scene_dev is None:
-                        e.scene_device_setup(self._backmasks)
-                    e.scene_device_update()                                   # own stream; next cycle's contact term waits
+            if scene_now and self.scene_update == 'host':
+                self._host_scene_update()
+            elif scene_now and self.scene_update == 'device':
+                e.scene_device_swap()
             if not self.optim_scale_factor:
                 e.leaf('xscale', e.grads).zero_()
             e.step(lr)                                                        # RMSprop(lr=.01, alpha=.5, momentum=.9) :355

@@ -141,6 +141,7 @@ def test_fit_builds_the_scene_on_the_device(smpl_struct, smpl_regs, tmp_path):
     want = scene_host.postprocess_depthmap(ma_depth, ma_mask, use_bilateral_filter=True)
     e.scene_device_setup(opt._backmasks)
     e.scene_device_update()
+    e.scene_device_swap()
     got, got_mask, pts = e.scene_device_result()
     np.testing.assert_array_equal(got_mask, ma_mask)
     bad = np.abs(got - want) > 1e-5 * np.maximum(1.0, np.abs(want))

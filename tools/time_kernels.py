@@ -82,7 +82,7 @@ def main():
     d = e._scene_dev
     Ls = _l.lib() if False else __import__('mhhip._lib', fromlist=['lib']).lib()
     stp = __import__('mhhip._lib', fromlist=['lib']).stream_ptr(e.dev)
-    print('  median ms', timeit(lambda: _ck(Ls.mh_scene_median(e.T, e.H, e.W, ptr(e.depths), ptr(d['back']), ptr(d['zsnap'][:e.T]), ptr(d['zsnap'][e.T:]), ptr(d['ma_depth']), ptr(d['ma_mask']), ptr(d['ws']), stp))))
+    print('  median ms', timeit(lambda: _ck(Ls.mh_scene_median(e.T, e.H, e.W, ptr(e.depths), ptr(d['back']), ptr(d['sets'][0]['zsnap'][:e.T]), ptr(d['sets'][0]['zsnap'][e.T:]), ptr(d['ma_depth']), ptr(d['ma_mask']), ptr(d['ws']), stp))))
     print('  postprocess ms', timeit(lambda: _ck(Ls.mh_scene_postprocess(e.H, e.W, ptr(d['ma_depth']), ptr(d['ma_mask']), 1, 7, ptr(d['depth']), ptr(d['ws']), stp))))
     hdr = e.scene_grid[:32].cpu().numpy()
     print('grid mn', hdr[:12].view(np.float32), 'cell', hdr[12:16].view(np.float32), 'dim', hdr[16:28].view(np.int32), 'ncells', hdr[28:32].view(np.int32))

@@ -101,7 +101,19 @@ def main():
     ap.add_argument('--eager', action='store_true', help='launch every kernel from the host instead of replaying captured graphs')
     ap.add_argument('--cpu-frames', type=int, default=20)
     ap.add_argument('--cpu-cycles', type=int, default=3)
+    # developer switches for the other BASELINE configs (parity-test cases, not bench lines): e.g. C5 =
+    # --humans 8 --frames 500 --image 600x338 ; the JSON then names the workload it actually ran
+    ap.add_argument('--humans', type=int, default=None)
+    ap.add_argument('--frames', type=int, default=None)
+    ap.add_argument('--image', type=str, default=None)
     args = ap.parse_args()
+    global N_PEOPLE, T_LOCAL, IMG
+    if args.humans:
+        N_PEOPLE = args.humans
+    if args.frames:
+        T_LOCAL = args.frames
+    if args.image:
+        IMG = tuple(int(x) for x in args.image.split('x'))
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -245,13 +257,13 @@ def main():
                                 'algorithmic_flops': fl, 'traffic': traffic.get(k)}
         out = {
             'metric': 'optimizer iterations/sec (N humans x T frames)', 'value': round(its * world, 3),
-            'unit': 'iterations/s (4 humans x 200 frames per iteration unit)', 'n_gpus': world, 'steps': args.steps,
+            'unit': 'iterations/s (%d humans x %d frames per iteration unit)' % (N_PEOPLE, T_LOCAL), 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'launch': 'eager' if args.eager else 'hipGraph replay',
-            'config': {'workload': 'MuPoTs TS13-shape 4 humans x %d frames, 240x135, batch 10, full nine-term loss stack '
+            'config': {'workload': 'MuPoTs TS13-shape %d humans x %d frames, %dx%d, batch 10, full nine-term loss stack '
                                    '(2D joints, raster depth, soft silhouette, contact, foot sliding, priors, velocity, '
                                    'filtered vertices) + RMSprop; scene injected (ground plane), one-euro filters live'
-                                   % (T_LOCAL * world),
+                                   % (N_PEOPLE, T_LOCAL * world, IMG[0], IMG[1]),
                        'humans': N_PEOPLE, 'frames': T_LOCAL * world, 'frames_per_gpu': T_LOCAL, 'image': list(IMG),
                        'parallelism': 'frames sharded x%d, RCCL all-reduce on betas/scale grads' % world},
             'organic_scene': organic, 'roofline': roof, 'roofline_mfma': roof_mfma, 'kernel_us': {k: round(v, 1) for k, v in kernel_us.items()},

@@ -89,3 +89,17 @@ def test_one_euro_time_base_matches_numpy_accumulation():
         t = t + (i / 25)
     assert one_euro_time_before(37) == float(np.float32(t))
     assert one_euro_time_before(0) == 0.0 and one_euro_time_before(1) == 0.0
+
+
+def test_argument_checks_return_status_and_message_without_a_device():
+    """bad arguments are rejected before any HIP call: status < 0 and a readable mh_last_error()"""
+    import ctypes
+    from mhhip import _lib
+    L = _lib.lib()
+    L.mh_last_error.restype = ctypes.c_char_p
+    rc = L.mh_raster_terms(1, 1, 10, 10, 8, 8, *([None] * 13), 0.0, 0.0, 1e-3, *([None] * 9))
+    assert rc < 0 and b'null' in L.mh_last_error()
+    rc = L.mh_contact_knn_grid(None, 10, None, 1, 32, None, None)
+    assert rc < 0 and L.mh_last_error()
+    assert L.mh_scene_median(0, 8, 8, *([None] * 8)) < 0
+    assert L.mh_scene_workspace_bytes(4, 8, 8) > 0 and L.mh_raster_workspace_bytes(1, 1, 10, 10, 8, 8) > 0

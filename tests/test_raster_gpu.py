@@ -147,3 +147,42 @@ def test_raster_terms_wide_window_column_tiles(smpl_struct, smpl_regs):
     span = [int(np.ptp(np.nonzero(c)[0])) if c.any() else 0 for c in (r['zbuf'][0] > 0).any(axis=1)]
     assert max(span) > 640, span
     _check(r)
+
+
+def test_bodies_behind_or_off_camera_contribute_nothing(smpl_struct, smpl_regs):
+    """edge cases: a body behind the camera, one far off screen, one straddling the image border"""
+    from mhhip import engine
+    from mhhip.sequence import SequenceEngine
+    from mhhip.raster import RasterTerms
+    T, N, W, H = 1, 3, 64, 48
+    K = synthetic.default_cam_K((W, H), 60.0)
+    sp = synthetic.make_sequence_params(N, T, 3)
+    pT = sp['trans_gt'].copy()
+    pT[0, 0] = [0.0, 0.0, -3.0]          # behind the camera
+    pT[0, 1] = [40.0, 0.0, 4.0]          # far off to the side
+    pT[0, 2] = [1.9, 0.1, 3.5]           # partly inside
+    model = engine.BodyModel(smpl_struct, smpl_regs)
+    e = SequenceEngine(model, (W, H), T, N, K, None, dict(depth=0.05, silhouette=0.1), batch_size=1)
+    e.set_leaves(pT.astype(np.float32), sp['poses_gt'], sp['betas_gt'], np.ones(T, np.float32), 5 * np.ones(T, np.float32),
+                 np.zeros(N, np.float32))
+    seg = np.zeros((T, N, H, W), np.float32)
+    seg[:, :, 10:40, 40:64] = 1
+    pose2d = np.zeros((T, N, 17, 3), np.float32)
+    pose2d[..., 2] = 0.9
+    e.stage(pose2d, sp['poses_init'], sp['valid'], sp['betas_gt'], seg, np.full((T, H, W), 0.5, np.float32))
+    e.forward()
+    L = __import__('mhhip._lib', fromlist=['lib']).lib()
+    from mhhip._lib import ptr, check, stream_ptr
+    check(L.mh_sil_mask_stats(ptr(e.bits), T, N, H, W, ptr(e.leaf('poses_T')), ptr(e.p2d_valid), ptr(e.mask_valid),
+                              ptr(e.front), ptr(e.sil_apply), ptr(e.sil_D), ptr(e.sil_S), stream_ptr(e.dev)))
+    gv = torch.zeros_like(e.verts)
+    e.grads.zero_()
+    log = torch.zeros(16, device=e.dev)
+    zbuf = torch.empty(T * N, H, W, device=e.dev)
+    RasterTerms(e)(e, gv, log, zbuf_out=zbuf)
+    torch.cuda.synchronize()
+    g = gv.cpu().numpy().reshape(N, -1, 3)
+    assert np.isfinite(g).all() and np.isfinite(log.cpu().numpy()).all()
+    assert (zbuf[0] < 0).all() and (zbuf[1] < 0).all()          # nothing rasterised for the first two bodies
+    assert np.abs(g[0]).max() == 0 and np.abs(g[1]).max() == 0
+    assert (zbuf[2] > 0).sum() > 20 and np.abs(g[2]).max() > 0

@@ -73,7 +73,7 @@ struct RasterP {
   float* ndc;                // [B][V][3] projected vertices (NDC x, y, view z)
   unsigned* frows;           // [B][F] conservative pixel-row range of every face: lo | hi << 16 (lo > hi: skip)
   unsigned* fsort;           // [B][F] faces ordered by their first row: hi << 20 | face
-  int* row_start;            // [B][H+1] first entry of fsort with lo >= row; [H] = number of visible faces
+  int* row_start;            // [B][2][H+1] (+1): per class (near class first), first entry of fsort with lo >= row
   int* maxh;                 // [B] tallest face (rows) of the body
   int* gunit_body;           // [max_units] gradient work units: RG_UNIT window pixels of one body, full units first
   int* gunit_p0;             // [max_units] first window pixel of the unit
@@ -441,7 +441,8 @@ __device__ __forceinline__ int r_wave_scan_max(int x) {              // values >
 // workgroup per body): a tile's candidate faces are then one contiguous range of fsort (first row in
 // [tile_row0 - tallest_face, tile_last_row]); entries are hi << 20 | face.
 #define RFS 512
-__device__ __forceinline__ unsigned r_face_rows(const RasterP& p, const float* nb, int f) {
+// lo | hi << 16 with bit 15 = sign of the screen-space area (which side of the face looks at the camera)
+__device__ __forceinline__ unsigned r_face_rows(const RasterP& p, const float* nb, int f, float* zmin_out) {
   float x[3], y[3], z[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -456,56 +457,82 @@ __device__ __forceinline__ unsigned r_face_rows(const RasterP& p, const float* n
     const float lo = floorf(r_ndc_to_pix(bymax, p.H, p.W)) - 1.f, hi = ceilf(r_ndc_to_pix(bymin, p.H, p.W)) + 1.f;
     if (hi >= 0.f && lo <= (float)(p.H - 1)) {
       const unsigned ulo = (unsigned)fmaxf(lo, 0.f), uhi = (unsigned)fminf(hi, (float)(p.H - 1));
-      out = ulo | (uhi << 16);
+      out = ulo | (uhi << 16) | (farea > 0.f ? 0x8000u : 0u);
     }
   }
+  *zmin_out = fminf(z[0], fminf(z[1], z[2]));
   return out;
 }
 
+// Two classes per row: the faces whose class is nearer to the camera on average (for a closed mesh: the ones looking at
+// it) come first in fsort, so that a tile rasterises them first and the depth cull of k_raster_strip then removes most
+// of the far-side candidates.  row_start: [2][H+1] (+ total), class-major in that order.
 __global__ __launch_bounds__(RFS) void k_raster_face_sort(RasterP p) {
-  extern __shared__ int hist[];                     // [H + 1]
-  __shared__ int s_maxh;
-  const int b = blockIdx.x, tid = threadIdx.x, H = p.H;
+  extern __shared__ int hist[];                     // [2][H + 1]: sign class, row
+  __shared__ int s_maxh, s_flip;
+  __shared__ float s_z[2];
+  __shared__ int s_n[2];
+  const int b = blockIdx.x, tid = threadIdx.x, H = p.H, HB = H + 1;
   const float* nb = p.ndc + (size_t)b * p.V * 3;
   unsigned* fr = p.frows + (size_t)b * p.F;
   unsigned* fs = p.fsort + (size_t)b * p.F;
-  int* rs = p.row_start + (size_t)b * (H + 1);
-  for (int i = tid; i <= H; i += RFS) hist[i] = 0;
-  if (tid == 0) s_maxh = 0;
+  int* rs = p.row_start + (size_t)b * (2 * HB + 1);
+  for (int i = tid; i < 2 * HB; i += RFS) hist[i] = 0;
+  if (tid == 0) { s_maxh = 0; s_z[0] = s_z[1] = 0.f; s_n[0] = s_n[1] = 0; }
   __syncthreads();
-  int mh = 0;
+  int mh = 0, n0 = 0, n1 = 0;
+  float z0 = 0.f, z1 = 0.f;
   for (int f = tid; f < p.F; f += RFS) {
-    const unsigned r = r_face_rows(p, nb, f);
+    float zm;
+    const unsigned r = r_face_rows(p, nb, f, &zm);
     fr[f] = r;
-    const int lo = (int)(r & 0xffffu), hi = (int)(r >> 16);
+    const int lo = (int)(r & 0x7fffu), hi = (int)(r >> 16), cls = (int)((r >> 15) & 1u);
     if (lo <= hi) {
-      atomicAdd(&hist[lo], 1);
+      atomicAdd(&hist[cls * HB + lo], 1);
       mh = max(mh, hi - lo);
+      if (cls) { z1 += zm; ++n1; } else { z0 += zm; ++n0; }
     }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mh = max(mh, __shfl_xor(mh, o, 64));
-  if ((tid & 63) == 0) atomicMax(&s_maxh, mh);
+  for (int o = 32; o > 0; o >>= 1) {
+    mh = max(mh, __shfl_xor(mh, o, 64));
+    z0 += __shfl_xor(z0, o, 64); z1 += __shfl_xor(z1, o, 64);
+    n0 += __shfl_xor(n0, o, 64); n1 += __shfl_xor(n1, o, 64);
+  }
+  if ((tid & 63) == 0) {
+    atomicMax(&s_maxh, mh);
+    atomicAdd(&s_z[0], z0); atomicAdd(&s_z[1], z1);
+    atomicAdd(&s_n[0], n0); atomicAdd(&s_n[1], n1);
+  }
   __syncthreads();
-  if (tid < 64) {                                   // exclusive scan of the row histogram by one wave
+  if (tid == 0) {
+    // class 1 first when it is the nearer one (or the only one)
+    const float m0 = s_n[0] ? s_z[0] / (float)s_n[0] : 3e38f, m1 = s_n[1] ? s_z[1] / (float)s_n[1] : 3e38f;
+    s_flip = m1 < m0 ? 1 : 0;
+  }
+  __syncthreads();
+  const int flip = s_flip;
+  if (tid < 64) {                                   // exclusive scan of the (class order, row) histogram by one wave
     int carry = 0;
-    for (int base = 0; base <= H; base += 64) {
-      const int i = base + tid;
-      const int v = i <= H ? hist[i] : 0;
+    for (int base = 0; base < 2 * HB; base += 64) {
+      const int i = base + tid;                     // position in the output order
+      const int o = i / HB, rrow = i - o * HB;
+      const int bin = ((o ^ flip) & 1) * HB + rrow;
+      const int v = i < 2 * HB ? hist[bin] : 0;
       const int incl = r_wave_scan_add(v);
-      if (i <= H) {
-        hist[i] = carry + incl - v;
+      if (i < 2 * HB) {
+        hist[bin] = carry + incl - v;
         rs[i] = carry + incl - v;
       }
       carry += __builtin_amdgcn_readlane(incl, 63);
     }
-    if (tid == 0) p.maxh[b] = s_maxh;
+    if (tid == 0) { p.maxh[b] = s_maxh; rs[2 * HB] = carry; }
   }
   __syncthreads();
   for (int f = tid; f < p.F; f += RFS) {
     const unsigned r = fr[f];
-    const int lo = (int)(r & 0xffffu), hi = (int)(r >> 16);
-    if (lo <= hi) fs[atomicAdd(&hist[lo], 1)] = ((unsigned)hi << 20) | (unsigned)f;
+    const int lo = (int)(r & 0x7fffu), hi = (int)(r >> 16), cls = (int)((r >> 15) & 1u);
+    if (lo <= hi) fs[atomicAdd(&hist[cls * HB + lo], 1)] = ((unsigned)hi << 20) | (unsigned)f;
   }
 }
 
@@ -537,8 +564,9 @@ __global__ __launch_bounds__(1024) void k_raster_strip_order(RasterP p) {
   auto cost_class = [&](int s) {
     const int b = p.strip_body[s];
     const int sy0 = p.strip_row0[s], sy1 = sy0 + p.strip_rows[s] - 1;
-    const int* rs = p.row_start + (size_t)b * (H + 1);
-    const int n = rs[min(sy1 + 1, H)] - rs[max(0, sy0 - p.maxh[b])];
+    const int* rs = p.row_start + (size_t)b * (2 * (H + 1) + 1);
+    const int ra = max(0, sy0 - p.maxh[b]), rb = min(sy1 + 1, H);
+    const int n = (rs[rb] - rs[ra]) + (rs[H + 1 + rb] - rs[H + 1 + ra]);
     return 63 - min(63, (int)((long long)n * 64 / (p.F + 1)));       // class 0 = most faces
   };
   for (int s = tid; s < total; s += 1024) atomicAdd(&hist[cost_class(s)], 1);
@@ -598,18 +626,22 @@ __global__ __launch_bounds__(RB) void k_raster_strip(RasterP p) {
     const int npx = nrows * tw;
     const float* nb = p.ndc + (size_t)b * p.V * 3;
     const unsigned* fs = p.fsort + (size_t)b * p.F;
-    const int* rs = p.row_start + (size_t)b * (H + 1);
+    const int* rs = p.row_start + (size_t)b * (2 * (H + 1) + 1);
     __syncthreads();
     for (int i = tid; i < npx * 5; i += RB) keys[i] = RS_EMPTY;
     for (int i = tid; i < tw; i += RB) sXf[i] = r_pix_to_ndc(W - 1 - (x0 + i), W, H);
     for (int i = tid; i < nrows; i += RB) sYf[i] = r_pix_to_ndc(H - 1 - (sy0 + i), H, W);
-    const int i0 = rs[max(0, sy0 - p.maxh[b])], i1 = rs[min(sy1 + 1, H)];
+    // candidate faces: the near class of the rows first, then the far class (two contiguous ranges of fsort)
+    const int ra_ = max(0, sy0 - p.maxh[b]), rb_ = min(sy1 + 1, H);
+    const int a0 = rs[ra_], na = rs[rb_] - a0, b0 = rs[H + 1 + ra_], nbk = rs[H + 1 + rb_] - b0;
+    const int i1 = na + nbk;
+    auto fs_at = [&](int j) { return fs[j < na ? a0 + j : b0 + (j - na)]; };
     __syncthreads();
-    if (i0 < i1) {
+    if (i1 > 0) {
       const int last = i1 - 1, stride = RW * 64;
-      int idx = i0 + wave * 64 + lane;
+      int idx = wave * 64 + lane;
       // pipeline registers: entry of round r+2, vertex ids of round r+1, coordinates of round r
-      unsigned e_a = fs[min(idx, last)], e_b = fs[min(idx + stride, last)], e_c = fs[min(idx + 2 * stride, last)];
+      unsigned e_a = fs_at(min(idx, last)), e_b = fs_at(min(idx + stride, last)), e_c = fs_at(min(idx + 2 * stride, last));
       int va[3], vb_[3];
       float ca[9];
 #pragma unroll
@@ -622,7 +654,7 @@ __global__ __launch_bounds__(RB) void k_raster_strip(RasterP p) {
       }
       for (; idx - lane < i1; idx += stride) {
         // ---- issue the next rounds' gathers before working on this one ------------------------------------
-        const unsigned e_n = fs[min(idx + 3 * stride, last)];
+        const unsigned e_n = fs_at(min(idx + 3 * stride, last));
         int vn[3];
         float cn[9];
 #pragma unroll
@@ -1137,7 +1169,7 @@ __global__ void k_fill(float* x, size_t n, float v) {
 static size_t r_align(size_t x) { return (x + 255) & ~(size_t)255; }
 static size_t r_max_units(size_t B, int H, int W) { return B + B * (size_t)H * W / RG_UNIT + 1; }
 static size_t r_ws_extra(size_t B, int V, int F, int H) {
-  return r_align(B * V * 3 * 4) + 2 * r_align(B * F * 4) + r_align(B * (size_t)(H + 1) * 4) + r_align(B * 4) + r_align(B * 8);
+  return r_align(B * V * 3 * 4) + 2 * r_align(B * F * 4) + r_align(B * (size_t)(2 * (H + 1) + 1) * 4) + r_align(B * 4) + r_align(B * 8);
 }
 static int r_max_strips(int B, int H, int W) {
   // full-width windows give the most tiles per body
@@ -1211,7 +1243,7 @@ extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const f
   p.ndc = (float*)c; c += r_align(B * V * 3 * 4);
   p.frows = (unsigned*)c; c += r_align(B * F * 4);
   p.fsort = (unsigned*)c; c += r_align(B * F * 4);
-  p.row_start = (int*)c; c += r_align(B * (size_t)(H + 1) * 4);
+  p.row_start = (int*)c; c += r_align(B * (size_t)(2 * (H + 1) + 1) * 4);
   p.maxh = (int*)c; c += r_align(B * 4);
   p.body_koff = (long long*)c; c += r_align(B * 8);
   p.gunit_body = (int*)c; c += r_align(r_max_units(B, H, W) * 4);
@@ -1228,7 +1260,7 @@ extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const f
   MH_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_raster_strip_table, dim3(1), dim3(1024), 0, st, p);
   MH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_raster_face_sort, dim3(p.B), dim3(RFS), (size_t)(H + 1) * sizeof(int), st, p);
+  hipLaunchKernelGGL(k_raster_face_sort, dim3(p.B), dim3(RFS), (size_t)2 * (H + 1) * sizeof(int), st, p);
   MH_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_raster_strip_order, dim3(1), dim3(1024), 0, st, p);
   MH_LAUNCH_CHECK();

@@ -469,18 +469,61 @@ extern "C" int mh_scene_grid_build_dev(const float* points, const int* M_dev, in
   return grid_build(points, M_cap, M_dev, grid_ws, (hipStream_t)stream);
 }
 
+// Keep the K smallest of the 128 buffered (distance^2, y) candidates of a wave in slots [0, K), unsorted, and return
+// the K-th smallest distance: the two entries of a lane live in registers, the K-th value comes from a bitwise
+// descent with ballots (non-negative floats order like unsigned integers), ties at the bound are kept in lane order.
+// (A bitonic sort of the LDS buffer costs 28 dependent LDS exchange steps per call and made the whole search
+// latency-bound.)  Slots [K, 128) are reset to +inf.
+__device__ __forceinline__ float knn_select(float* sd, float* sy, int lane, int K) {
+  const float d0 = sd[lane], d1 = sd[lane + 64], y0 = sy[lane], y1 = sy[lane + 64];
+  const unsigned u0 = __float_as_uint(d0), u1 = __float_as_uint(d1);
+  int k = K - 1;
+  unsigned prefix = 0u;
+#pragma unroll 4
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned m = (bit == 31 ? 0u : (0xffffffffu << (bit + 1))) | (1u << bit);
+    const int c0 = __popcll(__ballot((u0 & m) == prefix)) + __popcll(__ballot((u1 & m) == prefix));
+    if (k >= c0) { k -= c0; prefix |= 1u << bit; }
+  }
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const unsigned long long l0 = __ballot(u0 < prefix), l1 = __ballot(u1 < prefix);
+  const unsigned long long e0 = __ballot(u0 == prefix), e1 = __ballot(u1 == prefix);
+  const int nl0 = __popcll(l0), nless = nl0 + __popcll(l1), need = K - nless;
+  int p0 = -1, p1 = -1;
+  if (u0 < prefix) p0 = __popcll(l0 & below);
+  else if (u0 == prefix) { const int r = __popcll(e0 & below); if (r < need) p0 = nless + r; }
+  if (u1 < prefix) p1 = nl0 + __popcll(l1 & below);
+  else if (u1 == prefix) { const int r = __popcll(e0) + __popcll(e1 & below); if (r < need) p1 = nless + r; }
+  __builtin_amdgcn_wave_barrier();
+  sd[lane] = INFINITY; sd[lane + 64] = INFINITY;
+  __builtin_amdgcn_wave_barrier();
+  if (p0 >= 0) { sd[p0] = d0; sy[p0] = y0; }
+  if (p1 >= 0) { sd[p1] = d1; sy[p1] = y1; }
+  __builtin_amdgcn_wave_barrier();
+  return __uint_as_float(prefix);
+}
+
+#ifdef ABL_TIMEQ
+__device__ unsigned long long g_tq[8192];
+__device__ int g_rho[4096];
+extern "C" int mh_debug_tq(unsigned long long* out, int* rho) { hipMemcpyFromSymbol(rho, HIP_SYMBOL(g_rho), sizeof(g_rho)); return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tq), sizeof(g_tq)); }
+#endif
 // one wave per query
 __global__ __launch_bounds__(64) void k_contact_knn_grid(const GridHdr* hdr, const int* start, const float* sorted, int M,
                                                          const float* low_xyz, int K, float* dy) {
   __shared__ float sd_s[KNN_CAP];
   __shared__ float sy_s[KNN_CAP];
-  volatile float* sd = sd_s;
-  volatile float* sy = sy_s;
+  __shared__ int s_off[65], s_a0[64], s_la[64], s_b0[64];
+  float* sd = sd_s;
+  float* sy = sy_s;
   const int b = blockIdx.x, lane = threadIdx.x;
   const float qx = low_xyz[(size_t)b * 3], qy = low_xyz[(size_t)b * 3 + 1], qz = low_xyz[(size_t)b * 3 + 2];
   sd[lane] = INFINITY; sd[lane + 64] = INFINITY;
   sy[lane] = 0.f; sy[lane + 64] = 0.f;
   __builtin_amdgcn_wave_barrier();
+#ifdef ABL_TIMEQ
+  if (lane == 0 && b < 4096) g_tq[2 * b] = wall_clock64();
+#endif
   const float cell = hdr->cell;
   const int dx = hdr->dim[0], dyy = hdr->dim[1], dz = hdr->dim[2];
   // cell of the query clamped into the grid: for q outside the (convex) bbox with projection q', every cloud point p
@@ -495,45 +538,27 @@ __global__ __launch_bounds__(64) void k_contact_knn_grid(const GridHdr* hdr, con
   const int kk = npts < K ? npts : K;
   // enough shells to cover the whole grid from wherever the query is
   const int rmax = max(max(max(cqx, dx - 1 - cqx), max(cqy, dyy - 1 - cqy)), max(cqz, dz - 1 - cqz));
-  // the points of a run of x-adjacent cells are contiguous in the sorted cloud
-  auto scan = [&](int p0, int p1) {
-    for (int base = p0; base < p1; base += 64) {
-      const int i = base + lane;
-      float d2 = INFINITY, py = 0.f;
-      if (i < p1) {
-        const float ex = sorted[(size_t)i * 3] - qx;
-        py = sorted[(size_t)i * 3 + 1];
-        const float ey = py - qy, ez = sorted[(size_t)i * 3 + 2] - qz;
-        d2 = ex * ex + ey * ey + ez * ez;
-      }
-      const bool take = d2 < tau;
-      const unsigned long long m = __ballot(take);
-      if (m == 0ull) continue;
-      if (take) {
-        const int pos = fill + __popcll(m & ((1ull << lane) - 1ull));
-        sd[pos] = d2;
-        sy[pos] = py;
-      }
-      fill += __popcll(m);
-      found += __popcll(m);
-      __builtin_amdgcn_wave_barrier();
-      if (fill > KNN_CAP - 64) {
-        knn_sort128(sd, sy, lane);
-        tau = sd[K - 1];
-        if (lane + K < KNN_CAP) sd[lane + K] = INFINITY;
-        if (lane + 64 + K < KNN_CAP) sd[lane + 64 + K] = INFINITY;
-        fill = K;
-        __builtin_amdgcn_wave_barrier();
-      }
+  // append the candidates closer than the current bound (wave-aggregated); keep the best K when the buffer fills up
+  auto insert = [&](float d2, float py) {
+    const bool take = d2 < tau;
+    const unsigned long long m = __ballot(take);
+    if (m == 0ull) return;
+    if (take) {
+      const int pos = fill + __popcll(m & ((1ull << lane) - 1ull));
+      sd[pos] = d2;
+      sy[pos] = py;
+    }
+    fill += __popcll(m);
+    found += __popcll(m);
+    __builtin_amdgcn_wave_barrier();
+    if (fill > KNN_CAP - 64) {
+      tau = knn_select(sd, sy, lane, K);
+      fill = K;
     }
   };
   auto tighten = [&]() {
-    knn_sort128(sd, sy, lane);
-    tau = sd[K - 1];
-    if (lane + K < KNN_CAP) sd[lane + K] = INFINITY;
-    if (lane + 64 + K < KNN_CAP) sd[lane + 64 + K] = INFINITY;
+    tau = knn_select(sd, sy, lane, K);
     fill = K;
-    __builtin_amdgcn_wave_barrier();
   };
   auto axis_gap = [&](float q, float lo, float hi) { return fmaxf(fmaxf(lo - q, q - hi), 0.f); };
   const float mnx = hdr->mn[0], mny = hdr->mn[1], mnz = hdr->mn[2];
@@ -582,48 +607,49 @@ __global__ __launch_bounds__(64) void k_contact_knn_grid(const GridHdr* hdr, con
           }
         }
       }
-      // nearest box first; stop as soon as the nearest remaining box cannot hold a better neighbour
-      for (;;) {
-        float kmin = fminf(keya, keyb);
+      // every run of this chunk of rows whose box can still hold a neighbour, flattened into one index space: the
+      // points are then gathered 64 at a time with independent loads (a run-by-run walk, even nearest-first with a
+      // tightening bound, costs a dependent L2/HBM round trip per run and is latency-bound: 54 us per query)
+      const int lenA = keya < tau ? a1 - a0 : 0, lenB = keyb < tau ? b1 - b0 : 0;
+      const int incl = mh_wave_scan_add(lenA + lenB);
+      const int P = __builtin_amdgcn_readlane(incl, 63);
+      if (P > 0) {
+        s_off[lane] = incl - (lenA + lenB);
+        if (lane == 63) s_off[64] = P;
+        s_a0[lane] = a0; s_la[lane] = lenA; s_b0[lane] = b0;
+        __builtin_amdgcn_wave_barrier();
+        for (int base = 0; base < P; base += 64) {
+          const int i = base + lane;
+          float d2 = INFINITY, py = 0.f;
+          if (i < P) {
+            int lo = 0, hi = 64;                       // largest o with s_off[o] <= i (it has a non-empty run)
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) kmin = fminf(kmin, __shfl_xor(kmin, o, 64));
-        if (!(kmin < tau)) break;
-        const unsigned long long ma = __ballot(keya == kmin);
-        int p0, p1;
-        if (ma) {
-          const int l = __ffsll((long long)ma) - 1;
-          p0 = __shfl(a0, l, 64);
-          p1 = __shfl(a1, l, 64);
-          const int lx0 = __shfl(x0, l, 64), lx1 = __shfl(x1, l, 64);
-          if (lx1 > lx0 + 1 && tau < INFINITY) {       // long run: clip to the x interval the ball can reach
-            const float w = sqrtf(fmaxf(tau - __shfl(dyz2, l, 64), 0.f));
-            const int nx0 = max(lx0, (int)floorf((qx - w - mnx) / cell)), nx1 = min(lx1, (int)floorf((qx + w - mnx) / cell));
-            if (nx0 > nx1) p1 = p0;
-            else if (nx0 != lx0 || nx1 != lx1) {
-              const int rb = __shfl(rowbase, l, 64);
-              p0 = start[rb + nx0];
-              p1 = start[rb + nx1 + 1];
+            for (int it = 0; it < 6; ++it) {
+              const int mid = (lo + hi) >> 1;
+              if (s_off[mid] <= i) lo = mid; else hi = mid;
             }
+            const int k = i - s_off[lo], la = s_la[lo];
+            const int idx = k < la ? s_a0[lo] + k : s_b0[lo] + (k - la);
+            const float ex = sorted[(size_t)idx * 3] - qx;
+            py = sorted[(size_t)idx * 3 + 1];
+            const float ey = py - qy, ez = sorted[(size_t)idx * 3 + 2] - qz;
+            d2 = ex * ex + ey * ey + ez * ez;
           }
-          if (lane == l) keya = INFINITY;
-        } else {
-          const unsigned long long mb = __ballot(keyb == kmin);
-          const int l = __ffsll((long long)mb) - 1;
-          p0 = __shfl(b0, l, 64);
-          p1 = __shfl(b1, l, 64);
-          if (lane == l) keyb = INFINITY;
+          insert(d2, py);
         }
-        const bool had = found >= kk;
-        scan(p0, p1);
-        if (found >= kk && (!had || fill >= K + 8)) tighten();
+        __builtin_amdgcn_wave_barrier();
+        if (found >= kk && fill > K) tighten();
       }
     }
     if (found >= kk && fill > K) tighten();
   }
-  knn_sort128(sd, sy, lane);
+  knn_select(sd, sy, lane, K);          // the K nearest in slots [0, K) (fewer points than K: the rest is +inf)
   float s = (lane < kk) ? sy[lane] : 0.f;
   s = mh_wave_sum(s);
   if (lane == 0) dy[b] = s / (float)kk - qy;
+#ifdef ABL_TIMEQ
+  if (lane == 0 && b < 4096) { g_tq[2 * b + 1] = wall_clock64(); g_rho[b] = found; }
+#endif
 }
 
 extern "C" int mh_contact_knn_grid(const void* grid_ws, int M, const float* low_xyz, int B, int k, float* dy, void* stream) {

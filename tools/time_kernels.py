@@ -74,6 +74,13 @@ def main():
     print('knn ms (M=%d)' % e.scene_pts.shape[0], timeit(lambda: check(L.mh_contact_knn(ptr(e.scene_pts), e.scene_pts.shape[0], ptr(e.low_xyz), e.B, 32, ptr(e.dy), st))))
     print('knn grid ms', timeit(lambda: check(L.mh_contact_knn_grid(ptr(e.scene_grid), e.scene_pts.shape[0], ptr(e.low_xyz), e.B, 32, ptr(e.dy), st))))
     print('grid build ms', timeit(lambda: e._build_scene_grid()))
+    if hasattr(L, 'mh_debug_tq'):
+        import ctypes as _c2
+        check(L.mh_contact_knn_grid(ptr(e.scene_grid), e.scene_M, ptr(e.low_xyz), e.B, 32, ptr(e.dy), st)); torch.cuda.synchronize()
+        b1 = (_c2.c_ulonglong * 8192)(); b2 = (_c2.c_int * 4096)(); L.mh_debug_tq(b1, b2)
+        tq = np.array(list(b1), dtype=np.float64).reshape(4096, 2)[:e.B]; fnd = np.array(list(b2))[:e.B]
+        dur = (tq[:, 1] - tq[:, 0]) / 100.0; t0 = tq[:, 0].min()
+        print('knn queries: dur us mean %.1f p50 %.1f p90 %.1f max %.1f; start spread %.1f us; last end %.1f; points scanned mean %.0f max %d' % (dur.mean(), np.median(dur), np.percentile(dur, 90), dur.max(), (tq[:, 0].max() - t0) / 100.0, (tq[:, 1].max() - t0) / 100.0, fnd.mean(), fnd.max()))
     e.scene_device_setup(seq['backmasks'])
     def scene_upd():
         e.scene_device_update(); e._scene_dev['stream'].synchronize()

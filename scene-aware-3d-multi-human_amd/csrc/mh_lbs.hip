@@ -640,15 +640,26 @@ __global__ __launch_bounds__(256) void k_pose_bwd(PoseBwdP p) {
   const bool valid = b < p.B, act = j < MH_NJ;
   const size_t GB = (size_t)p.G * 32;
   // 1. sum the chunk partials (fixed order)
-  for (int e = j; e < 288; e += 32) {
-    float a = 0;
-    for (int c = 0; c < p.CH; ++c) a += p.pA[((size_t)c * GB + b) * 288 + e];
-    sGA[bl][e] = a;
-  }
-  for (int e = j; e < MH_FS; e += 32) {
-    float a = 0;
-    for (int c = 0; c < p.CH; ++c) a += p.pF[((size_t)c * GB + b) * MH_FS + e];
-    sGF[bl][e] = a;
+  // chunk-outer, element-inner: the 16 loads of a chunk are independent (the element-outer form waited for one
+  // L2 round trip per addend: 160 of them in a row); the per-element summation order (chunks ascending) is unchanged
+  {
+    float aA[9], aF[7];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) aA[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) aF[i] = 0.f;
+    for (int c = 0; c < p.CH; ++c) {
+      const float* qa = p.pA + ((size_t)c * GB + b) * 288 + j;
+      const float* qf = p.pF + ((size_t)c * GB + b) * MH_FS + j;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) aA[i] += qa[32 * i];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) aF[i] += qf[32 * i];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) sGA[bl][j + 32 * i] = aA[i];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) sGF[bl][j + 32 * i] = aF[i];
   }
   if (j < 4) {
     float a = 0;

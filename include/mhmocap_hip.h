@@ -183,6 +183,12 @@ int mh_filtered_verts_term(int T, size_t E, const float* verts, const float* ver
                            const float* prev_v, const float* prev_vf, const float* next_v,
                            const float* next_vf, float coef, float* gverts, float* loss_out,
                            void* stream);
+/* the same, but gverts = coef * d loss / d v (overwrites: the caller starts its vertex-gradient buffer with this
+ * term instead of clearing it first) */
+int mh_filtered_verts_term_init(int T, size_t E, const float* verts, const float* verts_filt,
+                                const float* prev_v, const float* prev_vf, const float* next_v,
+                                const float* next_vf, float coef, float* gverts, float* loss_out,
+                                void* stream);
 
 /* ---- staging of the constant per-frame inputs (once per sequence; optimizer.py:396-409, 434) --
  * The N float {0,1} instance masks of a frame become ONE 32-bit word per pixel (bit n = person n,

@@ -329,33 +329,57 @@ extern "C" int mh_velocity_term(int T, int N, const float* pT, const float* prev
   return MH_OK;
 }
 
+// VEC = float4 (E divisible by 4: SMPL's N*6890*3 always is) or float.  OVERWRITE: gverts = term (the caller
+// initialises the vertex-gradient buffer with this term instead of clearing it first).
+template <typename VEC, bool OVERWRITE>
 __global__ __launch_bounds__(256) void k_filtered_verts(int T, size_t E, const float* v, const float* vf,
                                                         const float* pv, const float* pvf, const float* nv,
                                                         const float* nvf, float coef, float* gv, float* partial) {
   // grid = (chunks of E, T): no index division; the t-1 / t+1 rows are re-read through L2
   __shared__ float s[256];
+  constexpr int L = sizeof(VEC) / sizeof(float);
   const int t = blockIdx.y;
-  const float* vc = v + (size_t)t * E;
-  const float* fc = vf + (size_t)t * E;
-  const float* vp = t > 0 ? vc - E : pv;
-  const float* fp = t > 0 ? fc - E : pvf;
-  const float* vn = t + 1 < T ? vc + E : nv;
-  const float* fn = t + 1 < T ? fc + E : nvf;
-  float* g = gv + (size_t)t * E;
+  const size_t EV = E / L;
+  const VEC* vc = (const VEC*)(v + (size_t)t * E);
+  const VEC* fc = (const VEC*)(vf + (size_t)t * E);
+  const VEC* vp = (const VEC*)(t > 0 ? v + (size_t)(t - 1) * E : pv);
+  const VEC* fp = (const VEC*)(t > 0 ? vf + (size_t)(t - 1) * E : pvf);
+  const VEC* vn = (const VEC*)(t + 1 < T ? v + (size_t)(t + 1) * E : nv);
+  const VEC* fn = (const VEC*)(t + 1 < T ? vf + (size_t)(t + 1) * E : nvf);
+  VEC* g = (VEC*)(gv + (size_t)t * E);
   float acc = 0.f;
-  for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < E; e += (size_t)gridDim.x * 256) {
-    const float c = vc[e], cf = fc[e];
-    float gr = 0.f;
+  for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < EV; e += (size_t)gridDim.x * 256) {
+    const VEC c = vc[e], cf = fc[e];
+    float gr[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) gr[k] = 0.f;
     if (vp) {
-      const float d = (c - vp[e]) - (cf - fp[e]);
-      acc += d * d;          // the pair (t-1, t) belongs to the owner of t
-      gr += 2.f * d;
+      const VEC a = vp[e], b = fp[e];
+#pragma unroll
+      for (int k = 0; k < L; ++k) {
+        const float d = (((const float*)&c)[k] - ((const float*)&a)[k]) - (((const float*)&cf)[k] - ((const float*)&b)[k]);
+        acc += d * d;          // the pair (t-1, t) belongs to the owner of t
+        gr[k] += 2.f * d;
+      }
     }
     if (vn) {
-      const float d = (vn[e] - c) - (fn[e] - cf);
-      gr -= 2.f * d;
+      const VEC a = vn[e], b = fn[e];
+#pragma unroll
+      for (int k = 0; k < L; ++k) {
+        const float d = (((const float*)&a)[k] - ((const float*)&c)[k]) - (((const float*)&b)[k] - ((const float*)&cf)[k]);
+        gr[k] -= 2.f * d;
+      }
     }
-    g[e] += coef * gr;
+    VEC o;
+    if (OVERWRITE) {
+#pragma unroll
+      for (int k = 0; k < L; ++k) ((float*)&o)[k] = coef * gr[k];
+    } else {
+      o = g[e];
+#pragma unroll
+      for (int k = 0; k < L; ++k) ((float*)&o)[k] += coef * gr[k];
+    }
+    g[e] = o;
   }
   s[threadIdx.x] = acc;
   __syncthreads();
@@ -383,9 +407,9 @@ __global__ __launch_bounds__(256) void k_sum_partials(const float* partial, int 
 static float* g_fv_partial = nullptr;   // per-block partial sums, allocated once per process
 static size_t g_fv_cap = 0;
 
-extern "C" int mh_filtered_verts_term(int T, size_t E, const float* verts, const float* verts_filt,
-                                      const float* prev_v, const float* prev_vf, const float* next_v,
-                                      const float* next_vf, float coef, float* gverts, float* loss_out, void* stream) {
+static int filtered_verts_term(int T, size_t E, const float* verts, const float* verts_filt, const float* prev_v,
+                               const float* prev_vf, const float* next_v, const float* next_vf, float coef, float* gverts,
+                               float* loss_out, bool overwrite, void* stream) {
   MH_CHECK(verts && verts_filt && gverts && loss_out, "null argument");
   MH_CHECK(T >= 1 && E >= 1, "empty input");
   MH_CHECK((prev_v == nullptr) == (prev_vf == nullptr) && (next_v == nullptr) == (next_vf == nullptr),
@@ -397,12 +421,32 @@ extern "C" int mh_filtered_verts_term(int T, size_t E, const float* verts, const
     g_fv_cap = nblk;
   }
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_filtered_verts, dim3(FV_XBLOCKS, T), dim3(256), 0, st, T, E, verts, verts_filt, prev_v, prev_vf,
-                     next_v, next_vf, coef, gverts, g_fv_partial);
+  auto aligned = [](const void* q) { return q == nullptr || ((uintptr_t)q & 15u) == 0; };
+  const bool vec = (E % 4 == 0) && aligned(verts) && aligned(verts_filt) && aligned(prev_v) && aligned(prev_vf) && aligned(next_v) &&
+                   aligned(next_vf) && aligned(gverts);
+  const dim3 grid(FV_XBLOCKS, T), blk(256);
+#define FV_LAUNCH(VEC, OW)                                                                                              \
+  hipLaunchKernelGGL((k_filtered_verts<VEC, OW>), grid, blk, 0, st, T, E, verts, verts_filt, prev_v, prev_vf, next_v, \
+                     next_vf, coef, gverts, g_fv_partial)
+  if (vec) { if (overwrite) FV_LAUNCH(float4, true); else FV_LAUNCH(float4, false); }
+  else { if (overwrite) FV_LAUNCH(float, true); else FV_LAUNCH(float, false); }
+#undef FV_LAUNCH
   MH_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, (const float*)g_fv_partial, (int)nblk, loss_out);
   MH_LAUNCH_CHECK();
   return MH_OK;
+}
+
+extern "C" int mh_filtered_verts_term(int T, size_t E, const float* verts, const float* verts_filt,
+                                      const float* prev_v, const float* prev_vf, const float* next_v,
+                                      const float* next_vf, float coef, float* gverts, float* loss_out, void* stream) {
+  return filtered_verts_term(T, E, verts, verts_filt, prev_v, prev_vf, next_v, next_vf, coef, gverts, loss_out, false, stream);
+}
+
+extern "C" int mh_filtered_verts_term_init(int T, size_t E, const float* verts, const float* verts_filt,
+                                           const float* prev_v, const float* prev_vf, const float* next_v,
+                                           const float* next_vf, float coef, float* gverts, float* loss_out, void* stream) {
+  return filtered_verts_term(T, E, verts, verts_filt, prev_v, prev_vf, next_v, next_vf, coef, gverts, loss_out, true, stream);
 }
 
 // =============================================================================================

@@ -68,6 +68,7 @@ def lib():
         L.mh_one_euro_scan_shard.argtypes = [vp, vp, ctypes.c_int, ctypes.c_size_t] + [ctypes.c_float] * 3 + [ctypes.c_int, ctypes.c_float, vp, vp, vp, vp]
         L.mh_velocity_term.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_float, vp, vp, vp]
         L.mh_filtered_verts_term.argtypes = [ctypes.c_int, ctypes.c_size_t] + [vp] * 6 + [ctypes.c_float, vp, vp, vp]
+        L.mh_filtered_verts_term_init.argtypes = [ctypes.c_int, ctypes.c_size_t] + [vp] * 6 + [ctypes.c_float, vp, vp, vp]
         u32p = vp
         L.mh_warmup_project.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, c_float_p, c_float_p, vp,
                                         ctypes.c_float, ctypes.c_float, vp, vp, vp]

@@ -297,9 +297,14 @@ class SequenceEngine(object):
         self._finish_b(row, use_images, raster)
 
     def _finish_a(self, use_images=True, raster=None):
-        """terms that do not read the scene: 2D joints, priors, velocity, rasterised depth / silhouette"""
+        """Everything between the LBS forward and the scene-dependent part.  The vertex-gradient buffer starts as the
+        filtered-vertex term (or zero); then the rasterised terms run on the main stream while the small independent
+        terms (2D joints, priors, velocity and -- with a static scene -- contact / foot sliding) run on a second
+        stream: in the captured graph they become a parallel branch that fills the tails of the raster kernels instead
+        of ~15 serial launches of a few microseconds each."""
         L = _lib.lib()
-        st = _lib.stream_ptr(self.dev)
+        main = torch.cuda.current_stream(self.dev)
+        st = main.cuda_stream
         c = self.c
         T, N, B = self.T, self.N, self.B
         g = self.grads
@@ -308,27 +313,49 @@ class SequenceEngine(object):
         pT = self.leaf('poses_T')
         Kp = self.K.ctypes.data_as(_lib.c_float_p)
         Kdp = None if self.Kd is None else self.Kd.ctypes.data_as(_lib.c_float_p)
-        check(L.mh_project_joints_loss(B, ptr(self.kp), Kp, Kdp, ptr(self.pose2d), self.thr, 0, float(self.W),
-                                       float(self.H), float(c['proj2d']), ptr(self.uv), ptr(self.gj), ptr(self.loss2d), st))
-        check(L.mh_prior_terms(T, N, self.nbatches, ptr(self.leaf('poses_smpl')), ptr(self.poses_ref), ptr(self.valid),
-                               ptr(self.leaf('betas')), ptr(self.betas_ref), ptr(self.leaf('xscale')),
-                               float(c['reg_poses']), float(c['reg_scales']), ptr(gposes), ptr(gbetas), ptr(gxs),
-                               ptr(self.prior_body), ptr(self.loss3), st))
         h = self.halo or {}
-        check(L.mh_velocity_term(T, N, ptr(pT), ptr(h.get('pT_prev')), ptr(h.get('pT_next')), float(c['reg_velocity']),
-                                 ptr(gpT), ptr(self.vel_loss), st))
         scene = self.scene_pts is not None
         filt = self.verts_filt is not None and self.pT_filt is not None
         images = use_images and self.has_images
         need_gv = scene or filt or (images and raster is not None)
+        log = self.tmp_log
+        log.zero_()
         gv = None
         if need_gv:
             if self.gverts is None:
                 self.gverts = torch.empty_like(self.verts)
             gv = self.gverts
-            gv.zero_()
-        log = self.tmp_log
-        log.zero_()
+            if filt:
+                E = N * self.V * 3
+                ev = self._tic('filtered_verts')
+                check(L.mh_filtered_verts_term_init(T, E, ptr(self.verts), ptr(self.verts_filt), ptr(h.get('v_prev')),
+                                                    ptr(h.get('vf_prev')), ptr(h.get('v_next')), ptr(h.get('vf_next')),
+                                                    float(c['reg_verts_filter']), ptr(gv), ptr(self.filt_loss), st))
+                self._toc(ev)
+            else:
+                gv.zero_()
+        self._gv_cur = gv
+        # ---- side branch ------------------------------------------------------------------------------------------
+        if not hasattr(self, '_side'):
+            self._side = torch.cuda.Stream(device=self.dev)
+        side = self._side
+        side.wait_stream(main)
+        s2 = side.cuda_stream
+        check(L.mh_project_joints_loss(B, ptr(self.kp), Kp, Kdp, ptr(self.pose2d), self.thr, 0, float(self.W),
+                                       float(self.H), float(c['proj2d']), ptr(self.uv), ptr(self.gj), ptr(self.loss2d), s2))
+        check(L.mh_prior_terms(T, N, self.nbatches, ptr(self.leaf('poses_smpl')), ptr(self.poses_ref), ptr(self.valid),
+                               ptr(self.leaf('betas')), ptr(self.betas_ref), ptr(self.leaf('xscale')),
+                               float(c['reg_poses']), float(c['reg_scales']), ptr(gposes), ptr(gbetas), ptr(gxs),
+                               ptr(self.prior_body), ptr(self.loss3), s2))
+        check(L.mh_velocity_term(T, N, ptr(pT), ptr(h.get('pT_prev')), ptr(h.get('pT_next')), float(c['reg_velocity']),
+                                 ptr(gpT), ptr(self.vel_loss), s2))
+        check(L.mh_reduce_sum(ptr(self.loss2d), B, 1.0, ptr(log[0:1]), s2))
+        check(L.mh_reduce_sum(ptr(self.prior_body), B, 1.0, ptr(log[3:4]), s2))
+        self._scene_done = False
+        if scene and self._scene_dev is None:          # static scene: no cross-stream event to wait for
+            self._scene_terms(s2)
+            self._scene_done = True
+        # ---- main branch: rasterised depth / silhouette terms ----------------------------------------------------------
         if images:
             check(L.mh_sil_mask_stats(ptr(self.bits), T, N, self.H, self.W, ptr(pT), ptr(self.p2d_valid),
                                       ptr(self.mask_valid), ptr(self.front), ptr(self.sil_apply), ptr(self.sil_D),
@@ -341,50 +368,49 @@ class SequenceEngine(object):
                 # no rasteriser: alpha = 0, zbuf empty -> the mask-only silhouette term (tests only)
                 self.sil_body.copy_(self.sil_apply * self.sil_S / (self.sil_D + 1.0))
                 check(L.mh_reduce_sum(ptr(self.sil_body), B, 1.0, ptr(log[2:3]), st))
-        self._gv_cur = gv
+        main.wait_stream(side)
+
+    def _scene_terms(self, st):
+        """contact + in-batch foot sliding (optimizer.py:485-518) on stream st; gradients by atomics / disjoint writes"""
+        L = _lib.lib()
+        c = self.c
+        T, N, B = self.T, self.N, self.B
+        gpT = self.leaf('poses_T', self.grads)
+        gv, log = self._gv_cur, self.tmp_log
+        check(L.mh_lowest_vertex(ptr(self.verts), B, self.V, ptr(self.low_idx), ptr(self.low_xyz), st))
+        check(L.mh_contact_knn_grid(ptr(self.scene_grid), self.scene_M, ptr(self.low_xyz), B, 32, ptr(self.dy), st))
+        check(L.mh_contact_foot_terms(T, N, self.V, self.batch, ptr(self.verts), ptr(self.low_idx), ptr(self.low_xyz),
+                                      ptr(self.dy), float(c['reg_contact']), float(c['reg_foot_sliding']), ptr(gpT),
+                                      ptr(gv), ptr(self.batch_contact), ptr(self.batch_foot), st))
+        check(L.mh_reduce_sum(ptr(self.batch_contact), self.nbatches, 1.0, ptr(log[5:6]), st))
+        check(L.mh_reduce_sum(ptr(self.batch_foot), self.nbatches, 1.0, ptr(log[6:7]), st))
 
     def _finish_b(self, row, use_images=True, raster=None):
-        """contact / foot sliding (read the scene cloud), filtered-vertex term, LBS backward, log row"""
+        """scene terms when the cloud is rebuilt on the device every cycle (they wait for its event), LBS backward,
+        log row"""
         L = _lib.lib()
         st = _lib.stream_ptr(self.dev)
-        c = self.c
         T, N, B = self.T, self.N, self.B
         g = self.grads
         gpT, gposes = self.leaf('poses_T', g), self.leaf('poses_smpl', g)
         gbetas, gxs = self.leaf('betas', g), self.leaf('xscale', g)
         pT = self.leaf('poses_T')
-        h = self.halo or {}
-        scene = self.scene_pts is not None
         filt = self.verts_filt is not None and self.pT_filt is not None
         gv, log = self._gv_cur, self.tmp_log
-        if scene:
+        if self.scene_pts is not None and not self._scene_done:
             ev = self._tic('scene_terms')
-            check(L.mh_lowest_vertex(ptr(self.verts), B, self.V, ptr(self.low_idx), ptr(self.low_xyz), st))
             if self._scene_pending:              # the scene of the previous cycle is built on its own stream
                 torch.cuda.current_stream(self.dev).wait_event(self._scene_event)
                 self._scene_pending = False
-            check(L.mh_contact_knn_grid(ptr(self.scene_grid), self.scene_M, ptr(self.low_xyz), B, 32, ptr(self.dy), st))
-            check(L.mh_contact_foot_terms(T, N, self.V, self.batch, ptr(self.verts), ptr(self.low_idx), ptr(self.low_xyz),
-                                          ptr(self.dy), float(c['reg_contact']), float(c['reg_foot_sliding']), ptr(gpT),
-                                          ptr(gv), ptr(self.batch_contact), ptr(self.batch_foot), st))
-            check(L.mh_reduce_sum(ptr(self.batch_contact), self.nbatches, 1.0, ptr(log[5:6]), st))
-            check(L.mh_reduce_sum(ptr(self.batch_foot), self.nbatches, 1.0, ptr(log[6:7]), st))
+            self._scene_terms(st)
             self._toc(ev)
-        if filt:
-            E = N * self.V * 3
-            ev = self._tic('filtered_verts')
-            check(L.mh_filtered_verts_term(T, E, ptr(self.verts), ptr(self.verts_filt), ptr(h.get('v_prev')),
-                                           ptr(h.get('vf_prev')), ptr(h.get('v_next')), ptr(h.get('vf_next')),
-                                           float(c['reg_verts_filter']), ptr(gv), ptr(self.filt_loss), st))
-            self._toc(ev)
-            log[8:9].copy_(self.filt_loss)
         ev = self._tic('lbs_backward')
         check(L.mh_lbs_backward(self.m.handle, B, N, ptr(self.leaf('betas')), ptr(self.leaf('poses_smpl')),
                                 ptr(self.leaf('xscale')), ptr(pT), ptr(self.vposed), ptr(gv), ptr(self.gj), ptr(gposes),
                                 ptr(gpT), ptr(gbetas), ptr(gxs), ptr(self.ws), ptr(self.ws2), st))
         self._toc(ev)
-        check(L.mh_reduce_sum(ptr(self.loss2d), B, 1.0, ptr(log[0:1]), st))
-        check(L.mh_reduce_sum(ptr(self.prior_body), B, 1.0, ptr(log[3:4]), st))
+        if filt:
+            log[8:9].copy_(self.filt_loss)
         log[9:12].copy_(self.loss3)
         log[7:8].copy_(self.vel_loss)
         if row is not None:

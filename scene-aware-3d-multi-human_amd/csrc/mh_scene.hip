@@ -379,32 +379,30 @@ __global__ void k_grid_count(const float* pts, const GridHdr* hdr, int* counts, 
   atomicAdd(&counts[c], 1);
 }
 
-// exclusive scan of counts[0..ncells] in place (single block), also resets the fill cursors
+// exclusive scan of counts[0..ncells] in place (single block), also resets the fill cursors: DPP scan inside the
+// waves, one LDS hop for the 16 wave totals
 __global__ __launch_bounds__(1024) void k_grid_scan(const GridHdr* hdr, int* counts, int* cursor) {
-  __shared__ int s[1024];
+  __shared__ int swave[16];
   __shared__ int carry;
-  const int nc = hdr->ncells;
+  const int nc = hdr->ncells, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) carry = 0;
   __syncthreads();
   for (int base = 0; base < nc; base += 1024) {
     const int i = base + threadIdx.x;
     const int v = i < nc ? counts[i] : 0;
-    s[threadIdx.x] = v;
+    const int incl = mh_wave_scan_add(v);
+    if (lane == 63) swave[wave] = incl;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-      int a = 0;
-      if ((int)threadIdx.x >= o) a = s[threadIdx.x - o];
-      __syncthreads();
-      s[threadIdx.x] += a;
-      __syncthreads();
-    }
+    int woff = carry;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) woff += (w < wave) ? swave[w] : 0;
     if (i < nc) {
-      const int start = carry + s[threadIdx.x] - v;
+      const int start = woff + incl - v;
       counts[i] = start;
       cursor[i] = start;
     }
     __syncthreads();
-    if (threadIdx.x == 1023) carry += s[1023];
+    if (threadIdx.x == 1023) carry = woff + incl;
     __syncthreads();
   }
   if (threadIdx.x == 0) counts[nc] = carry;

@@ -83,6 +83,7 @@ def lib():
         L.mh_scene_workspace_bytes.restype = ctypes.c_size_t
         L.mh_scene_workspace_bytes.argtypes = [ctypes.c_int] * 3
         L.mh_scene_median.argtypes = [ctypes.c_int] * 3 + [vp] * 8
+        L.mh_scene_median_t.argtypes = [ctypes.c_int] * 3 + [vp] * 8
         L.mh_scene_postprocess.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp]
         L.mh_scene_points.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp]
         L.mh_profile_enable.argtypes = [ctypes.c_int]

@@ -202,6 +202,9 @@ class SequenceEngine(object):
         d = {}
         d['back'] = torch.as_tensor(np.ascontiguousarray((np.asarray(backmasks) != 0).astype(np.uint8))).to(self.dev)
         d['ws'] = torch.empty(L.mh_scene_workspace_bytes(T, H, W), dtype=torch.uint8, device=self.dev)
+        if T <= 512:      # pixel-major copies of the constant inputs for the register form of the median
+            d['depths_t'] = self.depths.view(T, P).t().contiguous()
+            d['back_t'] = d['back'].view(T, P).t().contiguous()
         d['ma_depth'] = torch.zeros(H, W, device=self.dev)
         d['ma_mask'] = torch.zeros(H, W, device=self.dev)
         d['depth'] = torch.zeros(H, W, device=self.dev)
@@ -228,8 +231,12 @@ class SequenceEngine(object):
         side = d['stream']
         side.wait_event(d['ev_main'])
         st = side.cuda_stream
-        check(L.mh_scene_median(T, H, W, ptr(self.depths), ptr(d['back']), ptr(s['zsnap'][:T]), ptr(s['zsnap'][T:]),
-                                ptr(d['ma_depth']), ptr(d['ma_mask']), ptr(d['ws']), st))
+        if 'depths_t' in d:
+            check(L.mh_scene_median_t(T, H, W, ptr(d['depths_t']), ptr(d['back_t']), ptr(s['zsnap'][:T]), ptr(s['zsnap'][T:]),
+                                      ptr(d['ma_depth']), ptr(d['ma_mask']), ptr(d['ws']), st))
+        else:
+            check(L.mh_scene_median(T, H, W, ptr(self.depths), ptr(d['back']), ptr(s['zsnap'][:T]), ptr(s['zsnap'][T:]),
+                                    ptr(d['ma_depth']), ptr(d['ma_mask']), ptr(d['ws']), st))
         check(L.mh_scene_postprocess(H, W, ptr(d['ma_depth']), ptr(d['ma_mask']), 1, 7, ptr(d['depth']), ptr(d['ws']), st))
         check(L.mh_scene_points(H, W, self.K.ctypes.data_as(_lib.c_float_p), ptr(d['depth']), ptr(d['ma_mask']), ptr(s['pts']),
                                 ptr(s['count']), st))

@@ -48,6 +48,14 @@ def test_masked_median_over_time(T, H, W):
     got = md.cpu().numpy()
     np.testing.assert_allclose(got[want_mask], want[want_mask], rtol=3e-6)
     assert (got[~want_mask] == 0).all()
+    # pixel-major form (one wave per pixel, ballots)
+    md2, mm2 = torch.empty(H, W, device=dev), torch.empty(H, W, device=dev)
+    tdn_t, tback_t = tdn.view(T, H * W).t().contiguous(), tback.view(T, H * W).t().contiguous()
+    _l.check(L.mh_scene_median_t(T, H, W, _l.ptr(tdn_t), _l.ptr(tback_t), _l.ptr(tzmin), _l.ptr(tzmax), _l.ptr(md2), _l.ptr(mm2),
+                                 _l.ptr(ws), _l.stream_ptr(dev)))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(mm2.cpu().numpy(), mm.cpu().numpy())
+    np.testing.assert_array_equal(md2.cpu().numpy(), got)
 
 
 def _scene(H, W, seed):

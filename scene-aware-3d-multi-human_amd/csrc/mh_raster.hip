@@ -454,8 +454,11 @@ __device__ __forceinline__ unsigned r_face_rows(const RasterP& p, const float* n
   if (fminf(z[0], fminf(z[1], z[2])) >= R_KEPS && !(farea <= R_KEPS && farea >= -R_KEPS)) {
     const float blur_d = sqrtf(BLUR_D);
     const float bymin = fminf(y[0], fminf(y[1], y[2])) - blur_d, bymax = fmaxf(y[0], fmaxf(y[1], y[2])) + blur_d;
-    const float lo = floorf(r_ndc_to_pix(bymax, p.H, p.W)) - 1.f, hi = ceilf(r_ndc_to_pix(bymin, p.H, p.W)) + 1.f;
-    if (hi >= 0.f && lo <= (float)(p.H - 1)) {
+    // rows whose pixel centre lies inside the blurred bbox: r_ndc_to_pix is the continuous row coordinate (centres at
+    // the integers), 1e-3 px absorbs its rounding (~1e-5 px).  A tight range matters: the tallest face of a body sets
+    // how far above a tile its candidate range starts
+    const float lo = ceilf(r_ndc_to_pix(bymax, p.H, p.W) - 1e-3f), hi = floorf(r_ndc_to_pix(bymin, p.H, p.W) + 1e-3f);
+    if (hi >= lo && hi >= 0.f && lo <= (float)(p.H - 1)) {
       const unsigned ulo = (unsigned)fmaxf(lo, 0.f), uhi = (unsigned)fminf(hi, (float)(p.H - 1));
       out = ulo | (uhi << 16) | (farea > 0.f ? 0x8000u : 0u);
     }

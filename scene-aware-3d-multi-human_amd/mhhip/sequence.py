@@ -481,10 +481,23 @@ class SequenceEngine(object):
                                              _lib.stream_ptr(self.dev)))
 
     # -- filters (optimizer.py:383-392) -------------------------------------------------------------
+    def set_filters(self, pT_filt, verts_filt):
+        """Install new filtered trajectories.  The buffers keep their addresses from the first call on: captured
+        cycle graphs read them."""
+        verts_filt = verts_filt.view(self.T, self.N, self.V, 3)
+        if self.pT_filt is None or self.pT_filt.shape != pT_filt.shape:
+            self.pT_filt = pT_filt.clone()
+        else:
+            self.pT_filt.copy_(pT_filt)
+        if self.verts_filt is None or self.verts_filt.shape != verts_filt.shape:
+            self.verts_filt = verts_filt.clone()
+        else:
+            self.verts_filt.copy_(verts_filt)
+
     def update_filters(self, c1=0.01, b1=0.02, c2=0.001, b2=0.5):
-        self.pT_filt = engine.one_euro_scan(self.leaf('poses_T'), c1, b1)
+        pf = engine.one_euro_scan(self.leaf('poses_T'), c1, b1)
         self.forward()
-        self.verts_filt = engine.one_euro_scan(self.verts.view(self.T, -1), c2, b2).view(self.T, self.N, self.V, 3)
+        self.set_filters(pf, engine.one_euro_scan(self.verts.view(self.T, -1), c2, b2))
 
     def one_euro_shard(self, x, min_cutoff, beta, first_frame, state_in=None):
         return engine.one_euro_scan_shard(x, min_cutoff, beta, first_frame, state_in)

@@ -127,9 +127,13 @@ class ShardedSequence(object):
 
     def update_filters(self, c1=0.01, b1=0.02, c2=0.001, b2=0.5):
         e = self.e
-        e.pT_filt = self._scan(e.leaf('poses_T'), c1, b1)
+        pf = self._scan(e.leaf('poses_T'), c1, b1)
         e.forward()
-        e.verts_filt = self._scan(e.verts.view(e.T, -1), c2, b2).view(e.verts.shape[0] // e.N, e.N, -1, 3)
+        vf = self._scan(e.verts.view(e.T, -1), c2, b2).view(e.verts.shape[0] // e.N, e.N, -1, 3)
+        if hasattr(e, 'set_filters'):
+            e.set_filters(pf, vf)            # fixed addresses: the captured cycle graphs read these buffers
+        else:
+            e.pT_filt, e.verts_filt = pf, vf
         a, b = self._gather_boundaries(e.verts_filt.view(e.T, -1))
         self._vf_halo = (self._static('vf_prev', a), self._static('vf_next', b))
 

@@ -75,6 +75,7 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
                  reg_contact_coef=1.0, reg_foot_sliding_coef=1.0, joint_confidence_thr=0.5, eps=1e-3, **kargs):
         self.use_rasteriser = kargs.pop('use_rasteriser', True)
         self.scene_update = kargs.pop('scene_update', 'device')      # 'device' | 'host' (numpy, like the reference) | 'none'
+        self.use_graphs = kargs.pop('use_graphs', True)              # replay each cycle as a captured hipGraph
         super().__init__(**kargs)
         if focal_length is None:
             focal_length = get_focal(min(image_size), fov)
@@ -243,6 +244,8 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
             from mhhip import raster as _raster
             raster = _raster.RasterTerms(e, self.znear, self.zfar)
         lr = 0.01
+        if self.use_graphs and hasattr(e, 'lr_dev'):
+            e.lr_dev.fill_(lr)                                                # a new RMSprop + ExponentialLR per fit (:355-356)
         cycles = range(num_iter)
         if verbose and tqdm is not None:
             cycles = tqdm(cycles)
@@ -258,14 +261,20 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
                 if e._scene_dev is None:
                     e.scene_device_setup(self._backmasks)
                 e.scene_device_update()
-            e.cycle(cycle, raster=raster)
+            if self.use_graphs:
+                e.cycle_graphed(cycle, raster=raster)
+            else:
+                e.cycle(cycle, raster=raster)
             if scene_now and self.scene_update == 'host':
                 self._host_scene_update()
             elif scene_now and self.scene_update == 'device':
                 e.scene_device_swap()
             if not self.optim_scale_factor:
                 e.leaf('xscale', e.grads).zero_()
-            e.step(lr)                                                        # RMSprop(lr=.01, alpha=.5, momentum=.9) :355
+            if self.use_graphs:
+                e.step_dev()                                                  # the same update with lr and its decay on the device
+            else:
+                e.step(lr)                                                    # RMSprop(lr=.01, alpha=.5, momentum=.9) :355
             lr *= 0.99                                                        # ExponentialLR(0.99) :356
         self._finish_scene()
         return e.read_log(num_iter)

@@ -105,3 +105,33 @@ def test_fit_three_cycles_all_terms(smpl_struct, smpl_regs, oracle_model, tmp_pa
     np.testing.assert_allclose(ov['betas_smpl'], wv['betas_smpl'], atol=2e-3)
     np.testing.assert_allclose(ov['min_z'], wv['min_z'], atol=2e-3)
     np.testing.assert_allclose(ov['max_z'], wv['max_z'], atol=2e-3)
+
+
+def test_graph_replay_matches_eager_across_filter_updates(smpl_struct, smpl_regs, oracle_model, tmp_path):
+    """captured cycle graphs read the filter buffers by address: a second filter update must reach the replays"""
+    T, N, W, H, batch = 4, 2, 120, 68, 2
+    from mhhip.raster import RasterTerms
+    runs = []
+    for graphs in (False, True):
+        opt, dl, o, batches, seq = _setup(smpl_struct, smpl_regs, oracle_model, tmp_path, T, N, W, H, batch, 31, True)
+        opt._stage_from_dataloader(dl)
+        e = opt.engine
+        raster = RasterTerms(e)
+        for c in range(6):
+            if c in (1, 3):
+                e.update_filters()
+            if graphs:
+                e.cycle_graphed(c, raster=raster)
+                e.step_dev()
+            else:
+                e.cycle(c, raster=raster)
+                e.step(0.01 * 0.99 ** c)
+        torch.cuda.synchronize()
+        runs.append((e.params.cpu().numpy().copy(), e.grads.cpu().numpy().copy(), e.read_log(6)))
+    (p0, g0, l0), (p1, g1, l1) = runs
+    np.testing.assert_allclose(p1, p0, atol=2e-4 * np.abs(p0).max())
+    np.testing.assert_allclose(g1, g0, atol=2e-3 * np.abs(g0).max())
+    for c in range(6):
+        for k in l0[c]:
+            np.testing.assert_allclose(l1[c][k], l0[c][k], rtol=2e-3, atol=1e-6, err_msg='%s cycle %d' % (k, c))
+    assert l0[4]['reg_filter_verts'] > 0

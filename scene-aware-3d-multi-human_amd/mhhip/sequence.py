@@ -432,8 +432,12 @@ class SequenceEngine(object):
     # change between replays: the log row goes through a staging row, the learning rate lives on the
     # device.  Capture is per configuration (raster / scene / filters on or off).
     def _graph_key(self, raster):
-        return (raster is not None, self.scene_pts is not None and id(self.scene_pts),
-                self.verts_filt is not None and self.pT_filt is not None, self.halo is None)
+        # device addresses and the by-value sizes a capture bakes in (an address recycled by the allocator with the same
+        # sizes replays correctly: the kernels read whatever is there now)
+        scene = None
+        if self.scene_pts is not None:
+            scene = (self.scene_pts.data_ptr(), self.scene_grid.data_ptr(), self.scene_M)
+        return (raster is not None, scene, self.verts_filt is not None and self.pT_filt is not None, self.halo is None)
 
     def replay(self, key, fn, wait_scene=True):
         """Run ``fn`` (a fixed launch sequence on static buffers) through a captured graph; the first

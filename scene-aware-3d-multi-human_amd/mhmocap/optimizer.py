@@ -261,9 +261,9 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
                 if e._scene_dev is None:
                     e.scene_device_setup(self._backmasks)
                 e.scene_device_update()
-            if self.use_graphs:
+            if self.use_graphs and not (scene_now and self.scene_update == 'host'):
                 e.cycle_graphed(cycle, raster=raster)
-            else:
+            else:                                     # the host scene path hands over a new cloud every cycle: no replay
                 e.cycle(cycle, raster=raster)
             if scene_now and self.scene_update == 'host':
                 self._host_scene_update()

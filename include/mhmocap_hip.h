@@ -272,6 +272,10 @@ int mh_scene_median_t(int T, int H, int W, const float* depths_t /*(H*W,T)*/, co
                       const float* zmin_lin, const float* zmax_lin, float* ma_depth, float* ma_mask, void* ws, void* stream);
 int mh_scene_postprocess(int H, int W, const float* ma_depth, const float* ma_mask, int use_bilateral, int fillin_ksize,
                          float* scene_depth /*(H,W)*/, void* ws, void* stream);
+/* utils.py:91-135 looped until no masked pixel is left (optimizer.py:595-600 uses it with ksize 11 on the colour median):
+ * values / mask (H,W) are updated in place; truncate != 0 stores floor(median) (integer-valued planes).
+ * mh_scene_median_t with zmin_lin = zmax_lin = NULL takes the median of the raw (non-negative) values. */
+int mh_scene_fill(int H, int W, int ksize, int truncate, float* values, float* mask, void* ws, void* stream);
 int mh_scene_points(int H, int W, const float* K_host, const float* scene_depth, const float* mask, float* points,
                     int* count_dev, void* stream);
 

@@ -92,9 +92,13 @@ __global__ __launch_bounds__(256) void k_scene_median_t(int T, int P, const floa
     const int t = j * 64 + lane;
     v[j] = SM_INVALID;
     if (t < T && bp[t] != 0) {
-      const float inv_min = invz[2 * t], inv_max = invz[2 * t + 1];
-      const float disp = dp[t] * (inv_min - inv_max) + inv_max;      // optimizer.py:425
-      v[j] = __float_as_uint(1.0f / disp);                           // :426
+      if (invz) {
+        const float inv_min = invz[2 * t], inv_max = invz[2 * t + 1];
+        const float disp = dp[t] * (inv_min - inv_max) + inv_max;      // optimizer.py:425
+        v[j] = __float_as_uint(1.0f / disp);                           // :426
+      } else {
+        v[j] = __float_as_uint(dp[t]);                                 // raw non-negative values (colour planes)
+      }
     }
     n += __popcll(__ballot(v[j] != SM_INVALID));
   }
@@ -232,8 +236,8 @@ __global__ void k_scene_edges(int H, int W, const float* grad, const float* ma_m
 // window from the values of the valid pixels only (so a sweep is a pure function of the previous state), then the
 // updates are applied together.  Ends when the list is empty (or nothing can be filled any more).
 #define FILL_TH 1024
-__global__ __launch_bounds__(FILL_TH) void k_scene_fill(int H, int W, int ksize, float* depth, float* mask, int* list_a, int* list_b,
-                                                        float* upd) {
+__global__ __launch_bounds__(FILL_TH) void k_scene_fill(int H, int W, int ksize, int truncate, float* depth, float* mask, int* list_a,
+                                                        int* list_b, float* upd) {
   __shared__ int s_cnt, s_next, s_filled;
   const int tid = threadIdx.x, P = H * W, k = ksize / 2;
   if (tid == 0) s_cnt = 0;
@@ -264,7 +268,8 @@ __global__ __launch_bounds__(FILL_TH) void k_scene_fill(int H, int W, int ksize,
             v[j] = val;
           }
       if (c > 0) {
-        upd[i] = (c & 1) ? v[c >> 1] : (v[(c >> 1) - 1] + v[c >> 1]) / 2.f;
+        const float med = (c & 1) ? v[c >> 1] : (v[(c >> 1) - 1] + v[c >> 1]) / 2.f;
+        upd[i] = truncate ? floorf(med) : med;      // integer-valued planes (colour): the reference stores into uint8
         atomicAdd(&s_filled, 1);
       } else {
         upd[i] = -1.f;
@@ -382,16 +387,19 @@ extern "C" int mh_scene_median(int T, int H, int W, const float* depths, const u
 
 extern "C" int mh_scene_median_t(int T, int H, int W, const float* depths_t, const uint8_t* backmask_t, const float* zmin_lin,
                                  const float* zmax_lin, float* ma_depth, float* ma_mask, void* ws, void* stream) {
-  MH_CHECK(depths_t && backmask_t && zmin_lin && zmax_lin && ma_depth && ma_mask && ws, "null argument");
+  MH_CHECK(depths_t && backmask_t && ma_depth && ma_mask && ws, "null argument");
+  MH_CHECK((zmin_lin == nullptr) == (zmax_lin == nullptr), "depth-range leaves come in pairs (both NULL: median of the raw values)");
   MH_CHECK(T > 0 && H > 0 && W > 0, "empty input");
   MH_CHECK(T <= 64 * SMT_NV, "sequence too long for the register form: use mh_scene_median");
   const int P = H * W;
   SceneWs s = scene_carve(ws, P);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_scene_ranges, dim3((T + 127) / 128), dim3(128), 0, st, T, zmin_lin, zmax_lin, s.invz);
-  MH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_scene_median_t, dim3((P + 3) / 4), dim3(256), 0, st, T, P, depths_t, backmask_t, (const float*)s.invz, ma_depth,
-                     ma_mask);
+  if (zmin_lin) {
+    hipLaunchKernelGGL(k_scene_ranges, dim3((T + 127) / 128), dim3(128), 0, st, T, zmin_lin, zmax_lin, s.invz);
+    MH_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_scene_median_t, dim3((P + 3) / 4), dim3(256), 0, st, T, P, depths_t, backmask_t,
+                     zmin_lin ? (const float*)s.invz : (const float*)nullptr, ma_depth, ma_mask);
   MH_LAUNCH_CHECK();
   return MH_OK;
 }
@@ -419,9 +427,20 @@ extern "C" int mh_scene_postprocess(int H, int W, const float* ma_depth, const f
   MH_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_scene_edges, g256, b256, 0, st, H, W, (const float*)s.grad, ma_mask, (const double*)s.stats, s.dmask);
   MH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_scene_fill, dim3(1), dim3(FILL_TH), 0, st, H, W, fillin_ksize, s.depth1, s.dmask, s.list_a, s.list_b, s.upd);
+  hipLaunchKernelGGL(k_scene_fill, dim3(1), dim3(FILL_TH), 0, st, H, W, fillin_ksize, 0, s.depth1, s.dmask, s.list_a, s.list_b, s.upd);
   MH_LAUNCH_CHECK();
   MH_HIP(hipMemcpyAsync(scene_depth, s.depth1, (size_t)P * 4, hipMemcpyDeviceToDevice, st));
+  return MH_OK;
+}
+
+extern "C" int mh_scene_fill(int H, int W, int ksize, int truncate, float* values, float* mask, void* ws, void* stream) {
+  MH_CHECK(values && mask && ws, "null argument");
+  MH_CHECK(H > 0 && W > 0, "empty image");
+  MH_CHECK(ksize > 1 && ksize <= 11, "fill-in window must be 2..11");
+  SceneWs s = scene_carve(ws, H * W);
+  hipLaunchKernelGGL(k_scene_fill, dim3(1), dim3(FILL_TH), 0, (hipStream_t)stream, H, W, ksize, truncate, values, mask, s.list_a, s.list_b,
+                     s.upd);
+  MH_LAUNCH_CHECK();
   return MH_OK;
 }
 

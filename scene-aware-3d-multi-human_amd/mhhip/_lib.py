@@ -85,6 +85,7 @@ def lib():
         L.mh_scene_median.argtypes = [ctypes.c_int] * 3 + [vp] * 8
         L.mh_scene_median_t.argtypes = [ctypes.c_int] * 3 + [vp] * 8
         L.mh_scene_postprocess.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp]
+        L.mh_scene_fill.argtypes = [ctypes.c_int] * 4 + [vp] * 4
         L.mh_scene_points.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp]
         L.mh_profile_enable.argtypes = [ctypes.c_int]
         L.mh_profile_read.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_float)]

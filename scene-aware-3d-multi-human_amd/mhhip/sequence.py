@@ -259,6 +259,28 @@ class SequenceEngine(object):
         self._scene_event = s['ev']
         self._scene_pending = True
 
+    def scene_device_image(self, images):
+        """images (T,H,W,3) uint8 -> (H,W,3) uint8 masked median over time of the background colour, holes filled with
+        the 11x11 median like optimizer.py:595-600 (the colour median does not depend on the optimised variables: once
+        per fit).  Returns (scene_img, scene_mask)."""
+        d, L = self._scene_dev, _lib.lib()
+        T, H, W = self.T, self.H, self.W
+        P = H * W
+        st = _lib.stream_ptr(self.dev)
+        img = torch.as_tensor(np.ascontiguousarray(images)).to(self.dev)
+        back_t = d['back_t'] if 'back_t' in d else d['back'].view(T, P).t().contiguous()
+        out = torch.empty(H, W, 3, device=self.dev)
+        mask = torch.empty(H, W, device=self.dev)
+        for ch in range(3):
+            plane_t = img[..., ch].reshape(T, P).t().contiguous().float()
+            val = torch.empty(H, W, device=self.dev)
+            check(L.mh_scene_median_t(T, H, W, ptr(plane_t), ptr(back_t), None, None, ptr(val), ptr(mask), ptr(d['ws']), st))
+            val.floor_()                                        # .astype(np.uint8) of the reference
+            m = mask.clone()
+            check(L.mh_scene_fill(H, W, 11, 1, ptr(val), ptr(m), ptr(d['ws']), st))
+            out[..., ch] = val
+        return out.clamp_(0, 255).to(torch.uint8).cpu().numpy(), m.cpu().numpy()
+
     def scene_device_result(self):
         """(scene_depth (H,W), ma_mask (H,W) bool, points (M,3)) of the last device update, on the host."""
         d = self._scene_dev

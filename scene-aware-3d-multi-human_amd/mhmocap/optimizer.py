@@ -294,10 +294,14 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
             from . import scene_host
             self.scene_depth, ma_mask, pts = e.scene_device_result()
             self.scene_pcd = pts.unsqueeze(0).unsqueeze(0)
-            ma_image = None
-            if self._images is not None:          # the colour median does not depend on the optimised variables: once
+            self._ma = None
+            if self._images is not None and self.num_frames <= 512:
+                # colour median + 11x11 fill on the device (independent of the optimised variables: once per fit)
+                self.scene_img, self.scene_mask = e.scene_device_image(self._images)
+                return
+            if self._images is not None:
                 ma_image = scene_host.aggregate_scene_median(None, self._images, self._backmasks, images_only=True)[0]
-            self._ma = (ma_image, ma_mask)
+                self._ma = (ma_image, ma_mask)
         if getattr(self, '_ma', None) is None or self._ma[0] is None:
             return
         from . import scene_host

@@ -160,3 +160,25 @@ def test_fit_builds_the_scene_on_the_device(smpl_struct, smpl_regs, tmp_path):
     assert all(np.isfinite(float(v)) for row in log for v in row.values())
     assert log[29]['reg_contact'] == 0 and log[33]['reg_contact'] > 0
     assert opt.scene_depth.shape == (68, 120) and opt.scene_pcd.shape[2] > 1000 and opt.scene_img is not None
+
+
+def test_scene_image_median_and_fill_on_the_device(smpl_struct, smpl_regs, tmp_path):
+    """optimizer.py:595-600: colour median over time (background pixels only) + looped 11x11 median fill of the holes"""
+    from mhmocap import scene_host
+    opt, _ = _fit(smpl_struct, smpl_regs, tmp_path, 'none', 1)
+    e = opt.engine
+    T, H, W = e.T, e.H, e.W
+    rng = np.random.RandomState(4)
+    images = rng.randint(0, 256, (T, H, W, 3)).astype(np.uint8)
+    back = (rng.uniform(0, 1, (T, H, W)) > 0.5).astype(np.int64)
+    back[:, 20:44, 30:52] = 0                                         # a region no frame sees: filled in
+    back[:, 0:3, 0:3] = 0
+    want_img, _, _ = scene_host.aggregate_scene_median(None, images, back, images_only=True)
+    want_mask = (back.max(axis=0) > 0).astype(np.float32)
+    while want_mask.min() == 0:
+        want_img, want_mask = scene_host.fillin_values(want_img, want_mask, filter_size=11)
+    e.scene_device_setup(back)
+    got_img, got_mask = e.scene_device_image(images)
+    assert got_img.dtype == np.uint8 and got_img.shape == (H, W, 3)
+    np.testing.assert_array_equal(got_mask, np.ones((H, W), np.float32))
+    np.testing.assert_array_equal(got_img, want_img)

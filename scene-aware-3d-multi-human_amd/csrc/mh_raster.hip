@@ -79,6 +79,7 @@ struct RasterP {
   int* gunit_p0;             // [max_units] first window pixel of the unit
   int* gunit_total;          // [1]
   int* strip_order;          // [max_strips] tiles by decreasing candidate-face count (longest first)
+  float* sil_corr;           // [B] sum over the silhouette pixels of alpha^2 - 2 alpha seg (accumulated by k_raster_grads)
 };
 
 __device__ __forceinline__ float r_pix_to_ndc(int i, int S1, int S2) {
@@ -186,8 +187,7 @@ __device__ __forceinline__ float r_block_sum(float v, float* sh) {
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
   __syncthreads();
   float a = 0.f;
-#pragma unroll
-  for (int w = 0; w < RB / 64; ++w) a += sh[w];
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) a += sh[w];
   return a;
 }
 
@@ -556,6 +556,47 @@ extern "C" int mh_debug_tb(unsigned long long* out) { return (int)hipMemcpyFromS
 __device__ unsigned long long g_cnt[8];
 extern "C" int mh_debug_counters(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cnt), sizeof(g_cnt)); }
 #endif
+// depth-term sums of one tile straight from its LDS key window (optimizer.py:432-442): only the nearest key of a pixel is
+// needed -- no face gathers -- so this rides in the epilogue of k_raster_strip; the silhouette sum needs alpha and is taken
+// where alpha is evaluated anyway (k_raster_grads; k_raster_sums when no gradients are requested)
+__device__ __forceinline__ void r_tile_depth_sums(const RasterP& p, int s, int b, const unsigned long long* keys, int tw, int x0, int sy0,
+                                                  int npx, float* sh) {
+  const int tid = threadIdx.x;
+  const int W = p.W, P = p.H * W;
+  const int t = b / p.N, n = b % p.N;
+  const float min_z = logf(1.f + expf(p.zmin_lin[t]));                    // optimizer.py:683-688
+  const float max_z = min_z + 1.f + logf(1.f + expf(p.zmax_lin[t]));
+  const float inv_min = 1.f / min_z, inv_max = 1.f / max_z, dspan = inv_min - inv_max;
+  const float pvalid = p.p2d_valid[b];
+  float lA = 0.f, lB = 0.f, lC = 0.f, lS1 = 0.f, lS2 = 0.f;
+  for (int i = tid; i < npx; i += RB) {
+    const unsigned long long k0 = keys[(size_t)i * 5];
+    if (k0 == RS_EMPTY) continue;
+    const int yi = sy0 + i / tw, xi = x0 + i % tw;
+    const size_t gp = (size_t)t * P + (size_t)yi * W + xi;
+    const float z = __uint_as_float((unsigned)(k0 >> 32));
+    const float m = (z > 0.f ? 1.f : 0.f) * (float)((p.ebits[gp] >> n) & 1u) * pvalid;     // :432-438
+    if (m != 0.f) {
+      const float pred = 1.f / fmaxf(z + 0.2f, p.eps);                                    // :440
+      const float dh = p.depths[gp];
+      const float tg = dh * dspan + inv_max;                                              // :425
+      lA += logf(fmaxf(pred, 1e-3f));
+      lB += logf(fmaxf(tg, 1e-3f));
+      lC += 1.f;
+      if (tg >= 1e-3f) {
+        lS1 += dh / tg;
+        lS2 += (1.f - dh) / tg;
+      }
+    }
+  }
+  lA = r_block_sum(lA, sh); lB = r_block_sum(lB, sh); lC = r_block_sum(lC, sh);
+  lS1 = r_block_sum(lS1, sh); lS2 = r_block_sum(lS2, sh);
+  if (tid == 0) {
+    float* o = p.partial + (size_t)s * 6;
+    o[0] = lA; o[1] = lB; o[2] = lC; o[3] = lS1; o[4] = lS2; o[5] = 0.f;
+  }
+}
+
 // Longest-processing-time-first order of the tiles: a tile's cost is its candidate-face count (known once the faces
 // are sorted by row).  Counting sort into 64 cost classes, most expensive first; without it the last tiles to start
 // were often among the most expensive and the kernel ended ~40 % later than its work divided by the CU count.
@@ -591,7 +632,7 @@ __global__ __launch_bounds__(1024) void k_raster_strip_order(RasterP p) {
 // split evenly over the 64 lanes (every lane walks a contiguous run of pairs, the staged face stays in registers
 // while the run stays inside one face).  The run start -> face lookup is a scatter + prefix-max instead of a
 // search.  Only the key window is shared by the waves (LDS atomics).
-__global__ __launch_bounds__(RB) void k_raster_strip(RasterP p) {
+__global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 waves/SIMD: two workgroups per CU
   __shared__ unsigned long long keys[R_CAP * 5];
   __shared__ float wT[RW][64 * RT];         // staged faces of the wave's current round
   __shared__ int wPre[RW][65];              // exclusive prefix of the candidate counts
@@ -600,6 +641,7 @@ __global__ __launch_bounds__(RB) void k_raster_strip(RasterP p) {
   __shared__ int wMark[RW][64];
   __shared__ unsigned wZb[RW][64];          // bits of the nearest vertex depth of the staged faces
   __shared__ unsigned short wPl[RW][RPL];   // pair list of the sub-pixel path: face slot | pair index << 6
+  __shared__ float s_sums[RB / 64];
   __shared__ float sXf[R_CAP];              // NDC x of the tile columns
   __shared__ float sYf[R_CAP];              // NDC y of the tile rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -822,6 +864,7 @@ __global__ __launch_bounds__(RB) void k_raster_strip(RasterP p) {
       const int r = px / tw, cc = px - r * tw;
       gk[((size_t)(sy0 - wy0 + r) * ww + (x0 - wx0 + cc)) * 5 + c] = keys[i];
     }
+    r_tile_depth_sums(p, s, b, keys, tw, x0, sy0, npx, s_sums);
 #ifdef ABL_TIMES
     TBS(1);
 #endif
@@ -932,12 +975,20 @@ __global__ void k_raster_body_out(RasterP p) {
   p.dinv[(size_t)b * 2 + 1] = gB * S[4];      // d/d(1/max_z)
 }
 
+// silhouette loss value once k_raster_grads has accumulated the alpha-dependent part
+__global__ void k_raster_sil_out(RasterP p) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= p.B) return;
+  p.sil_body[b] = p.sil_apply[b] * (p.sil_S[b] + p.sil_corr[b]) / (p.sil_D[b] + 1.f);        // losses.py:35-38
+}
+
 // =============================================================================================
 // gradients per strip
 // =============================================================================================
 #define RGB 1024             // threads per body workgroup of the gradient kernel (one workgroup per CU: LDS table)
 template <bool TAB>
 __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
+  __shared__ float s_red[RGB / 64];
   float* gtab = rg_tab;
   const int tid = threadIdx.x;
   const int H = p.H, W = p.W, P = H * W;
@@ -970,6 +1021,8 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
     const float diff = S[0] / cnt - S[1] / cnt;
     const float gA = p.coef_depth * 2.f * diff / cnt;
     const float gAlphaScale = p.coef_sil * p.sil_apply[b] * 2.f / (p.sil_D[b] + 1.f);
+    const bool sil_on = p.sil_apply[b] != 0.f;     // alpha is also needed for the loss value (sil_corr), not only for gradients
+    float lcorr = 0.f;
     const float pvalid = p.p2d_valid[b];
     const uint32_t fr = p.front[b];
     TS(2);
@@ -983,7 +1036,7 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
       const size_t gp = (size_t)t * P + (size_t)yi * W + xi;
       const unsigned long long* q = gk + (size_t)i * 5;
       const bool dep = gA != 0.f && pvalid != 0.f && q[0] != RS_EMPTY && ((p.ebits[gp] >> n) & 1u);
-      const bool sil = gAlphaScale != 0.f && q[1] != RS_EMPTY && (p.bits[gp] & fr) == 0u;
+      const bool sil = sil_on && q[1] != RS_EMPTY && (p.bits[gp] & fr) == 0u;
       const bool live = dep || sil;
       const unsigned long long m = __ballot(live);
       if (m) {
@@ -1061,11 +1114,7 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
       // silhouette: the (up to) four selected faces are fetched together (independent gathers in
       // flight), evaluated, and scattered from registers
       const uint32_t wb = p.bits[gp];
-#ifdef ABL_NOSIL
-      if (false) {
-#else
-      if (gAlphaScale != 0.f && (wb & fr) == 0u && q[1] != RS_EMPTY) {
-#endif
+      if (sil_on && (wb & fr) == 0u && q[1] != RS_EMPTY) {
         Tri trs[4];
         bool have[4];
 #pragma unroll
@@ -1113,6 +1162,7 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
         }
         const float alpha = 1.f - qprod;
         const float seg = (float)((wb >> n) & 1u);
+        lcorr += alpha * alpha - 2.f * alpha * seg;                        // losses.py:35-38 through 1 - acc (value only)
         const float galpha = gAlphaScale * (alpha - seg);
         if (galpha != 0.f) {
 #pragma unroll
@@ -1135,6 +1185,8 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
     __syncthreads();
     TS(4);
     }   // classification pass
+    lcorr = r_block_sum(lcorr, s_red);
+    if (tid == 0 && lcorr != 0.f) atomicAdd(&p.sil_corr[b], lcorr);
     if (use_tab)
       for (int i = tid; i < p.V * 3; i += RGB) {
         const float g = gtab[i];
@@ -1172,7 +1224,7 @@ __global__ void k_fill(float* x, size_t n, float v) {
 static size_t r_align(size_t x) { return (x + 255) & ~(size_t)255; }
 static size_t r_max_units(size_t B, int H, int W) { return B + B * (size_t)H * W / RG_UNIT + 1; }
 static size_t r_ws_extra(size_t B, int V, int F, int H) {
-  return r_align(B * V * 3 * 4) + 2 * r_align(B * F * 4) + r_align(B * (size_t)(2 * (H + 1) + 1) * 4) + r_align(B * 4) + r_align(B * 8);
+  return r_align(B * V * 3 * 4) + 2 * r_align(B * F * 4) + r_align(B * (size_t)(2 * (H + 1) + 1) * 4) + 2 * r_align(B * 4) + r_align(B * 8);
 }
 static int r_max_strips(int B, int H, int W) {
   // full-width windows give the most tiles per body
@@ -1248,6 +1300,7 @@ extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const f
   p.fsort = (unsigned*)c; c += r_align(B * F * 4);
   p.row_start = (int*)c; c += r_align(B * (size_t)(2 * (H + 1) + 1) * 4);
   p.maxh = (int*)c; c += r_align(B * 4);
+  p.sil_corr = (float*)c; c += r_align(B * 4);
   p.body_koff = (long long*)c; c += r_align(B * 8);
   p.gunit_body = (int*)c; c += r_align(r_max_units(B, H, W) * 4);
   p.gunit_p0 = (int*)c; c += r_align(r_max_units(B, H, W) * 4);
@@ -1273,10 +1326,12 @@ extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const f
   hipLaunchKernelGGL(k_raster_strip, dim3(grid), dim3(RB), 0, st, p);
   MH_LAUNCH_CHECK();
   mh_prof_mark(MH_PROF_RASTER_STRIP, 1, st);
-  mh_prof_mark(MH_PROF_RASTER_SUMS, 0, st);
-  hipLaunchKernelGGL(k_raster_sums, dim3(grid), dim3(RB), 0, st, p);
-  MH_LAUNCH_CHECK();
-  mh_prof_mark(MH_PROF_RASTER_SUMS, 1, st);
+  if (!gverts || zbuf_out || alpha_out) {   // values only (render, loss evaluation) or images wanted: alpha is evaluated by k_raster_sums
+    mh_prof_mark(MH_PROF_RASTER_SUMS, 0, st);
+    hipLaunchKernelGGL(k_raster_sums, dim3(grid), dim3(RB), 0, st, p);
+    MH_LAUNCH_CHECK();
+    mh_prof_mark(MH_PROF_RASTER_SUMS, 1, st);
+  }
   hipLaunchKernelGGL(k_raster_body_out, dim3((p.B + 255) / 256), dim3(256), 0, st, p);
   MH_LAUNCH_CHECK();
   if (gverts) {
@@ -1287,6 +1342,7 @@ extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const f
       MH_HIP(hipFuncSetAttribute((const void*)k_raster_grads<true>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_MAXV * 3 * 4 + (RG_LIST + 1) * 4));
       attr_set = true;
     }
+    MH_HIP(hipMemsetAsync(p.sil_corr, 0, (size_t)p.B * sizeof(float), st));
     mh_prof_mark(MH_PROF_RASTER_GRADS, 0, st);
     // one workgroup per CU is resident (LDS table); the work-unit count is only known on the device
     const int ggrid = 256 * 6;
@@ -1294,6 +1350,8 @@ extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const f
     else hipLaunchKernelGGL(k_raster_grads<false>, dim3(ggrid), dim3(RGB), tab, st, p);
     MH_LAUNCH_CHECK();
     mh_prof_mark(MH_PROF_RASTER_GRADS, 1, st);
+    hipLaunchKernelGGL(k_raster_sil_out, dim3((p.B + 255) / 256), dim3(256), 0, st, p);
+    MH_LAUNCH_CHECK();
   }
   if (gzmin && gzmax) {
     hipLaunchKernelGGL(k_depth_range_grads, dim3((T + 127) / 128), dim3(128), 0, st, T, N, (const float*)p.dinv, zmin_lin,

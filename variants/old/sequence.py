@@ -300,24 +300,15 @@ class SequenceEngine(object):
         return self.scene_pts
 
     # -- forward of all local frames ---------------------------------------------------------------
-    def forward(self, regress=True):
+    def forward(self):
         m = self.m
         ev = self._tic('lbs_forward')
         check(_lib.lib().mh_lbs_forward(m.handle, self.B, self.N, ptr(self.leaf('betas')), ptr(self.leaf('poses_smpl')),
                                         ptr(self.leaf('xscale')), ptr(self.leaf('poses_T')), ptr(self.verts),
                                         ptr(self.vposed), None, ptr(self.ws), _lib.stream_ptr(self.dev)))
         self._toc(ev)
-        if regress:
-            self._regress(_lib.stream_ptr(self.dev))
-
-    def _regress(self, st):
-        check(_lib.lib().mh_joints_regress(self.m.handle, engine.REG_ALPHAPOSE, self.B, ptr(self.verts),
-                                           ptr(self.leaf('poses_T')), -1, ptr(self.kp), st))
-
-    def _side_stream(self):
-        if not hasattr(self, '_side'):
-            self._side = torch.cuda.Stream(device=self.dev)
-        return self._side
+        check(_lib.lib().mh_joints_regress(m.handle, engine.REG_ALPHAPOSE, self.B, ptr(self.verts),
+                                           ptr(self.leaf('poses_T')), -1, ptr(self.kp), _lib.stream_ptr(self.dev)))
 
     # -- one optimisation cycle (optimizer.py:375-575), gradients accumulated into self.grads -----
     def cycle(self, row, use_images=True, raster=None):
@@ -327,34 +318,8 @@ class SequenceEngine(object):
     def cycle_begin(self):
         """zero the gradient buffer and run the LBS forward of all local frames (the frame-sharded
         driver exchanges boundary vertices between this and ``cycle_finish``)."""
-        L = _lib.lib()
-        c = self.c
-        T, N = self.T, self.N
-        g = self.grads
-        g.zero_()
-        log = self.tmp_log
-        log.zero_()
-        # the terms that only read the leaves (silhouette mask statistics, priors, velocity) run on the second stream
-        # beside the MFMA-bound forward; their scalars land directly in the log row
-        main = torch.cuda.current_stream(self.dev)
-        side = self._side_stream()
-        side.wait_stream(main)
-        s2 = side.cuda_stream
-        pT = self.leaf('poses_T')
-        h = self.halo or {}
-        if self.has_images:
-            check(L.mh_sil_mask_stats(ptr(self.bits), T, N, self.H, self.W, ptr(pT), ptr(self.p2d_valid),
-                                      ptr(self.mask_valid), ptr(self.front), ptr(self.sil_apply), ptr(self.sil_D),
-                                      ptr(self.sil_S), s2))
-        check(L.mh_prior_terms(T, N, self.nbatches, ptr(self.leaf('poses_smpl')), ptr(self.poses_ref), ptr(self.valid),
-                               ptr(self.leaf('betas')), ptr(self.betas_ref), ptr(self.leaf('xscale')),
-                               float(c['reg_poses']), float(c['reg_scales']), ptr(self.leaf('poses_smpl', g)),
-                               ptr(self.leaf('betas', g)), ptr(self.leaf('xscale', g)), ptr(self.prior_body), ptr(log[9:12]), s2))
-        check(L.mh_velocity_term(T, N, ptr(pT), ptr(h.get('pT_prev')), ptr(h.get('pT_next')), float(c['reg_velocity']),
-                                 ptr(self.leaf('poses_T', g)), ptr(log[7:8]), s2))
-        check(L.mh_reduce_sum(ptr(self.prior_body), self.B, 1.0, ptr(log[3:4]), s2))
-        self.forward(regress=False)
-        main.wait_stream(side)
+        self.grads.zero_()
+        self.forward()
 
     def cycle_finish(self, row, use_images=True, raster=None):
         self._finish_a(use_images, raster)
@@ -362,15 +327,19 @@ class SequenceEngine(object):
 
     def _finish_a(self, use_images=True, raster=None):
         """Everything between the LBS forward and the scene-dependent part.  The vertex-gradient buffer starts as the
-        filtered-vertex term (or zero); then the rasterised terms run on the main stream while the small terms that
-        need the vertices (key-point regression + 2D joints and -- with a static scene -- contact / foot sliding) run
-        on the second stream: in the captured graph they are a parallel branch that fills the tails of the raster
-        kernels instead of a dozen serial launches of a few microseconds each."""
+        filtered-vertex term (or zero); then the rasterised terms run on the main stream while the small independent
+        terms (2D joints, priors, velocity and -- with a static scene -- contact / foot sliding) run on a second
+        stream: in the captured graph they become a parallel branch that fills the tails of the raster kernels instead
+        of ~15 serial launches of a few microseconds each."""
         L = _lib.lib()
         main = torch.cuda.current_stream(self.dev)
         st = main.cuda_stream
         c = self.c
         T, N, B = self.T, self.N, self.B
+        g = self.grads
+        gpT, gposes = self.leaf('poses_T', g), self.leaf('poses_smpl', g)
+        gbetas, gxs = self.leaf('betas', g), self.leaf('xscale', g)
+        pT = self.leaf('poses_T')
         Kp = self.K.ctypes.data_as(_lib.c_float_p)
         Kdp = None if self.Kd is None else self.Kd.ctypes.data_as(_lib.c_float_p)
         h = self.halo or {}
@@ -379,6 +348,7 @@ class SequenceEngine(object):
         images = use_images and self.has_images
         need_gv = scene or filt or (images and raster is not None)
         log = self.tmp_log
+        log.zero_()
         gv = None
         if need_gv:
             if self.gverts is None:
@@ -389,25 +359,36 @@ class SequenceEngine(object):
                 ev = self._tic('filtered_verts')
                 check(L.mh_filtered_verts_term_init(T, E, ptr(self.verts), ptr(self.verts_filt), ptr(h.get('v_prev')),
                                                     ptr(h.get('vf_prev')), ptr(h.get('v_next')), ptr(h.get('vf_next')),
-                                                    float(c['reg_verts_filter']), ptr(gv), ptr(log[8:9]), st))
+                                                    float(c['reg_verts_filter']), ptr(gv), ptr(self.filt_loss), st))
                 self._toc(ev)
             else:
                 gv.zero_()
         self._gv_cur = gv
         # ---- side branch ------------------------------------------------------------------------------------------
-        side = self._side_stream()
+        if not hasattr(self, '_side'):
+            self._side = torch.cuda.Stream(device=self.dev)
+        side = self._side
         side.wait_stream(main)
         s2 = side.cuda_stream
-        self._regress(s2)
         check(L.mh_project_joints_loss(B, ptr(self.kp), Kp, Kdp, ptr(self.pose2d), self.thr, 0, float(self.W),
                                        float(self.H), float(c['proj2d']), ptr(self.uv), ptr(self.gj), ptr(self.loss2d), s2))
+        check(L.mh_prior_terms(T, N, self.nbatches, ptr(self.leaf('poses_smpl')), ptr(self.poses_ref), ptr(self.valid),
+                               ptr(self.leaf('betas')), ptr(self.betas_ref), ptr(self.leaf('xscale')),
+                               float(c['reg_poses']), float(c['reg_scales']), ptr(gposes), ptr(gbetas), ptr(gxs),
+                               ptr(self.prior_body), ptr(self.loss3), s2))
+        check(L.mh_velocity_term(T, N, ptr(pT), ptr(h.get('pT_prev')), ptr(h.get('pT_next')), float(c['reg_velocity']),
+                                 ptr(gpT), ptr(self.vel_loss), s2))
         check(L.mh_reduce_sum(ptr(self.loss2d), B, 1.0, ptr(log[0:1]), s2))
+        check(L.mh_reduce_sum(ptr(self.prior_body), B, 1.0, ptr(log[3:4]), s2))
         self._scene_done = False
         if scene and self._scene_dev is None:          # static scene: no cross-stream event to wait for
             self._scene_terms(s2)
             self._scene_done = True
         # ---- main branch: rasterised depth / silhouette terms ----------------------------------------------------------
         if images:
+            check(L.mh_sil_mask_stats(ptr(self.bits), T, N, self.H, self.W, ptr(pT), ptr(self.p2d_valid),
+                                      ptr(self.mask_valid), ptr(self.front), ptr(self.sil_apply), ptr(self.sil_D),
+                                      ptr(self.sil_S), st))
             if raster is not None:
                 ev = self._tic('raster_terms')
                 raster(self, gv, log)
@@ -457,6 +438,10 @@ class SequenceEngine(object):
                                 ptr(self.leaf('xscale')), ptr(pT), ptr(self.vposed), ptr(gv), ptr(self.gj), ptr(gposes),
                                 ptr(gpT), ptr(gbetas), ptr(gxs), ptr(self.ws), ptr(self.ws2), st))
         self._toc(ev)
+        if filt:
+            log[8:9].copy_(self.filt_loss)
+        log[9:12].copy_(self.loss3)
+        log[7:8].copy_(self.vel_loss)
         if row is not None:
             self.log[row].copy_(log)
 

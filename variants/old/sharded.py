@@ -85,7 +85,6 @@ class ShardedSequence(object):
         halo = {}
         pp, pn = self._gather_boundaries(e.leaf('poses_T'))
         halo['pT_prev'], halo['pT_next'] = self._static('pT_prev', pp), self._static('pT_next', pn)
-        e.halo = halo                      # the velocity term runs inside cycle_begin, beside the forward
         if graphs:
             e.replay(('begin',), e.cycle_begin)
         else:

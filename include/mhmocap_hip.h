@@ -306,6 +306,17 @@ int mh_raster_terms(int T, int N, int V, int F, int H, int W, const float* cam_K
                     float coef_depth, float coef_sil, float eps, float* gverts, float* gzmin,
                     float* gzmax, float* depth_body, float* sil_body, void* ws,
                     float* zbuf_out, float* alpha_out, void* stream);
+/* the same call in two halves, so that a caller can order other writers of gverts between them: phases 1 = windows,
+ * face sort, selection and the loss values (does not touch gverts; depth_body final, sil_body final only without
+ * gradients), 2 = gradients into gverts / gzmin / gzmax and the final sil_body (same arguments, same ws), 3 = both */
+int mh_raster_terms_phase(int T, int N, int V, int F, int H, int W, const float* cam_K_host,
+                          const float* verts, const int32_t* faces, const uint32_t* bits,
+                          const uint32_t* ebits, const float* depths, const float* zmin_lin,
+                          const float* zmax_lin, const float* pose2d_valid, const uint32_t* front,
+                          const float* sil_apply, const float* sil_D, const float* sil_S,
+                          float coef_depth, float coef_sil, float eps, float* gverts, float* gzmin,
+                          float* gzmax, float* depth_body, float* sil_body, void* ws,
+                          float* zbuf_out, float* alpha_out, int phases, void* stream);
 
 /* ---- stand-alone forms of losses.py:19-40 and morphology.py:6-41 (call compatibility of
  * mhmocap.losses / mhmocap.morphology; the optimiser uses the fused kernels above) --------------

@@ -1241,13 +1241,13 @@ extern "C" size_t mh_raster_workspace_bytes(int T, int N, int V, int F, int H, i
 }
 
 
-extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const float* cam_K_host, const float* verts,
-                               const int32_t* faces, const uint32_t* bits, const uint32_t* ebits, const float* depths,
-                               const float* zmin_lin, const float* zmax_lin, const float* pose2d_valid,
-                               const uint32_t* front, const float* sil_apply, const float* sil_D, const float* sil_S,
-                               float coef_depth, float coef_sil, float eps, float* gverts, float* gzmin, float* gzmax,
-                               float* depth_body, float* sil_body, void* ws, float* zbuf_out, float* alpha_out,
-                               void* stream) {
+static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const float* cam_K_host, const float* verts,
+                             const int32_t* faces, const uint32_t* bits, const uint32_t* ebits, const float* depths,
+                             const float* zmin_lin, const float* zmax_lin, const float* pose2d_valid,
+                             const uint32_t* front, const float* sil_apply, const float* sil_D, const float* sil_S,
+                             float coef_depth, float coef_sil, float eps, float* gverts, float* gzmin, float* gzmax,
+                             float* depth_body, float* sil_body, void* ws, float* zbuf_out, float* alpha_out,
+                             int phases, void* stream) {
   MH_CHECK(cam_K_host && verts && faces && bits && ebits && depths && zmin_lin && zmax_lin && pose2d_valid && front &&
                sil_apply && sil_D && sil_S && depth_body && sil_body && ws,
            "null argument");
@@ -1307,6 +1307,7 @@ extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const f
   p.gunit_total = (int*)c; c += r_align(4);
   p.gkeys = (unsigned long long*)c;
   hipStream_t st = (hipStream_t)stream;
+  if (phases & 1) {
   if (zbuf_out) {   // -1 = empty, like fragments.zbuf
     hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, st, zbuf_out, (size_t)p.B * H * W, -1.f);
     MH_LAUNCH_CHECK();
@@ -1334,6 +1335,8 @@ extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const f
   }
   hipLaunchKernelGGL(k_raster_body_out, dim3((p.B + 255) / 256), dim3(256), 0, st, p);
   MH_LAUNCH_CHECK();
+  }   // selection phase
+  if (!(phases & 2)) return MH_OK;
   if (gverts) {
     const bool use_tab = V <= RG_MAXV;
     const size_t tab = (use_tab ? (size_t)V * 3 * sizeof(float) : 0) + (RG_LIST + 1) * sizeof(int);
@@ -1359,4 +1362,29 @@ extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const f
     MH_LAUNCH_CHECK();
   }
   return MH_OK;
+}
+
+extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const float* cam_K_host, const float* verts,
+                               const int32_t* faces, const uint32_t* bits, const uint32_t* ebits, const float* depths,
+                               const float* zmin_lin, const float* zmax_lin, const float* pose2d_valid,
+                               const uint32_t* front, const float* sil_apply, const float* sil_D, const float* sil_S,
+                               float coef_depth, float coef_sil, float eps, float* gverts, float* gzmin, float* gzmax,
+                               float* depth_body, float* sil_body, void* ws, float* zbuf_out, float* alpha_out,
+                               void* stream) {
+  return raster_terms_impl(T, N, V, F, H, W, cam_K_host, verts, faces, bits, ebits, depths, zmin_lin, zmax_lin, pose2d_valid, front,
+                           sil_apply, sil_D, sil_S, coef_depth, coef_sil, eps, gverts, gzmin, gzmax, depth_body, sil_body, ws, zbuf_out,
+                           alpha_out, 3, stream);
+}
+
+extern "C" int mh_raster_terms_phase(int T, int N, int V, int F, int H, int W, const float* cam_K_host, const float* verts,
+                                     const int32_t* faces, const uint32_t* bits, const uint32_t* ebits, const float* depths,
+                                     const float* zmin_lin, const float* zmax_lin, const float* pose2d_valid,
+                                     const uint32_t* front, const float* sil_apply, const float* sil_D, const float* sil_S,
+                                     float coef_depth, float coef_sil, float eps, float* gverts, float* gzmin, float* gzmax,
+                                     float* depth_body, float* sil_body, void* ws, float* zbuf_out, float* alpha_out,
+                                     int phases, void* stream) {
+  MH_CHECK(phases >= 1 && phases <= 3, "phases: 1 = selection + values, 2 = gradients, 3 = both");
+  return raster_terms_impl(T, N, V, F, H, W, cam_K_host, verts, faces, bits, ebits, depths, zmin_lin, zmax_lin, pose2d_valid, front,
+                           sil_apply, sil_D, sil_S, coef_depth, coef_sil, eps, gverts, gzmin, gzmax, depth_body, sil_body, ws, zbuf_out,
+                           alpha_out, phases, stream);
 }

@@ -17,20 +17,22 @@ class RasterTerms(object):
         self.ws = torch.empty(_lib.lib().mh_raster_workspace_bytes(e.T, e.N, e.V, self.faces.shape[0], e.H, e.W), dtype=torch.uint8, device=e.dev)
         self.K = np.ascontiguousarray(e.K.reshape(9))
 
-    def __call__(self, e, gverts, log, with_grads=True, zbuf_out=None, alpha_out=None):
+    def __call__(self, e, gverts, log, with_grads=True, zbuf_out=None, alpha_out=None, phases=3):
+        """phases: 1 = selection + values (does not touch gverts), 2 = gradients + log entries, 3 = both"""
         L = _lib.lib()
         st = _lib.stream_ptr(e.dev)
         g = e.grads
-        check(L.mh_raster_terms(e.T, e.N, e.V, self.faces.shape[0], e.H, e.W, self.K.ctypes.data_as(_lib.c_float_p),
-                                ptr(e.verts), ptr(self.faces), ptr(e.bits), ptr(e.ebits), ptr(e.depths),
-                                ptr(e.leaf('zmin_lin')), ptr(e.leaf('zmax_lin')), ptr(e.p2d_valid), ptr(e.front),
-                                ptr(e.sil_apply), ptr(e.sil_D), ptr(e.sil_S), float(e.c['depth']),
-                                float(e.c['silhouette']), float(e.eps), ptr(gverts) if with_grads else None,
-                                ptr(e.leaf('zmin_lin', g)) if with_grads else None,
-                                ptr(e.leaf('zmax_lin', g)) if with_grads else None, ptr(e.depth_body), ptr(e.sil_body),
-                                ptr(self.ws), ptr(zbuf_out), ptr(alpha_out), st))
-        check(L.mh_reduce_sum(ptr(e.depth_body), e.B, 1.0, ptr(log[1:2]), st))
-        check(L.mh_reduce_sum(ptr(e.sil_body), e.B, 1.0, ptr(log[2:3]), st))
+        check(L.mh_raster_terms_phase(e.T, e.N, e.V, self.faces.shape[0], e.H, e.W, self.K.ctypes.data_as(_lib.c_float_p),
+                                      ptr(e.verts), ptr(self.faces), ptr(e.bits), ptr(e.ebits), ptr(e.depths),
+                                      ptr(e.leaf('zmin_lin')), ptr(e.leaf('zmax_lin')), ptr(e.p2d_valid), ptr(e.front),
+                                      ptr(e.sil_apply), ptr(e.sil_D), ptr(e.sil_S), float(e.c['depth']),
+                                      float(e.c['silhouette']), float(e.eps), ptr(gverts) if with_grads else None,
+                                      ptr(e.leaf('zmin_lin', g)) if with_grads else None,
+                                      ptr(e.leaf('zmax_lin', g)) if with_grads else None, ptr(e.depth_body), ptr(e.sil_body),
+                                      ptr(self.ws), ptr(zbuf_out), ptr(alpha_out), int(phases), st))
+        if phases & 2:
+            check(L.mh_reduce_sum(ptr(e.depth_body), e.B, 1.0, ptr(log[1:2]), st))
+            check(L.mh_reduce_sum(ptr(e.sil_body), e.B, 1.0, ptr(log[2:3]), st))
 
 
 def render(model, verts, cam_K, image_size):

@@ -266,8 +266,8 @@ size_t mh_scene_workspace_bytes(int T, int H, int W);
 int mh_scene_median(int T, int H, int W, const float* depths /*(T,H,W)*/, const uint8_t* backmask /*(T,H,W)*/,
                     const float* zmin_lin /*(T)*/, const float* zmax_lin /*(T)*/, float* ma_depth /*(H,W)*/,
                     float* ma_mask /*(H,W) 0/1*/, void* ws, void* stream);
-/* the same with pixel-major inputs (P = H*W rows of T frames: the frames of a pixel contiguous), T <= 512: one wave
- * per pixel, no LDS */
+/* the same with pixel-major inputs (P = H*W rows of T frames: the frames of a pixel contiguous), T <= 2048: one wave
+ * per pixel, no LDS.  Any (H, W) with H*W = number of pixel rows works: a pixel-sharded caller passes its slice. */
 int mh_scene_median_t(int T, int H, int W, const float* depths_t /*(H*W,T)*/, const uint8_t* backmask_t /*(H*W,T)*/,
                       const float* zmin_lin, const float* zmax_lin, float* ma_depth, float* ma_mask, void* ws, void* stream);
 int mh_scene_postprocess(int H, int W, const float* ma_depth, const float* ma_mask, int use_bilateral, int fillin_ksize,

@@ -76,8 +76,9 @@ __global__ __launch_bounds__(64) void k_scene_median(int T, int P, const float* 
 // The same median with the frames of a pixel contiguous in memory (depths_t / backmask_t are (P, T)): one wave per
 // pixel, the values of a pixel spread over the lanes in registers, the bitwise descent done with ballots.  No LDS at
 // all (the column form above pins 51 KB of LDS per wave for T = 200 and crowds the concurrently running loss kernels
-// off the CUs) and ~6x less time.  T <= 64 * SMT_NV.
-#define SMT_NV 8
+// off the CUs) and ~6x less time.  T <= 64 * SMT_NV (8: 512 frames; 32: 2048, the whole sequence of a pixel-sharded
+// multi-GPU run).
+template <int SMT_NV>
 __global__ __launch_bounds__(256) void k_scene_median_t(int T, int P, const float* depths_t, const unsigned char* backmask_t,
                                                         const float* invz, float* ma_depth, float* ma_mask) {
   const int lane = threadIdx.x & 63;
@@ -390,7 +391,7 @@ extern "C" int mh_scene_median_t(int T, int H, int W, const float* depths_t, con
   MH_CHECK(depths_t && backmask_t && ma_depth && ma_mask && ws, "null argument");
   MH_CHECK((zmin_lin == nullptr) == (zmax_lin == nullptr), "depth-range leaves come in pairs (both NULL: median of the raw values)");
   MH_CHECK(T > 0 && H > 0 && W > 0, "empty input");
-  MH_CHECK(T <= 64 * SMT_NV, "sequence too long for the register form: use mh_scene_median");
+  MH_CHECK(T <= 2048, "sequence too long for the register form: use mh_scene_median");
   const int P = H * W;
   SceneWs s = scene_carve(ws, P);
   hipStream_t st = (hipStream_t)stream;
@@ -398,8 +399,9 @@ extern "C" int mh_scene_median_t(int T, int H, int W, const float* depths_t, con
     hipLaunchKernelGGL(k_scene_ranges, dim3((T + 127) / 128), dim3(128), 0, st, T, zmin_lin, zmax_lin, s.invz);
     MH_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(k_scene_median_t, dim3((P + 3) / 4), dim3(256), 0, st, T, P, depths_t, backmask_t,
-                     zmin_lin ? (const float*)s.invz : (const float*)nullptr, ma_depth, ma_mask);
+  const float* invz = zmin_lin ? (const float*)s.invz : (const float*)nullptr;
+  if (T <= 512) hipLaunchKernelGGL(k_scene_median_t<8>, dim3((P + 3) / 4), dim3(256), 0, st, T, P, depths_t, backmask_t, invz, ma_depth, ma_mask);
+  else hipLaunchKernelGGL(k_scene_median_t<32>, dim3((P + 3) / 4), dim3(256), 0, st, T, P, depths_t, backmask_t, invz, ma_depth, ma_mask);
   MH_LAUNCH_CHECK();
   return MH_OK;
 }

@@ -237,13 +237,19 @@ class SequenceEngine(object):
         else:
             check(L.mh_scene_median(T, H, W, ptr(self.depths), ptr(d['back']), ptr(s['zsnap'][:T]), ptr(s['zsnap'][T:]),
                                     ptr(d['ma_depth']), ptr(d['ma_mask']), ptr(d['ws']), st))
+        self._scene_finish(s, st)
+        s['ev'].record(side)
+        d['ready'] = k
+        d['next'] = 1 - k
+
+    def _scene_finish(self, s, st):
+        """median (d['ma_depth'], d['ma_mask']) -> post-processed depth map -> compacted cloud -> grid, into set s"""
+        d, L = self._scene_dev, _lib.lib()
+        H, W = self.H, self.W
         check(L.mh_scene_postprocess(H, W, ptr(d['ma_depth']), ptr(d['ma_mask']), 1, 7, ptr(d['depth']), ptr(d['ws']), st))
         check(L.mh_scene_points(H, W, self.K.ctypes.data_as(_lib.c_float_p), ptr(d['depth']), ptr(d['ma_mask']), ptr(s['pts']),
                                 ptr(s['count']), st))
         check(L.mh_scene_grid_build_dev(ptr(s['pts']), ptr(s['count']), H * W, ptr(s['grid']), st))
-        s['ev'].record(side)
-        d['ready'] = k
-        d['next'] = 1 - k
 
     def scene_device_swap(self):
         """Make the last update the scene the contact term reads from now on (pointer swap; its consumer waits on the

@@ -138,6 +138,87 @@ class ShardedSequence(object):
         a, b = self._gather_boundaries(e.verts_filt.view(e.T, -1))
         self._vf_halo = (self._static('vf_prev', a), self._static('vf_next', b))
 
+    # -- scene aggregation across the shards (optimizer.py:578-584): the median is over ALL frames of a pixel --------
+    # Pixels are sharded instead: once, every rank collects the constant inputs (normalised disparity, background
+    # mask) of all frames for its slice of the pixels, pixel-major; per update the depth-range leaves of all frames
+    # are all-gathered (2 floats per frame), every rank takes the median of its pixels over the whole sequence, the
+    # H*W medians are all-gathered, and post-processing / un-projection / grid run redundantly on every rank (they are
+    # single-image work).  Frames are padded to the longest shard with masked-out entries.
+    def scene_setup(self, backmasks_local):
+        e = self.e
+        e.scene_device_setup(backmasks_local)
+        if self.world == 1:
+            return
+        T, H, W = e.T, e.H, e.W
+        P = H * W
+        G = self.world
+        tl = torch.tensor([T], device=e.dev, dtype=torch.int64)
+        tls = [torch.zeros_like(tl) for _ in range(G)]
+        dist.all_gather(tls, tl, group=self.group)
+        Tmax = int(max(int(x.item()) for x in tls))
+        Pmax = (P + G - 1) // G
+        p0 = min(self.rank * Pmax, P)
+        p1 = min(p0 + Pmax, P)
+
+        def gather_padded(x, fill):
+            buf = torch.full((Tmax, P), fill, dtype=x.dtype, device=e.dev)
+            buf[:T] = x.view(T, P)
+            outs = [torch.empty_like(buf) for _ in range(G)]
+            dist.all_gather(outs, buf, group=self.group)
+            full = torch.cat(outs, 0)                                  # (G*Tmax, P), rank-major frame order
+            sl = torch.zeros(Pmax, G * Tmax, dtype=x.dtype, device=e.dev)
+            sl[:p1 - p0] = full[:, p0:p1].t()
+            return sl.contiguous()
+        d = e._scene_dev
+        self._sc = dict(Tmax=Tmax, Tall=G * Tmax, Pmax=Pmax, p0=p0, p1=p1,
+                        depths_t=gather_padded(e.depths, 0.0), back_t=gather_padded(d['back'], 0),
+                        z=torch.zeros(2 * Tmax, device=e.dev), med=torch.zeros(Pmax, device=e.dev),
+                        msk=torch.zeros(Pmax, device=e.dev))
+        assert self._sc['Tall'] <= 2048, 'pixel-sharded median: at most 2048 (padded) frames in total'
+
+    def scene_update(self):
+        """One scene update (call at the start of a cycle >= 30, like SequenceEngine.scene_device_update)."""
+        e = self.e
+        if self.world == 1:
+            return e.scene_device_update()
+        from . import _lib
+        from ._lib import check, ptr
+        L = _lib.lib()
+        sc, d = self._sc, e._scene_dev
+        T, H, W, G = e.T, e.H, e.W, self.world
+        Tmax, Tall, Pmax = sc['Tmax'], sc['Tall'], sc['Pmax']
+        k = d['next']
+        s = d['sets'][k]
+        sc['z'].fill_(1.0)
+        sc['z'][:T].copy_(e.leaf('zmin_lin').view(-1))
+        sc['z'][Tmax:Tmax + T].copy_(e.leaf('zmax_lin').view(-1))
+        main = torch.cuda.current_stream(e.dev)
+        d['ev_main'].record(main)
+        side = d['stream']
+        side.wait_event(d['ev_main'])
+        with torch.cuda.stream(side):
+            zs = [torch.empty_like(sc['z']) for _ in range(G)]
+            dist.all_gather(zs, sc['z'], group=self.group)
+            zmin_all = torch.cat([z[:Tmax] for z in zs]).contiguous()
+            zmax_all = torch.cat([z[Tmax:] for z in zs]).contiguous()
+            st = side.cuda_stream
+            check(L.mh_scene_median_t(Tall, 1, Pmax, ptr(sc['depths_t']), ptr(sc['back_t']), ptr(zmin_all), ptr(zmax_all),
+                                      ptr(sc['med']), ptr(sc['msk']), ptr(d['ws']), st))
+            both = torch.stack([sc['med'], sc['msk']])
+            outs = [torch.empty_like(both) for _ in range(G)]
+            dist.all_gather(outs, both, group=self.group)
+            full = torch.cat(outs, 1)[:, :H * W]                         # slices are Pmax wide, in rank order
+            d['ma_depth'].view(-1).copy_(full[0])
+            d['ma_mask'].view(-1).copy_(full[1])
+            e._scene_finish(s, st)
+            s['ev'].record(side)
+            self._keep = (zs, zmin_all, zmax_all, both, outs, full)      # alive until the stream has consumed them
+        d['ready'] = k
+        d['next'] = 1 - k
+
+    def scene_swap(self):
+        self.e.scene_device_swap()
+
     # -- logs: raw sums are all-reduced once, at the end ----------------------------------------------
     def read_log(self, rows):
         e = self.e

@@ -71,6 +71,15 @@ def _build(f0, f1):
     return e
 
 
+def _backmasks():
+    _paths()
+    from mhhip import synthetic, synthetic_seq, engine
+    struct = synthetic.make_smpl_struct(1)
+    model = engine.BodyModel(struct, synthetic.make_extra_regressors(1, struct))
+    K = synthetic.default_cam_K((W, H), 60.0)
+    return synthetic_seq.make_sequence(model, N, T, (W, H), 41, cam_K=K, z_range=(2.6, 3.6))['backmasks']
+
+
 def _run(sh, e):
     from mhhip.raster import RasterTerms
     raster = RasterTerms(e)
@@ -93,7 +102,15 @@ def _worker(rank, world, port, out):
     e = _build(f0, f1)
     sh = sharded.ShardedSequence(e, f0, T)
     log = _run(sh, e)
-    torch.save(dict(params=e.params.cpu(), log=log, f0=f0, f1=f1), os.path.join(out, 'rank%d.pt' % rank))
+    # pixel-sharded scene aggregation: every rank ends with the scene of the WHOLE sequence
+    import numpy as np_
+    from mhhip import synthetic as syn_, synthetic_seq as sseq_
+    sh.scene_setup(_backmasks()[f0:f1])
+    sh.scene_update()
+    sh.scene_swap()
+    depth, mask, pts = e.scene_device_result()
+    torch.save(dict(params=e.params.cpu(), log=log, f0=f0, f1=f1, scene_depth=depth, scene_mask=mask, npts=pts.shape[0]),
+               os.path.join(out, 'rank%d.pt' % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -127,3 +144,13 @@ def test_two_ranks_on_the_device_match_one(tmp_path):
             np.testing.assert_allclose(r[0]['log'][c][key], log[c][key], rtol=2e-3, atol=1e-6, err_msg='%s cycle %d' % (key, c))
             np.testing.assert_allclose(r[1]['log'][c][key], log[c][key], rtol=2e-3, atol=1e-6)
     assert log[2]['reg_filter_verts'] > 0 and log[0]['loss_depth'] > 0
+    # scene of the whole sequence from the single process (same leaves up to the atomics noise of the run above)
+    sh.scene_setup(_backmasks())
+    sh.scene_update()
+    sh.scene_swap()
+    depth, mask, pts = e.scene_device_result()
+    for k in range(2):
+        np.testing.assert_array_equal(r[k]['scene_mask'], mask)
+        bad = np.abs(r[k]['scene_depth'] - depth) > 2e-3 * np.maximum(1.0, np.abs(depth))
+        assert bad.mean() < 0.01, bad.sum()
+        assert abs(r[k]['npts'] - pts.shape[0]) == 0

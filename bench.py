@@ -166,12 +166,9 @@ def main():
     # bring the device to its steady state before the W warm-up steps: graph capture, lazy allocations, and enough
     # back-to-back work for the clocks to ramp (a fresh box that idled through the CPU-side set-up was once measured
     # at 0.57x for the first tens of milliseconds)
-    t_pre = time.perf_counter()
-    c_pre = 0
-    while time.perf_counter() - t_pre < 0.5 or c_pre < 30:
+    for c_pre in range(300):            # a fixed count: every rank must issue the same collectives
         one_cycle(1 + c_pre % 20, use_graphs)
-        c_pre += 1
-        if c_pre % 10 == 0:
+        if c_pre % 10 == 9:
             torch.cuda.synchronize()
     for c in range(args.warmup):
         one_cycle(c, use_graphs)

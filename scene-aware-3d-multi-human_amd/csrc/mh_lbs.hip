@@ -192,13 +192,8 @@ __global__ __launch_bounds__(256, 2) void k_skin_fwd(SkinFwdP p) {
   rx[0][0] = Dw[0]; rx[0][1] = Dw[1];
   ry[0][0] = Dw[128]; ry[0][1] = Dw[129];
   rz[0][0] = Dw[256]; rz[0][1] = Dw[257];
-#ifdef ABL_NOMFMA
-#define G8N 1
-#else
-#define G8N 14
-#endif
 #pragma unroll
-  for (int g8 = 0; g8 < G8N; ++g8) {
+  for (int g8 = 0; g8 < 14; ++g8) {
     const int cur = g8 & 1, nxt = cur ^ 1;
     if (g8 + 1 < 14) {
       const f32x4* d = Dw + (size_t)(g8 + 1) * 3 * 128;
@@ -214,10 +209,6 @@ __global__ __launch_bounds__(256, 2) void k_skin_fwd(SkinFwdP p) {
       az = MFMA32(a, rz[cur][u >> 2][u & 3], az);
     }
   }
-#ifdef ABL_NOEPI
-  if (ax[0] + ay[1] + az[2] == 1234.5f) p.verts[0] = 0.f;
-  return;
-#endif
   if (v >= p.V) return;
   const float t0 = p.vt[(size_t)v * 3], t1 = p.vt[(size_t)v * 3 + 1], t2 = p.vt[(size_t)v * 3 + 2];
   int sj[4];

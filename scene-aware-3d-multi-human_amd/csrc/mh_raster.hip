@@ -539,23 +539,6 @@ __global__ __launch_bounds__(RFS) void k_raster_face_sort(RasterP p) {
   }
 }
 
-#ifdef ABL_TIME
-__device__ unsigned long long g_ts[16];
-__device__ unsigned long long g_tb[8192];
-extern "C" int mh_debug_ts(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ts), sizeof(g_ts)); }
-extern "C" int mh_debug_tb(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tb), sizeof(g_tb)); }
-#define TB(i) do { if (threadIdx.x == 0 && u < 4096) g_tb[2 * u + (i)] = wall_clock64(); } while (0)
-#define TBS(i) do { if (threadIdx.x == 0 && s < 4096) g_tb[2 * s + (i)] = wall_clock64(); } while (0)
-#define TS(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_ts[i] = wall_clock64(); } while (0)
-#else
-#define TS(i)
-#define TB(i)
-#define TBS(i)
-#endif
-#ifdef ABL_COUNT
-__device__ unsigned long long g_cnt[8];
-extern "C" int mh_debug_counters(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cnt), sizeof(g_cnt)); }
-#endif
 // depth-term sums of one tile straight from its LDS key window (optimizer.py:432-442): only the nearest key of a pixel is
 // needed -- no face gathers -- so this rides in the epilogue of k_raster_strip; the silhouette sum needs alpha and is taken
 // where alpha is evaluated anyway (k_raster_grads; k_raster_sums when no gradients are requested)
@@ -662,9 +645,6 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
   unsigned short* pl = wPl[wave];
   for (int si = blockIdx.x; si < total; si += gridDim.x) {
     const int s = p.strip_order[si];
-#ifdef ABL_TIMES
-    TBS(0);
-#endif
     const int b = p.strip_body[s];
     const int x0 = p.strip_col0[s], tw = p.strip_cols[s], x1 = x0 + tw - 1;
     const int sy0 = p.strip_row0[s], nrows = p.strip_rows[s], sy1 = sy0 + nrows - 1;
@@ -742,10 +722,6 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
         const int incl = r_wave_scan_add(cnt);
         const int npairs = __builtin_amdgcn_readlane(incl, 63);
         const int excl = incl - cnt;
-#ifdef ABL_COUNT
-        if (lane == 0) { atomicAdd(&g_cnt[0], 1ull); atomicAdd(&g_cnt[1], (unsigned long long)npairs); if (!(npairs > 0 && npairs <= RPL && __ballot(cnt > 16) == 0ull) && npairs > 0) atomicAdd(&g_cnt[2], 1ull); }
-        { const unsigned long long mm = __ballot(cnt > 0); if (lane == 0) atomicAdd(&g_cnt[3], (unsigned long long)__popcll(mm)); }
-#endif
         if (npairs > 0 && npairs <= RPL && __ballot(cnt > 16) == 0ull) {
           // ---- sub-pixel faces (a few candidates each): every face writes its pair descriptors, then the pairs are
           // evaluated with full lanes straight from the list
@@ -776,9 +752,6 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
             nkeep += __popcll(m);
           }
           __builtin_amdgcn_wave_barrier();
-#ifdef ABL_COUNT
-          if (lane == 0) atomicAdd(&g_cnt[4], (unsigned long long)nkeep);
-#endif
           for (int i = lane; i < nkeep; i += 64) {
             const int e = (int)pl[i], lo = e & 63, k = e >> 6;
             const int d = desc[lo];
@@ -790,15 +763,8 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
             for (int q = 0; q < RT; ++q) T[q] = T_[lo * RT + q];
             float pz, dd;
             bool inside;
-#ifdef ABL_NOEVAL
-            if (T[0] == 1234.5f && xi == 77777) keys[0] = 0;
-#elif defined(ABL_NOINSERT)
-            r_eval_fast(T, sXf[xi], sYf[yi], &pz, &inside, &dd);
-            if (pz == 1234.5f && dd == 3.f) keys[0] = 0;
-#else
             r_eval_fast(T, sXf[xi], sYf[yi], &pz, &inside, &dd);
             r_insert(keys + (size_t)(yi * tw + xi) * 5, pz, inside, dd, fid[lo]);
-#endif
           }
           __builtin_amdgcn_wave_barrier();
         } else if (npairs > 0) {
@@ -865,9 +831,6 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
       gk[((size_t)(sy0 - wy0 + r) * ww + (x0 - wx0 + cc)) * 5 + c] = keys[i];
     }
     r_tile_depth_sums(p, s, b, keys, tw, x0, sy0, npx, s_sums);
-#ifdef ABL_TIMES
-    TBS(1);
-#endif
   }
 }
 
@@ -1004,15 +967,10 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
     const int sy0 = y0;
     const float* vb = p.ndc + (size_t)b * p.V * 3;
     float* gvb = p.gverts + (size_t)b * p.V * 3;
-    TS(0);
-#ifndef ABL_TIMES
-    TB(0);
-#endif
     __syncthreads();
     if (use_tab)
       for (int i = tid; i < p.V * 3; i += RGB) gtab[i] = 0.f;
     __syncthreads();
-    TS(1);
     // the strips of a body are consecutive in the work list, so its window is one contiguous key range
     const unsigned long long* gk = p.gkeys + (size_t)p.body_koff[b] * 5;
     float S[6];
@@ -1025,7 +983,6 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
     float lcorr = 0.f;
     const float pvalid = p.p2d_valid[b];
     const uint32_t fr = p.front[b];
-    TS(2);
     // most window pixels carry no gradient (outside the blur band, masked out, occluded by a nearer person's mask):
     // classify RG_LIST pixels at a time, compact the live ones into an LDS list and evaluate those with full waves
     for (int cbase = up0; cbase < npx; cbase += RG_LIST) {
@@ -1048,7 +1005,6 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
       }
     }
     __syncthreads();
-    TS(3);
     const int nlive = *s_n;
     for (int li_ = tid; li_ < nlive; li_ += RGB) {
       const int i = plist[li_];
@@ -1057,11 +1013,7 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
       const float yf = r_pix_to_ndc(H - 1 - yi, H, W), xf = r_pix_to_ndc(W - 1 - xi, W, H);
       const unsigned long long* q = gk + (size_t)i * 5;
       const unsigned long long k0 = q[0];
-#ifdef ABL_NODEP
-      if (false) {
-#else
       if (k0 != RS_EMPTY && gA != 0.f) {
-#endif
         const float z = __uint_as_float((unsigned)(k0 >> 32));
         const float m = (z > 0.f ? 1.f : 0.f) * (float)((p.ebits[gp] >> n) & 1u) * pvalid;
         const float zc = z + 0.2f;
@@ -1183,7 +1135,6 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
       }
     }
     __syncthreads();
-    TS(4);
     }   // classification pass
     lcorr = r_block_sum(lcorr, s_red);
     if (tid == 0 && lcorr != 0.f) atomicAdd(&p.sil_corr[b], lcorr);
@@ -1192,10 +1143,6 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
         const float g = gtab[i];
         if (g != 0.f) atomicAdd(&gvb[i], g);      // several units of one body may flush concurrently
       }
-    TS(5);
-#ifndef ABL_TIMES
-    TB(1);
-#endif
   }
 }
 

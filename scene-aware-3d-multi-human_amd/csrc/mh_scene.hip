@@ -501,11 +501,6 @@ __device__ __forceinline__ float knn_select(float* sd, float* sy, int lane, int 
   return __uint_as_float(prefix);
 }
 
-#ifdef ABL_TIMEQ
-__device__ unsigned long long g_tq[8192];
-__device__ int g_rho[4096];
-extern "C" int mh_debug_tq(unsigned long long* out, int* rho) { hipMemcpyFromSymbol(rho, HIP_SYMBOL(g_rho), sizeof(g_rho)); return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tq), sizeof(g_tq)); }
-#endif
 // one wave per query
 __global__ __launch_bounds__(64) void k_contact_knn_grid(const GridHdr* hdr, const int* start, const float* sorted, int M,
                                                          const float* low_xyz, int K, float* dy) {
@@ -519,9 +514,6 @@ __global__ __launch_bounds__(64) void k_contact_knn_grid(const GridHdr* hdr, con
   sd[lane] = INFINITY; sd[lane + 64] = INFINITY;
   sy[lane] = 0.f; sy[lane + 64] = 0.f;
   __builtin_amdgcn_wave_barrier();
-#ifdef ABL_TIMEQ
-  if (lane == 0 && b < 4096) g_tq[2 * b] = wall_clock64();
-#endif
   const float cell = hdr->cell;
   const int dx = hdr->dim[0], dyy = hdr->dim[1], dz = hdr->dim[2];
   // cell of the query clamped into the grid: for q outside the (convex) bbox with projection q', every cloud point p
@@ -645,9 +637,6 @@ __global__ __launch_bounds__(64) void k_contact_knn_grid(const GridHdr* hdr, con
   float s = (lane < kk) ? sy[lane] : 0.f;
   s = mh_wave_sum(s);
   if (lane == 0) dy[b] = s / (float)kk - qy;
-#ifdef ABL_TIMEQ
-  if (lane == 0 && b < 4096) { g_tq[2 * b + 1] = wall_clock64(); g_rho[b] = found; }
-#endif
 }
 
 extern "C" int mh_contact_knn_grid(const void* grid_ws, int M, const float* low_xyz, int B, int k, float* dy, void* stream) {

@@ -693,15 +693,19 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
         if (idx < i1 && (int)(e_a >> 20) >= sy0) {
           const float bxmin = fminf(ca[0], fminf(ca[3], ca[6])) - blur_d, bxmax = fmaxf(ca[0], fmaxf(ca[3], ca[6])) + blur_d;
           const float bymin = fminf(ca[1], fminf(ca[4], ca[7])) - blur_d, bymax = fmaxf(ca[1], fmaxf(ca[4], ca[7])) + blur_d;
-          // approximate pixel range, then the exact test on the tabulated pixel-centre NDC values
-          int xa = max(x0, (int)floorf((float)W - 0.5f - (bxmax + 0.5f * rx) * kx) - 1);
-          int xb = min(x1, (int)ceilf((float)W - 0.5f - (bxmin + 0.5f * rx) * kx) + 1);
-          int ya = max(sy0, (int)floorf((float)H - 0.5f - (bymax + 0.5f * ry) * ky) - 1);
-          int yb = min(sy1, (int)ceilf((float)H - 0.5f - (bymin + 0.5f * ry) * ky) + 1);
-          while (xa <= xb && sXf[xa - x0] > bxmax) ++xa;
-          while (xb >= xa && sXf[xb - x0] < bxmin) --xb;
-          while (ya <= yb && sYf[ya - sy0] > bymax) ++ya;
-          while (yb >= ya && sYf[yb - sy0] < bymin) --yb;
+          // pixel range of the blurred bbox: the continuous pixel coordinate of each bound, widened by 1e-3 px (its
+          // rounding error is ~1e-5 px), can only be one pixel too generous; one comparison per bound against the
+          // tabulated pixel-centre NDC values makes it exact (no refinement loops)
+          int xa = max(x0, (int)ceilf((float)W - 0.5f - (bxmax + 0.5f * rx) * kx - 1e-3f));
+          int xb = min(x1, (int)floorf((float)W - 0.5f - (bxmin + 0.5f * rx) * kx + 1e-3f));
+          int ya = max(sy0, (int)ceilf((float)H - 0.5f - (bymax + 0.5f * ry) * ky - 1e-3f));
+          int yb = min(sy1, (int)floorf((float)H - 0.5f - (bymin + 0.5f * ry) * ky + 1e-3f));
+          if (xa <= xb && ya <= yb) {
+            xa += sXf[xa - x0] > bxmax ? 1 : 0;
+            xb -= sXf[xb - x0] < bxmin ? 1 : 0;
+            ya += sYf[ya - sy0] > bymax ? 1 : 0;
+            yb -= sYf[yb - sy0] < bymin ? 1 : 0;
+          }
           cnt = max(0, xb - xa + 1) * max(0, yb - ya + 1);
           if (cnt > 0) {
             float* T = T_ + lane * RT;

@@ -9,7 +9,7 @@ Per cycle the ranks exchange, over ``torch.distributed`` (backend "nccl" == RCCL
     its replica of those leaves;
   * the boundary frame of ``poses_T`` with both neighbours (velocity term, optimizer.py:560), and,
     once the one-euro filters exist (cycle >= 50), the boundary frame's vertices (filtered-vertex
-    term, optimizer.py:571-573) -- gathered with one small all_gather each;
+    term, optimizer.py:571-573) -- exchanged point-to-point with the two neighbours;
   * every 25 cycles the one-euro filter state (filtered value + filtered derivative of the last
     local frame) is handed rank k -> k+1, because the filter is sequential in time
     (optimizer.py:664-675).
@@ -49,16 +49,23 @@ class ShardedSequence(object):
         self._vf_halo = None
         self._hbuf = {}
 
-    # -- neighbour exchange: every rank contributes its first and last frame ------------------------
+    # -- neighbour exchange: the last frame goes to the next rank, the first frame to the previous one -------------------
+    # (point-to-point over xGMI: an all_gather of the boundary vertices would move world x 660 KB to every rank for the two
+    # rows it needs)
     def _gather_boundaries(self, x):
         """x (T_local, E...) -> (prev_rank_last, next_rank_first) or None at the sequence ends."""
         if self.world == 1:
             return None, None
-        mine = torch.stack([x[0], x[-1]]).contiguous()
-        out = [torch.empty_like(mine) for _ in range(self.world)]
-        dist.all_gather(out, mine, group=self.group)
-        prev = None if self.is_first else out[self.rank - 1][1].contiguous()
-        nxt = None if self.is_last else out[self.rank + 1][0].contiguous()
+        first, last = x[0].contiguous(), x[-1].contiguous()
+        prev = None if self.is_first else torch.empty_like(last)
+        nxt = None if self.is_last else torch.empty_like(first)
+        ops = []
+        if not self.is_first:
+            ops += [dist.P2POp(dist.isend, first, self.rank - 1, self.group), dist.P2POp(dist.irecv, prev, self.rank - 1, self.group)]
+        if not self.is_last:
+            ops += [dist.P2POp(dist.isend, last, self.rank + 1, self.group), dist.P2POp(dist.irecv, nxt, self.rank + 1, self.group)]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
         return prev, nxt
 
     def _static(self, name, t):

@@ -46,6 +46,25 @@ def _host_staged_dist():
         dist.recv(c, src=src, group=group)
         t.copy_(c)
 
+    class P2POp(object):
+        def __init__(self, op, tensor, peer, group=None):
+            self.op, self.tensor, self.peer, self.group = op, tensor, peer, group
+
+    def batch_isend_irecv(ops):
+        staged, reqs = [], []
+        for o in ops:
+            c = o.tensor.detach().cpu() if o.op is shim.isend else torch.empty(o.tensor.shape, dtype=o.tensor.dtype)
+            staged.append(c)
+            reqs.append((dist.isend if o.op is shim.isend else dist.irecv)(c, o.peer, group=o.group))
+        for r in reqs:
+            r.wait()
+        for o, c in zip(ops, staged):
+            if o.op is shim.irecv:
+                o.tensor.copy_(c)
+        return []
+
+    shim.isend, shim.irecv = object(), object()
+    shim.P2POp, shim.batch_isend_irecv = P2POp, batch_isend_irecv
     shim.all_gather, shim.all_reduce, shim.send, shim.recv = all_gather, all_reduce, send, recv
     return shim
 

@@ -229,12 +229,13 @@ __device__ __forceinline__ void r_insert(unsigned long long* q, float pz, bool i
 // =============================================================================================
 // windows and strips
 // =============================================================================================
-__global__ __launch_bounds__(256) void k_raster_windows(RasterP p) {
-  __shared__ float sbb[4][4];
+#define RWT 1024             // threads of the window kernel (16 waves per body keep enough loads in flight)
+__global__ __launch_bounds__(RWT) void k_raster_windows(RasterP p) {
+  __shared__ float sbb[RWT / 64][4];
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* vb = p.verts + (size_t)b * p.V * 3;
   float mnx = 1e30f, mny = 1e30f, mxx = -1e30f, mxy = -1e30f;
-  for (int v = tid; v < p.V; v += 256) {
+  for (int v = tid; v < p.V; v += RWT) {
     const float X = vb[(size_t)v * 3], Y = vb[(size_t)v * 3 + 1], Z = vb[(size_t)v * 3 + 2];
     const float xn = p.s * (-X) / Z + p.w1, yn = p.s * (-Y) / Z + p.h1;
     float* o = p.ndc + ((size_t)b * p.V + v) * 3;
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(256) void k_raster_windows(RasterP p) {
   }
   __syncthreads();
   if (tid == 0) {
-    for (int w = 1; w < 4; ++w) {
+    for (int w = 1; w < RWT / 64; ++w) {
       mnx = fminf(mnx, sbb[w][0]); mny = fminf(mny, sbb[w][1]);
       mxx = fmaxf(mxx, sbb[w][2]); mxy = fmaxf(mxy, sbb[w][3]);
     }
@@ -1264,7 +1265,7 @@ static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const flo
     MH_LAUNCH_CHECK();
   }
   if (alpha_out) MH_HIP(hipMemsetAsync(alpha_out, 0, (size_t)p.B * H * W * sizeof(float), st));
-  hipLaunchKernelGGL(k_raster_windows, dim3(p.B), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(k_raster_windows, dim3(p.B), dim3(RWT), 0, st, p);
   MH_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_raster_strip_table, dim3(1), dim3(1024), 0, st, p);
   MH_LAUNCH_CHECK();

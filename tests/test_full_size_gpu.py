@@ -1,0 +1,111 @@
+"""Parity at BASELINE.json's full sizes.
+
+* C3 (the configuration the metric is quoted on): 4 humans x 200 frames at 240x135, full loss stack with a
+  scene cloud -- one complete cycle of the drop-in optimiser against the CPU oracle (loss log and the gradient
+  of every leaf), then the one-euro filters of the whole sequence and a second cycle with the filtered-vertex
+  term switched on.  The oracle needs ~10 s per cycle at this size.
+* C5 (contact term dominant): a 200 000-point scene cloud -- the grid search against the brute-force scan on
+  every lowest-vertex query of an 8 humans x 500 frames batch (4000 queries), and against a float64 numpy
+  search on a sample of them; then a cycle at the C5 shape whose per-frame gradients of the first batch must
+  equal the oracle's on that batch alone (the per-frame terms do not couple frames once the temporal
+  coefficients are zero), a size-independent restriction property."""
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+from test_fit_full_gpu import LEAF_MAP, _oracle_grad, _setup
+from test_scene_knn_gpu import _dy_reference, _run
+
+pytestmark = pytest.mark.gpu
+
+LOG_KEYS = ['loss_pose24j', 'loss_depth', 'loss_silhouette', 'reg_ref_poses', 'reg_scale', 'reg_contact',
+            'reg_foot_sliding', 'reg_vel']
+
+
+def _compare_grads(e, o, frac=0.01, tight=5e-3, med=1e-3):
+    for name, ename in LEAF_MAP:
+        w = _oracle_grad(o, name)
+        g = e.leaf(ename, e.grads).cpu().numpy().reshape(w.shape)
+        assert np.isfinite(g).all(), name
+        scale = max(np.abs(w).max(), 1e-8)
+        err = np.abs(g - w)
+        assert (err > tight * scale).mean() < frac, (name, err.max(), scale)
+        assert np.median(err) < med * scale, name
+
+
+def test_c3_full_size_cycle_matches_oracle(smpl_struct, smpl_regs, oracle_model, tmp_path):
+    T, N, W, H, batch = 200, 4, 240, 135, 50
+    opt, dl, o, batches, seq = _setup(smpl_struct, smpl_regs, oracle_model, tmp_path, T, N, W, H, batch, 41, True)
+    opt._stage_from_dataloader(dl)
+    from mhhip.raster import RasterTerms
+    e = opt.engine
+    raster = RasterTerms(e)
+    e.cycle(0, raster=raster)
+    log = e.read_log(1)[0]
+    want = o.cycle_grads(batches)
+    for k in LOG_KEYS:
+        np.testing.assert_allclose(log[k], want[k], rtol=3e-3, atol=1e-6, err_msg=k)
+    for k in ['loss_pose24j', 'loss_depth', 'loss_silhouette', 'reg_contact', 'reg_vel']:
+        assert want[k] > 0, k
+    _compare_grads(e, o)
+    # filters over the 200-frame sequence (optimizer.py:664-675), then the filtered-vertex term (:571-573)
+    e.update_filters()
+    o.update_filters()
+    np.testing.assert_allclose(e.verts_filt.cpu().numpy().reshape(T, -1), o.v_filt.numpy().reshape(T, -1), atol=2e-5)
+    np.testing.assert_allclose(e.pT_filt.cpu().numpy().reshape(T, -1), o.pT_filt.numpy().reshape(T, -1), atol=2e-6)
+    e.cycle(1, raster=raster)
+    log = e.read_log(2)[1]
+    want = o.cycle_grads(batches)
+    for k in LOG_KEYS + ['reg_filter_verts']:
+        np.testing.assert_allclose(log[k], want[k], rtol=3e-3, atol=1e-6, err_msg=k)
+    assert want['reg_filter_verts'] >= 0
+    _compare_grads(e, o)
+
+
+def test_c5_cloud_of_200k_points():
+    rng = np.random.RandomState(11)
+    M = 200000
+    # ground sheet with relief + furniture-like boxes, 8 humans x 500 frames of lowest-vertex queries above it
+    pts = np.stack([rng.uniform(-6, 6, M), 1.2 + 0.03 * rng.randn(M) + 0.1 * np.sin(rng.uniform(0, 6, M)),
+                    rng.uniform(2, 14, M)], 1).astype(np.float32)
+    box = rng.rand(M) < 0.15
+    pts[box, 1] -= rng.uniform(0.2, 0.9, box.sum()).astype(np.float32)
+    B = 8 * 500
+    q = np.stack([rng.uniform(-5, 5, B), 1.2 + rng.uniform(-0.3, 0.1, B), rng.uniform(2.5, 13, B)], 1).astype(np.float32)
+    brute, grid = _run(pts, q)
+    np.testing.assert_allclose(grid, brute, atol=1e-6, rtol=0)      # same 32 points (summation order differs)
+    sel = rng.choice(B, 96, replace=False)
+    np.testing.assert_allclose(grid[sel], _dy_reference(pts, q[sel], 32), atol=2e-5, rtol=1e-5)
+
+
+def test_c5_shape_cycle_restricts_to_the_first_batch(smpl_struct, smpl_regs, oracle_model, tmp_path, monkeypatch):
+    T, N, W, H, batch = 500, 8, 240, 135, 25
+    coefs = dict(gi.COEFS)
+    coefs.update(reg_velocity=0.0, reg_verts_filter=0.0, reg_foot_sliding=0.0)
+    monkeypatch.setattr(gi, 'COEFS', coefs)
+    opt, dl, o_full, batches, seq = _setup(smpl_struct, smpl_regs, oracle_model, tmp_path, T, N, W, H, batch, 43, True)
+    opt._stage_from_dataloader(dl)
+    from mhhip.raster import RasterTerms
+    e = opt.engine
+    e.cycle(0, raster=RasterTerms(e))
+    log = e.read_log(1)[0]
+    g_all = {ename: e.leaf(ename, e.grads).cpu().numpy() for _, ename in LEAF_MAP}
+    for v in g_all.values():
+        assert np.isfinite(v).all()
+    for k in LOG_KEYS:
+        assert np.isfinite(log[k]), k
+    assert log['reg_contact'] > 0 and log['loss_depth'] > 0 and log['loss_silhouette'] > 0
+    # the oracle on the first batch alone (same leaves, same scene): gradients of the per-frame leaves of these
+    # frames, and the first batch's share of the shared-shape gradient
+    want = o_full.cycle_grads(batches[:1])
+    for name, ename in [('poses_T', 'poses_T'), ('poses_smpl', 'poses_smpl'), ('zmin_lin', 'zmin_lin'),
+                        ('zmax_lin', 'zmax_lin')]:
+        w = _oracle_grad(o_full, name)
+        g = g_all[ename].reshape(w.shape)
+        w, g = w[:batch], g[:batch]
+        scale = max(np.abs(w).max(), 1e-8)
+        err = np.abs(g - w)
+        assert (err > 5e-3 * scale).mean() < 0.01, (name, err.max(), scale)
+        assert np.median(err) < 1e-3 * scale, name
+        assert np.abs(w).max() > 0, name

@@ -229,7 +229,9 @@ __device__ __forceinline__ void r_insert(unsigned long long* q, float pz, bool i
 // =============================================================================================
 // windows and strips
 // =============================================================================================
+#ifndef RWT
 #define RWT 1024             // threads of the window kernel (16 waves per body keep enough loads in flight)
+#endif
 __global__ __launch_bounds__(RWT) void k_raster_windows(RasterP p) {
   __shared__ float sbb[RWT / 64][4];
   const int b = blockIdx.x, tid = threadIdx.x;

@@ -34,6 +34,7 @@ N_PEOPLE, T_LOCAL, IMG, BATCH = 4, 200, (240, 135), 10
 # algorithmic bytes / flops of the LBS+projection kernels per human.frame.iteration (fwd+bwd)
 PEAK_HBM_GBS = 8000.0
 PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_VALU_GIPS = 614.4     # 256 CUs x 4 SIMDs x 2.4 GHz, one wave64 vector instruction per 4 cycles
 
 
 def build_optimizer(struct, regs, tmp, num_frames, device, K):
@@ -64,6 +65,22 @@ def load_pmc_traffic():
         return {}
     with open(path) as f:
         return json.load(f)
+
+
+def load_pmc_valu(kernel):
+    """Vector instructions per launch of `kernel` from the committed SQ counter pass (profiles/README.md)"""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_sq_counters.txt')
+    if not os.path.exists(path):
+        return None
+    cur = None
+    with open(path) as f:
+        for line in f:
+            w = line.split()
+            if line[:1] not in ' \t' and w:
+                cur = w[0]
+            elif cur == kernel and w and w[0] == 'SQ_INSTS_VALU':
+                return float(w[1])
+    return None
 
 
 def cpu_baseline(struct, regs, K, seq, pT0, frames, cycles):
@@ -253,6 +270,11 @@ def main():
                     'launch_us': round(us, 1), 'algorithmic_bytes': algo, 'window_pixels': window_px,
                     'note': 'dominant kernel by time; integer/LDS-atomic z-buffer selection, VALU-issue bound '
                             '(see DESIGN.md section 4 and profiles/)', 'dominant_by_events': dom}
+            nv = load_pmc_valu('k_raster_strip')
+            if nv:   # the bound that does apply: wave64 vector instructions against 1024 SIMDs x 2.4 GHz / 4 cycles
+                gi = nv / (us * 1e-6) / 1e9
+                roof['valu_issue'] = {'wave_instructions': nv, 'achieved': round(gi, 1), 'peak': PEAK_VALU_GIPS,
+                                      'unit': 'G wave-instr/s', 'frac': round(gi / PEAK_VALU_GIPS, 3)}
         # the GEMM-shaped kernels against the dense f32 MFMA peak: flops = 2 x 3 x 217 x V per body forward, plus the
         # 12 x 24 bone-transform adjoint per vertex backward
         roof_mfma = {}

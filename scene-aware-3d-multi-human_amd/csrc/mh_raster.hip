@@ -599,14 +599,27 @@ __global__ __launch_bounds__(1024) void k_raster_strip_order(RasterP p) {
     const int n = (rs[rb] - rs[ra]) + (rs[H + 1 + rb] - rs[H + 1 + ra]);
     return 63 - min(63, (int)((long long)n * 64 / (p.F + 1)));       // class 0 = most faces
   };
-  for (int s = tid; s < total; s += 1024) atomicAdd(&hist[cost_class(s)], 1);
+  // the classes of a thread's first eight tiles stay in registers (a class costs a chain of four dependent loads)
+  int cls[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int s = tid + i * 1024;
+    cls[i] = s < total ? cost_class(s) : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (cls[i] >= 0) atomicAdd(&hist[cls[i]], 1);
+  for (int s = tid + 8 * 1024; s < total; s += 1024) atomicAdd(&hist[cost_class(s)], 1);
   __syncthreads();
-  if (tid == 0) {
-    int a = 0;
-    for (int k = 0; k < 64; ++k) { cursor[k] = a; a += hist[k]; }
+  if (tid < 64) {           // exclusive scan of the 64 class counts by the first wave
+    const int h = hist[tid];
+    cursor[tid] = mh_wave_scan_add(h) - h;
   }
   __syncthreads();
-  for (int s = tid; s < total; s += 1024) p.strip_order[atomicAdd(&cursor[cost_class(s)], 1)] = s;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (cls[i] >= 0) p.strip_order[atomicAdd(&cursor[cls[i]], 1)] = tid + i * 1024;
+  for (int s = tid + 8 * 1024; s < total; s += 1024) p.strip_order[atomicAdd(&cursor[cost_class(s)], 1)] = s;
 }
 
 #define RW (RB / 64)         // waves per tile workgroup

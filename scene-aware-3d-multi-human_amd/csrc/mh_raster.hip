@@ -443,24 +443,33 @@ __device__ __forceinline__ int r_wave_scan_max(int x) {              // values >
 // conservative pixel-row range of every face + counting sort of the body's visible faces by their first row (one
 // workgroup per body): a tile's candidate faces are then one contiguous range of fsort (first row in
 // [tile_row0 - tallest_face, tile_last_row]); entries are hi << 20 | face.
+#ifndef RFS
 #define RFS 512
+#endif
+#ifndef RFS_U
+#define RFS_U 4              // faces whose gathers are in flight together (first pass)
+#endif
+#define RFS_V 7              // row words fetched together (second pass)
 // lo | hi << 16 with bit 15 = sign of the screen-space area (which side of the face looks at the camera)
-__device__ __forceinline__ unsigned r_face_rows(const RasterP& p, const float* nb, int f, float* zmin_out) {
-  float x[3], y[3], z[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int vi = p.faces[3 * f + k];
-    x[k] = nb[(size_t)vi * 3]; y[k] = nb[(size_t)vi * 3 + 1]; z[k] = nb[(size_t)vi * 3 + 2];
-  }
+// continuous row coordinate of an NDC y as one fused multiply-add: row = ra - y * rk (r_ndc_to_pix spelled out costs two
+// IEEE divisions per call; the difference is ~1e-5 px, inside the 1e-3 px guard below)
+__device__ __forceinline__ void r_row_affine(const RasterP& p, float* ra, float* rk) {
+  float range = 2.0f;
+  if (p.H > p.W) range = ((float)p.H * range) / (float)p.W;
+  *rk = (float)p.H / range;
+  *ra = (float)p.H - 0.5f - 0.5f * (float)p.H;
+}
+__device__ __forceinline__ unsigned r_face_rows_xyz(const RasterP& p, float ra, float rk, const float (&x)[3], const float (&y)[3],
+                                                     const float (&z)[3], float* zmin_out) {
   const float farea = r_edge(x[0], y[0], x[1], y[1], x[2], y[2]);
   unsigned out = 1u;                                     // lo = 1 > hi = 0: skipped
   if (fminf(z[0], fminf(z[1], z[2])) >= R_KEPS && !(farea <= R_KEPS && farea >= -R_KEPS)) {
     const float blur_d = sqrtf(BLUR_D);
     const float bymin = fminf(y[0], fminf(y[1], y[2])) - blur_d, bymax = fmaxf(y[0], fmaxf(y[1], y[2])) + blur_d;
-    // rows whose pixel centre lies inside the blurred bbox: r_ndc_to_pix is the continuous row coordinate (centres at
-    // the integers), 1e-3 px absorbs its rounding (~1e-5 px).  A tight range matters: the tallest face of a body sets
-    // how far above a tile its candidate range starts
-    const float lo = ceilf(r_ndc_to_pix(bymax, p.H, p.W) - 1e-3f), hi = floorf(r_ndc_to_pix(bymin, p.H, p.W) + 1e-3f);
+    // rows whose pixel centre lies inside the blurred bbox (centres at the integers of the row coordinate), 1e-3 px
+    // absorbs the rounding.  A tight range matters: the tallest face of a body sets how far above a tile its
+    // candidate range starts
+    const float lo = ceilf(fmaf(-bymax, rk, ra) - 1e-3f), hi = floorf(fmaf(-bymin, rk, ra) + 1e-3f);
     if (hi >= lo && hi >= 0.f && lo <= (float)(p.H - 1)) {
       const unsigned ulo = (unsigned)fmaxf(lo, 0.f), uhi = (unsigned)fminf(hi, (float)(p.H - 1));
       out = ulo | (uhi << 16) | (farea > 0.f ? 0x8000u : 0u);
@@ -469,11 +478,10 @@ __device__ __forceinline__ unsigned r_face_rows(const RasterP& p, const float* n
   *zmin_out = fminf(z[0], fminf(z[1], z[2]));
   return out;
 }
-
 // Two classes per row: the faces whose class is nearer to the camera on average (for a closed mesh: the ones looking at
 // it) come first in fsort, so that a tile rasterises them first and the depth cull of k_raster_strip then removes most
 // of the far-side candidates.  row_start: [2][H+1] (+ total), class-major in that order.
-__global__ __launch_bounds__(RFS) void k_raster_face_sort(RasterP p) {
+__global__ __launch_bounds__(RFS, 8) void k_raster_face_sort(RasterP p) {
   extern __shared__ int hist[];                     // [2][H + 1]: sign class, row
   __shared__ int s_maxh, s_flip;
   __shared__ float s_z[2];
@@ -487,16 +495,43 @@ __global__ __launch_bounds__(RFS) void k_raster_face_sort(RasterP p) {
   if (tid == 0) { s_maxh = 0; s_z[0] = s_z[1] = 0.f; s_n[0] = s_n[1] = 0; }
   __syncthreads();
   int mh = 0, n0 = 0, n1 = 0;
-  float z0 = 0.f, z1 = 0.f;
-  for (int f = tid; f < p.F; f += RFS) {
-    float zm;
-    const unsigned r = r_face_rows(p, nb, f, &zm);
-    fr[f] = r;
+  float z0 = 0.f, z1 = 0.f, ra, rk;
+  r_row_affine(p, &ra, &rk);
+  auto tally = [&](unsigned r, float zm, bool live) {
     const int lo = (int)(r & 0x7fffu), hi = (int)(r >> 16), cls = (int)((r >> 15) & 1u);
-    if (lo <= hi) {
+    if (live && lo <= hi) {
       atomicAdd(&hist[cls * HB + lo], 1);
       mh = max(mh, hi - lo);
       if (cls) { z1 += zm; ++n1; } else { z0 += zm; ++n0; }
+    }
+  };
+  // The gathers of RFS_U faces are in flight together: the kernel is one workgroup per body and was bound by the
+  // chain index load -> vertex gather -> histogram of one face after the other (27 chains per thread for SMPL).
+  // (Measured: the kernel stays at the rate of its 12-byte gathers, ~9 cycles per wave-wide gather per CU; combining
+  // the histogram atomics of a wave by ballot was 4x slower -- a wave's 64 faces fall into too many distinct bins.)
+  for (int f0 = tid; f0 < p.F; f0 += RFS_U * RFS) {
+    int vi[RFS_U][3];
+#pragma unroll
+    for (int u = 0; u < RFS_U; ++u) {
+      const int f = min(f0 + u * RFS, p.F - 1);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) vi[u][k] = p.faces[3 * f + k];
+    }
+    float x[RFS_U][3], y[RFS_U][3], z[RFS_U][3];
+#pragma unroll
+    for (int u = 0; u < RFS_U; ++u)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float* q = nb + (size_t)vi[u][k] * 3;
+        x[u][k] = q[0]; y[u][k] = q[1]; z[u][k] = q[2];
+      }
+#pragma unroll
+    for (int u = 0; u < RFS_U; ++u) {
+      const int f = f0 + u * RFS;
+      float zm;
+      const unsigned r = r_face_rows_xyz(p, ra, rk, x[u], y[u], z[u], &zm);
+      if (f < p.F) fr[f] = r;
+      tally(r, zm, f < p.F);
     }
   }
 #pragma unroll
@@ -535,10 +570,16 @@ __global__ __launch_bounds__(RFS) void k_raster_face_sort(RasterP p) {
     if (tid == 0) { p.maxh[b] = s_maxh; rs[2 * HB] = carry; }
   }
   __syncthreads();
-  for (int f = tid; f < p.F; f += RFS) {
-    const unsigned r = fr[f];
+  auto place = [&](unsigned r, int f, bool live) {
     const int lo = (int)(r & 0x7fffu), hi = (int)(r >> 16), cls = (int)((r >> 15) & 1u);
-    if (lo <= hi) fs[atomicAdd(&hist[cls * HB + lo], 1)] = ((unsigned)hi << 20) | (unsigned)f;
+    if (live && lo <= hi) fs[atomicAdd(&hist[cls * HB + lo], 1)] = ((unsigned)hi << 20) | (unsigned)f;
+  };
+  for (int f0 = tid; f0 < p.F; f0 += RFS_V * RFS) {       // the row words of RFS_V faces are fetched together
+    unsigned r[RFS_V];
+#pragma unroll
+    for (int u = 0; u < RFS_V; ++u) r[u] = fr[min(f0 + u * RFS, p.F - 1)];
+#pragma unroll
+    for (int u = 0; u < RFS_V; ++u) place(r[u], f0 + u * RFS, f0 + u * RFS < p.F);
   }
 }
 

@@ -116,36 +116,39 @@ __device__ __forceinline__ float r_seg(float px, float py, float ax, float ay, f
 
 struct Tri {
   float x[3], y[3], z[3];     // NDC xy + view z
-  float cx[3], cy[3];         // camera-space x, y (for the projection adjoint)
   int idx[3];
 };
 
-__device__ __forceinline__ void r_load_tri(const RasterP& p, const float* vb, int f, Tri& t) {
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int vi = p.faces[3 * f + k];
-    t.idx[k] = vi;
-    const float X = vb[(size_t)vi * 3], Y = vb[(size_t)vi * 3 + 1], Z = vb[(size_t)vi * 3 + 2];
-    t.cx[k] = X;
-    t.cy[k] = Y;
-    t.z[k] = Z;
-    t.x[k] = p.s * (-X) / Z + p.w1;
-    t.y[k] = p.s * (-Y) / Z + p.h1;
-  }
-}
-
-// the same from the projected-vertex buffer written by k_raster_windows (no divisions); the camera-space
-// x, y needed by the projection adjoint follow from x_ndc = -s X / Z + w1
+// a face from the projected-vertex buffer written by k_raster_windows (no divisions)
 __device__ __forceinline__ void r_load_tri_ndc(const RasterP& p, const float* nb, int f, Tri& t) {
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const int vi = p.faces[3 * f + k];
     t.idx[k] = vi;
-    const float xn = nb[(size_t)vi * 3], yn = nb[(size_t)vi * 3 + 1], Z = nb[(size_t)vi * 3 + 2];
-    t.x[k] = xn; t.y[k] = yn; t.z[k] = Z;
-    t.cx[k] = -(xn - p.w1) * Z / p.s;
-    t.cy[k] = -(yn - p.h1) * Z / p.s;
+    t.x[k] = nb[(size_t)vi * 3]; t.y[k] = nb[(size_t)vi * 3 + 1]; t.z[k] = nb[(size_t)vi * 3 + 2];
   }
+}
+
+// The gradient kernel divides by a handful of denominators many times over (1/area, 1/sum of clipped weights, 1/Z,
+// 1/|edge|^2): one v_rcp_f32 (1 ulp) and multiplications instead of IEEE divisions (~10 instructions each, ~100 of
+// them per live pixel before).  Only the gradient arithmetic is affected; which faces were selected, and the depth
+// they were selected with, come from the exact forward pass.
+__device__ __forceinline__ float r_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// squared distance to segment ab as r_seg, with the reciprocal
+__device__ __forceinline__ float r_seg_rcp(float px, float py, float ax, float ay, float bx, float by, float* t, bool* deg) {
+  const float bax = bx - ax, bay = by - ay;
+  const float l2 = bax * bax + bay * bay;
+  if (l2 <= R_KEPS) {
+    *t = 1.f;
+    *deg = true;
+    return (px - bx) * (px - bx) + (py - by) * (py - by);
+  }
+  float tt = (bax * (px - ax) + bay * (py - ay)) * r_rcp(l2);
+  tt = fminf(fmaxf(tt, 0.f), 1.f);
+  *t = tt;
+  *deg = false;
+  const float qx = ax + tt * bax - px, qy = ay + tt * bay - py;
+  return qx * qx + qy * qy;
 }
 
 // Gradient scatter.  One workgroup owns one body: every contribution of the body's window pixels is
@@ -172,12 +175,13 @@ __device__ __forceinline__ void r_acc_add(float* gvb, int vid, float gx, float g
     atomicAdd(o + 2, gz);
   }
 }
-// scatter d/d(ndc x, ndc y, z) of one vertex to camera space
+// scatter d/d(ndc x, ndc y, z) of one vertex to camera space: x_ndc = -s X / Z + w1, so d x_ndc / dX = -s / Z and
+// d x_ndc / dZ = s X / Z^2 = -(x_ndc - w1) / Z
 template <bool TAB>
 __device__ __forceinline__ void r_scatter(const RasterP& p, float* gvb, const Tri& t, int k, float gxn, float gyn, float gz) {
-  const float Z = t.z[k];
-  const float gx = -p.s / Z * gxn, gy = -p.s / Z * gyn;
-  const float gzz = gz + p.s * (t.cx[k] * gxn + t.cy[k] * gyn) / (Z * Z);
+  const float rz = r_rcp(t.z[k]);
+  const float gx = -p.s * rz * gxn, gy = -p.s * rz * gyn;
+  const float gzz = gz - ((t.x[k] - p.w1) * gxn + (t.y[k] - p.h1) * gyn) * rz;
   r_acc_add<TAB>(gvb, t.idx[k], gx, gy, gzz);
 }
 
@@ -1079,34 +1083,36 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
         const float m = (z > 0.f ? 1.f : 0.f) * (float)((p.ebits[gp] >> n) & 1u) * pvalid;
         const float zc = z + 0.2f;
         if (m != 0.f && zc > p.eps && 1.f / zc > 1e-3f) {
-          const float gpz = gA * (-1.f / zc);
+          const float gpz = -gA * r_rcp(zc);
           Tri tr;
           r_load_tri_ndc(p, vb, (int)(k0 & 0xffffffffu), tr);
           const float area = r_edge(tr.x[2], tr.y[2], tr.x[0], tr.y[0], tr.x[1], tr.y[1]) + R_KEPS;
-          float w[3] = {r_edge(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2]) / area,
-                        r_edge(xf, yf, tr.x[2], tr.y[2], tr.x[0], tr.y[0]) / area,
-                        r_edge(xf, yf, tr.x[0], tr.y[0], tr.x[1], tr.y[1]) / area};
+          const float ia = r_rcp(area);
+          float w[3] = {r_edge(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2]) * ia,
+                        r_edge(xf, yf, tr.x[2], tr.y[2], tr.x[0], tr.y[0]) * ia,
+                        r_edge(xf, yf, tr.x[0], tr.y[0], tr.x[1], tr.y[1]) * ia};
           const float c[3] = {fmaxf(w[0], 0.f), fmaxf(w[1], 0.f), fmaxf(w[2], 0.f)};
           const float craw = c[0] + c[1] + c[2];
           const float cs = fmaxf(craw, 1e-5f);
+          const float ics = r_rcp(cs);
           // pz = sum (c_i/cs) z_i
           float gwc[3], gz[3];
           float dotg = 0.f;
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
-            gz[k] = gpz * c[k] / cs;
+            gz[k] = gpz * c[k] * ics;
             gwc[k] = gpz * tr.z[k];          // d/d(normalised clipped weight)
             dotg += gwc[k] * c[k];
           }
           float gw[3];
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
-            const float gc = gwc[k] / cs - (craw > 1e-5f ? dotg / (cs * cs) : 0.f);
+            const float gc = gwc[k] * ics - (craw > 1e-5f ? dotg * ics * ics : 0.f);
             gw[k] = w[k] > 0.f ? gc : 0.f;
           }
           // w_i = e_i / area
-          const float ge[3] = {gw[0] / area, gw[1] / area, gw[2] / area};
-          const float garea = -(gw[0] * w[0] + gw[1] * w[1] + gw[2] * w[2]) / area;
+          const float ge[3] = {gw[0] * ia, gw[1] * ia, gw[2] * ia};
+          const float garea = -(gw[0] * w[0] + gw[1] * w[1] + gw[2] * w[2]) * ia;
           float gx[3] = {0, 0, 0}, gy[3] = {0, 0, 0};
           // e0 = edge(p; v1, v2), e1 = edge(p; v2, v0), e2 = edge(p; v0, v1); area = edge(v2; v0, v1)
 #define EDGE_ADJ(gE, A, Bv)                                           \
@@ -1145,14 +1151,15 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
           if (!have[k]) continue;
           const Tri& tr = trs[k];
           const float area = r_edge(tr.x[2], tr.y[2], tr.x[0], tr.y[0], tr.x[1], tr.y[1]) + R_KEPS;
-          const bool inside = r_edge(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2]) / area > 0.f &&
-                              r_edge(xf, yf, tr.x[2], tr.y[2], tr.x[0], tr.y[0]) / area > 0.f &&
-                              r_edge(xf, yf, tr.x[0], tr.y[0], tr.x[1], tr.y[1]) / area > 0.f;
+          const float ia = r_rcp(area);
+          const bool inside = r_edge(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2]) * ia > 0.f &&
+                              r_edge(xf, yf, tr.x[2], tr.y[2], tr.x[0], tr.y[0]) * ia > 0.f &&
+                              r_edge(xf, yf, tr.x[0], tr.y[0], tr.x[1], tr.y[1]) * ia > 0.f;
           float t01, t02, t12;
           bool g01, g02, g12;
-          const float d01 = r_seg(xf, yf, tr.x[0], tr.y[0], tr.x[1], tr.y[1], &t01, &g01);
-          const float d02 = r_seg(xf, yf, tr.x[0], tr.y[0], tr.x[2], tr.y[2], &t02, &g02);
-          const float d12 = r_seg(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2], &t12, &g12);
+          const float d01 = r_seg_rcp(xf, yf, tr.x[0], tr.y[0], tr.x[1], tr.y[1], &t01, &g01);
+          const float d02 = r_seg_rcp(xf, yf, tr.x[0], tr.y[0], tr.x[2], tr.y[2], &t02, &g02);
+          const float d12 = r_seg_rcp(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2], &t12, &g12);
           float d, tt;
           bool dg;
           int a, bb;
@@ -1169,7 +1176,7 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
           }
           ea[k] = a; eb[k] = bb;
           const float sd = inside ? -d : d;
-          pk[k] = 1.f / (1.f + expf(sd / SIGMA_S));
+          pk[k] = r_rcp(1.f + expf(sd * (1.f / SIGMA_S)));
           sgn[k] = inside ? -1.f : 1.f;
           qprod *= 1.f - pk[k];
         }

@@ -373,12 +373,29 @@ __global__ __launch_bounds__(1024) void k_raster_strip_table(RasterP p) {
     }
   }
   __syncthreads();
+  // the partial pieces by decreasing size (32 classes): the largest of them start first as well
+  __shared__ int p_hist[32], p_cur[32];
+  if (threadIdx.x < 32) p_hist[threadIdx.x] = 0;
+  __syncthreads();
   const int nf = c_full;
+  auto part_class = [&](int rem) { return 31 - min(31, rem * 32 / RG_UNIT); };
+  for (int b = threadIdx.x; b < p.B; b += 1024) {
+    const int ww = p.win[b * 4 + 2], wh = p.win[b * 4 + 3];
+    const int npx = (ww > 0 && wh > 0) ? ww * wh : 0;
+    if (npx % RG_UNIT) atomicAdd(&p_hist[part_class(npx % RG_UNIT)], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int a = 0;
+    for (int k = 0; k < 32; ++k) { p_cur[k] = a; a += p_hist[k]; }
+    c_part = a;
+  }
+  __syncthreads();
   for (int b = threadIdx.x; b < p.B; b += 1024) {
     const int ww = p.win[b * 4 + 2], wh = p.win[b * 4 + 3];
     const int npx = (ww > 0 && wh > 0) ? ww * wh : 0;
     if (npx % RG_UNIT) {
-      const int pos = nf + atomicAdd(&c_part, 1);
+      const int pos = nf + atomicAdd(&p_cur[part_class(npx % RG_UNIT)], 1);
       p.gunit_body[pos] = b;
       p.gunit_p0[pos] = (npx / RG_UNIT) * RG_UNIT;
     }
@@ -1013,7 +1030,9 @@ __global__ void k_raster_sil_out(RasterP p) {
 // =============================================================================================
 // gradients per strip
 // =============================================================================================
+#ifndef RGB
 #define RGB 1024             // threads per body workgroup of the gradient kernel (one workgroup per CU: LDS table)
+#endif
 template <bool TAB>
 __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
   __shared__ float s_red[RGB / 64];

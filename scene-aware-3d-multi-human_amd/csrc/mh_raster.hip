@@ -1051,10 +1051,6 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
     const int sy0 = y0;
     const float* vb = p.ndc + (size_t)b * p.V * 3;
     float* gvb = p.gverts + (size_t)b * p.V * 3;
-    __syncthreads();
-    if (use_tab)
-      for (int i = tid; i < p.V * 3; i += RGB) gtab[i] = 0.f;
-    __syncthreads();
     // the strips of a body are consecutive in the work list, so its window is one contiguous key range
     const unsigned long long* gk = p.gkeys + (size_t)p.body_koff[b] * 5;
     float S[6];
@@ -1068,17 +1064,37 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
     const float pvalid = p.p2d_valid[b];
     const uint32_t fr = p.front[b];
     // most window pixels carry no gradient (outside the blur band, masked out, occluded by a nearer person's mask):
-    // classify RG_LIST pixels at a time, compact the live ones into an LDS list and evaluate those with full waves
+    // classify RG_LIST pixels at a time, compact the live ones into an LDS list and evaluate those with full waves.
+    // The classification loads of all of a thread's pixels are issued first, and the table is cleared while they
+    // are in flight.
+    bool table_clear = !use_tab;
     for (int cbase = up0; cbase < npx; cbase += RG_LIST) {
-    if (tid == 0) *s_n = 0;
-    __syncthreads();
-    for (int i = cbase + tid; i < min(cbase + RG_LIST, npx); i += RGB) {
+    constexpr int NPT = RG_LIST / RGB;
+    unsigned long long c0[NPT], c1[NPT];
+    uint32_t ceb[NPT], cbt[NPT];
+    const int cend = min(cbase + RG_LIST, npx);
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+      const int i = min(cbase + tid + j * RGB, cend - 1);
       const int yi = sy0 + i / ww, xi = x0 + i % ww;
       const size_t gp = (size_t)t * P + (size_t)yi * W + xi;
       const unsigned long long* q = gk + (size_t)i * 5;
-      const bool dep = gA != 0.f && pvalid != 0.f && q[0] != RS_EMPTY && ((p.ebits[gp] >> n) & 1u);
-      const bool sil = sil_on && q[1] != RS_EMPTY && (p.bits[gp] & fr) == 0u;
-      const bool live = dep || sil;
+      c0[j] = q[0]; c1[j] = q[1];
+      ceb[j] = p.ebits[gp]; cbt[j] = p.bits[gp];
+    }
+    if (tid == 0) *s_n = 0;
+    if (!table_clear) {
+      __syncthreads();          // the previous unit's flush has read the table
+      for (int i = tid; i < p.V * 3; i += RGB) gtab[i] = 0.f;
+      table_clear = true;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+      const int i = cbase + tid + j * RGB;
+      const bool dep = gA != 0.f && pvalid != 0.f && c0[j] != RS_EMPTY && ((ceb[j] >> n) & 1u);
+      const bool sil = sil_on && c1[j] != RS_EMPTY && (cbt[j] & fr) == 0u;
+      const bool live = i < cend && (dep || sil);
       const unsigned long long m = __ballot(live);
       if (m) {
         int base = 0;

@@ -156,7 +156,9 @@ __device__ __forceinline__ float r_seg_rcp(float px, float py, float ax, float a
 // atomics), then added to dL/dverts with plain coalesced read-modify-writes -- no global atomics.
 // Bodies whose table does not fit in LDS (V > RG_MAXV) scatter with global atomics instead.
 #define RG_MAXV 11500
-#define RG_UNIT 2048           // window pixels per work unit of the gradient kernel (one classification pass)
+#ifndef RG_UNIT
+#define RG_UNIT 3072           // window pixels per work unit of the gradient kernel (one classification pass; swept 1536..4096)
+#endif
 #define RG_LIST RG_UNIT
 // dynamic LDS of the gradient kernel: [V][3] gradient table when it fits, then the live-pixel list.  The scatter
 // goes through this symbol (not through a pointer chosen at run time) so that the compiler emits ds_add_f32 rather
@@ -1069,7 +1071,7 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
     // are in flight.
     bool table_clear = !use_tab;
     for (int cbase = up0; cbase < npx; cbase += RG_LIST) {
-    constexpr int NPT = RG_LIST / RGB;
+    constexpr int NPT = (RG_LIST + RGB - 1) / RGB;
     unsigned long long c0[NPT], c1[NPT];
     uint32_t ceb[NPT], cbt[NPT];
     const int cend = min(cbase + RG_LIST, npx);

@@ -647,21 +647,24 @@ __device__ __forceinline__ void r_tile_depth_sums(const RasterP& p, int s, int b
   }
 }
 
-// Longest-processing-time-first order of the tiles: a tile's cost is its candidate-face count (known once the faces
-// are sorted by row).  Counting sort into 64 cost classes, most expensive first; without it the last tiles to start
+// Longest-processing-time-first order of the tiles: a tile's cost is estimated from its candidate-face count (known
+// once the faces are sorted by row) and its pixel count.  Counting sort into 64 cost classes, most expensive first; without it the last tiles to start
 // were often among the most expensive and the kernel ended ~40 % later than its work divided by the CU count.
 __global__ __launch_bounds__(1024) void k_raster_strip_order(RasterP p) {
   __shared__ int hist[64], cursor[64];
   const int tid = threadIdx.x, total = p.total[0], H = p.H;
   if (tid < 64) hist[tid] = 0;
   __syncthreads();
+  // measured on C3: a tile takes ~7 ns per candidate face and ~76 ns per window pixel
+  const long long cmax = (long long)p.F + 11ll * R_CAP + 1;
   auto cost_class = [&](int s) {
     const int b = p.strip_body[s];
     const int sy0 = p.strip_row0[s], sy1 = sy0 + p.strip_rows[s] - 1;
     const int* rs = p.row_start + (size_t)b * (2 * (H + 1) + 1);
     const int ra = max(0, sy0 - p.maxh[b]), rb = min(sy1 + 1, H);
     const int n = (rs[rb] - rs[ra]) + (rs[H + 1 + rb] - rs[H + 1 + ra]);
-    return 63 - min(63, (int)((long long)n * 64 / (p.F + 1)));       // class 0 = most faces
+    const long long cost = (long long)n + 11ll * p.strip_rows[s] * p.strip_cols[s];
+    return 63 - (int)min(63ll, cost * 64 / cmax);       // class 0 = most expensive
   };
   // the classes of a thread's first eight tiles stay in registers (a class costs a chain of four dependent loads)
   int cls[8];

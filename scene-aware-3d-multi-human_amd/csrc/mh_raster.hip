@@ -242,6 +242,7 @@ __global__ __launch_bounds__(RWT) void k_raster_windows(RasterP p) {
   __shared__ float sbb[RWT / 64][4];
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* vb = p.verts + (size_t)b * p.V * 3;
+  // extremes in NDC; the (monotonically decreasing) NDC -> pixel map is applied once to the four results
   float mnx = 1e30f, mny = 1e30f, mxx = -1e30f, mxy = -1e30f;
   for (int v = tid; v < p.V; v += RWT) {
     const float X = vb[(size_t)v * 3], Y = vb[(size_t)v * 3 + 1], Z = vb[(size_t)v * 3 + 2];
@@ -249,9 +250,8 @@ __global__ __launch_bounds__(RWT) void k_raster_windows(RasterP p) {
     float* o = p.ndc + ((size_t)b * p.V + v) * 3;
     o[0] = xn; o[1] = yn; o[2] = Z;
     if (Z > R_KEPS) {
-      const float fx = r_ndc_to_pix(xn, p.W, p.H), fy = r_ndc_to_pix(yn, p.H, p.W);
-      mnx = fminf(mnx, fx); mxx = fmaxf(mxx, fx);
-      mny = fminf(mny, fy); mxy = fmaxf(mxy, fy);
+      mnx = fminf(mnx, xn); mxx = fmaxf(mxx, xn);
+      mny = fminf(mny, yn); mxy = fmaxf(mxy, yn);
     }
   }
 #pragma unroll
@@ -267,6 +267,11 @@ __global__ __launch_bounds__(RWT) void k_raster_windows(RasterP p) {
     for (int w = 1; w < RWT / 64; ++w) {
       mnx = fminf(mnx, sbb[w][0]); mny = fminf(mny, sbb[w][1]);
       mxx = fmaxf(mxx, sbb[w][2]); mxy = fmaxf(mxy, sbb[w][3]);
+    }
+    if (mnx <= mxx) {       // at least one vertex in front of the camera
+      const float px0 = r_ndc_to_pix(mxx, p.W, p.H), px1 = r_ndc_to_pix(mnx, p.W, p.H);
+      const float py0 = r_ndc_to_pix(mxy, p.H, p.W), py1 = r_ndc_to_pix(mny, p.H, p.W);
+      mnx = px0; mxx = px1; mny = py0; mxy = py1;
     }
     // clamp in float first: a body far outside the image must not overflow the int conversion
     const float big = 1e6f;

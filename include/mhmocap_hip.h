@@ -221,6 +221,10 @@ int mh_prior_terms(int T, int N, int nbatches, const float* poses, const float* 
                    float* loss3, void* stream);
 /* out[0] = scale * sum(x[0..n)) in a fixed order (loss logging, optimizer.py:546-554, 588-593) */
 int mh_reduce_sum(const float* x, size_t n, float scale, float* out, void* stream);
+/* two arrays of the same length in one launch (the depth / silhouette log entries of a cycle); each sum in the order
+ * of mh_reduce_sum */
+int mh_reduce_sum2(const float* x0, const float* x1, size_t n, float scale, float* out0, float* out1,
+                   void* stream);
 
 /* ---- a15/a16: scene contact and foot sliding (optimizer.py:485-518) --------------------------- */
 /* argmax over vertices of y (first index on ties) and that vertex                           */

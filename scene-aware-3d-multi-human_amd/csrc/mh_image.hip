@@ -267,8 +267,9 @@ extern "C" int mh_prior_terms(int T, int N, int nbatches, const float* poses, co
 }
 
 // deterministic sum of n floats, scaled: out[0] = scale * sum(x)
-__global__ __launch_bounds__(256) void k_reduce_sum(const float* x, size_t n, float scale, float* out) {
+__global__ __launch_bounds__(256) void k_reduce_sum(const float* x, size_t n, float scale, float* out, const float* x1, float* out1) {
   __shared__ float s[256];
+  if (blockIdx.x == 1) { x = x1; out = out1; }        // second array of mh_reduce_sum2: same order, same launch
   float a = 0.f;
   for (size_t i = threadIdx.x; i < n; i += 256) a += x[i];
   s[threadIdx.x] = a;
@@ -282,7 +283,14 @@ __global__ __launch_bounds__(256) void k_reduce_sum(const float* x, size_t n, fl
 
 extern "C" int mh_reduce_sum(const float* x, size_t n, float scale, float* out, void* stream) {
   MH_CHECK(x && out, "null argument");
-  hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, (hipStream_t)stream, x, n, scale, out);
+  hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, (hipStream_t)stream, x, n, scale, out, (const float*)nullptr, (float*)nullptr);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+extern "C" int mh_reduce_sum2(const float* x0, const float* x1, size_t n, float scale, float* out0, float* out1, void* stream) {
+  MH_CHECK(x0 && x1 && out0 && out1, "null argument");
+  hipLaunchKernelGGL(k_reduce_sum, dim3(2), dim3(256), 0, (hipStream_t)stream, x0, n, scale, out0, x1, out1);
   MH_LAUNCH_CHECK();
   return MH_OK;
 }

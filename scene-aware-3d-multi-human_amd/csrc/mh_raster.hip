@@ -19,6 +19,7 @@
 //                         nearest of the blur 2e-5 silhouette pass (atomic-min cascade: the displaced key moves on).
 //                         The finished window is written to HBM once (40 B per window pixel).
 //   k_raster_sums         per tile: residual sums of the depth and silhouette terms
+//   k_raster_finish       silhouette value per body + chain of the depth-range leaves per frame
 //   k_raster_grads        per work unit (2048 window pixels of one body): live-pixel compaction, exact re-evaluation
 //                         of the selected faces, gradients scattered to an LDS vertex table, flushed with atomics
 // No (b,N,H,W,K) fragment tensor, z-buffer or alpha image is materialised (the reference builds
@@ -1028,13 +1029,31 @@ __global__ void k_raster_body_out(RasterP p) {
   const float gB = p.coef_depth * (-2.f) * diff / cnt;
   p.dinv[(size_t)b * 2] = gB * S[3];          // d/d(1/min_z) through the target disparity
   p.dinv[(size_t)b * 2 + 1] = gB * S[4];      // d/d(1/max_z)
+  p.sil_corr[b] = 0.f;                        // accumulated by k_raster_grads, consumed and cleared by k_raster_finish
 }
 
-// silhouette loss value once k_raster_grads has accumulated the alpha-dependent part
-__global__ void k_raster_sil_out(RasterP p) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= p.B) return;
-  p.sil_body[b] = p.sil_apply[b] * (p.sil_S[b] + p.sil_corr[b]) / (p.sil_D[b] + 1.f);        // losses.py:35-38
+// after k_raster_grads: silhouette loss value with the alpha-dependent part accumulated by the gradient kernel
+// (thread b < B), and the chain of the depth-range leaves (thread t < T; optimizer.py:683-688: min_z = softplus(zmin),
+// max_z = min_z.detach() + 1 + softplus(zmax))
+__global__ void k_raster_finish(RasterP p, int T, int do_sil, const float* zmin_lin, const float* zmax_lin, float* gzmin, float* gzmax) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (do_sil && i < p.B) {
+    p.sil_body[i] = p.sil_apply[i] * (p.sil_S[i] + p.sil_corr[i]) / (p.sil_D[i] + 1.f);        // losses.py:35-38
+    p.sil_corr[i] = 0.f;
+  }
+  if (gzmin && i < T) {
+    const int N = p.N;
+    float g0 = 0.f, g1 = 0.f;
+    for (int n = 0; n < N; ++n) {
+      g0 += p.dinv[((size_t)i * N + n) * 2];
+      g1 += p.dinv[((size_t)i * N + n) * 2 + 1];
+    }
+    const float e0 = expf(zmin_lin[i]), e1 = expf(zmax_lin[i]);
+    const float min_z = logf(1.f + e0);
+    const float max_z = min_z + 1.f + logf(1.f + e1);
+    gzmin[i] += g0 * (-1.f / (min_z * min_z)) * (e0 / (1.f + e0));
+    gzmax[i] += g1 * (-1.f / (max_z * max_z)) * (e1 / (1.f + e1));
+  }
 }
 
 // =============================================================================================
@@ -1259,24 +1278,6 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
   }
 }
 
-// chain of the depth-range leaves (optimizer.py:683-688): min_z = softplus(zmin),
-// max_z = min_z.detach() + 1 + softplus(zmax)
-__global__ void k_depth_range_grads(int T, int N, const float* dinv, const float* zmin_lin, const float* zmax_lin,
-                                    float* gzmin, float* gzmax) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= T) return;
-  float g0 = 0.f, g1 = 0.f;
-  for (int n = 0; n < N; ++n) {
-    g0 += dinv[((size_t)t * N + n) * 2];
-    g1 += dinv[((size_t)t * N + n) * 2 + 1];
-  }
-  const float e0 = expf(zmin_lin[t]), e1 = expf(zmax_lin[t]);
-  const float min_z = logf(1.f + e0);
-  const float max_z = min_z + 1.f + logf(1.f + e1);
-  gzmin[t] += g0 * (-1.f / (min_z * min_z)) * (e0 / (1.f + e0));
-  gzmax[t] += g1 * (-1.f / (max_z * max_z)) * (e1 / (1.f + e1));
-}
-
 __global__ void k_fill(float* x, size_t n, float v) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] = v;
 }
@@ -1405,7 +1406,7 @@ static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const flo
       MH_HIP(hipFuncSetAttribute((const void*)k_raster_grads<true>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_MAXV * 3 * 4 + (RG_LIST + 1) * 4));
       attr_set = true;
     }
-    MH_HIP(hipMemsetAsync(p.sil_corr, 0, (size_t)p.B * sizeof(float), st));
+    // sil_corr is zero here: cleared by k_raster_body_out (phase 1) and again by k_raster_finish after every use
     mh_prof_mark(MH_PROF_RASTER_GRADS, 0, st);
     // one workgroup per CU is resident (LDS table); the work-unit count is only known on the device
     const int ggrid = 256 * 6;
@@ -1413,12 +1414,11 @@ static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const flo
     else hipLaunchKernelGGL(k_raster_grads<false>, dim3(ggrid), dim3(RGB), tab, st, p);
     MH_LAUNCH_CHECK();
     mh_prof_mark(MH_PROF_RASTER_GRADS, 1, st);
-    hipLaunchKernelGGL(k_raster_sil_out, dim3((p.B + 255) / 256), dim3(256), 0, st, p);
-    MH_LAUNCH_CHECK();
   }
-  if (gzmin && gzmax) {
-    hipLaunchKernelGGL(k_depth_range_grads, dim3((T + 127) / 128), dim3(128), 0, st, T, N, (const float*)p.dinv, zmin_lin,
-                       zmax_lin, gzmin, gzmax);
+  if (gverts || (gzmin && gzmax)) {
+    const int n = p.B > T ? p.B : T;
+    hipLaunchKernelGGL(k_raster_finish, dim3((n + 255) / 256), dim3(256), 0, st, p, T, gverts ? 1 : 0, zmin_lin, zmax_lin,
+                       (gzmin && gzmax) ? gzmin : (float*)nullptr, gzmax);
     MH_LAUNCH_CHECK();
   }
   return MH_OK;

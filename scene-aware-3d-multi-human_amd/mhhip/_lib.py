@@ -78,6 +78,7 @@ def lib():
         L.mh_sil_mask_stats.argtypes = [u32p] + [ctypes.c_int] * 4 + [vp] * 8
         L.mh_prior_terms.argtypes = [ctypes.c_int] * 3 + [vp] * 6 + [ctypes.c_float] * 2 + [vp] * 6
         L.mh_reduce_sum.argtypes = [vp, ctypes.c_size_t, ctypes.c_float, vp, vp]
+        L.mh_reduce_sum2.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_float, vp, vp, vp]
         L.mh_lowest_vertex.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp]
         L.mh_contact_knn.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp]
         L.mh_scene_workspace_bytes.restype = ctypes.c_size_t

@@ -31,8 +31,7 @@ class RasterTerms(object):
                                       ptr(e.leaf('zmax_lin', g)) if with_grads else None, ptr(e.depth_body), ptr(e.sil_body),
                                       ptr(self.ws), ptr(zbuf_out), ptr(alpha_out), int(phases), st))
         if phases & 2:
-            check(L.mh_reduce_sum(ptr(e.depth_body), e.B, 1.0, ptr(log[1:2]), st))
-            check(L.mh_reduce_sum(ptr(e.sil_body), e.B, 1.0, ptr(log[2:3]), st))
+            check(L.mh_reduce_sum2(ptr(e.depth_body), ptr(e.sil_body), e.B, 1.0, ptr(log[1:2]), ptr(log[2:3]), st))
 
 
 def render(model, verts, cam_K, image_size):

@@ -169,6 +169,8 @@ def main():
     sh = sharded.ShardedSequence(e, rank * T_LOCAL, world * T_LOCAL)
     raster = RasterTerms(e)
     sh.update_filters()                                                                # filtered-vertex term live
+    nstep = [0]
+
     def one_cycle(c, graphs, scene=False):
         if c % 25 == 0 and c > 0:
             sh.update_filters()
@@ -177,7 +179,8 @@ def main():
         sh.cycle(c % e.log.shape[0], raster=raster, graphs=graphs)
         if scene:
             e.scene_device_swap()     # read by the next cycle's contact term (which waits on the update's event)
-        sh.step()                     # RMSprop with the device-resident lr (x0.99 per cycle)
+        sh.step(0.01 * 0.99 ** nstep[0])      # RMSprop, ExponentialLR(0.99) on the host as in the reference (optimizer.py:355-356)
+        nstep[0] += 1
 
     use_graphs = not args.eager
     # bring the device to its steady state before the W warm-up steps: graph capture, lazy allocations, and enough

@@ -52,7 +52,9 @@ class SequenceEngine(object):
         self.offs = np.concatenate([[0], np.cumsum(self.sizes)]).astype(np.int64)
         n = int(self.offs[-1])
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=self.dev)
-        self.params, self.grads, self.sq, self.buf = z(n), z(n), z(n), z(n)
+        self.params, self.sq, self.buf = z(n), z(n), z(n)
+        self._grads_log = z(n + 16)      # gradients | staging row of the loss log: cleared by one fill per cycle
+        self.grads = self._grads_log[:n]
         self.shared_lo = int(self.offs[4])          # betas | xscale: the all-reduced tail
         self.ws = model.workspace(B)
         self.ws2 = model.backward_workspace(B)
@@ -68,7 +70,7 @@ class SequenceEngine(object):
         self.vel_loss = z(1)
         self.filt_loss = z(1)
         self.log = z(max_cycles, 16)
-        self.tmp_log = z(16)
+        self.tmp_log = self._grads_log[n:]
         self.scene_pts = None
         self.scene_grid = None
         self.scene_M = 0                 # capacity the grid workspace was sized for
@@ -337,9 +339,8 @@ class SequenceEngine(object):
         c = self.c
         T, N = self.T, self.N
         g = self.grads
-        g.zero_()
         log = self.tmp_log
-        log.zero_()
+        self._grads_log.zero_()
         # the terms that only read the leaves (silhouette mask statistics, priors, velocity) run on the second stream
         # beside the MFMA-bound forward; their scalars land directly in the log row
         main = torch.cuda.current_stream(self.dev)

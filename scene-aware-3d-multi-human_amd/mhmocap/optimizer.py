@@ -243,9 +243,7 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
         if self.use_rasteriser and e.has_images:
             from mhhip import raster as _raster
             raster = _raster.RasterTerms(e, self.znear, self.zfar)
-        lr = 0.01
-        if self.use_graphs and hasattr(e, 'lr_dev'):
-            e.lr_dev.fill_(lr)                                                # a new RMSprop + ExponentialLR per fit (:355-356)
+        lr = 0.01                                                             # a new RMSprop + ExponentialLR per fit (:355-356)
         cycles = range(num_iter)
         if verbose and tqdm is not None:
             cycles = tqdm(cycles)
@@ -271,10 +269,7 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
                 e.scene_device_swap()
             if not self.optim_scale_factor:
                 e.leaf('xscale', e.grads).zero_()
-            if self.use_graphs:
-                e.step_dev()                                                  # the same update with lr and its decay on the device
-            else:
-                e.step(lr)                                                    # RMSprop(lr=.01, alpha=.5, momentum=.9) :355
+            e.step(lr)             # RMSprop(lr=.01, alpha=.5, momentum=.9) :355; launched outside the captured cycle, lr by value
             lr *= 0.99                                                        # ExponentialLR(0.99) :356
         self._finish_scene()
         return e.read_log(num_iter)

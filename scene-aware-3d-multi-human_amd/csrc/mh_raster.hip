@@ -9,7 +9,7 @@
 //   k_raster_windows      one workgroup per body: NDC projection of the vertices + screen window
 //   k_raster_face_sort    one workgroup per body: pixel-row range of every face, counting sort by first row
 //                         (a tile's candidate faces become one contiguous range)
-//   k_raster_strip_table  one workgroup: windows cut into tiles of <= R_CAP pixels, prefix-summed into a device-side
+//   (r_strip_table)       extra workgroup of k_raster_face_sort: windows cut into tiles of <= R_CAP pixels, prefix-summed into a device-side
 //                         work list (no host sync); also the work units of the gradient kernel
 //   k_raster_strip_order  one workgroup: tiles by decreasing candidate-face count (longest first)
 //   k_raster_strip        one workgroup per tile; every wave runs barrier-free rounds of 64 faces (3-deep gather
@@ -302,9 +302,12 @@ __device__ __forceinline__ void r_tiling(int ww, int wh, int* tw, int* th, int* 
   *nrow = (wh + *th - 1) / *th;
 }
 
-__global__ __launch_bounds__(1024) void k_raster_strip_table(RasterP p) {
-  __shared__ int s_ns[1024];
-  __shared__ long long s_px[1024];
+// tile list of all windows + work units of the gradient kernel, by one workgroup of NT threads (the extra workgroup of
+// k_raster_face_sort: it only needs the windows, so it runs beside the face sort instead of in front of it)
+template <int NT>
+__device__ __forceinline__ void r_strip_table(const RasterP& p) {
+  __shared__ int s_ns[NT];
+  __shared__ long long s_px[NT];
   __shared__ int carry_ns;
   __shared__ long long carry_px;
   if (threadIdx.x == 0) {
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(1024) void k_raster_strip_table(RasterP p) {
     carry_px = 0;
   }
   __syncthreads();
-  for (int base = 0; base < p.B; base += 1024) {
+  for (int base = 0; base < p.B; base += NT) {
     const int b = base + threadIdx.x;
     int ww = 0, wh = 0, tw = 1, th = 1, ncol = 0, nrow = 0, ns = 0;
     if (b < p.B) {
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(1024) void k_raster_strip_table(RasterP p) {
     s_px[threadIdx.x] = (long long)ww * wh;
     __syncthreads();
     // inclusive scan (Hillis-Steele)
-    for (int o = 1; o < 1024; o <<= 1) {
+    for (int o = 1; o < NT; o <<= 1) {
       int a = 0;
       long long c = 0;
       if ((int)threadIdx.x >= o) {
@@ -358,9 +361,9 @@ __global__ __launch_bounds__(1024) void k_raster_strip_table(RasterP p) {
       }
     }
     __syncthreads();
-    if (threadIdx.x == 1023) {
-      carry_ns += s_ns[1023];
-      carry_px += s_px[1023];
+    if (threadIdx.x == NT - 1) {
+      carry_ns += s_ns[NT - 1];
+      carry_px += s_px[NT - 1];
     }
     __syncthreads();
   }
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(1024) void k_raster_strip_table(RasterP p) {
   __shared__ int c_full, c_part;
   if (threadIdx.x == 0) c_full = c_part = 0;
   __syncthreads();
-  for (int b = threadIdx.x; b < p.B; b += 1024) {
+  for (int b = threadIdx.x; b < p.B; b += NT) {
     const int ww = p.win[b * 4 + 2], wh = p.win[b * 4 + 3];
     const int npx = (ww > 0 && wh > 0) ? ww * wh : 0;
     const int nfull = npx / RG_UNIT;
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(1024) void k_raster_strip_table(RasterP p) {
   __syncthreads();
   const int nf = c_full;
   auto part_class = [&](int rem) { return 31 - min(31, rem * 32 / RG_UNIT); };
-  for (int b = threadIdx.x; b < p.B; b += 1024) {
+  for (int b = threadIdx.x; b < p.B; b += NT) {
     const int ww = p.win[b * 4 + 2], wh = p.win[b * 4 + 3];
     const int npx = (ww > 0 && wh > 0) ? ww * wh : 0;
     if (npx % RG_UNIT) atomicAdd(&p_hist[part_class(npx % RG_UNIT)], 1);
@@ -399,7 +402,7 @@ __global__ __launch_bounds__(1024) void k_raster_strip_table(RasterP p) {
     c_part = a;
   }
   __syncthreads();
-  for (int b = threadIdx.x; b < p.B; b += 1024) {
+  for (int b = threadIdx.x; b < p.B; b += NT) {
     const int ww = p.win[b * 4 + 2], wh = p.win[b * 4 + 3];
     const int npx = (ww > 0 && wh > 0) ? ww * wh : 0;
     if (npx % RG_UNIT) {
@@ -515,7 +518,11 @@ __global__ __launch_bounds__(RFS, 8) void k_raster_face_sort(RasterP p) {
   __shared__ int s_maxh, s_flip;
   __shared__ float s_z[2];
   __shared__ int s_n[2];
-  const int b = blockIdx.x, tid = threadIdx.x, H = p.H, HB = H + 1;
+  if (blockIdx.x == 0) {               // one extra workgroup (dispatched first): the tile list
+    r_strip_table<RFS>(p);
+    return;
+  }
+  const int b = blockIdx.x - 1, tid = threadIdx.x, H = p.H, HB = H + 1;
   const float* nb = p.ndc + (size_t)b * p.V * 3;
   unsigned* fr = p.frows + (size_t)b * p.F;
   unsigned* fs = p.fsort + (size_t)b * p.F;
@@ -1376,9 +1383,7 @@ static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const flo
   if (alpha_out) MH_HIP(hipMemsetAsync(alpha_out, 0, (size_t)p.B * H * W * sizeof(float), st));
   hipLaunchKernelGGL(k_raster_windows, dim3(p.B), dim3(RWT), 0, st, p);
   MH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_raster_strip_table, dim3(1), dim3(1024), 0, st, p);
-  MH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_raster_face_sort, dim3(p.B), dim3(RFS), (size_t)2 * (H + 1) * sizeof(int), st, p);
+  hipLaunchKernelGGL(k_raster_face_sort, dim3(p.B + 1), dim3(RFS), (size_t)2 * (H + 1) * sizeof(int), st, p);
   MH_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_raster_strip_order, dim3(1), dim3(1024), 0, st, p);
   MH_LAUNCH_CHECK();

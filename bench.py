@@ -284,9 +284,15 @@ def main():
         for k, fl in (('k_skin_fwd', bodies * V * 217.0 * 6.0), ('k_skin_bwd', bodies * V * (217.0 * 6.0 + 12.0 * 24.0 * 2.0))):
             if k in kernel_us:
                 tf = fl / (kernel_us[k] * 1e-6) / 1e12
+                # the same launch against HBM: per body two vertex arrays of 12 V bytes (forward: skinned + posed
+                # vertices out; backward: vertex adjoints + posed vertices in) and the basis once (12 x 217 x V bytes)
+                by = bodies * 2.0 * 12.0 * V + 12.0 * 217.0 * V
+                gb = by / (kernel_us[k] * 1e-6) / 1e9
                 roof_mfma[k] = {'bound': 'mfma', 'achieved': round(tf, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                 'frac': round(tf / PEAK_F32_MFMA_TFLOPS, 4), 'launch_us': round(kernel_us[k], 1),
-                                'algorithmic_flops': fl, 'traffic': traffic.get(k)}
+                                'algorithmic_flops': fl, 'traffic': traffic.get(k),
+                                'hbm': {'algorithmic_bytes': by, 'achieved': round(gb, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                                        'frac': round(gb / PEAK_HBM_GBS, 4)}}
         out = {
             'metric': 'optimizer iterations/sec (N humans x T frames)', 'value': round(its * world, 3),
             'unit': 'iterations/s (%d humans x %d frames per iteration unit)' % (N_PEOPLE, T_LOCAL), 'n_gpus': world, 'steps': args.steps,

@@ -172,15 +172,22 @@ __global__ __launch_bounds__(256, 2) void k_skin_fwd(SkinFwdP p) {
   const int g = blockIdx.y;
   const int ntiles = p.VP / 32;
   if ((int)blockIdx.x * 4 >= ntiles) return;
+  // the feature panel is needed by the first MFMA; the bone transforms only by the epilogue: their loads are issued now
+  // and parked in registers (9 x 16 bytes per lane) until the matrix phase is over
+  constexpr int NA4 = 32 * MH_NJ * 12 / 4 / 256;      // = 9
+  static_assert(32 * MH_NJ * 12 / 4 == NA4 * 256, "transform panel must split evenly over the workgroup");
+  f32x4 ra[NA4];
   {
     const f32x4* srcF = (const f32x4*)(p.featT + (size_t)g * MH_FS * 32);
     for (int i = threadIdx.x; i < MH_FS * 32 / 4; i += 256) ((f32x4*)sF)[i] = srcF[i];
     const f32x4* srcA = (const f32x4*)(p.A + (size_t)g * 32 * MH_NJ * 12);
-    for (int i = threadIdx.x; i < 32 * MH_NJ * 12 / 4; i += 256) ((f32x4*)sA)[i] = srcA[i];
+#pragma unroll
+    for (int i = 0; i < NA4; ++i) ra[i] = srcA[threadIdx.x + i * 256];
   }
   __syncthreads();
-  const int tile = blockIdx.x * 4 + wave;
-  if (tile >= ntiles) return;
+  const int tile_ = blockIdx.x * 4 + wave;
+  const bool has_tile = tile_ < ntiles;
+  const int tile = has_tile ? tile_ : ntiles - 1;      // a wave without a tile still takes part in the barrier below
   const int v = tile * 32 + li;
   const float* fT = sF + li;
   // basis tile of this wave: [kg][c][lane][8]
@@ -209,7 +216,10 @@ __global__ __launch_bounds__(256, 2) void k_skin_fwd(SkinFwdP p) {
       az = MFMA32(a, rz[cur][u >> 2][u & 3], az);
     }
   }
-  if (v >= p.V) return;
+#pragma unroll
+  for (int i = 0; i < NA4; ++i) ((f32x4*)sA)[threadIdx.x + i * 256] = ra[i];
+  __syncthreads();
+  if (!has_tile || v >= p.V) return;
   const float t0 = p.vt[(size_t)v * 3], t1 = p.vt[(size_t)v * 3 + 1], t2 = p.vt[(size_t)v * 3 + 2];
   int sj[4];
   float sw[4];

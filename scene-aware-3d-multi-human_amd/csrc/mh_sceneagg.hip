@@ -107,9 +107,24 @@ __global__ __launch_bounds__(256) void k_scene_median_t(int T, int P, const floa
     if (lane == 0) { ma_depth[p] = 0.f; ma_mask[p] = 0.f; }
     return;
   }
+  // bits on which all valid values agree need no counting pass (the depths of a pixel share sign and most of the exponent)
+  unsigned all_or = 0u, all_and = 0xffffffffu;
+#pragma unroll
+  for (int j = 0; j < SMT_NV; ++j)
+    if (v[j] != SM_INVALID) { all_or |= v[j]; all_and &= v[j]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    all_or |= (unsigned)__shfl_xor((int)all_or, o, 64);
+    all_and &= (unsigned)__shfl_xor((int)all_and, o, 64);
+  }
+  const unsigned vary = all_or ^ all_and;
   int k = n >> 1;
   unsigned prefix = 0u;
   for (int bit = 31; bit >= 0; --bit) {
+    if (((vary >> bit) & 1u) == 0u) {                  // wave-uniform
+      prefix |= all_and & (1u << bit);
+      continue;
+    }
     const unsigned m = (bit == 31 ? 0u : (0xffffffffu << (bit + 1))) | (1u << bit);
     int c0 = 0;
 #pragma unroll
@@ -400,7 +415,8 @@ extern "C" int mh_scene_median_t(int T, int H, int W, const float* depths_t, con
     MH_LAUNCH_CHECK();
   }
   const float* invz = zmin_lin ? (const float*)s.invz : (const float*)nullptr;
-  if (T <= 512) hipLaunchKernelGGL(k_scene_median_t<8>, dim3((P + 3) / 4), dim3(256), 0, st, T, P, depths_t, backmask_t, invz, ma_depth, ma_mask);
+  if (T <= 256) hipLaunchKernelGGL(k_scene_median_t<4>, dim3((P + 3) / 4), dim3(256), 0, st, T, P, depths_t, backmask_t, invz, ma_depth, ma_mask);
+  else if (T <= 512) hipLaunchKernelGGL(k_scene_median_t<8>, dim3((P + 3) / 4), dim3(256), 0, st, T, P, depths_t, backmask_t, invz, ma_depth, ma_mask);
   else hipLaunchKernelGGL(k_scene_median_t<32>, dim3((P + 3) / 4), dim3(256), 0, st, T, P, depths_t, backmask_t, invz, ma_depth, ma_mask);
   MH_LAUNCH_CHECK();
   return MH_OK;

@@ -174,9 +174,9 @@ def main():
     def one_cycle(c, graphs, scene=False):
         if c % 25 == 0 and c > 0:
             sh.update_filters()
-        if scene:                     # the organic path of fit (cycle >= 30): scene rebuilt from the sequence every cycle
-            e.scene_device_update()   # own stream, from the leaves as they are before this cycle's step
-        sh.cycle(c % e.log.shape[0], raster=raster, graphs=graphs)
+        # scene: the organic path of fit (cycle >= 30): scene rebuilt from the sequence every cycle, on its own stream, from
+        # the leaves as they are before this cycle's step
+        sh.cycle(c % e.log.shape[0], raster=raster, graphs=graphs, scene_update=scene)
         if scene:
             e.scene_device_swap()     # read by the next cycle's contact term (which waits on the update's event)
         sh.step(0.01 * 0.99 ** nstep[0])      # RMSprop, ExponentialLR(0.99) on the host as in the reference (optimizer.py:355-356)

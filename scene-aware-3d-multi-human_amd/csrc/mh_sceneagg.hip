@@ -252,13 +252,85 @@ __global__ void k_scene_edges(int H, int W, const float* grad, const float* ma_m
 // window from the values of the valid pixels only (so a sweep is a pure function of the previous state), then the
 // updates are applied together.  Ends when the list is empty (or nothing can be filled any more).
 #define FILL_TH 1024
-__global__ __launch_bounds__(FILL_TH) void k_scene_fill(int H, int W, int ksize, int truncate, float* depth, float* mask, int* list_a,
-                                                        int* list_b, float* upd) {
+// median of the valid pixels of the KS x KS window around (y, x): all window loads are issued together (the loop form
+// waited for one mask load and one depth load after the other: 49 x 2 dependent round trips per pixel, 270 us per
+// sweep), invalid entries become +inf, and a bitonic network sorts the window in registers (static indexing only: a
+// per-thread array indexed at run time lives in scratch memory).  Returns the number of valid pixels.
+// windows of more than 64 pixels (9 x 9, 11 x 11: the scene image, once per fit): the same with rolled loops on a
+// per-thread array (the network of 128 does not fit the register file next to 1024 threads anyway)
+template <int KS>
+__device__ int fill_window_median_big(int H, int W, int y, int x, const float* depth, const float* mask, float* med) {
+  constexpr int k = KS / 2;
+  float v[KS * KS];
+  int c = 0;
+  for (int yy = max(0, y - k); yy < min(H, y + k + 1); ++yy)
+    for (int xx = max(0, x - k); xx < min(W, x + k + 1); ++xx)
+      if (mask[yy * W + xx] > 0.f) {
+        const float val = depth[yy * W + xx];       // insertion sort
+        int j = c++;
+        while (j > 0 && v[j - 1] > val) { v[j] = v[j - 1]; --j; }
+        v[j] = val;
+      }
+  if (c == 0) return 0;
+  *med = (c & 1) ? v[c >> 1] : (v[(c >> 1) - 1] + v[c >> 1]) / 2.f;
+  return c;
+}
+
+template <int KS, int NP>
+__device__ __forceinline__ int fill_window_median(int H, int W, int y, int x, const float* depth, const float* mask, float* med) {
+  if constexpr (NP > 64) return fill_window_median_big<KS>(H, W, y, x, depth, mask, med);
+  constexpr int k = KS / 2;
+  float v[NP];
+  int c = 0;
+#pragma unroll
+  for (int dy = 0; dy < KS; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < KS; ++dx) {
+      const int yy = y + dy - k, xx = x + dx - k;
+      const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+      const int q = in ? yy * W + xx : 0;
+      const float m = mask[q], d = depth[q];
+      const bool ok = in && m > 0.f;
+      v[dy * KS + dx] = ok ? d : INFINITY;
+      c += ok ? 1 : 0;
+    }
+#pragma unroll
+  for (int i = KS * KS; i < NP; ++i) v[i] = INFINITY;
+  if (c == 0) return 0;
+#pragma unroll
+  for (int kk = 2; kk <= NP; kk <<= 1)
+#pragma unroll
+    for (int j = kk >> 1; j > 0; j >>= 1)
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int l = i ^ j;
+        if (l > i) {
+          const float lo = fminf(v[i], v[l]), hi = fmaxf(v[i], v[l]);
+          if ((i & kk) == 0) { v[i] = lo; v[l] = hi; } else { v[i] = hi; v[l] = lo; }
+        }
+      }
+  const int k1 = (c - 1) >> 1, k2 = c >> 1;
+  float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < KS * KS; ++i) {
+    m1 = i == k1 ? v[i] : m1;
+    m2 = i == k2 ? v[i] : m2;
+  }
+  *med = (c & 1) ? m2 : (m1 + m2) / 2.f;
+  return c;
+}
+
+// One workgroup: the masked pixels form a shrinking list; a sweep fills every listed pixel that sees a valid pixel in its
+// window from the values of the valid pixels only (so a sweep is a pure function of the previous state), then the
+// updates are applied together.  Ends when the list is empty (or nothing can be filled any more).
+template <int KS, int NP, int NT>
+__global__ __launch_bounds__(NT) void k_scene_fill(int H, int W, int truncate, float* depth, float* mask, int* list_a, int* list_b,
+                                                   float* upd) {
   __shared__ int s_cnt, s_next, s_filled;
-  const int tid = threadIdx.x, P = H * W, k = ksize / 2;
+  const int tid = threadIdx.x, P = H * W;
   if (tid == 0) s_cnt = 0;
   __syncthreads();
-  for (int p = tid; p < P; p += FILL_TH)
+  for (int p = tid; p < P; p += NT)
     if (!(mask[p] > 0.f)) list_a[atomicAdd(&s_cnt, 1)] = p;
   __syncthreads();
   int* cur = list_a;
@@ -269,22 +341,12 @@ __global__ __launch_bounds__(FILL_TH) void k_scene_fill(int H, int W, int ksize,
     __syncthreads();
     if (tid == 0) { s_next = 0; s_filled = 0; }
     __syncthreads();
-    for (int i = tid; i < n; i += FILL_TH) {
+    for (int i = tid; i < n; i += NT) {
       const int p = cur[i];
       const int y = p / W, x = p - y * W;
-      float v[121];                                   // ksize <= 11
-      int c = 0;
-      for (int yy = max(0, y - k); yy < min(H, y + k + 1); ++yy)
-        for (int xx = max(0, x - k); xx < min(W, x + k + 1); ++xx)
-          if (mask[yy * W + xx] > 0.f) {
-            // insertion sort
-            const float val = depth[yy * W + xx];
-            int j = c++;
-            while (j > 0 && v[j - 1] > val) { v[j] = v[j - 1]; --j; }
-            v[j] = val;
-          }
+      float med = 0.f;
+      const int c = fill_window_median<KS, NP>(H, W, y, x, depth, mask, &med);
       if (c > 0) {
-        const float med = (c & 1) ? v[c >> 1] : (v[(c >> 1) - 1] + v[c >> 1]) / 2.f;
         upd[i] = truncate ? floorf(med) : med;      // integer-valued planes (colour): the reference stores into uint8
         atomicAdd(&s_filled, 1);
       } else {
@@ -293,7 +355,7 @@ __global__ __launch_bounds__(FILL_TH) void k_scene_fill(int H, int W, int ksize,
       }
     }
     __syncthreads();
-    for (int i = tid; i < n; i += FILL_TH)
+    for (int i = tid; i < n; i += NT)
       if (upd[i] >= 0.f) { depth[cur[i]] = upd[i]; mask[cur[i]] = 1.f; }
     __threadfence_block();
     __syncthreads();
@@ -303,6 +365,25 @@ __global__ __launch_bounds__(FILL_TH) void k_scene_fill(int H, int W, int ksize,
     __syncthreads();
     int* t = cur; cur = nxt; nxt = t;
   }
+}
+
+static int scene_fill_launch(int H, int W, int ksize, int truncate, float* depth, float* mask, int* list_a, int* list_b, float* upd,
+                             hipStream_t st) {
+  // window sizes of the reference: 7 (scene depth, every cycle), 11 (scene image, once per fit); the others for completeness
+#define FILL_CASE(KS, NP, NT)                                                                                              \
+  case KS:                                                                                                                 \
+    hipLaunchKernelGGL((k_scene_fill<KS, NP, NT>), dim3(1), dim3(NT), 0, st, H, W, truncate, depth, mask, list_a, list_b, upd); \
+    break;
+  switch (ksize | 1) {      // an even size covers the same pixels as the next odd one minus a row/column: not used by the reference
+    FILL_CASE(3, 16, 1024)
+    FILL_CASE(5, 32, 1024)
+    FILL_CASE(7, 64, 1024)
+    FILL_CASE(9, 128, 256)
+    FILL_CASE(11, 128, 256)
+    default: return -1;
+  }
+#undef FILL_CASE
+  return 0;
 }
 
 // ---- un-projection of the valid pixels, compacted in row-major order (optimizer.py:605-613) ------------------------------------
@@ -445,7 +526,7 @@ extern "C" int mh_scene_postprocess(int H, int W, const float* ma_depth, const f
   MH_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_scene_edges, g256, b256, 0, st, H, W, (const float*)s.grad, ma_mask, (const double*)s.stats, s.dmask);
   MH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_scene_fill, dim3(1), dim3(FILL_TH), 0, st, H, W, fillin_ksize, 0, s.depth1, s.dmask, s.list_a, s.list_b, s.upd);
+  MH_CHECK(scene_fill_launch(H, W, fillin_ksize, 0, s.depth1, s.dmask, s.list_a, s.list_b, s.upd, st) == 0, "fill-in window must be 2..11");
   MH_LAUNCH_CHECK();
   MH_HIP(hipMemcpyAsync(scene_depth, s.depth1, (size_t)P * 4, hipMemcpyDeviceToDevice, st));
   return MH_OK;
@@ -456,8 +537,8 @@ extern "C" int mh_scene_fill(int H, int W, int ksize, int truncate, float* value
   MH_CHECK(H > 0 && W > 0, "empty image");
   MH_CHECK(ksize > 1 && ksize <= 11, "fill-in window must be 2..11");
   SceneWs s = scene_carve(ws, H * W);
-  hipLaunchKernelGGL(k_scene_fill, dim3(1), dim3(FILL_TH), 0, (hipStream_t)stream, H, W, ksize, truncate, values, mask, s.list_a, s.list_b,
-                     s.upd);
+  MH_CHECK(scene_fill_launch(H, W, ksize, truncate, values, mask, s.list_a, s.list_b, s.upd, (hipStream_t)stream) == 0,
+           "fill-in window must be 2..11");
   MH_LAUNCH_CHECK();
   return MH_OK;
 }

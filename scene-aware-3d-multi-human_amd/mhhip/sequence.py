@@ -212,6 +212,10 @@ class SequenceEngine(object):
         d['depth'] = torch.zeros(H, W, device=self.dev)
         d['stream'] = torch.cuda.Stream(device=self.dev)
         d['ev_main'] = torch.cuda.Event()
+        d['ev_snap'] = torch.cuda.Event()
+        with torch.cuda.stream(d['stream']):      # first submission now: the stream gets its hardware queue before any
+            d['ma_depth'].zero_()                 # cycle graph exists
+        d['stream'].synchronize()
         d['sets'] = [dict(pts=torch.zeros(P, 3, device=self.dev), count=torch.zeros(1, dtype=torch.int32, device=self.dev),
                           grid=torch.empty(L.mh_scene_grid_bytes(P), dtype=torch.uint8, device=self.dev),
                           zsnap=torch.zeros(2 * T, device=self.dev), ev=torch.cuda.Event()) for _ in range(2)]
@@ -222,17 +226,33 @@ class SequenceEngine(object):
 
     def scene_device_update(self):
         """Launch one scene update from the current depth-range leaves into the back set (own stream)."""
+        self.scene_device_mark()
+        self.scene_device_launch()
+
+    def scene_device_mark(self):
+        """The point of the main stream whose depth-range leaves the next ``scene_device_launch`` reads (an event, no
+        work): ``cycle_graphed`` marks before it enqueues the cycle and launches the update after the first replay, so
+        the first kernels of the cycle are not queued behind the update's dozen launches."""
+        d = self._scene_dev
+        d['ev_main'].record(torch.cuda.current_stream(self.dev))
+        d['marked'] = True
+
+    def scene_device_launch(self):
         d, L = self._scene_dev, _lib.lib()
         T, H, W = self.T, self.H, self.W
+        if not d.get('marked'):
+            self.scene_device_mark()
+        d['marked'] = False
         k = d['next']
         s = d['sets'][k]
-        s['zsnap'][:T].copy_(self.leaf('zmin_lin').view(-1))
-        s['zsnap'][T:].copy_(self.leaf('zmax_lin').view(-1))
-        main = torch.cuda.current_stream(self.dev)
-        d['ev_main'].record(main)
         side = d['stream']
         side.wait_event(d['ev_main'])
         st = side.cuda_stream
+        with torch.cuda.stream(side):        # snapshot of the leaves on the update's own stream; step() waits for it
+            s['zsnap'][:T].copy_(self.leaf('zmin_lin').view(-1))
+            s['zsnap'][T:].copy_(self.leaf('zmax_lin').view(-1))
+        d['ev_snap'].record(side)
+        d['snap_pending'] = True
         if 'depths_t' in d:
             check(L.mh_scene_median_t(T, H, W, ptr(d['depths_t']), ptr(d['back_t']), ptr(s['zsnap'][:T]), ptr(s['zsnap'][T:]),
                                       ptr(d['ma_depth']), ptr(d['ma_mask']), ptr(d['ws']), st))
@@ -243,6 +263,13 @@ class SequenceEngine(object):
         s['ev'].record(side)
         d['ready'] = k
         d['next'] = 1 - k
+
+    def _wait_scene_snapshot(self):
+        """the leaves must not change before a pending scene update has copied them"""
+        d = self._scene_dev
+        if d is not None and d.get('snap_pending'):
+            torch.cuda.current_stream(self.dev).wait_event(d['ev_snap'])
+            d['snap_pending'] = False
 
     def _scene_finish(self, s, st):
         """median (d['ma_depth'], d['ma_mask']) -> post-processed depth map -> compacted cloud -> grid, into set s"""
@@ -480,6 +507,7 @@ class SequenceEngine(object):
             self.log[row].copy_(log)
 
     def step(self, lr, alpha=0.5, momentum=0.9, eps=1e-8):
+        self._wait_scene_snapshot()
         engine.rmsprop_step(self.params, self.grads, self.sq, self.buf, float(lr), alpha, momentum, eps)
 
     # -- hipGraph replay of a cycle -------------------------------------------------------------------
@@ -514,10 +542,13 @@ class SequenceEngine(object):
         else:
             g.replay()
 
-    def cycle_graphed(self, row, raster=None):
+    def cycle_graphed(self, row, raster=None, scene_update=False):
         """``cycle`` through a captured graph (single-process form; the sharded driver replays
-        ``cycle_begin`` / ``cycle_finish`` separately around its exchanges)."""
+        ``cycle_begin`` / ``cycle_finish`` separately around its exchanges).  scene_update: also launch this cycle's
+        device-side scene update (``scene_device_update``), after the first replay has been enqueued."""
         key = self._graph_key(raster)
+        if scene_update:
+            self.scene_device_mark()
         if self._scene_dev is not None:
             # the scene cloud is rebuilt every cycle on its own stream: everything up to the rasteriser replays
             # without waiting for it, only the contact part does
@@ -525,17 +556,22 @@ class SequenceEngine(object):
                 self.cycle_begin()
                 self._finish_a(True, raster)
             self.replay(('a',) + key, part_a, wait_scene=False)
+            if scene_update:
+                self.scene_device_launch()
             self.replay(('b',) + key, lambda: self._finish_b(None, True, raster))
         else:
             def body():
                 self.cycle_begin()
                 self.cycle_finish(None, raster=raster)
             self.replay(('full',) + key, body)
+            if scene_update:
+                self.scene_device_launch()
         self.log[row].copy_(self.tmp_log)
 
     def step_dev(self, alpha=0.5, momentum=0.9, eps=1e-8, gamma=0.99, lr0=0.01):
         if not hasattr(self, 'lr_dev'):
             self.lr_dev = torch.full((1,), lr0, dtype=torch.float32, device=self.dev)
+        self._wait_scene_snapshot()
         check(_lib.lib().mh_rmsprop_step_dev(ptr(self.params), ptr(self.grads), ptr(self.sq), ptr(self.buf),
                                              self.params.numel(), ptr(self.lr_dev), gamma, alpha, momentum, eps,
                                              _lib.stream_ptr(self.dev)))

@@ -79,13 +79,17 @@ class ShardedSequence(object):
         buf.copy_(t)
         return buf
 
-    def cycle(self, row, raster=None, graphs=False):
+    def cycle(self, row, raster=None, graphs=False, scene_update=False):
+        """scene_update (single process only): launch the device-side scene update of this cycle from inside
+        ``cycle_graphed``; the frame-sharded form calls ``scene_update()`` itself before the cycle"""
         e = self.e
         if self.world == 1:
             e.halo = None
             if graphs:
-                e.cycle_graphed(row, raster=raster)
+                e.cycle_graphed(row, raster=raster, scene_update=scene_update)
             else:
+                if scene_update:
+                    e.scene_device_update()
                 e.cycle_begin()
                 e.cycle_finish(row, raster=raster)
             return

@@ -255,13 +255,15 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
             scene_now = cycle >= 30 and e.has_images and self._backmasks is not None      # :578-584
             if scene_now and self.scene_update == 'device':
                 # the update only reads the depth-range leaves as they are before this cycle's step and is first used by
-                # the NEXT cycle's contact term: launch it now on its own stream, swap it in after the cycle
+                # the NEXT cycle's contact term: launched on its own stream during this cycle, swapped in after it
                 if e._scene_dev is None:
                     e.scene_device_setup(self._backmasks)
-                e.scene_device_update()
+            dev_scene = scene_now and self.scene_update == 'device'
             if self.use_graphs and not (scene_now and self.scene_update == 'host'):
-                e.cycle_graphed(cycle, raster=raster)
+                e.cycle_graphed(cycle, raster=raster, scene_update=dev_scene)    # update issued after the first replay
             else:                                     # the host scene path hands over a new cloud every cycle: no replay
+                if dev_scene:
+                    e.scene_device_update()
                 e.cycle(cycle, raster=raster)
             if scene_now and self.scene_update == 'host':
                 self._host_scene_update()

@@ -331,55 +331,63 @@ extern "C" int mh_velocity_term(int T, int N, const float* pT, const float* prev
 
 // VEC = float4 (E divisible by 4: SMPL's N*6890*3 always is) or float.  OVERWRITE: gverts = term (the caller
 // initialises the vertex-gradient buffer with this term instead of clearing it first).
+// Sliding window over time: a workgroup owns FV_TB consecutive frames of a slice of the elements and walks through
+// them with (t-1, t, t+1) in registers, so every vertex and filtered vertex is read once
+// (plus one halo frame per FV_TB) instead of three times.
+#define FV_TB 8
 template <typename VEC, bool OVERWRITE>
-__global__ __launch_bounds__(256) void k_filtered_verts(int T, size_t E, const float* v, const float* vf,
-                                                        const float* pv, const float* pvf, const float* nv,
-                                                        const float* nvf, float coef, float* gv, float* partial) {
-  // grid = (chunks of E, T): no index division; the t-1 / t+1 rows are re-read through L2
+__global__ __launch_bounds__(256) void k_filtered_verts(int T, size_t E, const float* v, const float* vf, const float* pv,
+                                                           const float* pvf, const float* nv, const float* nvf, float coef,
+                                                           float* gv, float* partial) {
   __shared__ float s[256];
   constexpr int L = sizeof(VEC) / sizeof(float);
-  const int t = blockIdx.y;
   const size_t EV = E / L;
-  const VEC* vc = (const VEC*)(v + (size_t)t * E);
-  const VEC* fc = (const VEC*)(vf + (size_t)t * E);
-  const VEC* vp = (const VEC*)(t > 0 ? v + (size_t)(t - 1) * E : pv);
-  const VEC* fp = (const VEC*)(t > 0 ? vf + (size_t)(t - 1) * E : pvf);
-  const VEC* vn = (const VEC*)(t + 1 < T ? v + (size_t)(t + 1) * E : nv);
-  const VEC* fn = (const VEC*)(t + 1 < T ? vf + (size_t)(t + 1) * E : nvf);
-  VEC* g = (VEC*)(gv + (size_t)t * E);
+  const int t0 = blockIdx.y * FV_TB, t1 = min(t0 + FV_TB, T);
   float acc = 0.f;
   for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < EV; e += (size_t)gridDim.x * 256) {
-    const VEC c = vc[e], cf = fc[e];
-    float gr[L];
+    auto row = [&](const float* base, int t) { return ((const VEC*)(base + (size_t)t * E))[e]; };
+    bool has_p = t0 > 0 || pv != nullptr;
+    VEC a = {}, b = {};                                   // frame t-1: vertices, filtered vertices
+    if (t0 > 0) { a = row(v, t0 - 1); b = row(vf, t0 - 1); }
+    else if (pv) { a = ((const VEC*)pv)[e]; b = ((const VEC*)pvf)[e]; }
+    VEC c = row(v, t0), cf = row(vf, t0);
+    for (int t = t0; t < t1; ++t) {
+      const bool has_n = t + 1 < T || nv != nullptr;
+      VEC n = {}, nf = {};
+      if (t + 1 < T) { n = row(v, t + 1); nf = row(vf, t + 1); }
+      else if (nv) { n = ((const VEC*)nv)[e]; nf = ((const VEC*)nvf)[e]; }
+      float gr[L];
 #pragma unroll
-    for (int k = 0; k < L; ++k) gr[k] = 0.f;
-    if (vp) {
-      const VEC a = vp[e], b = fp[e];
+      for (int k = 0; k < L; ++k) gr[k] = 0.f;
+      if (has_p) {
 #pragma unroll
-      for (int k = 0; k < L; ++k) {
-        const float d = (((const float*)&c)[k] - ((const float*)&a)[k]) - (((const float*)&cf)[k] - ((const float*)&b)[k]);
-        acc += d * d;          // the pair (t-1, t) belongs to the owner of t
-        gr[k] += 2.f * d;
+        for (int k = 0; k < L; ++k) {
+          const float d = (((const float*)&c)[k] - ((const float*)&a)[k]) - (((const float*)&cf)[k] - ((const float*)&b)[k]);
+          acc += d * d;          // the pair (t-1, t) belongs to the owner of t
+          gr[k] += 2.f * d;
+        }
       }
-    }
-    if (vn) {
-      const VEC a = vn[e], b = fn[e];
+      if (has_n) {
 #pragma unroll
-      for (int k = 0; k < L; ++k) {
-        const float d = (((const float*)&a)[k] - ((const float*)&c)[k]) - (((const float*)&b)[k] - ((const float*)&cf)[k]);
-        gr[k] -= 2.f * d;
+        for (int k = 0; k < L; ++k) {
+          const float d = (((const float*)&n)[k] - ((const float*)&c)[k]) - (((const float*)&nf)[k] - ((const float*)&cf)[k]);
+          gr[k] -= 2.f * d;
+        }
       }
-    }
-    VEC o;
-    if (OVERWRITE) {
+      VEC* g = (VEC*)(gv + (size_t)t * E);
+      VEC o;
+      if (OVERWRITE) {
 #pragma unroll
-      for (int k = 0; k < L; ++k) ((float*)&o)[k] = coef * gr[k];
-    } else {
-      o = g[e];
+        for (int k = 0; k < L; ++k) ((float*)&o)[k] = coef * gr[k];
+      } else {
+        o = g[e];
 #pragma unroll
-      for (int k = 0; k < L; ++k) ((float*)&o)[k] += coef * gr[k];
+        for (int k = 0; k < L; ++k) ((float*)&o)[k] += coef * gr[k];
+      }
+      g[e] = o;
+      a = c; b = cf; c = n; cf = nf;
+      has_p = true;
     }
-    g[e] = o;
   }
   s[threadIdx.x] = acc;
   __syncthreads();
@@ -403,7 +411,6 @@ __global__ __launch_bounds__(256) void k_sum_partials(const float* partial, int 
   if (threadIdx.x == 0) out[0] = s[0];
 }
 
-#define FV_XBLOCKS 16
 static float* g_fv_partial = nullptr;   // per-block partial sums, allocated once per process
 static size_t g_fv_cap = 0;
 
@@ -414,23 +421,27 @@ static int filtered_verts_term(int T, size_t E, const float* verts, const float*
   MH_CHECK(T >= 1 && E >= 1, "empty input");
   MH_CHECK((prev_v == nullptr) == (prev_vf == nullptr) && (next_v == nullptr) == (next_vf == nullptr),
            "halo vertices and filtered halo vertices come in pairs");
-  const size_t nblk = (size_t)FV_XBLOCKS * T;
+  hipStream_t st = (hipStream_t)stream;
+  auto aligned = [](const void* q) { return q == nullptr || ((uintptr_t)q & 15u) == 0; };
+  const bool vec = (E % 4 == 0) && aligned(verts) && aligned(verts_filt) && aligned(prev_v) && aligned(prev_vf) && aligned(next_v) &&
+                   aligned(next_vf) && aligned(gverts);
+  const size_t EVh = vec ? E / 4 : E;
+  const unsigned gx = (unsigned)std::min<size_t>((EVh + 255) / 256, 1024), gy = (unsigned)((T + FV_TB - 1) / FV_TB);
+  const size_t nblk = (size_t)gx * gy;
   if (nblk > g_fv_cap) {
     if (g_fv_partial) (void)hipFree(g_fv_partial);
     MH_HIP(hipMalloc((void**)&g_fv_partial, nblk * sizeof(float)));
     g_fv_cap = nblk;
   }
-  hipStream_t st = (hipStream_t)stream;
-  auto aligned = [](const void* q) { return q == nullptr || ((uintptr_t)q & 15u) == 0; };
-  const bool vec = (E % 4 == 0) && aligned(verts) && aligned(verts_filt) && aligned(prev_v) && aligned(prev_vf) && aligned(next_v) &&
-                   aligned(next_vf) && aligned(gverts);
-  const dim3 grid(FV_XBLOCKS, T), blk(256);
-#define FV_LAUNCH(VEC, OW)                                                                                              \
-  hipLaunchKernelGGL((k_filtered_verts<VEC, OW>), grid, blk, 0, st, T, E, verts, verts_filt, prev_v, prev_vf, next_v, \
+  const dim3 grid(gx, gy), blk(256);
+#define FV_KERNEL k_filtered_verts
+#define FV_LAUNCH(VEC, OW)                                                                                       \
+  hipLaunchKernelGGL((FV_KERNEL<VEC, OW>), grid, blk, 0, st, T, E, verts, verts_filt, prev_v, prev_vf, next_v, \
                      next_vf, coef, gverts, g_fv_partial)
   if (vec) { if (overwrite) FV_LAUNCH(float4, true); else FV_LAUNCH(float4, false); }
   else { if (overwrite) FV_LAUNCH(float, true); else FV_LAUNCH(float, false); }
 #undef FV_LAUNCH
+#undef FV_KERNEL
   MH_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, (const float*)g_fv_partial, (int)nblk, loss_out);
   MH_LAUNCH_CHECK();

@@ -334,7 +334,9 @@ extern "C" int mh_velocity_term(int T, int N, const float* pT, const float* prev
 // Sliding window over time: a workgroup owns FV_TB consecutive frames of a slice of the elements and walks through
 // them with (t-1, t, t+1) in registers, so every vertex and filtered vertex is read once
 // (plus one halo frame per FV_TB) instead of three times.
+#ifndef FV_TB
 #define FV_TB 8
+#endif
 template <typename VEC, bool OVERWRITE>
 __global__ __launch_bounds__(256) void k_filtered_verts(int T, size_t E, const float* v, const float* vf, const float* pv,
                                                            const float* pvf, const float* nv, const float* nvf, float coef,

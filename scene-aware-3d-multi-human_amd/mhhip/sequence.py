@@ -521,7 +521,16 @@ class SequenceEngine(object):
         scene = None
         if self.scene_pts is not None:
             scene = (self.scene_pts.data_ptr(), self.scene_grid.data_ptr(), self.scene_M)
-        return (raster is not None, scene, self.verts_filt is not None and self.pT_filt is not None, self.halo is None)
+        rast = None if raster is None else (raster.ws.data_ptr(), raster.faces.data_ptr())
+        return (rast, scene, self.verts_filt is not None and self.pT_filt is not None, self.halo is None)
+
+    def raster_terms(self, znear=1.0, zfar=100.0):
+        """The engine's rasteriser binding (workspace + face table), created once and kept alive with the engine:
+        captured cycle graphs hold its device addresses, so it must outlive every ``fit`` call."""
+        if getattr(self, '_raster', None) is None:
+            from . import raster as _raster
+            self._raster = _raster.RasterTerms(self, znear, zfar)
+        return self._raster
 
     def replay(self, key, fn, wait_scene=True):
         """Run ``fn`` (a fixed launch sequence on static buffers) through a captured graph; the first

@@ -45,3 +45,9 @@ class Erode2D(BinaryMorphology):
 
     def __init__(self, kernel_size=5):
         BinaryMorphology.__init__(self, kernel_size=kernel_size, type='erode')
+
+
+# names of the shadowed reference module this file does not define (mhhip/_overlay.py)
+from mhhip._overlay import inherit as _inherit  # noqa: E402
+
+_inherit(globals())

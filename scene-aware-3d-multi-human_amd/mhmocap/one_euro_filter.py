@@ -31,3 +31,9 @@ class OneEuroFilter(object):
         self.dx_prev = keep * self.dx_prev + mask * dx_hat
         self.t_prev = keep * self.t_prev + mask * t
         return keep * x + mask * x_hat
+
+
+# names of the shadowed reference module this file does not define (mhhip/_overlay.py)
+from mhhip._overlay import inherit as _inherit  # noqa: E402
+
+_inherit(globals())

@@ -241,8 +241,7 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
             e.log = torch.zeros(num_iter, 16, device=self.device)
         raster = None
         if self.use_rasteriser and e.has_images:
-            from mhhip import raster as _raster
-            raster = _raster.RasterTerms(e, self.znear, self.zfar)
+            raster = e.raster_terms(self.znear, self.zfar)        # one per engine: captured graphs bake its addresses
         lr = 0.01                                                             # a new RMSprop + ExponentialLR per fit (:355-356)
         cycles = range(num_iter)
         if verbose and tqdm is not None:

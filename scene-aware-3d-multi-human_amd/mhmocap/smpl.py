@@ -196,3 +196,10 @@ def lbs(betas, pose, v_template, shapedirs, posedirs, J_regressor, parents, lbs_
         b = b.expand(p.shape[0], -1)
     verts, _, posed = _LbsFn.apply(b.contiguous(), p.contiguous(), m, False)
     return verts, posed
+
+
+# helper names of the shadowed reference module (VertexJointSelector, batch_rodrigues, vertices2joints ...; pure
+# torch utilities outside the accelerated path) stay importable from here (mhhip/_overlay.py)
+from mhhip._overlay import inherit as _inherit  # noqa: E402
+
+_inherit(globals())

@@ -1,7 +1,12 @@
 """Camera helpers with the call surface of reference ``mhmocap/transforms.py`` (the functions the
-optimisation path uses: :57-95, :114-130, :222-255, :263-265, :296-297).  Host-side scalars are
-numpy; the per-point device work of the hot path is fused into the HIP kernels
-(``mh_project_joints_loss``, ``mh_scene_unproject``, ``mh_raster_*``)."""
+optimisation path and its direct callers use: :19-54, :57-95, :98-130, :222-255, :258-265, :296-306).
+Host-side scalars are numpy; the per-point device work of the hot path is fused into the HIP kernels
+(``mh_project_joints_loss``, ``mh_scene_unproject``, ``mh_raster_*``).
+
+This module SHADOWS the reference's ``mhmocap.transforms`` in the namespace overlay: every
+public name of the reference module that is not defined here (``batch_orthographic_projection``,
+``transform_3dpoints``, ``recover_camera_intrinsics*``, ``disp_from_depth``, ``bounded_splus_exp*`` ... used by
+``datautils.py:19``, ``evaluate.py:5``) is re-exported from it by ``mhhip._overlay.inherit`` at the bottom."""
 import math
 
 import numpy as np
@@ -46,9 +51,19 @@ def compute_calibration_matrix(znear, zfar, cam_K, image_size):
     return np.array([[s, 0, w1, 0], [0, s, h1, 0], [0, 0, f1, f2], [0, 0, 1, 0]], np.float32)
 
 
-def camera_projection(pts3d, K, return_depth=False):
-    """numpy twin of the pinhole projection: pts3d (M,3), K (3,3)."""
-    uv = (pts3d[:, :2] / pts3d[:, 2:3]) @ K[:2, :2].T + K[:2, 2][None]
+def camera_projection(pts3d, K, return_depth=False, Kd=None):
+    """numpy pinhole projection, pts3d (M,3), K (3,3), optional distortion Kd = [k1,k2,p1,p2,k3] (reference
+    :19-54, called by evaluate.py:234,256 and predict.py:105-106).  Same tangential form as the torch version
+    (:78-90), including its second term ``2*p2*y^2`` where OpenCV has ``2*p2*x*y``."""
+    xy = pts3d[:, :2] / pts3d[:, 2:3]
+    if Kd is not None:
+        x, y = xy[:, 0].copy(), xy[:, 1].copy()
+        r = x * x + y * y
+        radial = 1 + Kd[0] * r + Kd[1] * r * r + Kd[4] * r * r * r
+        xd = x * radial + 2 * Kd[2] * x * y + Kd[3] * (r + 2 * x * x)
+        yd = y * radial + 2 * Kd[3] * y * y + Kd[2] * (r + 2 * y * y)      # (sic)
+        xy = np.stack([xd, yd], axis=-1)
+    uv = xy @ K[:2, :2].T + K[0:2, 2:3].T
     return np.concatenate([uv, pts3d[:, 2:]], -1) if return_depth else uv
 
 
@@ -57,9 +72,21 @@ def camera_inverse_projection(ptsuvd, K):
     return np.concatenate([xy, ptsuvd[:, 2:3]], axis=-1)
 
 
+def _shadowed(name):
+    m = globals().get('__shadowed__')
+    return getattr(m, name, None) if m is not None else None
+
+
 def camera_projection_torch(pts3d, K, return_depth=False, Kd=None):
-    """pts3d (N,M,3), K (N,3,3) device tensors -> (N,M,2) pixels (reference :57-95); forward only."""
+    """pts3d (N,M,3), K (N,3,3) device tensors -> (N,M,2) pixels (reference :57-95); forward only (the optimiser's
+    differentiable projection is fused into ``mh_project_joints_loss``).  Host tensors are not part of the
+    accelerated path: they go to the shadowed reference function when the overlay runs over a reference tree."""
     import torch
+    if not pts3d.is_cuda:
+        ref = _shadowed('camera_projection_torch')
+        if ref is None:
+            raise RuntimeError('camera_projection_torch (MI355X build) needs device tensors: no CPU path')
+        return ref(pts3d, K, return_depth=return_depth, Kd=Kd)
     L = _hip()
     p = pts3d.contiguous().float()
     Kc = K.contiguous().float()
@@ -74,6 +101,11 @@ def camera_projection_torch(pts3d, K, return_depth=False, Kd=None):
 def camera_inverse_projection_torch(ptsuvd, K):
     """ptsuvd (N,M,3) pixels + depth, K (N,3,3) -> camera-space points (reference :114-130)."""
     import torch
+    if not ptsuvd.is_cuda:
+        ref = _shadowed('camera_inverse_projection_torch')
+        if ref is None:
+            raise RuntimeError('camera_inverse_projection_torch (MI355X build) needs device tensors: no CPU path')
+        return ref(ptsuvd, K)
     L = _hip()
     p = ptsuvd.contiguous().float()
     Kc = K.contiguous().float()
@@ -86,3 +118,13 @@ def softplus(x):
     """reference :296-297 (naive form); a one-liner on tensors, kept for call compatibility"""
     import torch
     return torch.log(1.0 + torch.exp(x))
+
+
+def inverse_softplus(s):
+    import torch
+    return torch.log(torch.exp(s) - 1.0)
+
+
+from mhhip._overlay import inherit as _inherit  # noqa: E402
+
+_inherit(globals())

@@ -20,6 +20,13 @@ def golden():
 
 
 @pytest.fixture(scope='session')
+def golden_raster():
+    """reference ``fit`` run on the oracle rasteriser through the pytorch3d stubs (make_golden_raster.py)"""
+    import numpy as np
+    return np.load(os.path.join(ROOT, 'tests', 'golden', 'reference_raster_cpu.npz'), allow_pickle=False)
+
+
+@pytest.fixture(scope='session')
 def smpl_struct():
     from mhhip import synthetic
     return synthetic.make_smpl_struct(1)

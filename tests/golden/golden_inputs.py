@@ -95,5 +95,32 @@ def fit_inputs(T=20, N=2, H=32, W=48, seed=21):
                 scene_depth=scene_depth, scene_mask=scene_mask)
 
 
+def median_inputs(T=23, H=12, W=20, seed=51):
+    """Normalised disparity, background masks and colour frames for the scene-median fixture: ties, a pixel no frame
+    sees, pixels one / two / an even number of frames see."""
+    rng = np.random.RandomState(seed)
+    dn = rng.uniform(0, 1, (T, H, W)).astype(np.float32)
+    dn[:, :2] = np.round(dn[:, :2] * 4) / 4
+    back = (rng.uniform(0, 1, (T, H, W)) > 0.4).astype(np.int64)
+    back[:, 0, 0] = 0
+    back[:, 5:7, 8:11] = 0
+    back[1:, 0, 1] = 0; back[0, 0, 1] = 1
+    back[2:, 0, 2] = 0; back[:2, 0, 2] = 1
+    back[4:, 0, 3] = 0; back[:4, 0, 3] = 1
+    imgs = rng.randint(0, 255, (T, H, W, 3)).astype(np.uint8)
+    return dn, back, imgs
+
+
 COEFS = dict(proj2d=1.0, depth=0.05, silhouette=0.1, reg_poses=0.002, reg_scales=1e-4,
              reg_velocity=0.05, reg_verts_filter=0.002, reg_contact=0.001, reg_foot_sliding=0.01)
+
+
+def fit_raster_inputs(gr):
+    """Inputs of the raster-pinned ``fit`` fixtures (tests/golden/make_golden_raster.py).  They were rendered
+    once in the build container and are stored in the fixture file itself (``in_*`` arrays of ``gr``)."""
+    T, N, H, W = [int(v) for v in gr['in_dims']]
+    return dict(T=T, N=N, H=H, W=W, cam_K=gr['in_cam_K'], pose2d=gr['in_pose2d'],
+                seg_mask=gr['in_seg_mask'].astype(np.float32), depths=gr['in_depths'], images=gr['in_images'],
+                backmasks=gr['in_backmasks'].astype(np.int64), poses_smpl=gr['in_poses_smpl'],
+                betas_smpl=gr['in_betas_smpl'], valid_smpl=gr['in_valid_smpl'], trans_gt=gr['in_trans_gt'],
+                scene_depth=gr['in_scene_depth'], scene_mask=gr['in_scene_mask'] > 0)

@@ -135,3 +135,24 @@ def test_graph_replay_matches_eager_across_filter_updates(smpl_struct, smpl_regs
         for k in l0[c]:
             np.testing.assert_allclose(l1[c][k], l0[c][k], rtol=2e-3, atol=1e-6, err_msg='%s cycle %d' % (k, c))
     assert l0[4]['reg_filter_verts'] > 0
+
+
+def test_second_fit_on_the_same_optimizer_replays_valid_graphs(smpl_struct, smpl_regs, oracle_model, tmp_path):
+    """``fit`` twice on one optimiser (round-1 advisor finding): the rasteriser workspace the captured graphs point
+    at belongs to the engine, so the second call replays against live memory -- same result as launching eagerly."""
+    T, N, W, H, batch = 4, 2, 120, 68, 2
+    runs = []
+    for graphs in (False, True):
+        opt, dl, o, batches, seq = _setup(smpl_struct, smpl_regs, oracle_model, tmp_path, T, N, W, H, batch, 33, True)
+        opt.use_graphs = graphs
+        opt.fit(dl, num_iter=3)
+        junk = [torch.empty(1 << 22, device='cuda:0').normal_() for _ in range(8)]      # churn the caching allocator
+        del junk
+        log = opt.fit(dl, num_iter=3)
+        torch.cuda.synchronize()
+        runs.append((opt.engine.params.cpu().numpy().copy(), log))
+    (p0, l0), (p1, l1) = runs
+    np.testing.assert_allclose(p1, p0, atol=2e-4 * np.abs(p0).max())
+    for c in range(3):
+        for k in ['loss_depth', 'loss_silhouette', 'loss_pose24j']:
+            np.testing.assert_allclose(l1[c][k], l0[c][k], rtol=2e-3, atol=1e-6, err_msg='%s cycle %d' % (k, c))

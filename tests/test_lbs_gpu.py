@@ -198,3 +198,28 @@ def test_temporal_terms():
     engine.filtered_verts_term(dev(v[:h]), dev(vf[:h]), 0.002, g1, nxt=(dev(v[h]), dev(vf[h])))
     engine.filtered_verts_term(dev(v[h:]), dev(vf[h:]), 0.002, g2, prev=(dev(v[h - 1]), dev(vf[h - 1])))
     np.testing.assert_allclose(torch.cat([g1, g2]).cpu().numpy(), tv.grad.numpy(), atol=1e-6)
+
+
+def test_rodrigues_edge_cases_through_the_hip_path(golden, oracle_model, hip_model):
+    """The ``rodrigues`` fixture of the reference (zero vector, |r| = pi, 1e-7, large angle; smpl.py:647-678 with the
+    eps-shifted norm) on the HIP path: as the ROOT orientation (all other joints at rest: the vertices are the
+    reference's rotation matrix applied to the template about the root joint) and at a non-root joint (the matrix
+    also feeds the pose blend-shapes and the kinematic chain; checked against the golden-pinned oracle)."""
+    r = gi.rodrigues_inputs()
+    B = r.shape[0]
+    R = golden['rodrigues'].astype(np.float64)                          # (B,3,3) from the reference
+    betas = np.zeros((B, 10), np.float32)
+    poses = np.zeros((B, 72), np.float32)
+    poses[:, 0:3] = r
+    verts, _, posed, _ = hip_model.lbs_forward(dev(betas), dev(poses), want_posed=True)
+    vt = oracle_model.v_template.double().numpy()
+    j0 = (oracle_model.J_regressor.double().numpy() @ vt)[0]
+    want = np.einsum('bij,vj->bvi', R, vt - j0) + j0
+    np.testing.assert_allclose(verts.cpu().numpy(), want, atol=1e-5)
+    poses2 = np.zeros((B, 72), np.float32)
+    poses2[:, 3 * 16:3 * 16 + 3] = r                                    # left shoulder
+    poses2[:, 3 * 4:3 * 4 + 3] = r[::-1]                                # left knee
+    verts2, _, posed2, _ = hip_model.lbs_forward(dev(betas), dev(poses2), want_posed=True)
+    ref = lo.smpl_forward(oracle_model, torch.tensor(betas), torch.tensor(poses2))
+    np.testing.assert_allclose(verts2.cpu().numpy(), ref['verts'].numpy(), atol=1e-5)
+    np.testing.assert_allclose(posed2.cpu().numpy(), ref['joints_smpl24'].numpy(), atol=1e-5)

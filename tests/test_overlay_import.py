@@ -1,0 +1,96 @@
+"""The namespace overlay must not break the reference's own callers: with the overlay in front of a
+reference tree on the module path, every module ``python -m mhmocap.predict_mupots`` pulls in has to import
+(``datautils.py:17-19`` and ``evaluate.py:5-6`` take names from ``mhmocap.transforms`` that the overlay does not
+implement itself), the optimiser / body model must resolve to the overlay, and the call surfaces must agree.
+Needs the reference tree (build container only) -- the stand-alone half runs everywhere."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import golden_inputs as gi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OVERLAY = os.path.join(ROOT, 'scene-aware-3d-multi-human_amd')
+REF = '/root/reference'
+
+PROBE = r'''
+import importlib, inspect, sys, types
+sys.argv = ['x']
+sys.modules['cv2'] = types.ModuleType('cv2')          # OpenCV is absent in the image; the import graph is what is tested
+sys.path[:0] = [%r, %r]
+where = {}
+for m in ['transforms', 'losses', 'morphology', 'one_euro_filter', 'smpl', 'optimizer', 'datautils', 'evaluate',
+          'predict', 'predict_mupots']:
+    where[m] = importlib.import_module('mhmocap.' + m).__file__
+for m in ['transforms', 'losses', 'morphology', 'one_euro_filter', 'smpl', 'optimizer']:
+    assert where[m].startswith(%r), (m, where[m])
+for m in ['datautils', 'evaluate', 'predict', 'predict_mupots']:
+    assert where[m].startswith(%r), (m, where[m])
+import mhmocap.predict as P, mhmocap.datautils as D, mhmocap.transforms as T, mhmocap.evaluate as E
+assert P.SMPLDepthSequenceOptimizer.__module__ == 'mhmocap.optimizer' and 'mhhip' in inspect.getsource(sys.modules['mhmocap.optimizer'])
+assert D.SMPL is sys.modules['mhmocap.smpl'].SMPL
+ref = T.__shadowed__
+# every public name of the shadowed modules is importable from the overlay module
+for m in ['transforms', 'losses', 'morphology', 'one_euro_filter', 'smpl']:
+    ov = sys.modules['mhmocap.' + m]
+    sh = ov.__shadowed__
+    missing = [k for k in vars(sh) if not k.startswith('_') and not hasattr(ov, k)]
+    assert not missing, (m, missing)
+# signatures of the functions the overlay re-implements are the reference's
+for name in ['camera_projection', 'camera_projection_torch', 'camera_inverse_projection', 'camera_inverse_projection_torch',
+             'compute_calibration_matrix', 'get_fov', 'get_focal', 'softplus', 'softplus_np', 'inverse_softplus',
+             'inverse_softplus_np']:
+    a, b = inspect.signature(getattr(T, name)), inspect.signature(getattr(ref, name))
+    assert list(a.parameters) == list(b.parameters), (name, a, b)
+    assert getattr(T, name).__module__ == 'mhmocap.transforms', name
+print('OVERLAY-OK')
+''' % (OVERLAY, REF, OVERLAY, REF)
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, 'mhmocap')), reason='reference tree not present')
+def test_reference_entry_points_import_over_the_overlay():
+    env = dict(os.environ)
+    env.pop('PYTHONPATH', None)
+    r = subprocess.run([sys.executable, '-c', PROBE], capture_output=True, text=True, cwd='/tmp', env=env, timeout=600)
+    assert r.returncode == 0 and 'OVERLAY-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, 'mhmocap')), reason='reference tree not present')
+def test_optimizer_constructor_signatures_match_the_reference():
+    """kwargs of the two classes predict.py:290-306 constructs, against the reference source (parsed, not imported:
+    its module needs pytorch3d)."""
+    import ast
+    import inspect
+    from mhmocap import optimizer as ov
+    tree = ast.parse(open(os.path.join(REF, 'mhmocap', 'optimizer.py')).read())
+    for cls in [n for n in tree.body if isinstance(n, ast.ClassDef)]:
+        mine = getattr(ov, cls.name)
+        for fn in [n for n in cls.body if isinstance(n, ast.FunctionDef) and not n.name.startswith('_SMPL')]:
+            if fn.name.startswith('__') and fn.name != '__init__':
+                continue
+            assert hasattr(mine, fn.name), (cls.name, fn.name)
+            want = [a.arg for a in fn.args.args]
+            got = list(inspect.signature(getattr(mine, fn.name)).parameters)
+            if fn.name == '__init__':
+                got = ['self'] + got if got[:1] != ['self'] else got
+                missing = [a for a in want if a not in got and not inspect.signature(mine.__init__).parameters.get('kargs')]
+                assert not missing, (cls.name, missing)
+                assert got[:len([a for a in want if a in got])] == [a for a in want if a in got], (cls.name, got, want)
+            else:
+                assert got[:len(want)] == want, (cls.name, fn.name, got, want)
+
+
+def test_numpy_projection_with_distortion(golden_raster):
+    """overlay ``camera_projection`` / ``camera_inverse_projection`` (numpy, host side of evaluate.py:234,256) against the
+    reference's output, with and without the distortion vector"""
+    from mhmocap import transforms as T
+    pts, K, Kd = gi.projection_inputs()
+    p = pts.reshape(-1, 3)
+    np.testing.assert_allclose(T.camera_projection(p.copy(), K[0], return_depth=True), golden_raster['proj_np_plain'], rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(T.camera_projection(p.copy(), K[0], Kd=Kd), golden_raster['proj_np_dist'], rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(T.camera_inverse_projection(golden_raster['proj_np_plain'].copy(), K[0]),
+                               golden_raster['unproj_np'], rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(golden_raster['unproj_np'], p, atol=2e-5)

@@ -100,6 +100,14 @@ int mh_lbs_forward(const mh_model* m, int B, int NB, const float* betas /*(NB,10
                    float* vposed /*(B,V,3) or NULL*/, float* posed_joints /*(B,24,3) or NULL*/,
                    void* ws, void* stream);
 
+/* Arithmetic of the two dense contractions of the LBS pair (pose/shape blend and its adjoint):
+ * split16 = 1 (default): operands carried as two 16-bit terms, three products on the 16-bit matrix pipe with fp32
+ * accumulation -- fp16 terms in the forward (vertices within ~1e-7 m of the fp32 result), bf16 terms in the backward
+ * (gradients within ~2e-5 relative).  split16 = 0: exact fp32 MFMA (the round-1 kernels; A/B reference, 3-4x slower).
+ * Process-wide; also selectable with MHHIP_LBS_FP32=1 in the environment before the first call.             */
+int mh_lbs_set_mode(int split16);
+int mh_lbs_get_mode(void);
+
 /* sparse joint regression from vertices (smpl.py:603-620, 367-386):
  * joints[b][j] = sum_v R[j][v] * verts[b][v]  (+ (1 - rowsum_j) * corr[b] when corr != NULL,
  * which turns regression of translated/scaled vertices into s*R*x + t exactly).

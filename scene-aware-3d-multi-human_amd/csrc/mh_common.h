@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/mhmocap_hip.h"
@@ -14,6 +15,15 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+// Split-precision contraction: an fp32 operand x is carried as two 16-bit terms x = hi + lo and the
+// product a.b is evaluated as a_hi.b_hi + a_hi.b_lo + a_lo.b_hi on the 16-bit matrix pipe (16x the fp32 MFMA
+// rate) with fp32 accumulation.  Forward (values): fp16 terms, operands pre-scaled by powers of two so that the
+// low terms stay normal -> x is carried to 2^-22, result error ~3 x 2^-22 relative to sum |a.b|.
+// Backward (gradients, any magnitude): bf16 terms -> 2^-16..2^-18.
+#define MH_F16_FEAT_SHIFT 8   // features (beta | R - I) are multiplied by 2^8 before the split (|beta| < 255)
 
 void mh_set_error(const char* fmt, ...);
 // event brackets around the named kernels (no-ops unless mh_profile_enable(1)); edge 0 = before, 1 = after
@@ -66,6 +76,9 @@ struct mh_model {
   float* vt;       // [VP][3]   template, zero padded
   float* D;        // [VP/32][MH_KD/16][3][64][8] basis tiled for the forward MFMA B operand (see mh_model.hip)
   float* Dt;       // [3][VP][16][16] the same, tiled for the backward MFMA B operand (see mh_model.hip)
+  uint16_t* D16;   // [VP/32][14][3][2][64][8] fp16 (hi, lo) terms of 2^d16_shift x basis, forward B operand of
+                   // v_mfma_f32_32x32x16_f16: lane l = (vertex l&31, k half l>>5) holds k = 16 s + 8 (l>>5) + 0..7
+  int d16_shift;
   int* skidx;      // [VP][nw] bones of the <= nw non-zero skinning weights per vertex
   float* skw;      // [VP][nw]
   float* Jt;       // [24][3]     J_regressor . v_template

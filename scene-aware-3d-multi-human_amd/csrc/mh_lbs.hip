@@ -27,6 +27,7 @@ struct PoseFwdP {
   const float* Jt;
   const float* JS;
   float* featT;   // [G][224][32]
+  uint16_t* F16;  // [G][14][2][64][8] fp16 (hi, lo) terms of 2^8 x features, MFMA A operand of k_skin_fwd16
   float* A;       // [G*32][24][12]
   float* scale;   // [G*32]
   float* posed;   // [B][24][3] or null
@@ -140,6 +141,27 @@ __global__ __launch_bounds__(256) void k_pose_fwd(PoseFwdP p) {
     }
     if (j >= 24 && j < 31) fT[(217 + (j - 24)) * 32] = 0.f;
     if (j == 0) p.scale[b] = (valid && p.xscale) ? powf(1.1f, p.xscale[b % p.NB]) : 1.f;   // optimizer.py:681
+    if (p.F16) {
+      // the same features as two fp16 terms in the A-operand layout of v_mfma_f32_32x32x16_f16:
+      // lane = (k half) * 32 + body, eight consecutive k per lane
+      auto put = [&](int k, float x) {
+        const float xs = x * (float)(1 << MH_F16_FEAT_SHIFT);
+        const _Float16 hi = (_Float16)xs;
+        const _Float16 lo = (_Float16)(xs - (float)hi);
+        _Float16* q = (_Float16*)p.F16 + ((((size_t)g * (MH_FS / 16) + (k >> 4)) * 2) * 64 + ((k >> 3) & 1) * 32 + bi) * 8 + (k & 7);
+        q[0] = hi;
+        q[64 * 8] = lo;
+      };
+      if (j < MH_NUM_BETAS) put(j, beta[j]);
+      if (act && j >= 1) {
+#pragma unroll
+        for (int e = 0; e < 9; ++e) {
+          float id = (e == 0 || e == 4 || e == 8) ? 1.f : 0.f;
+          put(10 + (j - 1) * 9 + e, valid ? (R[e] - id) : 0.f);
+        }
+      }
+      if (j >= 24 && j < 31) put(217 + (j - 24), 0.f);
+    }
   }
 }
 
@@ -279,12 +301,180 @@ __global__ __launch_bounds__(256, 2) void k_skin_fwd(SkinFwdP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Split-fp16 forward (default): the K = 224 contraction v_posed = v_template + [S;P]^T.feat on the fp16 matrix pipe
+// as three products of (hi, lo) terms per operand (mh_common.h), 16x the rate of the exact-fp32 MFMA form above, so
+// that the kernel is bound by its stores instead of by the matrix phase.  Same tiling: one workgroup = one group of
+// 32 bodies x four vertex tiles (one per wave); the group's feature panel (28 KB of fp16 terms) and its bone
+// transforms (36 KB) are staged in LDS once.  Per 16-k step a wave issues 2 ds_read_b128 (A operand: both terms),
+// six 16-byte global loads (B operand: three components x two terms, double buffered) and nine MFMAs.
+// ---------------------------------------------------------------------------------------------------------------
+#define MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+struct SkinFwd16P {
+  int B, G, V, VP, nw;
+  float unscale;           // 2^-(feature shift + basis shift)
+  const uint16_t* F16;
+  const float* A;
+  const float* scale;
+  const float* transl;
+  const uint16_t* D16;
+  const float* vt;
+  const int* skidx;
+  const float* skw;
+  float* verts;
+  float* vposed;
+};
+
+#define FWD16_SF_BYTES ((MH_FS / 16) * 2 * 64 * 16)       // 28672: feature terms
+#define FWD16_SA_BYTES (32 * MH_NJ * 12 * 4)              // 36864: bone transforms
+#define FWD16_LDS_BYTES (FWD16_SF_BYTES + FWD16_SA_BYTES + 32 * 16)   // + (scale, translation) per body
+
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+
+// FULL: every body of the group exists (no store guards); NW4: at most four bones per vertex (SMPL).
+// The epilogue is written for instruction count: per accumulator row 13 LDS reads whose row part is an immediate
+// offset (per-lane bases are set up once), 63 fp32 FMAs and two 12-byte stores addressed by a wave-uniform row base
+// plus one 32-bit lane offset.
+template <bool FULL, bool NW4>
+__global__ __launch_bounds__(256, 2) void k_skin_fwd16(SkinFwd16P p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
+  f16x8* sF = (f16x8*)smem16;                                           // [14][2][64]
+  float* sA = (float*)(smem16 + FWD16_SF_BYTES);                        // [32][24][12]
+  f32x4* sS = (f32x4*)(smem16 + FWD16_SF_BYTES + FWD16_SA_BYTES);       // [32] (scale, tx, ty, tz)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int g = blockIdx.y;
+  const int ntiles = p.VP / 32;
+  if ((int)blockIdx.x * 4 >= ntiles) return;
+  {
+    const f32x4* srcF = (const f32x4*)(p.F16 + (size_t)g * (MH_FS / 16) * 2 * 64 * 8);
+#pragma unroll
+    for (int i = 0; i < FWD16_SF_BYTES / 16 / 256; ++i) ((f32x4*)sF)[threadIdx.x + i * 256] = srcF[threadIdx.x + i * 256];
+    const f32x4* srcA = (const f32x4*)(p.A + (size_t)g * 32 * MH_NJ * 12);
+#pragma unroll
+    for (int i = 0; i < FWD16_SA_BYTES / 16 / 256; ++i) ((f32x4*)sA)[threadIdx.x + i * 256] = srcA[threadIdx.x + i * 256];
+    if (threadIdx.x < 32) {
+      const int b = g * 32 + threadIdx.x;
+      f32x4 q = {1.f, 0.f, 0.f, 0.f};
+      if (b < p.B) {
+        q[0] = p.scale[b];
+        if (p.transl) { q[1] = p.transl[(size_t)b * 3]; q[2] = p.transl[(size_t)b * 3 + 1]; q[3] = p.transl[(size_t)b * 3 + 2]; }
+      }
+      sS[threadIdx.x] = q;
+    }
+  }
+  __syncthreads();
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile >= ntiles) return;
+  const int v = tile * 32 + li;
+  // this lane's vertex constants: issued before the matrix phase, consumed after it
+  const bool vok = v < p.V;
+  const int vc = vok ? v : p.V - 1;
+  const f32x3 tv = *(const f32x3*)(p.vt + (size_t)vc * 3);
+  int sj[4] = {0, 0, 0, 0};
+  float sw[4] = {0.f, 0.f, 0.f, 0.f};
+  if (NW4 && p.nw == 4) {
+    const int4 j4 = *(const int4*)(p.skidx + (size_t)vc * 4);
+    const f32x4 w4 = *(const f32x4*)(p.skw + (size_t)vc * 4);
+    sj[0] = j4.x; sj[1] = j4.y; sj[2] = j4.z; sj[3] = j4.w;
+    sw[0] = w4[0]; sw[1] = w4[1]; sw[2] = w4[2]; sw[3] = w4[3];
+  } else {
+    const int nwl = p.nw < 4 ? p.nw : 4;
+    for (int k = 0; k < nwl; ++k) {
+      const int jj = p.skidx[(size_t)vc * p.nw + k];
+      const float ww = p.skw[(size_t)vc * p.nw + k];
+      if (k == 0) { sj[0] = jj; sw[0] = ww; }
+      if (k == 1) { sj[1] = jj; sw[1] = ww; }
+      if (k == 2) { sj[2] = jj; sw[2] = ww; }
+      if (k == 3) { sj[3] = jj; sw[3] = ww; }
+    }
+  }
+  // basis tile of this wave: [s][c][term][lane] in 16-byte units
+  const f16x8* Dw = (const f16x8*)p.D16 + (size_t)tile * (MH_KD / 16) * 6 * 64 + lane;
+  f32x16 ax = {0}, ay = {0}, az = {0};
+  f16x8 bq[2][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) bq[0][i] = Dw[i * 64];
+#pragma unroll
+  for (int s16 = 0; s16 < MH_KD / 16; ++s16) {
+    const int cur = s16 & 1, nxt = cur ^ 1;
+    if (s16 + 1 < MH_KD / 16) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) bq[nxt][i] = Dw[((s16 + 1) * 6 + i) * 64];
+    }
+    const f16x8 ah = sF[(s16 * 2) * 64 + lane], al = sF[(s16 * 2 + 1) * 64 + lane];
+    ax = MFMA_F16(ah, bq[cur][0], ax);
+    ay = MFMA_F16(ah, bq[cur][2], ay);
+    az = MFMA_F16(ah, bq[cur][4], az);
+    ax = MFMA_F16(ah, bq[cur][1], ax);
+    ay = MFMA_F16(ah, bq[cur][3], ay);
+    az = MFMA_F16(ah, bq[cur][5], az);
+    ax = MFMA_F16(al, bq[cur][0], ax);
+    ay = MFMA_F16(al, bq[cur][2], ay);
+    az = MFMA_F16(al, bq[cur][4], az);
+  }
+  if (!vok) return;
+  const float us = p.unscale;
+  // per-lane LDS bases (bytes): the row part (r&3)+8(r>>2) is a compile-time offset, the half-wave part 4*lh is here
+  const unsigned char* aB[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) aB[k] = (const unsigned char*)sA + (4 * lh) * (MH_NJ * 48) + sj[k] * 48;
+  const unsigned char* sB = (const unsigned char*)sS + (4 * lh) * 16;
+  const unsigned lane_off = (unsigned)(4 * lh * p.V + v) * 12u;          // bytes inside a group's row block (< 2^32)
+  const size_t row_bytes = (size_t)p.V * 12;
+  unsigned char* const vg = (unsigned char*)p.verts + (size_t)g * 32 * row_bytes;
+  unsigned char* const qg = p.vposed ? (unsigned char*)p.vposed + (size_t)g * 32 * row_bytes : nullptr;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    constexpr int dummy = 0; (void)dummy;
+    const int row0 = (r & 3) + 8 * (r >> 2);                              // + 4*lh = accumulator row = body in group
+    const float vp0 = fmaf(ax[r], us, tv[0]), vp1 = fmaf(ay[r], us, tv[1]), vp2 = fmaf(az[r], us, tv[2]);
+    float T[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) T[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f32x4* Aj = (const f32x4*)(aB[k] + row0 * (MH_NJ * 48));
+      const f32x4 q0 = Aj[0], q1 = Aj[1], q2 = Aj[2];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        T[e] = fmaf(sw[k], q0[e], T[e]);
+        T[4 + e] = fmaf(sw[k], q1[e], T[4 + e]);
+        T[8 + e] = fmaf(sw[k], q2[e], T[8 + e]);
+      }
+    }
+    if (!NW4) {
+      const float* Ab = sA + (row0 + 4 * lh) * MH_NJ * 12;
+      for (int k = 4; k < p.nw; ++k) {   // models with more than 4 bones per vertex
+        const float w = p.skw[(size_t)v * p.nw + k];
+        const float* Aj = Ab + p.skidx[(size_t)v * p.nw + k] * 12;
+#pragma unroll
+        for (int e = 0; e < 12; ++e) T[e] = fmaf(w, Aj[e], T[e]);
+      }
+    }
+    const f32x4 st = *(const f32x4*)(sB + row0 * 16);                    // (scale, translation) of this body
+    const float x0 = fmaf(T[2], vp2, fmaf(T[1], vp1, T[0] * vp0)) + T[3];
+    const float x1 = fmaf(T[6], vp2, fmaf(T[5], vp1, T[4] * vp0)) + T[7];
+    const float x2 = fmaf(T[10], vp2, fmaf(T[9], vp1, T[8] * vp0)) + T[11];
+    const f32x3 o = {fmaf(st[0], x0, st[1]), fmaf(st[0], x1, st[2]), fmaf(st[0], x2, st[3])};
+    if (FULL || g * 32 + row0 + 4 * lh < p.B) {
+      *(f32x3*)(vg + (size_t)row0 * row_bytes + lane_off) = o;
+      if (qg) {
+        const f32x3 q = {vp0, vp1, vp2};
+        *(f32x3*)(qg + (size_t)row0 * row_bytes + lane_off) = q;
+      }
+    }
+  }
+}
+
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct FwdWs {
   float* featT;
   float* A;
   float* scale;
+  uint16_t* F16;
 };
 static FwdWs carve_fwd(void* ws, int G) {
   char* p = (char*)ws;
@@ -294,12 +484,30 @@ static FwdWs carve_fwd(void* ws, int G) {
   w.A = (float*)p;
   p += align256((size_t)G * 32 * MH_NJ * 12 * 4);
   w.scale = (float*)p;
+  p += align256((size_t)G * 32 * 4);
+  w.F16 = (uint16_t*)p;
   return w;
 }
 
+// 1 (default): split-fp16 / split-bf16 contractions on the 16-bit matrix pipe; 0: exact-fp32 MFMA (A/B reference)
+static int g_lbs_mode = -1;
+static int lbs_mode() {
+  if (g_lbs_mode < 0) {
+    const char* e = getenv("MHHIP_LBS_FP32");
+    g_lbs_mode = (e && e[0] == '1') ? 0 : 1;
+  }
+  return g_lbs_mode;
+}
+extern "C" int mh_lbs_set_mode(int split16) {
+  g_lbs_mode = split16 ? 1 : 0;
+  return MH_OK;
+}
+extern "C" int mh_lbs_get_mode(void) { return lbs_mode(); }
+
 extern "C" size_t mh_lbs_workspace_bytes(int B) {
   int G = mh_groups(B < 1 ? 1 : B);
-  return align256((size_t)G * MH_FS * 32 * 4) + align256((size_t)G * 32 * MH_NJ * 12 * 4) + align256((size_t)G * 32 * 4);
+  return align256((size_t)G * MH_FS * 32 * 4) + align256((size_t)G * 32 * MH_NJ * 12 * 4) + align256((size_t)G * 32 * 4) +
+         align256((size_t)G * (MH_FS / 16) * 2 * 64 * 16);
 }
 
 extern "C" int mh_lbs_forward(const mh_model* m, int B, int NB, const float* betas, const float* poses,
@@ -316,8 +524,34 @@ extern "C" int mh_lbs_forward(const mh_model* m, int B, int NB, const float* bet
   pp.Jt = m->Jt; pp.JS = m->JS;
   pp.featT = w.featT; pp.A = w.A; pp.scale = w.scale; pp.posed = posed_joints;
   pp.tree = m->tree;
+  const bool split16 = lbs_mode() != 0;
+  pp.F16 = split16 ? w.F16 : nullptr;
   hipLaunchKernelGGL(k_pose_fwd, dim3(G * 4), dim3(256), 0, st, pp);
   MH_LAUNCH_CHECK();
+  if (split16) {
+    SkinFwd16P sp;
+    sp.B = B; sp.G = G; sp.V = m->V; sp.VP = m->VP; sp.nw = m->nw;
+    sp.unscale = ldexpf(1.f, -(MH_F16_FEAT_SHIFT + m->d16_shift));
+    sp.F16 = w.F16; sp.A = w.A; sp.scale = w.scale; sp.transl = transl;
+    sp.D16 = m->D16; sp.vt = m->vt; sp.skidx = m->skidx; sp.skw = m->skw;
+    sp.verts = verts; sp.vposed = vposed;
+    MH_CHECK((size_t)32 * m->V * 12 < ((size_t)1 << 32), "model too large for 32-bit lane offsets");
+    const size_t lds = FWD16_LDS_BYTES;
+    const bool full = (B % 32) == 0, nw4 = m->nw <= 4;
+    auto kern = full ? (nw4 ? k_skin_fwd16<true, true> : k_skin_fwd16<true, false>)
+                     : (nw4 ? k_skin_fwd16<false, true> : k_skin_fwd16<false, false>);
+    static bool attr16[4] = {false, false, false, false};
+    const int ki = (full ? 2 : 0) + (nw4 ? 1 : 0);
+    if (!attr16[ki]) {
+      MH_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr16[ki] = true;
+    }
+    mh_prof_mark(MH_PROF_SKIN_FWD, 0, st);
+    hipLaunchKernelGGL(kern, dim3(((m->VP / 32 + 3) / 4 + 7) / 8 * 8, G), dim3(256), lds, st, sp);
+    MH_LAUNCH_CHECK();
+    mh_prof_mark(MH_PROF_SKIN_FWD, 1, st);
+    return MH_OK;
+  }
   SkinFwdP sp;
   sp.B = B; sp.G = G; sp.V = m->V; sp.VP = m->VP; sp.nw = m->nw;
   sp.featT = w.featT; sp.A = w.A; sp.scale = w.scale; sp.transl = transl;

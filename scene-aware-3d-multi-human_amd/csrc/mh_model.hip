@@ -1,6 +1,7 @@
 // mh_model: immutable SMPL constants, re-laid for the gfx950 kernels and uploaded once.
 // Replaces SMPL.__init__ (reference smpl.py:124-275).
 #include <algorithm>
+#include <cmath>
 #include <vector>
 
 #include "mh_common.h"
@@ -162,6 +163,39 @@ extern "C" int mh_model_create(mh_model** out, const mh_model_host* h) {
       }
     if ((rc = upload(&m->D, D))) return rc;
     if ((rc = upload(&m->Dt, Dt))) return rc;
+    // split-fp16 forward operand: the basis scaled by 2^shift so that its largest entry lies in [2^12, 2^13) (the
+    // low terms of all but vanishing entries stay normal fp16 numbers), as hi = fp16(x), lo = fp16(x - hi)
+    float dmax = 0.f;
+    for (float x : D) dmax = std::max(dmax, std::fabs(x));
+    int shift = 0;
+    if (dmax > 0.f) {
+      int e;
+      (void)std::frexp(dmax, &e);        // dmax = f * 2^e, f in [0.5, 1)
+      shift = 13 - e;
+    }
+    m->d16_shift = shift;
+    std::vector<uint16_t> D16((size_t)(VP / 32) * (MH_KD / 16) * 3 * 2 * 64 * 8, 0);
+    auto bits16 = [](_Float16 hv) { uint16_t u; memcpy(&u, &hv, 2); return u; };
+    auto load = [&](int c, int k, int v) -> float {
+      if (v >= V) return 0.f;
+      if (k < MH_NUM_BETAS) return h->shapedirs[((size_t)v * 3 + c) * MH_NUM_BETAS + k];
+      if (k < MH_NUM_BETAS + MH_NUM_POSE_BASIS) return h->posedirs[((size_t)v * 3 + c) * MH_NUM_POSE_BASIS + (k - MH_NUM_BETAS)];
+      return 0.f;
+    };
+    for (int tile = 0; tile < VP / 32; ++tile)
+      for (int s16 = 0; s16 < MH_KD / 16; ++s16)
+        for (int c = 0; c < 3; ++c)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int t = 0; t < 8; ++t) {
+              const int v = tile * 32 + (lane & 31), k = 16 * s16 + 8 * (lane >> 5) + t;
+              const float x = std::ldexp(load(c, k, v), shift);
+              const _Float16 hi = (_Float16)x;
+              const _Float16 lo = (_Float16)(x - (float)hi);
+              const size_t base = ((((size_t)tile * (MH_KD / 16) + s16) * 3 + c) * 2) * 64 * 8;
+              D16[base + (size_t)lane * 8 + t] = bits16(hi);
+              D16[base + 64 * 8 + (size_t)lane * 8 + t] = bits16(lo);
+            }
+    if ((rc = upload(&m->D16, D16))) return rc;
   }
   {
     // skinning weights: keep the non-zeros per vertex (<= 4 in SMPL); nw = max count
@@ -246,7 +280,7 @@ extern "C" int mh_model_create(mh_model** out, const mh_model_host* h) {
 
 extern "C" int mh_model_destroy(mh_model* m) {
   if (!m) return MH_OK;
-  void* ptrs[] = {m->vt, m->D, m->Dt, m->skidx, m->skw, m->Jt, m->JS, m->faces, m->kpv_ptr, m->kpv_j, m->kpv_w};
+  void* ptrs[] = {m->vt, m->D, m->Dt, m->D16, m->skidx, m->skw, m->Jt, m->JS, m->faces, m->kpv_ptr, m->kpv_j, m->kpv_w};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < 4; ++i) {

@@ -1,24 +1,51 @@
-"""Compile the HIP sources into the in-tree C-ABI shared library (gfx950 only)."""
+"""Compile the HIP sources into the in-tree C-ABI shared library (gfx950 only).
+
+Every ``csrc/*.hip`` is compiled to its own object (in parallel, only when stale) and the objects are linked into
+``mhhip/libmhmocap_hip.so``.  Per-file flags:
+
+* ``mh_lbs.hip`` is built with ``-fno-slp-vectorize``.  With SLP on, hipcc (ROCm 7.2) packs the fp32 epilogue arithmetic
+  that consumes the accumulators of ``v_mfma_f32_32x32x16_f16`` into ``v_pk_fma_f32`` / ``v_pk_mul_f32``; that code
+  produced WRONG values on lanes 48-63 of the first / last accumulator rows of some waves of some launches (run-to-run
+  non-deterministic, more often under back-to-back launches; every input of the affected expression verified
+  deterministic and correct; tools/stress_lbs.py).  Without SLP the same source is exact and deterministic
+  over thousands of launches.  The packed forms buy nothing on gfx950 anyway (same FLOP rate as two plain VALU ops).
+"""
+import concurrent.futures
 import glob
 import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), 'csrc')
+OBJ = os.path.join(os.path.dirname(HERE), 'build')
 LIB = os.path.join(HERE, 'libmhmocap_hip.so')
+
+COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result', '-munsafe-fp-atomics']
+PER_FILE = {'mh_lbs.hip': ['-fno-slp-vectorize']}
 
 
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
 
 
-def is_stale():
-    if not os.path.exists(LIB):
+def _headers():
+    return glob.glob(os.path.join(CSRC, '*.h')) + \
+        glob.glob(os.path.join(os.path.dirname(os.path.dirname(HERE)), 'include', '*.h')) + [os.path.abspath(__file__)]
+
+
+def _obj(src):
+    return os.path.join(OBJ, os.path.basename(src)[:-4] + '.o')
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + \
-        glob.glob(os.path.join(os.path.dirname(os.path.dirname(HERE)), 'include', '*.h'))
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(f) > t for f in deps)
+
+
+def is_stale():
+    return _stale(LIB, sources() + _headers())
 
 
 def build(force=False, verbose=False):
@@ -26,11 +53,22 @@ def build(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
-           '-Wno-unused-result', '-munsafe-fp-atomics'] + sources() + ['-o', LIB + '.tmp']
-    if verbose:
-        print(' '.join(cmd))
-    subprocess.run(cmd, check=True)
+    extra = os.environ.get('MHHIP_CXXFLAGS', '').split()
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = _headers()
+    jobs = []
+    for src in sources():
+        if force or extra or _stale(_obj(src), [src] + hdrs):
+            jobs.append([hipcc] + COMMON + PER_FILE.get(os.path.basename(src), []) + extra + ['-c', src, '-o', _obj(src)])
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.run(cmd, check=True)
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + [_obj(s) for s in sources()] + ['-o', LIB + '.tmp'])
     os.replace(LIB + '.tmp', LIB)
     return LIB
 

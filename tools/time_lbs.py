@@ -22,7 +22,16 @@ def main():
     L = _lib.lib(); st = _lib.stream_ptr(e.dev)
     fwd = lambda: check(L.mh_lbs_forward(e.m.handle, e.B, e.N, ptr(e.leaf('betas')), ptr(e.leaf('poses_smpl')), ptr(e.leaf('xscale')),
                                          ptr(e.leaf('poses_T')), ptr(e.verts), ptr(e.vposed), None, ptr(e.ws), st))
-    print('lbs fwd ms %.4f' % timeit(fwd, 50))
+    for mode in (0, 1):
+        L.mh_lbs_set_mode(mode)
+        e.verts.zero_(); e.vposed.zero_()
+        t = timeit(fwd, 50)
+        torch.cuda.synchronize()
+        if mode == 0:
+            v0, q0 = e.verts.clone(), e.vposed.clone()
+        print('lbs fwd mode %d ms %.4f' % (mode, t))
+    print('split16 vs fp32: max |dverts| %.3e  max |dvposed| %.3e  (max |verts| %.2f)' % (
+        float((e.verts - v0).abs().max()), float((e.vposed - q0).abs().max()), float(v0.abs().max())))
     gv = torch.randn_like(e.verts) * 1e-3
     g = e.grads
     bwd = lambda: check(L.mh_lbs_backward(e.m.handle, e.B, e.N, ptr(e.leaf('betas')), ptr(e.leaf('poses_smpl')), ptr(e.leaf('xscale')),

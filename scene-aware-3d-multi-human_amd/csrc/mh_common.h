@@ -79,6 +79,11 @@ struct mh_model {
   uint16_t* D16;   // [VP/32][14][3][2][64][8] fp16 (hi, lo) terms of 2^d16_shift x basis, forward B operand of
                    // v_mfma_f32_32x32x16_f16: lane l = (vertex l&31, k half l>>5) holds k = 16 s + 8 (l>>5) + 0..7
   int d16_shift;
+  uint16_t* Dt16;  // [VP/16][3][7][2][64][8] bf16 (hi, lo) terms of the basis, backward B operand of
+                   // v_mfma_f32_32x32x16_bf16 (contraction over the 16 vertices of a block): lane l = (basis column
+                   // 32 ct + (l&31), vertex half l>>5) holds vertices 16 blk + 8 (l>>5) + 0..7 of component c
+  uint16_t* W16;   // [VP/32][2][2][64][8] bf16 (hi, lo) terms of the dense skinning weights, B operand of
+                   // v_mfma_f32_16x16x32_bf16 (two joint tiles of 16, 24 joints used)
   int* skidx;      // [VP][nw] bones of the <= nw non-zero skinning weights per vertex
   float* skw;      // [VP][nw]
   float* Jt;       // [24][3]     J_regressor . v_template

@@ -12,6 +12,8 @@
 //   k_skin_bwd   per (body group, vertex chunk): lane = (body, vertex) so the element-wise
 //                adjoints ARE the MFMA A operands: gfeat += g_vposed x Dt, gA += gT x W
 //   k_pose_bwd   per body: adjoint of the chain and of rodrigues, priors-free
+#include <algorithm>
+
 #include "mh_common.h"
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
@@ -326,6 +328,12 @@ struct SkinFwd16P {
   float* vposed;
 };
 
+#ifndef FWD16_STAGES
+#define FWD16_STAGES 2
+#endif
+#ifndef FWD16_WAVES
+#define FWD16_WAVES 8
+#endif
 #define FWD16_SF_BYTES ((MH_FS / 16) * 2 * 64 * 16)       // 28672: feature terms
 #define FWD16_SA_BYTES (32 * MH_NJ * 12 * 4)              // 36864: bone transforms
 #define FWD16_LDS_BYTES (FWD16_SF_BYTES + FWD16_SA_BYTES + 32 * 16)   // + (scale, translation) per body
@@ -337,7 +345,7 @@ typedef float f32x3 __attribute__((ext_vector_type(3)));
 // offset (per-lane bases are set up once), 63 fp32 FMAs and two 12-byte stores addressed by a wave-uniform row base
 // plus one 32-bit lane offset.
 template <bool FULL, bool NW4>
-__global__ __launch_bounds__(256, 2) void k_skin_fwd16(SkinFwd16P p) {
+__global__ __launch_bounds__(FWD16_WAVES * 64, 2 * FWD16_WAVES / 4) void k_skin_fwd16(SkinFwd16P p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
   f16x8* sF = (f16x8*)smem16;                                           // [14][2][64]
   float* sA = (float*)(smem16 + FWD16_SF_BYTES);                        // [32][24][12]
@@ -346,14 +354,12 @@ __global__ __launch_bounds__(256, 2) void k_skin_fwd16(SkinFwd16P p) {
   const int li = lane & 31, lh = lane >> 5;
   const int g = blockIdx.y;
   const int ntiles = p.VP / 32;
-  if ((int)blockIdx.x * 4 >= ntiles) return;
+  if ((int)blockIdx.x * FWD16_WAVES >= ntiles) return;
   {
     const f32x4* srcF = (const f32x4*)(p.F16 + (size_t)g * (MH_FS / 16) * 2 * 64 * 8);
-#pragma unroll
-    for (int i = 0; i < FWD16_SF_BYTES / 16 / 256; ++i) ((f32x4*)sF)[threadIdx.x + i * 256] = srcF[threadIdx.x + i * 256];
+    for (int i = threadIdx.x; i < FWD16_SF_BYTES / 16; i += FWD16_WAVES * 64) ((f32x4*)sF)[i] = srcF[i];
     const f32x4* srcA = (const f32x4*)(p.A + (size_t)g * 32 * MH_NJ * 12);
-#pragma unroll
-    for (int i = 0; i < FWD16_SA_BYTES / 16 / 256; ++i) ((f32x4*)sA)[threadIdx.x + i * 256] = srcA[threadIdx.x + i * 256];
+    for (int i = threadIdx.x; i < FWD16_SA_BYTES / 16; i += FWD16_WAVES * 64) ((f32x4*)sA)[i] = srcA[i];
     if (threadIdx.x < 32) {
       const int b = g * 32 + threadIdx.x;
       f32x4 q = {1.f, 0.f, 0.f, 0.f};
@@ -365,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void k_skin_fwd16(SkinFwd16P p) {
     }
   }
   __syncthreads();
-  const int tile = blockIdx.x * 4 + wave;
+  const int tile = blockIdx.x * FWD16_WAVES + wave;
   if (tile >= ntiles) return;
   const int v = tile * 32 + li;
   // this lane's vertex constants: issued before the matrix phase, consumed after it
@@ -393,16 +399,21 @@ __global__ __launch_bounds__(256, 2) void k_skin_fwd16(SkinFwd16P p) {
   // basis tile of this wave: [s][c][term][lane] in 16-byte units
   const f16x8* Dw = (const f16x8*)p.D16 + (size_t)tile * (MH_KD / 16) * 6 * 64 + lane;
   f32x16 ax = {0}, ay = {0}, az = {0};
-  f16x8 bq[2][6];
+  // B operand ring: FWD16_STAGES k-steps (6 KB per wave each) in flight -- one step ahead left the phase latency-bound
+  // (8 waves x 6 KB per CU against ~1.5 us of L2 latency under load)
+  f16x8 bq[FWD16_STAGES][6];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) bq[0][i] = Dw[i * 64];
+  for (int st = 0; st < FWD16_STAGES - 1; ++st)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) bq[st][i] = Dw[(st * 6 + i) * 64];
 #pragma unroll
   for (int s16 = 0; s16 < MH_KD / 16; ++s16) {
-    const int cur = s16 & 1, nxt = cur ^ 1;
-    if (s16 + 1 < MH_KD / 16) {
+    const int cur = s16 % FWD16_STAGES, nxt = (s16 + FWD16_STAGES - 1) % FWD16_STAGES;
+    if (s16 + FWD16_STAGES - 1 < MH_KD / 16) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) bq[nxt][i] = Dw[((s16 + 1) * 6 + i) * 64];
+      for (int i = 0; i < 6; ++i) bq[nxt][i] = Dw[((s16 + FWD16_STAGES - 1) * 6 + i) * 64];
     }
+    __builtin_amdgcn_sched_barrier(0);   // keep the ring: the scheduler otherwise sinks each load next to its first use
     const f16x8 ah = sF[(s16 * 2) * 64 + lane], al = sF[(s16 * 2 + 1) * 64 + lane];
     ax = MFMA_F16(ah, bq[cur][0], ax);
     ay = MFMA_F16(ah, bq[cur][2], ay);
@@ -413,6 +424,7 @@ __global__ __launch_bounds__(256, 2) void k_skin_fwd16(SkinFwd16P p) {
     ax = MFMA_F16(al, bq[cur][0], ax);
     ay = MFMA_F16(al, bq[cur][2], ay);
     az = MFMA_F16(al, bq[cur][4], az);
+    __builtin_amdgcn_sched_barrier(0);
   }
   if (!vok) return;
   const float us = p.unscale;
@@ -547,7 +559,7 @@ extern "C" int mh_lbs_forward(const mh_model* m, int B, int NB, const float* bet
       attr16[ki] = true;
     }
     mh_prof_mark(MH_PROF_SKIN_FWD, 0, st);
-    hipLaunchKernelGGL(kern, dim3(((m->VP / 32 + 3) / 4 + 7) / 8 * 8, G), dim3(256), lds, st, sp);
+    hipLaunchKernelGGL(kern, dim3(((m->VP / 32 + FWD16_WAVES - 1) / FWD16_WAVES + 7) / 8 * 8, G), dim3(FWD16_WAVES * 64), lds, st, sp);
     MH_LAUNCH_CHECK();
     mh_prof_mark(MH_PROF_SKIN_FWD, 1, st);
     return MH_OK;
@@ -843,6 +855,424 @@ __global__ __launch_bounds__(256, 2) void k_skin_bwd(SkinBwdP p) {
   for (int i = tid; i < 64; i += 256) oS[i] = sRed[BWD_NACC * 4 * 64 + i];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Split-bf16 backward (default).  The two dense adjoints of the skinning pass are contractions over the vertices
+// with a per-lane element-wise operand:
+//     gfeat[b][k]      = sum_{v,c} gv[b][v][c] . D[k][v][c]              gv = T^T (s g)    (k_featgrad16)
+//     gA[b][j][r][c]   = sum_v     W[v][j] . (s g_r)[b][v] . [q;1]_c[b][v]                 (k_jointgrad16)
+// Lane = (body of a group of 32, vertex half): a lane evaluates its body at the 8 vertices 16 blk + 8 half + 0..7, and
+// those eight values, as two bf16 terms, ARE the A operand of v_mfma_f32_32x32x16_bf16; the B operands are the
+// constant tables Dt16 / W16 (two bf16 terms each); three products per operand pair, fp32 accumulation.  Two kernels
+// because the accumulators do not fit one register file (7 x 16 + 12 x 16); the joint kernel needs no bone blend.
+// A workgroup = one body group x one vertex chunk, its four waves take the chunk's 16-vertex blocks round-robin and
+// are summed through LDS in fixed order; chunks are summed in fixed order by k_pose_bwd (deterministic).
+// ---------------------------------------------------------------------------------------------------------------
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+typedef __bf16 bfx8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bfx2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2a __attribute__((ext_vector_type(2), aligned(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// eight fp32 values -> (hi, lo) bf16 operand fragments: hi = bf16(x), lo = bf16(x - hi), round to nearest even
+__device__ __forceinline__ void mh_split_bf16x8(const float x[8], bfx8& hi, bfx8& lo) {
+  u32x4 h, l;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x2 v = {x[2 * i], x[2 * i + 1]};
+    const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bfx2));
+    const f32x2 r = {v[0] - __builtin_bit_cast(float, u << 16), v[1] - __builtin_bit_cast(float, u & 0xffff0000u)};
+    h[i] = u;
+    l[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bfx2));
+  }
+  hi = __builtin_bit_cast(bfx8, h);
+  lo = __builtin_bit_cast(bfx8, l);
+}
+
+struct Bwd16P {
+  int B, G, V, VP, nw, CH, PB;   // G groups of 32 bodies, PB = 16-vertex blocks per chunk
+  const float* A;
+  const float* scale;
+  const float* vposed;
+  const float* gverts;
+  const float* gjoints;   // [B][17][3] or null
+  const uint16_t* Dt16;
+  const uint16_t* W16;
+  const int* skidx;
+  const float* skw;
+  const int* kpv_ptr;
+  const int* kpv_j;
+  const float* kpv_w;
+  float* pF;   // [CH][GB][224]
+  float* pA;   // [CH][GB][12][24]
+  float* pS;   // [CH][GB][4]  (gT.xyz, gscale)
+};
+
+// One wave's (32 bodies x 16 vertices) block of a (B,V,3) array, fetched with row-coalesced 12-byte loads (16 lanes
+// = the 192 contiguous bytes of one body) and transposed through a wave-private LDS buffer into the operand layout:
+// lane (body l&31, half l>>5) receives its eight vertices 8 (l>>5) + 0..7.  (Letting every lane read its own body row
+// straight from memory touches 64 cache lines per instruction and thrashed the 32 KB L1: 6x the bytes from L2.)
+#define BW_TS 20                                   // padded row stride (floats): conflict-free ds_read_b128
+#define BW_TBUF (3 * 32 * BW_TS)                   // floats per wave
+__device__ __forceinline__ void bwd16_fetch(const float* __restrict__ src, int B, int V, int g, int blk, int lane,
+                                            f32x3 r[8]) {
+  if (!src) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = (f32x3){0.f, 0.f, 0.f};
+    return;
+  }
+  const int vx = blk * 16 + (lane & 15);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int b = g * 32 + 4 * k + (lane >> 4);
+    const bool ok = b < B && vx < V;                 // clamped address + select: no divergent branch per load
+    const f32x3 x = *(const f32x3*)(src + ((size_t)(b < B ? b : B - 1) * V + (vx < V ? vx : V - 1)) * 3);
+    r[k] = (f32x3){ok ? x[0] : 0.f, ok ? x[1] : 0.f, ok ? x[2] : 0.f};
+  }
+}
+__device__ __forceinline__ void bwd16_transpose(float* buf, int lane, const f32x3 r[8], float out[8][3]) {
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) buf[(c * 32 + 4 * k + (lane >> 4)) * BW_TS + (lane & 15)] = r[k][c];
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const f32x4* q = (const f32x4*)(buf + (c * 32 + (lane & 31)) * BW_TS + 8 * (lane >> 5));
+    const f32x4 a = q[0], b = q[1];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { out[t][c] = a[t]; out[4 + t][c] = b[t]; }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+// key-point regressor adjoint of the lane's eight vertices: dL/dverts += R^T dL/djoints (~670 entries over the mesh)
+__device__ __forceinline__ void bwd16_kp(const Bwd16P& p, int v0, const float* sGjb, float g[8][3]) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int ke0 = p.kpv_ptr[v0 + t], ke1 = p.kpv_ptr[v0 + t + 1];
+    for (int e = ke0; e < ke1; ++e) {
+      const float w = p.kpv_w[e];
+      const float* gj = sGjb + p.kpv_j[e] * 3;
+      g[t][0] = fmaf(w, gj[0], g[t][0]);
+      g[t][1] = fmaf(w, gj[1], g[t][1]);
+      g[t][2] = fmaf(w, gj[2], g[t][2]);
+    }
+  }
+}
+
+#ifndef JG_OCC
+#define JG_OCC 2
+#endif
+#ifndef FG_OCC
+#define FG_OCC 1
+#endif
+#define MFMA16_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#define JG_TS 36                                   // padded row stride (floats) of the joint kernel's transpose buffer
+#define JG_TBUF (3 * 16 * JG_TS)
+// Joint-transform gradient on 16x16x32 tiles (12 x 2 x 4 accumulator registers for 16 bodies x 24 joints x 12 entries):
+// a wave = 16 bodies of the group (wave & 1) on one of two vertex streams (wave >> 1), blocks of 32 vertices;
+// lane = (body l&15, vertex quarter l>>4) with the vertices 32 blk + 8 (l>>4) + 0..7.
+template <bool HASG, bool KP>
+__global__ __launch_bounds__(256, JG_OCC) void k_jointgrad16(Bwd16P p) {
+  extern __shared__ __attribute__((aligned(16))) float smj[];
+  float* sGj = smj;                    // [32][52]
+  float* sRed = smj + 32 * 52;         // [2][12*2*4][64]; the waves' transpose buffers alias it until the reduction
+  const int g = blockIdx.x, ch = blockIdx.y;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
+  const int bh = wave & 1, vs = wave >> 1;
+  for (int i = tid; i < 32 * 51; i += 256) {
+    const int bb = i / 51, e = i % 51;
+    const int b = g * 32 + bb;
+    sGj[bb * 52 + e] = (p.gjoints && b < p.B) ? p.gjoints[(size_t)b * 51 + e] : 0.f;
+  }
+  __syncthreads();
+  const int b = g * 32 + 16 * bh + li;
+  const bool bvalid = b < p.B;
+  const float sb = bvalid ? p.scale[b] : 0.f;
+  f32x4 acc[12][2];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) acc[i][0] = acc[i][1] = (f32x4){0, 0, 0, 0};
+  const int nblk = p.VP / 32;
+  const int PB32 = (p.PB + 1) / 2;
+  const int bend = min((ch + 1) * PB32, nblk);
+  const bfx8* Wb = (const bfx8*)p.W16 + lane;          // [blk32][joint tile][term][lane]
+  float* tb = sRed + wave * JG_TBUF;
+  for (int blk = ch * PB32 + vs; blk < bend; blk += 2) {
+    const bfx8 wh0 = Wb[(size_t)blk * 256], wl0 = Wb[(size_t)blk * 256 + 64];
+    const bfx8 wh1 = Wb[(size_t)blk * 256 + 128], wl1 = Wb[(size_t)blk * 256 + 192];
+    float gq[8][3], q[8][3];
+    {
+      // row-coalesced fetch (32 lanes = the 384 contiguous bytes of one body), then transpose through LDS
+      const int vx = blk * 32 + (lane & 31);
+      f32x3 rg[8], rq[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int bb = g * 32 + 16 * bh + 2 * k + (lane >> 5);
+        const bool ok = bb < p.B && vx < p.V;
+        const size_t o = ((size_t)(bb < p.B ? bb : p.B - 1) * p.V + (vx < p.V ? vx : p.V - 1)) * 3;
+        const f32x3 xq = *(const f32x3*)(p.vposed + o);
+        f32x3 xg = {0.f, 0.f, 0.f};
+        if (HASG) xg = *(const f32x3*)(p.gverts + o);
+        rq[k] = (f32x3){ok ? xq[0] : 0.f, ok ? xq[1] : 0.f, ok ? xq[2] : 0.f};
+        rg[k] = (f32x3){ok ? xg[0] : 0.f, ok ? xg[1] : 0.f, ok ? xg[2] : 0.f};
+      }
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) tb[(c * 16 + 2 * k + (lane >> 5)) * JG_TS + (lane & 31)] = pass ? rq[k][c] : rg[k][c];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const f32x4* src = (const f32x4*)(tb + (c * 16 + li) * JG_TS + 8 * lq);
+          const f32x4 a = src[0], bq = src[1];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            if (pass) { q[t][c] = a[t]; q[4 + t][c] = bq[t]; }
+            else { gq[t][c] = a[t]; gq[4 + t][c] = bq[t]; }
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (KP) bwd16_kp(p, blk * 32 + 8 * lq, sGj + (16 * bh + li) * 52, gq);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float a[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) a[t] = (c < 3) ? sb * gq[t][r] * q[t][c] : sb * gq[t][r];
+        bfx8 ah, al;
+        mh_split_bf16x8(a, ah, al);
+        const int rc = r * 4 + c;
+        acc[rc][0] = MFMA16_BF16(ah, wh0, acc[rc][0]);
+        acc[rc][1] = MFMA16_BF16(ah, wh1, acc[rc][1]);
+        acc[rc][0] = MFMA16_BF16(ah, wl0, acc[rc][0]);
+        acc[rc][1] = MFMA16_BF16(ah, wl1, acc[rc][1]);
+        acc[rc][0] = MFMA16_BF16(al, wh0, acc[rc][0]);
+        acc[rc][1] = MFMA16_BF16(al, wh1, acc[rc][1]);
+      }
+    }
+  }
+  // sum the two vertex streams of each body half through LDS (fixed order); element (rc, jt, reg) of lane l is
+  // C[body = 4 (l>>4) + reg][joint = 16 jt + (l&15)]
+  __syncthreads();                     // every wave is done with its transpose buffer
+  float* myRed = sRed + bh * (12 * 2 * 4 * 64);
+  for (int w = 0; w < 2; ++w) {
+    if (vs == w) {
+#pragma unroll
+      for (int rc = 0; rc < 12; ++rc)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* qd = myRed + ((rc * 2 + jt) * 4 + r) * 64 + lane;
+            *qd = (w == 0) ? acc[rc][jt][r] : (*qd + acc[rc][jt][r]);
+          }
+    }
+    __syncthreads();
+  }
+  const size_t GB = (size_t)p.G * 32;
+  float* oA = p.pA + ((size_t)ch * GB + (size_t)g * 32) * 288;
+  for (int i = tid; i < 2 * 12 * 2 * 4 * 64; i += 256) {
+    const int hb = i / (12 * 2 * 4 * 64), e = i % (12 * 2 * 4 * 64);
+    const int rc = e >> 9, jt = (e >> 8) & 1, r = (e >> 6) & 3, l = e & 63;
+    const int row = 16 * hb + 4 * (l >> 4) + r, joint = 16 * jt + (l & 15);
+    if (joint < MH_NJ) oA[(size_t)row * 288 + rc * MH_NJ + joint] = sRed[i];
+  }
+}
+
+#ifndef FG_RING
+#define FG_RING 8
+#endif
+template <bool NW4, bool KP>
+__global__ __launch_bounds__(256, FG_OCC) void k_featgrad16(Bwd16P p) {
+  extern __shared__ __attribute__((aligned(16))) float smf[];
+  float* sA = smf;                        // [32][BWD_AS]
+  float* sGj = sA + 32 * BWD_AS;          // [32][52]
+  float* sRed = sGj + 32 * 52;            // [7*16][64] + [32][4]; the waves' transpose buffers alias it until the reduction
+  const int g = blockIdx.x, ch = blockIdx.y;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  for (int i = tid; i < 32 * MH_NJ * 12; i += 256) {
+    const int bb = i / (MH_NJ * 12), e = i % (MH_NJ * 12);
+    sA[bb * BWD_AS + e] = p.A[(size_t)(g * 32 + bb) * MH_NJ * 12 + e];
+  }
+  for (int i = tid; i < 32 * 51; i += 256) {
+    const int bb = i / 51, e = i % 51;
+    const int b = g * 32 + bb;
+    sGj[bb * 52 + e] = (p.gjoints && b < p.B) ? p.gjoints[(size_t)b * 51 + e] : 0.f;
+  }
+  __syncthreads();
+  const int b = g * 32 + li;
+  const bool bvalid = b < p.B;
+  const float sb = bvalid ? p.scale[b] : 0.f;
+  f32x16 acc[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) acc[i] = (f32x16){0};
+  float sT0 = 0, sT1 = 0, sT2 = 0;
+  const float sS = 0.f;                // see k_pose_bwd (scale_from_joint_sums)
+  const int nblk = p.VP / 16;
+  const int bend = min((ch + 1) * p.PB, nblk);
+  const float* sAb = sA + li * BWD_AS;
+  const bfx8* Db = (const bfx8*)p.Dt16 + lane;     // [blk][c][ct][term][lane] in 16-byte units: 42 x 64 per block
+  const int nw4 = p.nw < 4 ? p.nw : 4;
+  // One wave per SIMD: the 7 x 16 accumulators plus the element-wise phase do not fit 256 registers without spilling
+  // accumulators to scratch (measured: 163 us with 2 waves + spills against 100 us with 1 wave).
+  for (int blk = ch * p.PB + wave; blk < bend; blk += 4) {
+    const bfx8* Dk = Db + (size_t)blk * 42 * 64;
+    const int v0 = blk * 16 + 8 * lh;
+    float gv[3][8];
+    float* tbuf = sRed + wave * BW_TBUF;
+    {
+      // stage the adjoints [component][body][vertex] in the wave's LDS buffer; they are read back four vertices at
+      // a time inside the blend loop
+      f32x3 rg[8];
+      bwd16_fetch(p.gverts, p.B, p.V, g, blk, lane, rg);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tbuf[(c * 32 + 4 * k + (lane >> 4)) * BW_TS + (lane & 15)] = rg[k][c];
+      __builtin_amdgcn_wave_barrier();
+    }
+    float gq[4][3];
+    // skinning rows are fetched one vertex ahead (and no further: the scheduler is fenced per vertex, it otherwise
+    // hoists all eight rows and spills)
+    int4 nj4 = {0, 0, 0, 0};
+    f32x4 nw4v = {0.f, 0.f, 0.f, 0.f};
+    if (NW4) { nj4 = *(const int4*)(p.skidx + (size_t)v0 * 4); nw4v = *(const f32x4*)(p.skw + (size_t)v0 * 4); }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int v = v0 + t;                                       // padded rows of the skinning table exist up to VP
+      if ((t & 3) == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const f32x4 a = *(const f32x4*)(tbuf + (c * 32 + li) * BW_TS + 8 * lh + t);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) gq[u][c] = a[u];
+        }
+        if (KP) {   // key-point regressor adjoint: dL/dverts += R^T dL/djoints (~670 entries over the mesh)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int ke0 = p.kpv_ptr[v + u], ke1 = p.kpv_ptr[v + u + 1];
+            for (int e = ke0; e < ke1; ++e) {
+              const float w = p.kpv_w[e];
+              const float* gj = sGj + li * 52 + p.kpv_j[e] * 3;
+              gq[u][0] = fmaf(w, gj[0], gq[u][0]);
+              gq[u][1] = fmaf(w, gj[1], gq[u][1]);
+              gq[u][2] = fmaf(w, gj[2], gq[u][2]);
+            }
+          }
+        }
+      }
+      float T[12];
+#pragma unroll
+      for (int e = 0; e < 12; ++e) T[e] = 0.f;
+      if (NW4) {
+        const int4 j4 = nj4;
+        const f32x4 w4 = nw4v;
+        if (t < 7) { nj4 = *(const int4*)(p.skidx + (size_t)(v + 1) * 4); nw4v = *(const f32x4*)(p.skw + (size_t)(v + 1) * 4); }
+        const int jj[4] = {j4.x, j4.y, j4.z, j4.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const f32x4* Aj = (const f32x4*)(sAb + jj[k] * 12);
+          const f32x4 a0 = Aj[0], a1 = Aj[1], a2 = Aj[2];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            T[e] = fmaf(w4[k], a0[e], T[e]);
+            T[4 + e] = fmaf(w4[k], a1[e], T[4 + e]);
+            T[8 + e] = fmaf(w4[k], a2[e], T[8 + e]);
+          }
+          if (k == 1) __builtin_amdgcn_sched_barrier(0);      // two bones (24 registers of LDS data) in flight at a time
+        }
+      } else {
+        for (int k = 0; k < p.nw; ++k) {
+          const int j = p.skidx[(size_t)v * p.nw + k];
+          const float w = p.skw[(size_t)v * p.nw + k];
+          const f32x4* Aj = (const f32x4*)(sAb + j * 12);
+          const f32x4 a0 = Aj[0], a1 = Aj[1], a2 = Aj[2];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            T[e] = fmaf(w, a0[e], T[e]);
+            T[4 + e] = fmaf(w, a1[e], T[4 + e]);
+            T[8 + e] = fmaf(w, a2[e], T[8 + e]);
+          }
+        }
+      }
+      const float g0 = gq[t & 3][0], g1 = gq[t & 3][1], g2 = gq[t & 3][2];
+      sT0 += g0; sT1 += g1; sT2 += g2;
+      // d/d v_posed = R_T^T (s g).  (The scale gradient sum_v g.x needs neither x nor v_posed here: it equals
+      // (1/s) sum_j <A_j, dL/dA_j> and is taken from the joint-gradient sums in k_pose_bwd.)
+      const float gx0 = sb * g0, gx1 = sb * g1, gx2 = sb * g2;
+      gv[0][t] = fmaf(T[8], gx2, fmaf(T[4], gx1, T[0] * gx0));
+      gv[1][t] = fmaf(T[9], gx2, fmaf(T[5], gx1, T[1] * gx0));
+      gv[2][t] = fmaf(T[10], gx2, fmaf(T[6], gx1, T[2] * gx0));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // B ring: the first FG_RING (component, column tile) steps are requested behind the element-wise phase (their
+    // registers are not free earlier) and land while the operands are being split
+    bfx8 rb[FG_RING][2];
+#pragma unroll
+    for (int i = 0; i < FG_RING; ++i) { rb[i][0] = Dk[(i * 2) * 64]; rb[i][1] = Dk[(i * 2 + 1) * 64]; }
+    bfx8 ah[3], al[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) mh_split_bf16x8(gv[c], ah[c], al[c]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int st = 0; st < 21; ++st) {
+      const int c = st / 7, ct = st % 7, cur = st % FG_RING;
+      const bfx8 bh = rb[cur][0], bl = rb[cur][1];
+      if (st + FG_RING < 21) {
+        rb[cur][0] = Dk[((st + FG_RING) * 2) * 64];
+        rb[cur][1] = Dk[((st + FG_RING) * 2 + 1) * 64];
+      }
+      acc[ct] = MFMA_BF16(ah[c], bh, acc[ct]);
+      acc[ct] = MFMA_BF16(ah[c], bl, acc[ct]);
+      acc[ct] = MFMA_BF16(al[c], bh, acc[ct]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_wave_barrier();
+  }
+  // ---- reduce: halves of a wave hold different vertices of the same body; then the four waves through LDS ----
+  __syncthreads();                     // every wave is done with its transpose buffer
+  sT0 += __shfl_xor(sT0, 32, 64);
+  sT1 += __shfl_xor(sT1, 32, 64);
+  sT2 += __shfl_xor(sT2, 32, 64);
+  float* sSc = sRed + 7 * 16 * 64;
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int ct = 0; ct < 7; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float* qd = sRed + (ct * 16 + r) * 64 + lane;
+          *qd = (w == 0) ? acc[ct][r] : (*qd + acc[ct][r]);
+        }
+      if (lh == 0) {
+        float* qd = sSc + li * 4;
+        if (w == 0) { qd[0] = sT0; qd[1] = sT1; qd[2] = sT2; qd[3] = sS; }
+        else { qd[0] += sT0; qd[1] += sT1; qd[2] += sT2; qd[3] += sS; }
+      }
+    }
+    __syncthreads();
+  }
+  const size_t GB = (size_t)p.G * 32;
+  const size_t base = (size_t)ch * GB + (size_t)g * 32;
+  float* oF = p.pF + base * MH_FS;
+  for (int i = tid; i < 7 * 16 * 64; i += 256) {
+    const int ct = i >> 10, r = (i >> 6) & 15, l = i & 63;
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    oF[(size_t)row * MH_FS + ct * 32 + (l & 31)] = sRed[i];
+  }
+  float* oS = p.pS + base * 4;
+  for (int i = tid; i < 128; i += 256) oS[i] = sSc[i];
+}
+
 struct PoseBwdP {
   int B, NB, G, CH;
   const float* betas;
@@ -859,6 +1289,7 @@ struct PoseBwdP {
   float* gtransl;   // [B][3] += (null ok)
   float* gbeta_b;   // [G*32][10]
   float* gxs_b;     // [G*32]
+  int scale_from_joint_sums;   // 1: d/dlog-scale = sum_j <A_j, dL/dA_j> (pS[3] is not filled by the split kernels)
   mh_tree tree;
 };
 
@@ -899,6 +1330,7 @@ __global__ __launch_bounds__(256) void k_pose_bwd(PoseBwdP p) {
   if (j < 4) {
     float a = 0;
     for (int c = 0; c < p.CH; ++c) a += p.pS[((size_t)c * GB + b) * 4 + j];
+    if (j == 3 && p.scale_from_joint_sums) a = 0.f;
     sS[bl][j] = a;
   }
   // 2. recompute the forward chain
@@ -949,6 +1381,16 @@ __global__ __launch_bounds__(256) void k_pose_bwd(PoseBwdP p) {
   if (act) {
 #pragma unroll
     for (int e = 0; e < 12; ++e) gA[e] = sGA[bl][e * MH_NJ + j];
+    if (p.scale_from_joint_sums) {
+      // verts = s.x + t with x = sum_j w_j A_j [q;1]  =>  sum_v g.x = (1/s) sum_j <A_j, dL/dA_j>  (dL/dA_j carries the s)
+      float d = 0.f;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float gj = fmaf(Gm[r * 4 + 2], J[2], fmaf(Gm[r * 4 + 1], J[1], Gm[r * 4 + 0] * J[0]));
+        d += gA[r * 4] * Gm[r * 4] + gA[r * 4 + 1] * Gm[r * 4 + 1] + gA[r * 4 + 2] * Gm[r * 4 + 2] + gA[r * 4 + 3] * (Gm[r * 4 + 3] - gj);
+      }
+      atomicAdd(&sS[bl][3], d / fmaxf(p.scale[valid ? b : 0], 1e-30f));
+    }
     float gJ[3] = {0, 0, 0};
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -1080,6 +1522,13 @@ __global__ __launch_bounds__(256) void k_person_reduce(int B, int NB, const floa
   }
 }
 
+static int bwd16_chunks(int G) {
+  int ch = (500 + G / 2) / G;          // ~ two workgroups per CU
+  if (ch < 1) ch = 1;
+  if (ch > 54) ch = 54;
+  return ch;
+}
+
 static int bwd_chunks(int G16) {
   int ch = (512 + G16 / 2) / G16;
   if (ch < 1) ch = 1;
@@ -1107,7 +1556,7 @@ static BwdWs carve_bwd(void* ws, int G, int CH) {
 }
 
 extern "C" size_t mh_lbs_backward_workspace_bytes(int B) {
-  const int G = mh_groups(B < 1 ? 1 : B), CH = bwd_chunks(2 * G);
+  const int G = mh_groups(B < 1 ? 1 : B), CH = std::max(bwd_chunks(2 * G), bwd16_chunks(G));
   const size_t GB = (size_t)G * 32;
   return align256((size_t)CH * GB * MH_FS * 4) + align256((size_t)CH * GB * 288 * 4) + align256((size_t)CH * GB * 16) +
          align256(GB * MH_NUM_BETAS * 4) + align256(GB * 4);
@@ -1123,9 +1572,44 @@ extern "C" int mh_lbs_backward(const mh_model* m, int B, int NB, const float* be
   MH_CHECK(B > 0 && NB > 0, "B and NB must be positive");
   MH_CHECK(!gjoints || m->reg[MH_REG_ALPHAPOSE].J == MH_NKP, "gjoints needs the key-point regressor");
   hipStream_t st = (hipStream_t)stream;
-  const int G = mh_groups(B), G16 = 2 * G, CH = bwd_chunks(G16);
+  const bool split16 = lbs_mode() != 0;
+  const int G = mh_groups(B), G16 = 2 * G, CH = split16 ? bwd16_chunks(G) : bwd_chunks(G16);
   FwdWs fw = carve_fwd(ws, G);
   BwdWs bw = carve_bwd(ws2, G, CH);
+  if (split16) {
+    Bwd16P sp;
+    sp.B = B; sp.G = G; sp.V = m->V; sp.VP = m->VP; sp.nw = m->nw; sp.CH = CH;
+    sp.PB = (m->VP / 16 + CH - 1) / CH;
+    sp.A = fw.A; sp.scale = fw.scale; sp.vposed = vposed; sp.gverts = gverts; sp.gjoints = gjoints;
+    sp.Dt16 = m->Dt16; sp.W16 = m->W16; sp.skidx = m->skidx; sp.skw = m->skw;
+    sp.kpv_ptr = m->kpv_ptr; sp.kpv_j = m->kpv_j; sp.kpv_w = m->kpv_w;
+    sp.pF = bw.pF; sp.pA = bw.pA; sp.pS = bw.pS;
+    const size_t ldsF = (size_t)(32 * BWD_AS + 32 * 52 + std::max(7 * 16 * 64 + 128, 4 * BW_TBUF)) * 4;
+    const size_t ldsJ = (size_t)(32 * 52 + std::max(2 * 12 * 2 * 4 * 64, 4 * JG_TBUF)) * 4;
+    static bool attr_b16 = false;
+    if (!attr_b16) {
+      const void* fk[4] = {(const void*)k_featgrad16<false, false>, (const void*)k_featgrad16<false, true>,
+                           (const void*)k_featgrad16<true, false>, (const void*)k_featgrad16<true, true>};
+      const void* jk[4] = {(const void*)k_jointgrad16<false, false>, (const void*)k_jointgrad16<false, true>,
+                           (const void*)k_jointgrad16<true, false>, (const void*)k_jointgrad16<true, true>};
+      for (int i = 0; i < 4; ++i) {
+        MH_HIP(hipFuncSetAttribute(fk[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsF));
+        MH_HIP(hipFuncSetAttribute(jk[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsJ));
+      }
+      attr_b16 = true;
+    }
+    const bool nw4 = m->nw == 4, kp = gjoints != nullptr, hasg = gverts != nullptr;
+    auto fkern = nw4 ? (kp ? k_featgrad16<true, true> : k_featgrad16<true, false>)
+                     : (kp ? k_featgrad16<false, true> : k_featgrad16<false, false>);
+    auto jkern = hasg ? (kp ? k_jointgrad16<true, true> : k_jointgrad16<true, false>)
+                      : (kp ? k_jointgrad16<false, true> : k_jointgrad16<false, false>);
+    mh_prof_mark(MH_PROF_SKIN_BWD, 0, st);
+    hipLaunchKernelGGL(fkern, dim3(G, CH), dim3(256), ldsF, st, sp);
+    MH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(jkern, dim3(G, CH), dim3(256), ldsJ, st, sp);
+    MH_LAUNCH_CHECK();
+    mh_prof_mark(MH_PROF_SKIN_BWD, 1, st);
+  } else {
   static bool attr_set = false;
   const size_t lds = (size_t)(16 * BWD_AS + 16 * 52 + BWD_NACC * 4 * 64 + 64) * 4;
   if (!attr_set) {
@@ -1143,6 +1627,7 @@ extern "C" int mh_lbs_backward(const mh_model* m, int B, int NB, const float* be
   hipLaunchKernelGGL(k_skin_bwd, dim3(G16, CH), dim3(256), lds, st, sp);
   MH_LAUNCH_CHECK();
   mh_prof_mark(MH_PROF_SKIN_BWD, 1, st);
+  }
   PoseBwdP pp;
   pp.B = B; pp.NB = NB; pp.G = G; pp.CH = CH;
   pp.betas = betas; pp.poses = poses; pp.gjoints = gjoints;
@@ -1150,6 +1635,7 @@ extern "C" int mh_lbs_backward(const mh_model* m, int B, int NB, const float* be
   pp.scale = fw.scale; pp.Jt = m->Jt; pp.JS = m->JS;
   pp.pF = bw.pF; pp.pA = bw.pA; pp.pS = bw.pS;
   pp.gposes = gposes; pp.gtransl = gtransl; pp.gbeta_b = bw.gbeta_b; pp.gxs_b = bw.gxs_b;
+  pp.scale_from_joint_sums = split16 ? 1 : 0;
   pp.tree = m->tree;
   hipLaunchKernelGGL(k_pose_bwd, dim3(G * 4), dim3(256), 0, st, pp);
   MH_LAUNCH_CHECK();

@@ -196,6 +196,48 @@ extern "C" int mh_model_create(mh_model** out, const mh_model_host* h) {
               D16[base + 64 * 8 + (size_t)lane * 8 + t] = bits16(lo);
             }
     if ((rc = upload(&m->D16, D16))) return rc;
+    // split-bf16 backward operands (round to nearest even; hi = bf16(x), lo = bf16(x - hi))
+    auto f2bf = [](float x) -> uint16_t {
+      uint32_t u;
+      memcpy(&u, &x, 4);
+      u += 0x7fffu + ((u >> 16) & 1u);
+      return (uint16_t)(u >> 16);
+    };
+    auto bf2f = [](uint16_t hb) -> float {
+      const uint32_t u = (uint32_t)hb << 16;
+      float f;
+      memcpy(&f, &u, 4);
+      return f;
+    };
+    const int NBLK = VP / 16;
+    std::vector<uint16_t> Dt16((size_t)NBLK * 3 * 7 * 2 * 64 * 8, 0), W16((size_t)(VP / 32) * 2 * 2 * 64 * 8, 0);
+    for (int blk = 0; blk < NBLK; ++blk)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int t = 0; t < 8; ++t) {
+          const int v = blk * 16 + 8 * (lane >> 5) + t, n = lane & 31;
+          for (int c = 0; c < 3; ++c)
+            for (int ct = 0; ct < 7; ++ct) {
+              const float x = load(c, ct * 32 + n, v);
+              const uint16_t hi = f2bf(x), lo = f2bf(x - bf2f(hi));
+              const size_t base = ((((size_t)blk * 3 + c) * 7 + ct) * 2) * 64 * 8;
+              Dt16[base + (size_t)lane * 8 + t] = hi;
+              Dt16[base + 64 * 8 + (size_t)lane * 8 + t] = lo;
+            }
+        }
+    // W16 [VP/32][joint tile 2][term 2][lane][8]: B operand of v_mfma_f32_16x16x32_bf16, lane l = (joint 16 jt + (l&15),
+    // vertex quarter l>>4) holds vertices 32 blk + 8 (l>>4) + 0..7
+    for (int blk = 0; blk < VP / 32; ++blk)
+      for (int jt = 0; jt < 2; ++jt)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int t = 0; t < 8; ++t) {
+            const int v = blk * 32 + 8 * (lane >> 4) + t, n = 16 * jt + (lane & 15);
+            const float w = (v < V && n < MH_NJ) ? h->lbs_weights[(size_t)v * MH_NJ + n] : 0.f;
+            const uint16_t hi = f2bf(w), lo = f2bf(w - bf2f(hi));
+            W16[(((size_t)blk * 2 + jt) * 2) * 64 * 8 + (size_t)lane * 8 + t] = hi;
+            W16[(((size_t)blk * 2 + jt) * 2 + 1) * 64 * 8 + (size_t)lane * 8 + t] = lo;
+          }
+    if ((rc = upload(&m->Dt16, Dt16))) return rc;
+    if ((rc = upload(&m->W16, W16))) return rc;
   }
   {
     // skinning weights: keep the non-zeros per vertex (<= 4 in SMPL); nw = max count
@@ -280,7 +322,7 @@ extern "C" int mh_model_create(mh_model** out, const mh_model_host* h) {
 
 extern "C" int mh_model_destroy(mh_model* m) {
   if (!m) return MH_OK;
-  void* ptrs[] = {m->vt, m->D, m->Dt, m->D16, m->skidx, m->skw, m->Jt, m->JS, m->faces, m->kpv_ptr, m->kpv_j, m->kpv_w};
+  void* ptrs[] = {m->vt, m->D, m->Dt, m->D16, m->Dt16, m->W16, m->skidx, m->skw, m->Jt, m->JS, m->faces, m->kpv_ptr, m->kpv_j, m->kpv_w};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < 4; ++i) {

@@ -1,0 +1,26 @@
+#!/bin/bash
+# developer tool: PMC counters of the LBS forward kernels (run on the GPU box through gpurun)
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/pmc_fwd
+mkdir -p $OUT
+i=0
+for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES" \
+           "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
+           "SQ_INSTS_MFMA SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR GRBM_GUI_ACTIVE" \
+           "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --output-format csv --pmc $set -d $OUT/s$i -o p -- python $R/tools/${PMC_SCRIPT:-time_fwd.py} > $OUT/s$i.log 2>&1
+done
+python - <<PY
+import csv, glob, collections
+for d in sorted(glob.glob('$OUT/s*/')):
+    for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            k = r['Kernel_Name'][:40]
+            if any(x in k for x in ("skin", "pose_", "grad16")):
+                acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
+        for k, c in acc.items():
+            print(k, {n: round(sum(v) / len(v)) for n, v in c.items()}, 'launches', len(next(iter(c.values()))))
+PY

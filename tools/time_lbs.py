@@ -38,7 +38,20 @@ def main():
                                           ptr(e.leaf('poses_T')), ptr(e.vposed), ptr(gv), ptr(e.gj), ptr(e.leaf('poses_smpl', g)),
                                           ptr(e.leaf('poses_T', g)), ptr(e.leaf('betas', g)), ptr(e.leaf('xscale', g)), ptr(e.ws),
                                           ptr(e.ws2), st))
-    print('lbs bwd ms %.4f' % timeit(bwd, 50))
+    res = {}
+    for mode in (0, 1):
+        L.mh_lbs_set_mode(mode)
+        fwd()
+        for n in ('poses_smpl', 'poses_T', 'betas', 'xscale'):
+            e.leaf(n, g).zero_()
+        bwd()
+        torch.cuda.synchronize()
+        res[mode] = {n: e.leaf(n, g).clone() for n in ('poses_smpl', 'poses_T', 'betas', 'xscale')}
+        print('lbs bwd mode %d ms %.4f' % (mode, timeit(bwd, 50)))
+    for n in res[0]:
+        a, b = res[0][n], res[1][n]
+        print('  grad %-10s max|fp32| %.3e  max|split16 - fp32| %.3e  rel %.2e' % (n, float(a.abs().max()), float((a - b).abs().max()),
+                                                                                 float((a - b).abs().max() / a.abs().max())))
 
 
 if __name__ == '__main__':

@@ -100,6 +100,12 @@ int mh_lbs_forward(const mh_model* m, int B, int NB, const float* betas /*(NB,10
                    float* vposed /*(B,V,3) or NULL*/, float* posed_joints /*(B,24,3) or NULL*/,
                    void* ws, void* stream);
 
+/* lbs(..., pose2rot=False) (smpl.py:490-491, 553-558): the 24 joint rotations are given as matrices
+ * rotmats (B,24,3,3) instead of axis-angle vectors; forward only.                                             */
+int mh_lbs_forward_rotmats(const mh_model* m, int B, int NB, const float* betas, const float* rotmats /*(B,24,3,3)*/,
+                           const float* xscale, const float* transl, float* verts, float* posed_joints /*or NULL*/,
+                           void* ws, void* stream);
+
 /* Arithmetic of the two dense contractions of the LBS pair (pose/shape blend and its adjoint):
  * split16 = 1 (default): operands carried as two 16-bit terms, three products on the 16-bit matrix pipe with fp32
  * accumulation -- fp16 terms in the forward (vertices within ~1e-7 m of the fp32 result), bf16 terms in the backward
@@ -141,6 +147,12 @@ int mh_project_joints_loss(int B, const float* joints /*(B,17,3)*/, const float*
                            float img_w, float img_h, float coef, float* uv, float* gjoints,
                            float* loss, void* stream);
 
+/* the same with per-key-point weights joint_w (HOST, 17 floats, or NULL = all ones): the reference multiplies the
+ * confidence mask by `pose17j_weights` normalised to mean 1 (optimizer.py:75-130, 259, 419-420).           */
+int mh_project_joints_loss_w(int B, const float* joints, const float* K_host, const float* Kd_host,
+                             const float* joint_w_host, const float* pose2d, float thr, int mode, float img_w,
+                             float img_h, float coef, float* uv, float* gjoints, float* loss, void* stream);
+
 /* a9 warm-up (optimizer.py:710-770): only poses_T is a leaf there, so the 17 key-points of every
  * body are computed ONCE (mh_lbs_forward + mh_joints_regress) and each Adam iteration is
  * joints = 1.1^xscale[b%NB] * local + transl -> projection -> mean-reduced pixel residual
@@ -149,6 +161,10 @@ int mh_warmup_project(int B, int NB, const float* local_joints /*(B,17,3)*/, con
                       const float* transl /*(B,3)*/, const float* K_host, const float* Kd_host,
                       const float* pose2d, float thr, float coef, float* gtransl, float* loss,
                       void* stream);
+
+int mh_warmup_project_w(int B, int NB, const float* local_joints, const float* xscale, const float* transl,
+                        const float* K_host, const float* Kd_host, const float* joint_w_host, const float* pose2d,
+                        float thr, float coef, float* gtransl, float* loss, void* stream);
 
 /* ---- a20: optimiser updates (optimizer.py:355-356, 586-587, 738-739, 764-765) --------------- */
 int mh_rmsprop_step(float* params, const float* grads, float* square_avg, float* momentum_buf,

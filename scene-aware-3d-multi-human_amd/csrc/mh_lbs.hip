@@ -24,7 +24,8 @@
 struct PoseFwdP {
   int B, NB, G;
   const float* betas;
-  const float* poses;
+  const float* poses;     // [B][72] axis-angle, or
+  const float* rotmats;   // [B][24][3][3] rotation matrices (lbs(pose2rot=False), smpl.py:553-558); one of the two
   const float* xscale;
   const float* Jt;
   const float* JS;
@@ -69,7 +70,10 @@ __global__ __launch_bounds__(256) void k_pose_fwd(PoseFwdP p) {
   float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, J[3] = {0, 0, 0};
   if (valid && act) {
     mh_joint_rest(p.Jt, p.JS, beta, j, J);
-    if (j < 22) {   // hands (22,23) stay identity: smpl.py:542-546
+    if (p.rotmats) {   // given rotations are used for all 24 joints, hands included (smpl.py:554-555)
+#pragma unroll
+      for (int e = 0; e < 9; ++e) R[e] = p.rotmats[((size_t)b * MH_NJ + j) * 9 + e];
+    } else if (j < 22) {   // hands (22,23) stay identity: smpl.py:542-546
       float r[3] = {p.poses[(size_t)b * 72 + 3 * j], p.poses[(size_t)b * 72 + 3 * j + 1], p.poses[(size_t)b * 72 + 3 * j + 2]};
       mh_rodrigues(r, R);
     }
@@ -522,17 +526,35 @@ extern "C" size_t mh_lbs_workspace_bytes(int B) {
          align256((size_t)G * (MH_FS / 16) * 2 * 64 * 16);
 }
 
+static int lbs_forward_impl(const mh_model* m, int B, int NB, const float* betas, const float* poses, const float* rotmats,
+                            const float* xscale, const float* transl, float* verts, float* vposed, float* posed_joints,
+                            void* ws, void* stream);
+
 extern "C" int mh_lbs_forward(const mh_model* m, int B, int NB, const float* betas, const float* poses,
                               const float* xscale, const float* transl, float* verts, float* vposed,
                               float* posed_joints, void* ws, void* stream) {
-  MH_CHECK(m && betas && poses && verts && ws, "null argument");
+  MH_CHECK(poses, "null argument");
+  return lbs_forward_impl(m, B, NB, betas, poses, nullptr, xscale, transl, verts, vposed, posed_joints, ws, stream);
+}
+
+extern "C" int mh_lbs_forward_rotmats(const mh_model* m, int B, int NB, const float* betas, const float* rotmats,
+                                      const float* xscale, const float* transl, float* verts, float* posed_joints,
+                                      void* ws, void* stream) {
+  MH_CHECK(rotmats, "null argument");
+  return lbs_forward_impl(m, B, NB, betas, nullptr, rotmats, xscale, transl, verts, nullptr, posed_joints, ws, stream);
+}
+
+static int lbs_forward_impl(const mh_model* m, int B, int NB, const float* betas, const float* poses, const float* rotmats,
+                            const float* xscale, const float* transl, float* verts, float* vposed, float* posed_joints,
+                            void* ws, void* stream) {
+  MH_CHECK(m && betas && verts && ws, "null argument");
   MH_CHECK(B > 0 && NB > 0, "B and NB must be positive");
   hipStream_t st = (hipStream_t)stream;
   const int G = mh_groups(B);
   FwdWs w = carve_fwd(ws, G);
   PoseFwdP pp;
   pp.B = B; pp.NB = NB; pp.G = G;
-  pp.betas = betas; pp.poses = poses; pp.xscale = xscale;
+  pp.betas = betas; pp.poses = poses; pp.rotmats = rotmats; pp.xscale = xscale;
   pp.Jt = m->Jt; pp.JS = m->JS;
   pp.featT = w.featT; pp.A = w.A; pp.scale = w.scale; pp.posed = posed_joints;
   pp.tree = m->tree;

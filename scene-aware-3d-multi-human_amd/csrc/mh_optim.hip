@@ -9,6 +9,7 @@ struct ProjP {
   int B, mode, has_kd;
   float K[9];
   float Kd[5];
+  float jw[MH_NKP];   // per-key-point weights (optimizer.py:75-130, normalised to mean 1 by the caller)
   float thr, w, h, coef;
   const float* joints;
   const float* pose2d;
@@ -61,14 +62,14 @@ __global__ __launch_bounds__(64) void k_project_loss(ProjP p) {
     const float conf = p.pose2d[o * 3 + 2];
     float gu, gvv;
     if (p.mode == 0) {   // optimizer.py:364-368, 404, 419-420
-      const float c = conf >= p.thr ? 1.f : 0.f;
+      const float c = conf >= p.thr ? p.jw[j] : 0.f;   // mask = pose_weights * (conf >= thr)  (:404, 419-420)
       const float du = c * u / p.w - c * p.pose2d[o * 3] / p.w;
       const float dv = c * v / p.h - c * p.pose2d[o * 3 + 1] / p.h;
       l = du * du + dv * dv;
       gu = 2 * du * c / p.w;
       gvv = 2 * dv * c / p.h;
     } else {             // optimizer.py:735, 754-756 (mean over B*17*2 elements, pixels)
-      const float c = conf > p.thr ? 1.f : 0.f;
+      const float c = conf > p.thr ? p.jw[j] : 0.f;    // w = pose_weights * vis  (:753)
       const float du = c * u - c * p.pose2d[o * 3];
       const float dv = c * v - c * p.pose2d[o * 3 + 1];
       const float inv = 1.f / ((float)p.B * MH_NKP * 2);
@@ -101,12 +102,13 @@ __global__ __launch_bounds__(64) void k_project_loss(ProjP p) {
   }
 }
 
-extern "C" int mh_project_joints_loss(int B, const float* joints, const float* K_host, const float* Kd_host,
-                                      const float* pose2d, float thr, int mode, float img_w, float img_h, float coef,
-                                      float* uv, float* gjoints, float* loss, void* stream) {
+extern "C" int mh_project_joints_loss_w(int B, const float* joints, const float* K_host, const float* Kd_host,
+                                        const float* joint_w_host, const float* pose2d, float thr, int mode, float img_w,
+                                        float img_h, float coef, float* uv, float* gjoints, float* loss, void* stream) {
   MH_CHECK(joints && K_host && pose2d && gjoints && loss, "null argument");
   MH_CHECK(B > 0, "B must be positive");
   ProjP p;
+  for (int i = 0; i < MH_NKP; ++i) p.jw[i] = joint_w_host ? joint_w_host[i] : 1.f;
   p.B = B; p.mode = mode; p.has_kd = Kd_host != nullptr;
   for (int i = 0; i < 9; ++i) p.K[i] = K_host[i];
   for (int i = 0; i < 5; ++i) p.Kd[i] = Kd_host ? Kd_host[i] : 0.f;
@@ -118,12 +120,20 @@ extern "C" int mh_project_joints_loss(int B, const float* joints, const float* K
   return MH_OK;
 }
 
-extern "C" int mh_warmup_project(int B, int NB, const float* local_joints, const float* xscale, const float* transl,
-                                 const float* K_host, const float* Kd_host, const float* pose2d, float thr, float coef,
-                                 float* gtransl, float* loss, void* stream) {
+extern "C" int mh_project_joints_loss(int B, const float* joints, const float* K_host, const float* Kd_host,
+                                      const float* pose2d, float thr, int mode, float img_w, float img_h, float coef,
+                                      float* uv, float* gjoints, float* loss, void* stream) {
+  return mh_project_joints_loss_w(B, joints, K_host, Kd_host, nullptr, pose2d, thr, mode, img_w, img_h, coef, uv, gjoints,
+                                  loss, stream);
+}
+
+extern "C" int mh_warmup_project_w(int B, int NB, const float* local_joints, const float* xscale, const float* transl,
+                                   const float* K_host, const float* Kd_host, const float* joint_w_host,
+                                   const float* pose2d, float thr, float coef, float* gtransl, float* loss, void* stream) {
   MH_CHECK(local_joints && transl && K_host && pose2d && gtransl && loss, "null argument");
   MH_CHECK(B > 0 && NB > 0, "B and NB must be positive");
   ProjP p;
+  for (int i = 0; i < MH_NKP; ++i) p.jw[i] = joint_w_host ? joint_w_host[i] : 1.f;
   p.B = B; p.mode = 1; p.has_kd = Kd_host != nullptr;
   for (int i = 0; i < 9; ++i) p.K[i] = K_host[i];
   for (int i = 0; i < 5; ++i) p.Kd[i] = Kd_host ? Kd_host[i] : 0.f;
@@ -133,6 +143,13 @@ extern "C" int mh_warmup_project(int B, int NB, const float* local_joints, const
   hipLaunchKernelGGL(k_project_loss, dim3(B), dim3(64), 0, (hipStream_t)stream, p);
   MH_LAUNCH_CHECK();
   return MH_OK;
+}
+
+extern "C" int mh_warmup_project(int B, int NB, const float* local_joints, const float* xscale, const float* transl,
+                                 const float* K_host, const float* Kd_host, const float* pose2d, float thr, float coef,
+                                 float* gtransl, float* loss, void* stream) {
+  return mh_warmup_project_w(B, NB, local_joints, xscale, transl, K_host, Kd_host, nullptr, pose2d, thr, coef, gtransl,
+                             loss, stream);
 }
 
 // =============================================================================================

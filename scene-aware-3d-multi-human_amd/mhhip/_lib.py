@@ -57,10 +57,16 @@ def lib():
         L.mh_model_destroy.argtypes = [vp]
         L.mh_model_faces.argtypes = [vp]
         L.mh_lbs_forward.argtypes = [vp, ctypes.c_int, ctypes.c_int] + [vp] * 9
+        L.mh_lbs_forward_rotmats.argtypes = [vp, ctypes.c_int, ctypes.c_int] + [vp] * 8
         L.mh_joints_regress.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int, vp, vp]
         L.mh_lbs_backward.argtypes = [vp, ctypes.c_int, ctypes.c_int] + [vp] * 14
         L.mh_project_joints_loss.argtypes = [ctypes.c_int, vp, c_float_p, c_float_p, vp, ctypes.c_float, ctypes.c_int,
                                              ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp]
+        L.mh_project_joints_loss_w.argtypes = [ctypes.c_int, vp, c_float_p, c_float_p, c_float_p, vp, ctypes.c_float,
+                                               ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp]
+        L.mh_warmup_project_w.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, c_float_p, c_float_p, c_float_p, vp,
+                                          ctypes.c_float, ctypes.c_float, vp, vp, vp]
+        L.mh_lbs_set_mode.argtypes = [ctypes.c_int]
         L.mh_rmsprop_step.argtypes = [vp, vp, vp, vp, ctypes.c_size_t] + [ctypes.c_float] * 4 + [vp]
         L.mh_rmsprop_step_dev.argtypes = [vp, vp, vp, vp, ctypes.c_size_t, vp] + [ctypes.c_float] * 4 + [vp]
         L.mh_adam_step.argtypes = [vp, vp, vp, vp, ctypes.c_size_t, ctypes.c_int] + [ctypes.c_float] * 4 + [vp]

@@ -20,11 +20,11 @@ class _ChStub(object):
     def __setstate__(self, state):
         self.__dict__.update(state if isinstance(state, dict) else {'x': state})
 
-    def __array__(self, dtype=None):
+    def __array__(self, dtype=None, copy=None):
         x = self.__dict__.get('x', None)
         if x is None:
             raise ValueError('unsupported chumpy object in the SMPL pickle')
-        return np.asarray(x, dtype=dtype)
+        return np.array(x, dtype=dtype) if copy else np.asarray(x, dtype=dtype)
 
 
 class _SmplUnpickler(pickle.Unpickler):
@@ -126,6 +126,18 @@ class BodyModel(object):
         check(_lib.lib().mh_lbs_forward(self.handle, B, NB, ptr(betas), ptr(poses), ptr(xscale), ptr(transl),
                                         ptr(verts), ptr(vposed), ptr(posed), ptr(ws), _lib.stream_ptr(self.device)))
         return verts, vposed, posed, ws
+
+    def lbs_forward_rotmats(self, betas, rotmats, xscale=None, transl=None, want_posed=True):
+        """``lbs(pose2rot=False)``: rotmats (B,24,3,3); forward only."""
+        B, NB = rotmats.shape[0], betas.shape[0]
+        f = lambda t: None if t is None else t.contiguous().float()
+        betas, rotmats, xscale, transl = f(betas), f(rotmats), f(xscale), f(transl)
+        verts = torch.empty(B, self.V, 3, dtype=torch.float32, device=self.device)
+        posed = torch.empty(B, 24, 3, dtype=torch.float32, device=self.device) if want_posed else None
+        ws = self.workspace(B)
+        check(_lib.lib().mh_lbs_forward_rotmats(self.handle, B, NB, ptr(betas), ptr(rotmats), ptr(xscale), ptr(transl),
+                                                ptr(verts), ptr(posed), ptr(ws), _lib.stream_ptr(self.device)))
+        return verts, posed
 
     def joints_regress(self, which, verts, corr=None, root=-1):
         B = verts.shape[0]

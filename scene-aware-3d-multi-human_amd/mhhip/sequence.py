@@ -32,8 +32,10 @@ def _dev(a, device, dtype=torch.float32):
 
 class SequenceEngine(object):
     def __init__(self, model, image_size, num_frames, num_people, cam_K, cam_dist_coef=None, coefs=None,
-                 joint_confidence_thr=0.5, eps=1e-3, batch_size=10, max_cycles=1024):
+                 joint_confidence_thr=0.5, eps=1e-3, batch_size=10, max_cycles=1024, joint_weights=None):
         self.m = model
+        # per-key-point weights of the 2D term (reference optimizer.py:75-130, 259), mean 1; None = uniform
+        self.joint_w = None if joint_weights is None else np.ascontiguousarray(np.asarray(joint_weights, np.float32).reshape(17))
         self.dev = model.device
         self.W, self.H = int(image_size[0]), int(image_size[1])
         self.T, self.N = int(num_frames), int(num_people)
@@ -429,8 +431,9 @@ class SequenceEngine(object):
         side.wait_stream(main)
         s2 = side.cuda_stream
         self._regress(s2)
-        check(L.mh_project_joints_loss(B, ptr(self.kp), Kp, Kdp, ptr(self.pose2d), self.thr, 0, float(self.W),
-                                       float(self.H), float(c['proj2d']), ptr(self.uv), ptr(self.gj), ptr(self.loss2d), s2))
+        jwp = None if self.joint_w is None else self.joint_w.ctypes.data_as(_lib.c_float_p)
+        check(L.mh_project_joints_loss_w(B, ptr(self.kp), Kp, Kdp, jwp, ptr(self.pose2d), self.thr, 0, float(self.W),
+                                         float(self.H), float(c['proj2d']), ptr(self.uv), ptr(self.gj), ptr(self.loss2d), s2))
         check(L.mh_reduce_sum(ptr(self.loss2d), B, 1.0, ptr(log[0:1]), s2))
         with torch.cuda.stream(side):
             if need_gv:

@@ -55,9 +55,13 @@ class SMPLOptimizerBase(object):
         self.faces_smpl = torch.tensor(np.asarray(self.SMPLPY.faces)[np.newaxis, :].astype(np.int32), device=self.device)
         self.smpl_sparse_joints_key = smpl_sparse_joints_key
         w17 = np.ones(17, np.float32) if pose17j_weights is None else np.asarray(pose17j_weights, np.float32)
-        w17 = len(w17) * w17 / np.sum(w17)
-        assert np.allclose(w17, 1.0), 'non-uniform key-point weights are not supported by the fused 2D kernel'
+        assert w17.shape == (17,), 'pose17j_weights must hold one weight per key-point'
+        w17 = (len(w17) * w17 / np.sum(w17)).astype(np.float32)            # normalised to mean 1 (reference :128-130)
+        self._joint_w = None if np.allclose(w17, 1.0) else w17
         self.pose17j_weights = torch.tensor(w17[np.newaxis, :, np.newaxis], device=self.device)
+        if pose24j_weights is not None:                                  # kept for call compatibility (:118-126)
+            w24 = np.asarray(pose24j_weights, np.float32)
+            self.pose24j_weights = torch.tensor((len(w24) * w24 / np.sum(w24))[np.newaxis, :, np.newaxis], device=self.device)
 
     def predict(self, poses_T, poses_smpl, betas_smpl, scale_factor):
         res = self.SMPLPY(betas=torch.as_tensor(betas_smpl), poses=torch.as_tensor(poses_smpl))
@@ -161,7 +165,8 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
     def _build_engine(self, batch_size):
         m = self.SMPLPY.body_model
         self.engine = SequenceEngine(m, (self.img_w, self.img_h), self.num_frames, self.num_people, self.cam_K,
-                                     self.cam_dist_coef, self.coefs, self.joint_confidence_thr, self.eps, batch_size)
+                                     self.cam_dist_coef, self.coefs, self.joint_confidence_thr, self.eps, batch_size,
+                                     joint_weights=self._joint_w)
         self.engine.set_leaves(**self._init_leaves)
         self.valid_smpl = torch.tensor(self._valid, device=self.device)
         self._staged = False
@@ -189,9 +194,10 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
         Kd = None if self.cam_dist_coef is None else np.ascontiguousarray(self.cam_dist_coef, np.float32)
         Kdp = None if Kd is None else Kd.ctypes.data_as(_lib.c_float_p)
         lr = 0.5
+        jwp = None if self._joint_w is None else self._joint_w.ctypes.data_as(_lib.c_float_p)
         for it in range(num_iter):
-            _lib.check(L.mh_warmup_project(B, N, _lib.ptr(local), _lib.ptr(xs), _lib.ptr(pT), Kp, Kdp, _lib.ptr(p2d),
-                                           joints_thr, float(self.coefs['proj2d']), _lib.ptr(g), _lib.ptr(body_loss), st))
+            _lib.check(L.mh_warmup_project_w(B, N, _lib.ptr(local), _lib.ptr(xs), _lib.ptr(pT), Kp, Kdp, jwp, _lib.ptr(p2d),
+                                             joints_thr, float(self.coefs['proj2d']), _lib.ptr(g), _lib.ptr(body_loss), st))
             _lib.check(L.mh_velocity_term(T, N, _lib.ptr(pT), None, None, float(self.coefs['reg_velocity']),
                                           _lib.ptr(g), _lib.ptr(vel), st))
             _lib.check(L.mh_reduce_sum(_lib.ptr(body_loss), B, 1.0, _lib.ptr(log_dev[it:it + 1]), st))
@@ -205,6 +211,13 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
         T, N = self.num_frames, self.num_people
         H, W = self.img_h, self.img_w
         bs = getattr(dataloader, 'batch_size', None)
+        sampler = getattr(dataloader, 'sampler', None)
+        if sampler is not None and type(sampler).__name__ == 'RandomSampler':
+            import warnings
+            warnings.warn('dataloader has shuffle=True (configs/predict_mupots.yml:14): the reference then pairs RANDOM '
+                          'in-batch neighbours for the foot-sliding term (optimizer.py:512-518); this build stages the '
+                          'frames once and pairs CONSECUTIVE frames inside contiguous batches of %s frames '
+                          '(shuffle=False semantics).  Every other term is independent of the batch order.' % bs)
         first = True
         have_img = True
         store = {}

@@ -173,10 +173,8 @@ _LBS_CACHE = {}
 
 def lbs(betas, pose, v_template, shapedirs, posedirs, J_regressor, parents, lbs_weights, pose2rot=True,
         dtype=torch.float32):
-    """Call-compatible with reference smpl.py:490-576 (``pose2rot=True`` only): builds (and caches)
-    a device model from the given tensors and runs the HIP forward."""
-    if not pose2rot:
-        raise NotImplementedError('rotation-matrix input is not part of the accelerated path')
+    """Call-compatible with reference smpl.py:490-576: builds (and caches) a device model from the given tensors
+    and runs the HIP forward.  ``pose2rot=False`` (pose = (B,24,3,3) rotation matrices, :553-558) is forward only."""
     key = (v_template.data_ptr(), posedirs.data_ptr(), lbs_weights.data_ptr())
     if key not in _LBS_CACHE:
         V = v_template.shape[0]
@@ -194,6 +192,8 @@ def lbs(betas, pose, v_template, shapedirs, posedirs, J_regressor, parents, lbs_
     p = pose.to(m.device).float()
     if b.shape[0] != p.shape[0]:
         b = b.expand(p.shape[0], -1)
+    if not pose2rot:
+        return m.lbs_forward_rotmats(b.contiguous(), p.reshape(p.shape[0], 24, 3, 3))
     verts, _, posed = _LbsFn.apply(b.contiguous(), p.contiguous(), m, False)
     return verts, posed
 

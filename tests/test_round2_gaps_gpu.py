@@ -1,0 +1,240 @@
+"""Round-2 coverage of inputs and sizes the round-1 suite refused or never ran:
+per-key-point weights of the 2D term, ``lbs(pose2rot=False)``, the shuffle warning, a camera with distortion
+coefficients through ``fit``, models with more than four bones per vertex, BASELINE config C2 at its size, C1's shape
+(1 human, 256x256), and one 250-frame shard of C4 with its halos taken from the neighbouring frames."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+from oracle import fit_oracle as fo
+from oracle import lbs_oracle as lo
+from oracle import raster_oracle as ro
+from test_fit_full_gpu import LEAF_MAP, _oracle_grad, _setup
+
+pytestmark = pytest.mark.gpu
+
+
+def _save_regs(tmp_path, smpl_regs):
+    for k, fn in [('extra9', 'J_regressor_extra.npy'), ('h36m', 'J_regressor_h36m.npy'),
+                  ('alphapose', 'SMPL_AlphaPose_Regressor_RMSprop_6.npy')]:
+        np.save(str(tmp_path / fn), smpl_regs[k])
+
+
+def _new_opt(smpl_struct, smpl_regs, tmp_path, fin, **kw):
+    from mhmocap.optimizer import SMPLDepthSequenceOptimizer
+    _save_regs(tmp_path, smpl_regs)
+    c = gi.COEFS
+    args = dict(image_size=(fin['W'], fin['H']), num_frames=fin['T'], cam_K=fin['cam_K'], device='cuda:0',
+                smpl_model_parameters_path=str(tmp_path), smpl_data_struct=smpl_struct, use_rasteriser=False, scene_update='none',
+                proj2d_loss_coef=c['proj2d'], depth_loss_coef=c['depth'], silhouette_loss_coef=c['silhouette'],
+                reg_velocity_coef=c['reg_velocity'], reg_verts_filter_coef=c['reg_verts_filter'], reg_poses_coef=c['reg_poses'],
+                reg_scales_coef=c['reg_scales'], reg_contact_coef=c['reg_contact'], reg_foot_sliding_coef=c['reg_foot_sliding'])
+    args.update(kw)
+    return SMPLDepthSequenceOptimizer(**args)
+
+
+class _DS(torch.utils.data.Dataset):
+    def __init__(self, fin):
+        self.f = fin
+
+    def __len__(self):
+        return self.f['T']
+
+    def __getitem__(self, i):
+        f = self.f
+        return dict(images=f['images'][i], depths=f['depths'][i], seg_mask=f['seg_mask'][i], backmasks=f['backmasks'][i],
+                    pose2d=f['pose2d'][i], poses_smpl=f['poses_smpl'][i], betas_smpl=f['betas_smpl'][i],
+                    valid_smpl=f['valid_smpl'][i], idxs=i)
+
+
+def _batches(fin, b=5):
+    out = []
+    for s in range(0, fin['T'], b):
+        sl = slice(s, s + b)
+        out.append(dict(idxs=torch.arange(s, min(s + b, fin['T'])), pose2d=torch.tensor(fin['pose2d'][sl]),
+                        seg_mask=torch.tensor(fin['seg_mask'][sl]), depths=torch.tensor(fin['depths'][sl]),
+                        poses_smpl=torch.tensor(fin['poses_smpl'][sl])))
+    return out
+
+
+W17 = np.array([1, 1, 1, 1, 1, 2, 2, 3, 3, 5, 5, 2, 2, 3, 3, 4, 4], np.float32)
+
+
+def test_non_uniform_keypoint_weights(golden, smpl_struct, smpl_regs, oracle_model, tmp_path):
+    """pose17j_weights (reference optimizer.py:108-130): warm-up and the 2D term of a cycle against the oracle"""
+    fin = gi.fit_inputs()
+    opt = _new_opt(smpl_struct, smpl_regs, tmp_path, fin, pose17j_weights=W17)
+    wn = 17 * W17 / W17.sum()
+    np.testing.assert_allclose(opt.pose17j_weights.cpu().numpy().reshape(-1), wn, rtol=1e-6)
+    log = opt.init_optimized_variables(fin['pose2d'], fin['poses_smpl'], fin['betas_smpl'], fin['valid_smpl'], num_iter=5)
+    o = fo.SequenceOracle(oracle_model, (fin['W'], fin['H']), fin['T'], fin['cam_K'], coefs=gi.COEFS)
+    o.joint_w = torch.tensor(wn).view(1, 1, 17, 1)
+    o.xscale = torch.zeros(1, fin['N'], 1, 1)
+    olog = o.init_optimized_variables(fin['pose2d'], fin['poses_smpl'], fin['betas_smpl'], fin['valid_smpl'], num_iter=5)
+    np.testing.assert_allclose([l['loss_2d'] for l in log], olog, rtol=1e-4)
+    err = np.abs(opt.poses_T.cpu().numpy() - o.poses_T.detach().numpy())
+    # Adam's m/sqrt(v) is sign-like for near-zero gradients: measured 2 of 120 entries at 2e-3, the rest below 5e-5
+    assert (err > 5e-5).mean() <= 0.03 and err.max() <= 5e-3, (float((err > 5e-5).mean()), float(err.max()))
+    assert abs(olog[0] - float(golden['init_loss2d_log'][0])) > 1e-3 * olog[0]        # the weights matter
+    opt._stage_from_dataloader(torch.utils.data.DataLoader(_DS(fin), batch_size=5, shuffle=False))
+    opt.engine.leaf('poses_T').copy_(torch.tensor(o.poses_T.detach().numpy()).view(fin['T'], fin['N'], 3))
+    opt.engine.cycle(0)
+    stub = lambda v: (-torch.ones(v.shape[0], fin['H'], fin['W']) + 0.0 * v.sum(),
+                      torch.zeros(v.shape[0], fin['H'], fin['W']) + 0.0 * v.sum())
+    o.rasteriser = stub
+    want = o.cycle_grads(_batches(fin))
+    got = opt.engine.read_log(1)[0]
+    np.testing.assert_allclose(got['loss_pose24j'], want['loss_pose24j'], rtol=1e-4)
+    for name, ename in LEAF_MAP:
+        w = _oracle_grad(o, name)
+        g = opt.engine.leaf(ename, opt.engine.grads).cpu().numpy().reshape(w.shape)
+        np.testing.assert_allclose(g, w, atol=3e-4 * max(np.abs(w).max(), 1e-6), err_msg=name)
+
+
+def test_lbs_with_rotation_matrices(oracle_model, smpl_struct):
+    """``lbs(pose2rot=False)`` (reference smpl.py:553-558): rotation matrices in, hands included"""
+    from mhmocap import smpl as hsmpl
+    betas, poses = gi.lbs_inputs()
+    B = poses.shape[0]
+    rng = np.random.RandomState(5)
+    poses[:, 66:] = rng.normal(0, 0.2, (B, 6)).astype(np.float32)       # the given hand rotations ARE used in this mode
+    R = lo.rodrigues(torch.tensor(poses).view(-1, 3)).view(B, 24, 3, 3)
+    dev = 'cuda:0'
+    m = oracle_model
+    posedirs = m.posedirs.to(dev)
+    args = (m.v_template.to(dev), m.shapedirs.to(dev), posedirs, m.J_regressor.to(dev), torch.tensor(m.parents).to(dev),
+            m.weights.to(dev))
+    verts, joints = hsmpl.lbs(torch.tensor(betas).to(dev), R.to(dev), *args, pose2rot=False)
+    # oracle: the same kinematics written out (v_posed from R - I of joints 1..23, chain over all 24 rotations)
+    b = torch.tensor(betas).double()
+    Rd = R.double()
+    v_shaped = m.v_template.double() + torch.einsum('bl,vcl->bvc', b, m.shapedirs.double())
+    J = torch.einsum('jv,bvc->bjc', m.J_regressor.double(), v_shaped)
+    feat = (Rd[:, 1:] - torch.eye(3).double()).reshape(B, -1)
+    v_posed = v_shaped + (feat @ m.posedirs.double()).view(B, -1, 3)
+    G = [None] * 24
+    for j in range(24):
+        par = int(m.parents[j])
+        rel = J[:, j] - (J[:, par] if par >= 0 else 0)
+        Tj = torch.cat([torch.cat([Rd[:, j], rel[:, :, None]], 2), torch.tensor([[[0, 0, 0, 1.0]]]).double().expand(B, 1, 4)], 1)
+        G[j] = Tj if par < 0 else G[par] @ Tj
+    Gs = torch.stack(G, 1)
+    posed = Gs[:, :, :3, 3]
+    A = Gs.clone()
+    A[:, :, :3, 3] -= torch.einsum('bjrc,bjc->bjr', Gs[:, :, :3, :3], J)
+    Tm = torch.einsum('vj,bjrc->bvrc', m.weights.double(), A)
+    want = torch.einsum('bvrc,bvc->bvr', Tm[:, :, :3, :3], v_posed) + Tm[:, :, :3, 3]
+    np.testing.assert_allclose(verts.cpu().numpy(), want.numpy(), atol=1e-5)
+    np.testing.assert_allclose(joints.cpu().numpy(), posed.numpy(), atol=1e-5)
+    # and the axis-angle mode agrees when the hands are at rest
+    poses[:, 66:] = 0
+    R0 = lo.rodrigues(torch.tensor(poses).view(-1, 3)).view(B, 24, 3, 3)
+    R0[:, 22:] = torch.eye(3)
+    v_rot, _ = hsmpl.lbs(torch.tensor(betas).to(dev), R0.to(dev), *args, pose2rot=False)
+    v_aa, _ = hsmpl.lbs(torch.tensor(betas).to(dev), torch.tensor(poses).to(dev), *args, pose2rot=True)
+    np.testing.assert_allclose(v_rot.cpu().numpy(), v_aa.detach().cpu().numpy(), atol=2e-6)
+
+
+def test_shuffled_dataloader_warns_and_stages_in_frame_order(smpl_struct, smpl_regs, tmp_path):
+    fin = gi.fit_inputs()
+    opt = _new_opt(smpl_struct, smpl_regs, tmp_path, fin)
+    opt.init_optimized_variables(fin['pose2d'], fin['poses_smpl'], fin['betas_smpl'], fin['valid_smpl'], num_iter=0)
+    with pytest.warns(UserWarning, match='shuffle=True'):
+        opt._stage_from_dataloader(torch.utils.data.DataLoader(_DS(fin), batch_size=5, shuffle=True))
+    np.testing.assert_array_equal(opt.engine.pose2d.cpu().numpy().reshape(fin['pose2d'].shape), fin['pose2d'])
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        opt2 = _new_opt(smpl_struct, smpl_regs, tmp_path, fin)
+        opt2.init_optimized_variables(fin['pose2d'], fin['poses_smpl'], fin['betas_smpl'], fin['valid_smpl'], num_iter=0)
+        opt2._stage_from_dataloader(torch.utils.data.DataLoader(_DS(fin), batch_size=5, shuffle=False))
+
+
+def test_distortion_coefficients_through_fit(smpl_struct, smpl_regs, oracle_model, tmp_path):
+    """``cam_dist_coef`` (MuPoTs passes None, predict.py:285-288; other data sets do not): three cycles of ``fit``"""
+    fin = gi.fit_inputs()
+    Kd = np.array([-0.12, 0.05, 1e-3, -2e-3, 0.01], np.float32)
+    opt = _new_opt(smpl_struct, smpl_regs, tmp_path, fin, cam_dist_coef=Kd)
+    log0 = opt.init_optimized_variables(fin['pose2d'], fin['poses_smpl'], fin['betas_smpl'], fin['valid_smpl'], num_iter=5)
+    o = fo.SequenceOracle(oracle_model, (fin['W'], fin['H']), fin['T'], fin['cam_K'], cam_dist_coef=Kd, coefs=gi.COEFS,
+                          rasteriser=lambda v: (-torch.ones(v.shape[0], fin['H'], fin['W']) + 0.0 * v.sum(),
+                                                torch.zeros(v.shape[0], fin['H'], fin['W']) + 0.0 * v.sum()))
+    o.xscale = torch.zeros(1, fin['N'], 1, 1)
+    ol = o.init_optimized_variables(fin['pose2d'], fin['poses_smpl'], fin['betas_smpl'], fin['valid_smpl'], num_iter=5)
+    np.testing.assert_allclose([l['loss_2d'] for l in log0], ol, rtol=1e-4)
+    opt.engine.leaf('poses_T').copy_(torch.tensor(o.poses_T.detach().numpy()).view(fin['T'], fin['N'], 3))
+    opt.engine.leaf('zmax_lin').copy_(torch.tensor(o.zmax_lin.detach().numpy()).view(-1))
+    log = opt.fit(torch.utils.data.DataLoader(_DS(fin), batch_size=5, shuffle=False), num_iter=3)
+    want = o.fit(_batches(fin), 3)
+    np.testing.assert_allclose([l['loss_pose24j'] for l in log], [l['loss_pose24j'] for l in want], rtol=2e-3)
+    ov, wv = opt.get_optimized_variables(), o.optimized_variables()
+    for k in ['poses_T', 'poses_smpl', 'betas_smpl']:
+        np.testing.assert_allclose(ov[k], wv[k], atol=2e-4, err_msg=k)
+
+
+@pytest.mark.parametrize('nbones', [6, 24])
+def test_models_with_more_than_four_bones_per_vertex(smpl_struct, smpl_regs, nbones):
+    """``nw`` > 4 (the skinning tables fall back to 8 / 24 entries per vertex): forward and backward vs autograd"""
+    import copy
+    from mhhip import engine
+    st = copy.copy(smpl_struct)
+    rng = np.random.RandomState(nbones)
+    V = st.v_template.shape[0]
+    w = np.zeros((V, 24))
+    for v in range(V):
+        idx = rng.choice(24, nbones, replace=False)
+        w[v, idx] = rng.uniform(0.1, 1.0, nbones)
+    st.weights = w / w.sum(1, keepdims=True)
+    hm = engine.BodyModel(st, smpl_regs)
+    om = lo.BodyModel(st, smpl_regs, dtype=torch.float64)
+    B, NB = 5, 5
+    betas = rng.normal(0, 0.6, (NB, 10)).astype(np.float32)
+    poses = rng.normal(0, 0.3, (B, 72)).astype(np.float32)
+    dev = lambda a: torch.tensor(np.asarray(a, np.float32), device='cuda:0')
+    verts, vposed, _, ws = hm.lbs_forward(dev(betas), dev(poses))
+    tb = torch.tensor(betas, dtype=torch.float64, requires_grad=True)
+    tp = torch.tensor(poses, dtype=torch.float64, requires_grad=True)
+    out = lo.smpl_forward(om, tb, tp)
+    np.testing.assert_allclose(verts.cpu().numpy(), out['verts'].detach().numpy(), atol=1e-5)
+    wv = rng.normal(0, 1, (B, V, 3)).astype(np.float32)
+    wj = rng.normal(0, 1, (B, 17, 3)).astype(np.float32)
+    ((out['verts'] * torch.tensor(wv).double()).sum() + (out['joints_alphapose'] * torch.tensor(wj).double()).sum()).backward()
+    gposes, _, gbetas, _ = hm.lbs_backward(dev(betas), dev(poses), None, None, vposed, dev(wv), dev(wj), ws)
+    gp, gb = tp.grad.numpy(), tb.grad.numpy()
+    np.testing.assert_allclose(gposes.cpu().numpy()[:, :66], gp[:, :66], atol=2e-4 * np.abs(gp).max())
+    np.testing.assert_allclose(gbetas.cpu().numpy(), gb, atol=2e-4 * np.abs(gb).max())
+
+
+def _cycle_vs_oracle(opt, dl, o, batches, frac=0.01):
+    from mhhip.raster import RasterTerms
+    opt._stage_from_dataloader(dl)
+    e = opt.engine
+    e.cycle(0, raster=RasterTerms(e))
+    log = e.read_log(1)[0]
+    want = o.cycle_grads(batches)
+    for k in ['loss_pose24j', 'loss_depth', 'loss_silhouette', 'reg_ref_poses', 'reg_scale', 'reg_contact', 'reg_foot_sliding', 'reg_vel']:
+        np.testing.assert_allclose(log[k], want[k], rtol=3e-3, atol=1e-6, err_msg=k)
+    assert want['loss_depth'] > 0 and want['loss_silhouette'] > 0
+    for name, ename in LEAF_MAP:
+        w = _oracle_grad(o, name)
+        g = e.leaf(ename, e.grads).cpu().numpy().reshape(w.shape)
+        scale = max(np.abs(w).max(), 1e-8)
+        err = np.abs(g - w)
+        bad = float((err > 5e-3 * scale).mean())
+        assert bad < frac and np.median(err) < 1e-3 * scale, '%s: %.4f of entries above 5e-3*max, median %.2e (scale %.2e)' % (
+            name, bad, np.median(err), scale)
+    return e, want
+
+
+def test_c2_two_humans_100_frames_at_size(smpl_struct, smpl_regs, oracle_model, tmp_path):
+    """BASELINE config C2: 2 humans x 100 frames, 240x135, batch 10 -- one full nine-term cycle against the oracle"""
+    opt, dl, o, batches, seq = _setup(smpl_struct, smpl_regs, oracle_model, tmp_path, 100, 2, 240, 135, 10, 52, True)
+    _cycle_vs_oracle(opt, dl, o, batches)
+
+
+def test_c1_shape_one_human_square_image(smpl_struct, smpl_regs, oracle_model, tmp_path):
+    """C1's shape (MuPoTs TS1: 2048^2 x 0.125 = 256x256, one human, 50 frames, batch 10) on the device"""
+    opt, dl, o, batches, seq = _setup(smpl_struct, smpl_regs, oracle_model, tmp_path, 50, 1, 256, 256, 10, 53, True)
+    _cycle_vs_oracle(opt, dl, o, batches)

@@ -139,6 +139,8 @@ class ShardedSequence(object):
 
     def update_filters(self, c1=0.01, b1=0.02, c2=0.001, b2=0.5):
         e = self.e
+        if self.world == 1 and hasattr(e, 'update_filters'):
+            return e.update_filters(c1, b1, c2, b2)
         pf = self._scan(e.leaf('poses_T'), c1, b1)
         e.forward()
         vf = self._scan(e.verts.view(e.T, -1), c2, b2).view(e.verts.shape[0] // e.N, e.N, -1, 3)
@@ -183,7 +185,7 @@ class ShardedSequence(object):
         d = e._scene_dev
         self._sc = dict(Tmax=Tmax, Tall=G * Tmax, Pmax=Pmax, p0=p0, p1=p1,
                         depths_t=gather_padded(e.depths, 0.0), back_t=gather_padded(d['back'], 0),
-                        z=torch.zeros(2 * Tmax, device=e.dev), med=torch.zeros(Pmax, device=e.dev),
+                        z=[torch.zeros(2 * Tmax, device=e.dev) for _ in range(2)], med=torch.zeros(Pmax, device=e.dev),
                         msk=torch.zeros(Pmax, device=e.dev))
         assert self._sc['Tall'] <= 2048, 'pixel-sharded median: at most 2048 (padded) frames in total'
 
@@ -200,16 +202,17 @@ class ShardedSequence(object):
         Tmax, Tall, Pmax = sc['Tmax'], sc['Tall'], sc['Pmax']
         k = d['next']
         s = d['sets'][k]
-        sc['z'].fill_(1.0)
-        sc['z'][:T].copy_(e.leaf('zmin_lin').view(-1))
-        sc['z'][Tmax:Tmax + T].copy_(e.leaf('zmax_lin').view(-1))
+        z = sc['z'][k]                # one snapshot buffer per set: the previous update's all_gather (other stream) may
+        z.fill_(1.0)                  # still be reading the other one
+        z[:T].copy_(e.leaf('zmin_lin').view(-1))
+        z[Tmax:Tmax + T].copy_(e.leaf('zmax_lin').view(-1))
         main = torch.cuda.current_stream(e.dev)
         d['ev_main'].record(main)
         side = d['stream']
         side.wait_event(d['ev_main'])
         with torch.cuda.stream(side):
-            zs = [torch.empty_like(sc['z']) for _ in range(G)]
-            dist.all_gather(zs, sc['z'], group=self.group)
+            zs = [torch.empty_like(z) for _ in range(G)]
+            dist.all_gather(zs, z, group=self.group)
             zmin_all = torch.cat([z[:Tmax] for z in zs]).contiguous()
             zmax_all = torch.cat([z[Tmax:] for z in zs]).contiguous()
             st = side.cuda_stream

@@ -19,6 +19,7 @@ import os
 
 import numpy as np
 import torch
+import torch.distributed as dist
 
 from mhhip import _lib, engine
 from mhhip.sequence import SequenceEngine, COEF_KEYS
@@ -38,13 +39,17 @@ class SMPLOptimizerBase(object):
                  smpl_J_reg_extra_path='J_regressor_extra.npy', smpl_J_reg_h37m_path='J_regressor_h36m.npy',
                  smpl_J_reg_alphapose_path='SMPL_AlphaPose_Regressor_RMSprop_6.npy',
                  smpl_sparse_joints_key='joints_alphapose', pose24j_weights=None, pose17j_weights=None,
-                 smpl_data_struct=None):
+                 smpl_data_struct=None, engine_factory=None):
+        # engine_factory: test hook of the frame-sharded orchestration (tests/test_fit_sharded_cpu.py plugs a torch-CPU
+        # stand-in with SequenceEngine's interface under the gloo backend); the product never passes it, and without
+        # it a HIP device is mandatory
+        self._engine_factory = engine_factory
         if device is None:
             if not torch.cuda.is_available():
                 raise RuntimeError('the MI355X build of mhmocap.optimizer needs a HIP device (no CPU fallback)')
             device = 'cuda:0'
         self.device = torch.device(device)
-        if self.device.type != 'cuda':
+        if self.device.type != 'cuda' and engine_factory is None:
             raise RuntimeError('the MI355X build of mhmocap.optimizer needs a HIP device, got %s' % device)
         assert smpl_sparse_joints_key == 'joints_alphapose', 'only the 17 AlphaPose key-points are accelerated'
         self.smpl_model_parameters_path = os.path.abspath(smpl_model_parameters_path)
@@ -80,6 +85,9 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
         self.use_rasteriser = kargs.pop('use_rasteriser', True)
         self.scene_update = kargs.pop('scene_update', 'device')      # 'device' | 'host' (numpy, like the reference) | 'none'
         self.use_graphs = kargs.pop('use_graphs', True)              # replay each cycle as a captured hipGraph
+        # frame sharding: when torch.distributed is initialised with more than one rank, every rank is
+        # handed the SAME full-sequence inputs (predict.py under torchrun) and keeps the frames of its contiguous block
+        self.process_group = kargs.pop('process_group', None)
         super().__init__(**kargs)
         if focal_length is None:
             focal_length = get_focal(min(image_size), fov)
@@ -109,9 +117,11 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
         self.verts_filtered = None
 
     # -- leaves, exposed with the reference's shapes ------------------------------------------------
+    # (frame-sharded run: the per-frame leaves are the LOCAL frames [self.first_frame, self.last_frame);
+    # get_optimized_variables() returns the whole sequence on every rank)
     @property
     def poses_T(self):
-        return self.engine.leaf('poses_T').view(self.num_frames, self.num_people, 1, 3)
+        return self.engine.leaf('poses_T').view(self.engine.T, self.num_people, 1, 3)
 
     @property
     def poses_smpl(self):
@@ -127,11 +137,56 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
 
     @property
     def zmin_lin(self):
-        return self.engine.leaf('zmin_lin').view(self.num_frames, 1, 1)
+        return self.engine.leaf('zmin_lin').view(self.engine.T, 1, 1)
 
     @property
     def zmax_lin(self):
-        return self.engine.leaf('zmax_lin').view(self.num_frames, 1, 1)
+        return self.engine.leaf('zmax_lin').view(self.engine.T, 1, 1)
+
+    # -- frame sharding ---------------------------------------------------------------------------------
+    def _world(self):
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.process_group), dist.get_rank(self.process_group)
+        return 1, 0
+
+    def _bcast(self, arr, src=0):
+        """numpy array -> the same array on every rank (replicas must start bit-identical)"""
+        world, _ = self._world()
+        if world == 1:
+            return arr
+        t = torch.as_tensor(np.ascontiguousarray(arr)).to(self.device)
+        dist.broadcast(t, src=dist.get_global_rank(self.process_group, src) if self.process_group is not None else src,
+                       group=self.process_group)
+        return t.cpu().numpy()
+
+    def _gather_frames(self, local):
+        """(T_local, ...) tensor of this rank -> (T, ...) numpy array of the whole sequence, on every rank"""
+        world, _ = self._world()
+        local = local.detach().contiguous()
+        if world == 1:
+            return local.cpu().numpy().copy()
+        tmax = max(b - a for a, b in self._bounds)
+        pad = torch.zeros((tmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        pad[:local.shape[0]] = local
+        outs = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(outs, pad, group=self.process_group)
+        return torch.cat([o[:b - a] for o, (a, b) in zip(outs, self._bounds)]).cpu().numpy()
+
+    def check_replicas(self):
+        """Debug aid (MHHIP_CHECK_REPLICAS=1 runs it every 25 cycles): the shared leaves betas | xscale and their
+        RMSprop state must be bit-identical on every rank."""
+        world, rank = self._world()
+        if world == 1:
+            return True
+        e = self.engine
+        mine = torch.cat([e.params[e.shared_lo:], e.sq[e.shared_lo:], e.buf[e.shared_lo:]]).contiguous()
+        outs = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(outs, mine, group=self.process_group)
+        for r, o in enumerate(outs):
+            if not torch.equal(o, outs[0]):
+                raise RuntimeError('replicated shape/scale leaves diverged between rank 0 and rank %d (max |diff| %.3e)'
+                                   % (r, float((o - outs[0]).abs().max())))
+        return True
 
     # -- reference optimizer.py:262-321 ---------------------------------------------------------------
     def init_optimized_variables(self, pose2d, poses_smpl, betas_smpl, valid_smpl, scale_factor=None, num_iter=100):
@@ -150,31 +205,65 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
         self._poses_ref = np.asarray(poses_smpl, np.float32)
         self._valid = (np.asarray(valid_smpl) > 0.7).astype(np.float32)       # :299
         init_log, poses_T = self.__init_global_poses(pose2d, poses_smpl, betas_smpl, xscale, num_iter)
+        poses_T = self._bcast(poses_T)           # frame-sharded run: every rank starts from rank 0's warm-up result
         max_z = np.clip(np.max(poses_T[..., 2], axis=1), 2, None)            # (T,)  :292
         avg_betas = np.mean(betas_smpl, axis=0).astype(np.float32)            # (N,10) :296
         self._betas_ref = avg_betas
         self._init_leaves = dict(poses_T=poses_T, poses_smpl=self._poses_ref, betas=avg_betas,
                                  zmin_lin=np.ones_like(max_z), zmax_lin=2.0 * max_z, xscale=xscale)
-        self._build_engine(batch_size=10)
+        # the dataloader's batch size is only known in fit(): provisional blocks now (every rank must own frames for
+        # get_optimized_variables() to work before fit, predict.py:333), re-sharded at staging if the batch differs
+        bs0 = 10
+        while self._world()[0] > 1 and bs0 > 1 and (T + bs0 - 1) // bs0 < self._world()[0]:
+            bs0 -= 1
+        self._build_engine(batch_size=bs0)
         self.scene_depth = None
         self.scene_pcd = None
         self.poses_T_filtered = None
         self.verts_filtered = None
         return init_log
 
-    def _build_engine(self, batch_size):
-        m = self.SMPLPY.body_model
-        self.engine = SequenceEngine(m, (self.img_w, self.img_h), self.num_frames, self.num_people, self.cam_K,
-                                     self.cam_dist_coef, self.coefs, self.joint_confidence_thr, self.eps, batch_size,
-                                     joint_weights=self._joint_w)
-        self.engine.set_leaves(**self._init_leaves)
+    def _build_engine(self, batch_size, leaves=None):
+        """(Re)build the engine for this rank's frames.  ``leaves``: whole-sequence arrays (default: the initial ones)."""
+        from mhhip import sharded
+        leaves = self._init_leaves if leaves is None else leaves
+        world, rank = self._world()
+        self._bounds = sharded.shard_bounds(self.num_frames, world, int(batch_size))
+        self.first_frame, self.last_frame = self._bounds[rank]
+        if world > 1 and self.last_frame <= self.first_frame:
+            raise RuntimeError('rank %d owns no frames: %d frames in batches of %d over %d ranks' %
+                               (rank, self.num_frames, batch_size, world))
+        sl = slice(self.first_frame, self.last_frame)
+        kw = dict(image_size=(self.img_w, self.img_h), num_frames=self.last_frame - self.first_frame,
+                  num_people=self.num_people, cam_K=self.cam_K, cam_dist_coef=self.cam_dist_coef, coefs=self.coefs,
+                  joint_confidence_thr=self.joint_confidence_thr, eps=self.eps, batch_size=int(batch_size),
+                  joint_weights=self._joint_w)
+        if self._engine_factory is not None:
+            self.engine = self._engine_factory(**kw)
+        else:
+            self.engine = SequenceEngine(self.SMPLPY.body_model, **kw)
+        self.engine.set_leaves(poses_T=np.asarray(leaves['poses_T'])[sl], poses_smpl=np.asarray(leaves['poses_smpl'])[sl],
+                               betas=self._bcast(np.asarray(leaves['betas'], np.float32)),
+                               zmin_lin=np.asarray(leaves['zmin_lin'])[sl], zmax_lin=np.asarray(leaves['zmax_lin'])[sl],
+                               xscale=self._bcast(np.asarray(leaves['xscale'], np.float32)))
+        self.sh = sharded.ShardedSequence(self.engine, self.first_frame, self.num_frames, group=self.process_group)
+        self._engine_batch = int(batch_size)
         self.valid_smpl = torch.tensor(self._valid, device=self.device)
         self._staged = False
+
+    def _global_leaves(self):
+        e = self.engine
+        return dict(poses_T=self._gather_frames(e.leaf('poses_T')).reshape(self.num_frames, self.num_people, 1, 3),
+                    poses_smpl=self._gather_frames(e.leaf('poses_smpl')), betas=e.leaf('betas').cpu().numpy().copy(),
+                    zmin_lin=self._gather_frames(e.leaf('zmin_lin')), zmax_lin=self._gather_frames(e.leaf('zmax_lin')),
+                    xscale=e.leaf('xscale').cpu().numpy().copy())
 
     # -- reference optimizer.py:710-770: only poses_T is a leaf, so SMPL runs once --------------------
     def __init_global_poses(self, pose2d, poses_smpl, betas_smpl, xscale, num_iter, joints_thr=0.15):
         T, N = pose2d.shape[0:2]
         B = T * N
+        if num_iter <= 0:
+            return [], np.tile(np.array([[[[0, 0, 1]]]], np.float32), (T, N, 1, 1))          # :729
         m = self.SMPLPY.body_model
         dev = self.device
         L = _lib.lib()
@@ -235,10 +324,15 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
                     store[k] = np.zeros((T,) + a.shape[1:], a.dtype)
                 store[k][idx] = a
             first = False
+        world, _ = self._world()
+        if world > 1 and int(bs) != self._engine_batch:
+            # block boundaries are multiples of the batch size: re-shard with the dataloader's
+            self._build_engine(int(bs), leaves=self._global_leaves())
         self.engine.set_batch_size(int(bs))
-        self.engine.stage(store['pose2d'], store.get('poses_smpl', self._poses_ref), self._valid, self._betas_ref,
-                          store['seg_mask'] if have_img else None, store['depths'] if have_img else None)
-        self._images = store.get('images')
+        sl = slice(self.first_frame, self.last_frame)
+        self.engine.stage(store['pose2d'][sl], store.get('poses_smpl', self._poses_ref)[sl], self._valid[sl], self._betas_ref,
+                          store['seg_mask'][sl] if have_img else None, store['depths'][sl] if have_img else None)
+        self._images = store.get('images')          # whole sequence (colour median of the scene image, once per fit)
         self._backmasks = store.get('backmasks')
         self._staged = True
 
@@ -247,7 +341,8 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
             update_filters_every=25, verbose=False):
         if not self._staged:
             self._stage_from_dataloader(dataloader)
-        e = self.engine
+        e, sh = self.engine, self.sh
+        world, rank = self._world()
         if not self.optim_scale_factor:
             print('WARNING!!! Not optimizing scale_factor!')
         if num_iter > e.log.shape[0]:
@@ -255,38 +350,51 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
         raster = None
         if self.use_rasteriser and e.has_images:
             raster = e.raster_terms(self.znear, self.zfar)        # one per engine: captured graphs bake its addresses
+        scene_mode = self.scene_update
+        if world > 1 and scene_mode == 'host':
+            raise RuntimeError("scene_update='host' is a single-process path; the frame-sharded run aggregates on the device")
+        check_every = 25 if os.environ.get('MHHIP_CHECK_REPLICAS') == '1' else 0
         lr = 0.01                                                             # a new RMSprop + ExponentialLR per fit (:355-356)
         cycles = range(num_iter)
-        if verbose and tqdm is not None:
+        if verbose and tqdm is not None and rank == 0:
             cycles = tqdm(cycles)
         for cycle in cycles:
             if cycle >= 30 and cycle % update_filters_every == 0:            # :383-392
-                e.update_filters(min_cutoff1, beta1, min_cutoff2, beta2)
-                self.poses_T_filtered = e.pT_filt.view(self.num_frames, self.num_people, 1, 3)
+                if world > 1:
+                    sh.update_filters(min_cutoff1, beta1, min_cutoff2, beta2)    # state handed rank k -> k+1
+                else:
+                    e.update_filters(min_cutoff1, beta1, min_cutoff2, beta2)
+                self.poses_T_filtered = e.pT_filt.view(e.T, self.num_people, 1, 3)
                 self.verts_filtered = e.verts_filt
             scene_now = cycle >= 30 and e.has_images and self._backmasks is not None      # :578-584
-            if scene_now and self.scene_update == 'device':
+            dev_scene = scene_now and scene_mode == 'device'
+            if dev_scene and e._scene_dev is None:
                 # the update only reads the depth-range leaves as they are before this cycle's step and is first used by
                 # the NEXT cycle's contact term: launched on its own stream during this cycle, swapped in after it
-                if e._scene_dev is None:
-                    e.scene_device_setup(self._backmasks)
-            dev_scene = scene_now and self.scene_update == 'device'
-            if self.use_graphs and not (scene_now and self.scene_update == 'host'):
-                e.cycle_graphed(cycle, raster=raster, scene_update=dev_scene)    # update issued after the first replay
-            else:                                     # the host scene path hands over a new cloud every cycle: no replay
+                sh.scene_setup(self._backmasks[self.first_frame:self.last_frame])
+            if world > 1:
+                # frame-sharded: halos + ONE all-reduce of the betas|xscale gradient tail per cycle (mhhip/sharded.py);
+                # the median of the scene update runs pixel-sharded over all ranks' frames
                 if dev_scene:
-                    e.scene_device_update()
-                e.cycle(cycle, raster=raster)
-            if scene_now and self.scene_update == 'host':
+                    sh.scene_update()
+                sh.cycle(cycle, raster=raster, graphs=self.use_graphs)
+            else:
+                # single process: one captured graph per cycle (the device scene update is issued after the first
+                # replay); the host scene path hands over a new cloud every cycle, so it launches eagerly
+                sh.cycle(cycle, raster=raster, graphs=self.use_graphs and not (scene_now and scene_mode == 'host'),
+                         scene_update=dev_scene)
+            if scene_now and scene_mode == 'host':
                 self._host_scene_update()
-            elif scene_now and self.scene_update == 'device':
+            elif dev_scene:
                 e.scene_device_swap()
             if not self.optim_scale_factor:
                 e.leaf('xscale', e.grads).zero_()
             e.step(lr)             # RMSprop(lr=.01, alpha=.5, momentum=.9) :355; launched outside the captured cycle, lr by value
             lr *= 0.99                                                        # ExponentialLR(0.99) :356
+            if check_every and cycle % check_every == 0:
+                self.check_replicas()
         self._finish_scene()
-        return e.read_log(num_iter)
+        return sh.read_log(num_iter)
 
     def _host_scene_update(self):
         from . import scene_host
@@ -304,7 +412,7 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
             self.scene_depth, ma_mask, pts = e.scene_device_result()
             self.scene_pcd = pts.unsqueeze(0).unsqueeze(0)
             self._ma = None
-            if self._images is not None and self.num_frames <= 512:
+            if self._images is not None and self.num_frames <= 512 and self._world()[0] == 1:
                 # colour median + 11x11 fill on the device (independent of the optimised variables: once per fit)
                 self.scene_img, self.scene_mask = e.scene_device_image(self._images)
                 return
@@ -328,15 +436,15 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
     def get_optimized_variables(self):
         e = self.engine
         T, N = self.num_frames, self.num_people
-        zmin = e.leaf('zmin_lin').cpu().numpy().reshape(T, 1, 1)
-        zmax = e.leaf('zmax_lin').cpu().numpy().reshape(T, 1, 1)
+        g = self._global_leaves()             # frame-sharded run: the whole sequence, gathered on every rank
+        zmin, zmax = g['zmin_lin'].reshape(T, 1, 1), g['zmax_lin'].reshape(T, 1, 1)
         min_z = softplus_np(zmin)
         max_z = min_z + self.min_delta_z + softplus_np(zmax)
         return {
-            'scale_factor': np.power(np.float32(1.1), e.leaf('xscale').cpu().numpy()).reshape(1, N, 1, 1),
-            'poses_T': e.leaf('poses_T').cpu().numpy().reshape(T, N, 1, 3),
-            'poses_smpl': e.leaf('poses_smpl').cpu().numpy(),
-            'betas_smpl': e.leaf('betas').cpu().numpy().reshape(1, N, 10),
+            'scale_factor': np.power(np.float32(1.1), g['xscale']).reshape(1, N, 1, 1),
+            'poses_T': g['poses_T'].reshape(T, N, 1, 3),
+            'poses_smpl': g['poses_smpl'].reshape(T, N, 72),
+            'betas_smpl': g['betas'].reshape(1, N, 10),
             'valid_smpl': self._valid.copy(),
             'min_z': min_z, 'max_z': max_z,
             'scene_depth': self.scene_depth if hasattr(self, 'scene_depth') else None,

@@ -66,6 +66,49 @@ class CpuShardEngine(object):
         self.pT_filt = None
         self.halo = None
         self.log = torch.zeros(64, 16)
+        self.dev = torch.device('cpu')
+
+    # -- the part of SequenceEngine's interface the drop-in optimiser drives (tests/test_fit_sharded_cpu.py) --------
+    @classmethod
+    def factory(cls, model):
+        def make(image_size, num_frames, num_people, cam_K, cam_dist_coef=None, coefs=None, joint_confidence_thr=0.5,
+                 eps=1e-3, batch_size=10, joint_weights=None):
+            T, N = num_frames, num_people
+            z = lambda *s: np.zeros(s, np.float32)
+            e = cls(model, image_size, T, N, cam_K, coefs, batch_size, z(T, N, 17, 3), z(T, N, 72), z(T, N, 1), z(N, 10))
+            e.dev = torch.device('cpu')
+            e.has_images = False
+            e._scene_dev = None
+            return e
+        return make
+
+    def set_leaves(self, poses_T, poses_smpl, betas, zmin_lin, zmax_lin, xscale=None):
+        f = lambda a: torch.tensor(np.asarray(a, np.float32))
+        self.leaf('poses_T').copy_(f(poses_T).view(self.T, self.N, 3))
+        self.leaf('poses_smpl').copy_(f(poses_smpl).view(self.T, self.N, 72))
+        self.leaf('betas').copy_(f(betas).view(self.N, 10))
+        self.leaf('zmin_lin').copy_(f(zmin_lin).view(self.T))
+        self.leaf('zmax_lin').copy_(f(zmax_lin).view(self.T))
+        self.leaf('xscale').copy_(f(xscale).view(self.N) if xscale is not None else torch.zeros(self.N))
+        self.sq.zero_()
+        self.buf.zero_()
+
+    def set_batch_size(self, batch_size):
+        self.batch = int(batch_size)
+        self.nbatches = (self.T + self.batch - 1) // self.batch
+
+    def stage(self, pose2d, poses_ref, valid, betas_ref, seg_mask=None, depths=None):
+        B, N = self.B, self.N
+        self.pose2d = torch.tensor(np.asarray(pose2d, np.float32)).view(B, 17, 3)
+        self.poses_ref = torch.tensor(np.asarray(poses_ref, np.float32)).view(B, 72)
+        self.valid = torch.tensor(np.asarray(valid, np.float32)).view(B, 1)
+        self.betas_ref = torch.tensor(np.asarray(betas_ref, np.float32)).view(N, 10)
+
+    def update_filters(self, c1=0.01, b1=0.02, c2=0.001, b2=0.5):
+        pf, _ = self.one_euro_shard(self.leaf('poses_T'), c1, b1, 0)
+        self.forward()
+        vf, _ = self.one_euro_shard(self.verts.view(self.T, -1), c2, b2, 0)
+        self.pT_filt, self.verts_filt = pf, vf.view(self.T, self.N, -1, 3)
 
     def leaf(self, name, buf=None):
         buf = self.params if buf is None else buf

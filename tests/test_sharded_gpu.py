@@ -65,7 +65,12 @@ def _host_staged_dist():
 
     shim.isend, shim.irecv = object(), object()
     shim.P2POp, shim.batch_isend_irecv = P2POp, batch_isend_irecv
-    shim.all_gather, shim.all_reduce, shim.send, shim.recv = all_gather, all_reduce, send, recv
+    def broadcast(t, src, group=None):
+        c = t.detach().cpu()
+        dist.broadcast(c, src=src, group=group)
+        t.copy_(c)
+
+    shim.all_gather, shim.all_reduce, shim.send, shim.recv, shim.broadcast = all_gather, all_reduce, send, recv, broadcast
     return shim
 
 
@@ -173,3 +178,100 @@ def test_two_ranks_on_the_device_match_one(tmp_path):
         bad = np.abs(r[k]['scene_depth'] - depth) > 2e-3 * np.maximum(1.0, np.abs(depth))
         assert bad.mean() < 0.01, bad.sum()
         assert abs(r[k]['npts'] - pts.shape[0]) == 0
+
+
+# ---- the drop-in's fit() on two ranks (the entry predict.py:343 calls), all terms, scene organic from cycle 30 ------------
+FT, FCYCLES = 8, 34
+
+
+def _fit_run(tmp, world):
+    _paths()
+    from mhhip import synthetic, synthetic_seq
+    from mhmocap.optimizer import SMPLDepthSequenceOptimizer
+    import golden_inputs as gi
+    struct = synthetic.make_smpl_struct(1)
+    regs = synthetic.make_extra_regressors(1, struct)
+    for k, fn in [('extra9', 'J_regressor_extra.npy'), ('h36m', 'J_regressor_h36m.npy'),
+                  ('alphapose', 'SMPL_AlphaPose_Regressor_RMSprop_6.npy')]:
+        np.save(os.path.join(tmp, fn), regs[k])
+    K = synthetic.default_cam_K((W, H), 60.0)
+    c = gi.COEFS
+    opt = SMPLDepthSequenceOptimizer(
+        image_size=(W, H), num_frames=FT, cam_K=K, device='cuda:0', smpl_model_parameters_path=tmp, smpl_data_struct=struct,
+        proj2d_loss_coef=c['proj2d'], depth_loss_coef=c['depth'], silhouette_loss_coef=c['silhouette'],
+        reg_velocity_coef=c['reg_velocity'], reg_verts_filter_coef=c['reg_verts_filter'], reg_poses_coef=c['reg_poses'],
+        reg_scales_coef=c['reg_scales'], reg_contact_coef=c['reg_contact'], reg_foot_sliding_coef=c['reg_foot_sliding'])
+    seq = synthetic_seq.make_sequence(opt.SMPLPY.body_model, N, FT, (W, H), 45, cam_K=K, z_range=(2.6, 3.6))
+    opt.init_optimized_variables(seq['pose2d'], seq['poses_smpl'], seq['betas_smpl'], seq['valid_smpl'], num_iter=30)
+    dl = torch.utils.data.DataLoader(synthetic_seq.SequenceDataset(seq), batch_size=BATCH, shuffle=False)
+    opt.fit(dl, num_iter=6)
+    ov6 = opt.get_optimized_variables()
+    log = opt.fit(dl, num_iter=FCYCLES, update_filters_every=31)          # a second fit on the same (sharded) optimiser
+    opt.check_replicas()
+    torch.cuda.synchronize()
+    return opt, log, (ov6, opt.get_optimized_variables())
+
+
+def _fit_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), MHHIP_CHECK_REPLICAS='1')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    _paths()
+    from mhhip import sharded
+    import mhmocap.optimizer as mo
+    shim = _host_staged_dist()
+    sharded.dist = shim
+    mo.dist = shim
+    tmp = os.path.join(out, 'regs%d' % rank)
+    os.makedirs(tmp, exist_ok=True)
+    opt, log, ov = _fit_run(tmp, world)
+    torch.save(dict(ov=ov, log=log, first=opt.first_frame, last=opt.last_frame), os.path.join(out, 'fit%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_fit_of_the_drop_in_on_two_ranks(tmp_path):
+    """``SMPLDepthSequenceOptimizer.fit`` under an initialised process group: frames sharded, leaves broadcast, halos,
+    one all-reduce per cycle, filters handed over at cycle 31, scene aggregated pixel-sharded from cycle 30 on, whole
+    sequence gathered by ``get_optimized_variables`` -- against the same call in one process."""
+    port = 30500 + os.getpid() % 2000
+    mp.spawn(_fit_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    one = os.path.join(str(tmp_path), 'one')
+    os.makedirs(one)
+    opt, log, (ov6, ov) = _fit_run(one, 1)
+    r = [torch.load(os.path.join(str(tmp_path), 'fit%d.pt' % k), weights_only=False) for k in range(2)]
+    assert (r[0]['first'], r[0]['last'], r[1]['first'], r[1]['last']) == (0, 4, 4, 8)
+    for k in ['scale_factor', 'poses_T', 'poses_smpl', 'betas_smpl', 'min_z', 'max_z']:
+        # six cycles: the sharded run IS the single-process run up to the float atomics of the raster gradients
+        np.testing.assert_array_equal(r[0]['ov'][0][k], r[1]['ov'][0][k], err_msg=k)
+        err = np.abs(r[0]['ov'][0][k] - ov6[k])
+        assert np.percentile(err, 90) <= 2e-4 and err.max() <= 2e-2, (k, float(np.percentile(err, 90)), float(err.max()))
+    for rr in r:
+        rr['ov'] = rr['ov'][1]
+    # per-cycle loss logs: tight while the trajectories coincide (atomics noise only), within a few percent to the end
+    worst = {}
+    for c in range(FCYCLES):
+        for key in log[c]:
+            a, b = float(r[0]['log'][c][key]), float(log[c][key])
+            if key == 'reg_scale':        # ((s-1)^2 terms ~5e-5: the scale leaf's 1e-3 chaos shows as tens of percent of it)
+                assert abs(a - b) <= 5e-4, (c, a, b)
+                continue
+            rel = abs(a - b) / max(abs(b), 1e-6)
+            if rel > worst.get(c, (0.0, ''))[0]:
+                worst[c] = (round(rel, 5), key, a, b)
+            assert float(r[1]['log'][c][key]) == a, (key, c)           # the reduced log is the same on both ranks
+    assert max(worst.get(c, (0.0,))[0] for c in range(6)) <= 3e-2, worst     # (this fit starts from the state after six cycles)
+    # after ~20 cycles the two runs are different samples of a chaotic trajectory (float atomics, sign-like gradients):
+    # small terms differ by tens of percent (measured: loss_depth 6e-4 vs 9e-4 at cycle 25); the dominant term stays close
+    assert max(worst.get(c, (0.0,))[0] for c in range(12)) <= 0.15, [(c, worst[c]) for c in sorted(worst) if c < 12]
+    for c in range(FCYCLES):
+        np.testing.assert_allclose(r[0]['log'][c]['loss_pose24j'], log[c]['loss_pose24j'], rtol=0.2)
+    for k in ['scale_factor', 'poses_T', 'poses_smpl', 'betas_smpl', 'min_z', 'max_z']:
+        np.testing.assert_array_equal(r[0]['ov'][k], r[1]['ov'][k], err_msg=k)
+        assert r[0]['ov'][k].shape == ov[k].shape, k
+        err = np.abs(r[0]['ov'][k] - ov[k])
+        # 34 RMSprop steps (lr 0.01, momentum 0.9) with float atomics in the raster gradients and sign-like contact
+        # gradients: the bulk agrees, single entries take another branch
+        assert np.median(err) <= 5e-2 and np.isfinite(r[0]['ov'][k]).all(), (k, float(np.median(err)), float(np.percentile(err, 90)))
+    assert log[33]['reg_filter_verts'] > 0 and log[33]['reg_contact'] > 0 and r[0]['log'][33]['reg_contact'] > 0
+    assert r[0]['ov']['scene_depth'].shape == (H, W) and np.isfinite(r[0]['ov']['scene_depth']).all()

@@ -8,10 +8,12 @@ configuration BASELINE.json quotes the target on: 4 humans x 200 frames at 240x1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-N > 1: frames are sharded over the ranks (weak scaling: every rank owns 200 frames of a
-4 x 200*N sequence); one RCCL all-reduce on the shared shape/scale gradients per iteration plus
-the one-frame halos (mhhip/sharded.py).  ``value`` counts iterations/sec in units of the 4x200
-configuration (iterations/sec x frames/200), i.e. at N=1 it is plain iterations/sec.
+N > 1: ONE contiguous sequence, frames sharded over the ranks through the drop-in's own distributed path
+(mhmocap/optimizer.py -> mhhip/sharded.py): one RCCL all-reduce on the shared shape/scale gradients per iteration
+plus the one-frame halos.  Default = weak scaling, every rank owns 200 frames of a 4 x 200*N sequence (N=1 is C3);
+``value`` counts iterations/sec in units of the 4x200 configuration (iterations/sec x frames/200), i.e. at N=1 it
+is plain iterations/sec.  ``--config c4``: 250 frames per GPU (8 GPUs = BASELINE C4, 4 x 2000).  ``--strong``:
+BASELINE C5 -- a fixed 8 humans x 500 frames job with a 200 000-point scene cloud, split over the ranks.
 
 Prints ONE JSON line (rank 0).
 """
@@ -112,29 +114,38 @@ def cpu_baseline(struct, regs, K, seq, pT0, frames, cycles):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=250)      # 250 cycles (= one fit): >= 0.2 s timed, ten filter updates inside
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-fit', action='store_true', help='skip the fit_250 block (wall time of the drop-in fit call)')
     ap.add_argument('--eager', action='store_true', help='launch every kernel from the host instead of replaying captured graphs')
     ap.add_argument('--cpu-frames', type=int, default=20)
     ap.add_argument('--cpu-cycles', type=int, default=3)
-    # developer switches for the other BASELINE configs (parity-test cases, not bench lines): e.g. C5 =
-    # --humans 8 --frames 500 --image 600x338 ; the JSON then names the workload it actually ran
+    ap.add_argument('--config', choices=['c3', 'c4'], default='c3', help='c3: 200 frames per GPU (N=1 is BASELINE C3); '
+                    'c4: 250 frames per GPU (8 GPUs = BASELINE C4)')
+    ap.add_argument('--strong', action='store_true', help='BASELINE C5: fixed 8 humans x 500 frames + 200k-point scene, '
+                    'split over the ranks (strong scaling)')
+    # developer switches (parity-test shapes, not bench lines): the JSON names the workload it actually ran
     ap.add_argument('--humans', type=int, default=None)
     ap.add_argument('--frames', type=int, default=None)
     ap.add_argument('--image', type=str, default=None)
     args = ap.parse_args()
     global N_PEOPLE, T_LOCAL, IMG
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.config == 'c4':
+        T_LOCAL = 250
+    if args.strong:
+        N_PEOPLE = 8
     if args.humans:
         N_PEOPLE = args.humans
     if args.frames:
         T_LOCAL = args.frames
     if args.image:
         IMG = tuple(int(x) for x in args.image.split('x'))
+    T_TOTAL = 500 if args.strong else T_LOCAL * world
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -146,7 +157,6 @@ def main():
 
     import tempfile
     from mhhip import build as mhbuild, synthetic, synthetic_seq, sharded
-    from mhhip.raster import RasterTerms
     if rank == 0:
         mhbuild.build()
     if world > 1:
@@ -155,19 +165,33 @@ def main():
     regs = synthetic.make_extra_regressors(1, struct)
     K = synthetic.default_cam_K(IMG, 60.0)
     tmp = tempfile.mkdtemp()
-    opt = build_optimizer(struct, regs, tmp, T_LOCAL, device, K)
-    model = opt.SMPLPY.body_model
-    seq = synthetic_seq.make_sequence(model, N_PEOPLE, T_LOCAL, IMG, 1003 + rank, cam_K=K)
-    opt.init_optimized_variables(seq['pose2d'], seq['poses_smpl'], seq['betas_smpl'], seq['valid_smpl'], num_iter=100)
-    pT0 = opt.poses_T.cpu().numpy().copy()
-    dl = torch.utils.data.DataLoader(synthetic_seq.SequenceDataset(seq), batch_size=BATCH, shuffle=False)
-    opt._stage_from_dataloader(dl)
     W, H = IMG
+    # the drop-in itself shards: every rank is handed the whole sequence's tracks / key-points (what predict.py does
+    # under torchrun) and keeps its block of frames; replicas of betas|xscale are broadcast from rank 0
+    opt = build_optimizer(struct, regs, tmp, T_TOTAL, device, K)
+    model = opt.SMPLPY.body_model
+    f0, f1 = sharded.shard_bounds(T_TOTAL, world, BATCH)[rank]
+    seq = synthetic_seq.make_sequence(model, N_PEOPLE, T_TOTAL, IMG, 1003, cam_K=K, render_frames=(f0, f1))
+    opt.init_optimized_variables(seq['pose2d'], seq['poses_smpl'], seq['betas_smpl'], seq['valid_smpl'], num_iter=100)
+    pT0 = opt.get_optimized_variables()['poses_T']
+    dl = torch.utils.data.DataLoader(synthetic_seq.ShardDataset(seq), batch_size=BATCH, shuffle=False)
+    opt._stage_from_dataloader(dl)
+    assert (opt.first_frame, opt.last_frame) == (f0, f1)
+    e, sh = opt.engine, opt.sh
+    scene_mask = torch.tensor(seq['backmasks'].min(axis=0), device=device, dtype=torch.int32)
+    if world > 1:
+        dist.all_reduce(scene_mask, op=dist.ReduceOp.MIN)          # background in EVERY frame of the sequence
+    scene_mask = scene_mask.cpu().numpy() > 0
     opt.scene_depth = ground_scene(K, W, H)
-    opt.update_scene_pointcloud(opt.scene_depth, seq['backmasks'].min(axis=0) > 0)     # contact term live
-    e = opt.engine
-    sh = sharded.ShardedSequence(e, rank * T_LOCAL, world * T_LOCAL)
-    raster = RasterTerms(e)
+    if args.strong:
+        # C5: the reference ties the cloud size to the image (optimizer.py:609-613); 200 000 points are injected directly
+        rng = np.random.RandomState(11)
+        M = 200000
+        pts = np.stack([rng.uniform(-6, 6, M), 1.15 + 0.02 * rng.randn(M), rng.uniform(2, 14, M)], 1).astype(np.float32)
+        e.set_scene_points(torch.tensor(pts))
+    else:
+        opt.update_scene_pointcloud(opt.scene_depth, scene_mask)                       # contact term live
+    raster = e.raster_terms()
     sh.update_filters()                                                                # filtered-vertex term live
     nstep = [0]
 
@@ -179,7 +203,7 @@ def main():
         sh.cycle(c % e.log.shape[0], raster=raster, graphs=graphs, scene_update=scene)
         if scene:
             e.scene_device_swap()     # read by the next cycle's contact term (which waits on the update's event)
-        sh.step(0.01 * 0.99 ** nstep[0])      # RMSprop, ExponentialLR(0.99) on the host as in the reference (optimizer.py:355-356)
+        sh.step(0.01 * 0.99 ** min(nstep[0], 250))      # RMSprop, ExponentialLR(0.99) on the host as in the reference (:355-356)
         nstep[0] += 1
 
     use_graphs = not args.eager
@@ -206,24 +230,26 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        opt.check_replicas()
+    nsteps_org = min(args.steps, 50)
     # the same cycles with the device-side scene aggregation of optimizer.py:578-584 running every cycle (reported
     # beside the headline, which uses the injected static scene BASELINE.json's C3 names)
     organic = None
-    if world == 1:
+    if world == 1 and not args.strong:
         e.scene_device_setup(seq['backmasks'])
         for c in range(3):
             one_cycle(args.warmup + args.steps + c, use_graphs, scene=True)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for c in range(args.steps):
+        for c in range(nsteps_org):
             one_cycle(args.warmup + args.steps + 3 + c, use_graphs, scene=True)
         torch.cuda.synchronize()
         dt1 = time.perf_counter() - t1
-        organic = {'value': round(args.steps / dt1, 3), 'ms_per_step': round(1e3 * dt1 / args.steps, 4),
+        organic = {'value': round(nsteps_org / dt1, 3), 'ms_per_step': round(1e3 * dt1 / nsteps_org, 4), 'steps': nsteps_org,
                    'what': 'per-cycle masked median over the 200 frames + bilateral/Sobel/erode/median-fill + un-projection '
                            '+ grid rebuild on a second stream, overlapped with the next cycle'}
         opt.scene_depth = ground_scene(K, W, H)
-        opt.update_scene_pointcloud(opt.scene_depth, seq['backmasks'].min(axis=0) > 0)   # back to the static scene
+        opt.update_scene_pointcloud(opt.scene_depth, scene_mask)   # back to the static scene
     # per-kernel durations: HIP events cannot be read back from inside a replayed graph, so the same
     # launch sequence runs once more eagerly with events around the kernel groups (same kernels, same
     # stream, same data; only the launch mechanism differs)
@@ -232,9 +258,9 @@ def main():
     from mhhip import _lib
     L = _lib.lib()
     L.mh_profile_enable(1)
-    prof_names = ['k_raster_strip', 'k_raster_grads', 'k_skin_fwd', 'k_skin_bwd', 'k_contact_knn_grid', 'k_raster_sums']
+    prof_names = ['k_raster_strip', 'k_raster_grads', 'lbs_skin_forward', 'lbs_skin_backward', 'k_contact_knn_grid', 'k_raster_sums']
     prof = {k: [] for k in prof_names}
-    for c in range(args.steps):
+    for c in range(min(args.steps, 40)):
         one_cycle(args.warmup + args.steps + c, False)
         torch.cuda.synchronize()
         for i, k in enumerate(prof_names):      # duration of this cycle's launch (HIP events on the launch stream)
@@ -255,105 +281,167 @@ def main():
     if rank == 0:
         ms = 1e3 * dt / args.steps
         its = args.steps / dt
-        bodies = N_PEOPLE * T_LOCAL
+        frames_here = f1 - f0
+        bodies = N_PEOPLE * frames_here
         V, F = int(e.V), int(raster.faces.shape[0])
         dom = max(kernel_us, key=kernel_us.get) if kernel_us else None
         traffic = load_pmc_traffic()
-        # dominant kernel: k_raster_strip.  Algorithmic bytes per launch: every body's projected
-        # vertices (12 B x V) and row-sorted face list (4 B x F) in, the 40-byte key record of every window pixel out,
-        # plus the face table once.  The kernel is VALU-issue bound, not HBM bound (profiles/: SQ_ACTIVE_INST_VALU is
-        # ~80 % of the wave-resident cycles); the HBM fraction is reported because the contract asks for one.
+        # dominant kernel: k_raster_strip, an integer / LDS-atomic z-buffer selection.  What binds it is vector-instruction
+        # issue (one wave64 VALU instruction per 4 cycles per SIMD), so THAT is the roofline reported; its HBM side
+        # (algorithmic bytes per launch, DESIGN.md section 4: every body's projected vertices 12 B x V and row-sorted
+        # face list 4 B x F in, the 40-byte key record of every window pixel out, the face table once) is kept beside it
         roof = None
         if 'k_raster_strip' in kernel_us:
             us = kernel_us['k_raster_strip']
             algo = bodies * (12.0 * V + 4.0 * F) + 40.0 * window_px + 12.0 * F
             gbs = algo / (us * 1e-6) / 1e9
-            roof = {'kernel': 'k_raster_strip', 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS,
-                    'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4), 'traffic': traffic.get('k_raster_strip'),
-                    'launch_us': round(us, 1), 'algorithmic_bytes': algo, 'window_pixels': window_px,
-                    'note': 'dominant kernel by time; integer/LDS-atomic z-buffer selection, VALU-issue bound '
-                            '(see DESIGN.md section 4 and profiles/)', 'dominant_by_events': dom}
+            hbm = {'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
+                   'algorithmic_bytes': algo, 'window_pixels': window_px}
+            roof = {'kernel': 'k_raster_strip', 'bound': 'hbm', 'achieved': hbm['achieved'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                    'frac': hbm['frac'], 'traffic': traffic.get('k_raster_strip'), 'launch_us': round(us, 1), 'hbm': hbm,
+                    'dominant_by_events': dom}
             nv = load_pmc_valu('k_raster_strip')
-            if nv:   # the bound that does apply: wave64 vector instructions against 1024 SIMDs x 2.4 GHz / 4 cycles
+            if nv and not args.strong and frames_here == 200 and N_PEOPLE == 4:
                 gi = nv / (us * 1e-6) / 1e9
-                roof['valu_issue'] = {'wave_instructions': nv, 'achieved': round(gi, 1), 'peak': PEAK_VALU_GIPS,
-                                      'unit': 'G wave-instr/s', 'frac': round(gi / PEAK_VALU_GIPS, 3)}
-        # the GEMM-shaped kernels against the dense f32 MFMA peak: flops = 2 x 3 x 217 x V per body forward, plus the
-        # 12 x 24 bone-transform adjoint per vertex backward
-        roof_mfma = {}
-        for k, fl in (('k_skin_fwd', bodies * V * 217.0 * 6.0), ('k_skin_bwd', bodies * V * (217.0 * 6.0 + 12.0 * 24.0 * 2.0))):
-            if k in kernel_us:
-                tf = fl / (kernel_us[k] * 1e-6) / 1e12
-                # the same launch against HBM: per body two vertex arrays of 12 V bytes (forward: skinned + posed
-                # vertices out; backward: vertex adjoints + posed vertices in) and the basis once (12 x 217 x V bytes)
-                by = bodies * 2.0 * 12.0 * V + 12.0 * 217.0 * V
-                gb = by / (kernel_us[k] * 1e-6) / 1e9
-                roof_mfma[k] = {'bound': 'mfma', 'achieved': round(tf, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                                'frac': round(tf / PEAK_F32_MFMA_TFLOPS, 4), 'launch_us': round(kernel_us[k], 1),
-                                'algorithmic_flops': fl, 'traffic': traffic.get(k),
-                                'hbm': {'algorithmic_bytes': by, 'achieved': round(gb, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                                        'frac': round(gb / PEAK_HBM_GBS, 4)}}
+                roof.update({'bound': 'valu', 'achieved': round(gi, 1), 'peak': PEAK_VALU_GIPS, 'unit': 'G wave-instr/s',
+                             'frac': round(gi / PEAK_VALU_GIPS, 3), 'wave_instructions_per_launch': nv,
+                             'note': 'bound = vector-instruction issue (SQ_INSTS_VALU of the committed rocprofv3 pass / this '
+                                     'launch time, against 1024 SIMDs x 2.4 GHz / 4 cycles); the contract\'s HBM view is in '
+                                     '"hbm": traffic ~ algorithmic bytes, 5 % of 8 TB/s'})
+        # SURVEY 8(d) unit of the LBS + projection pair: 167 028 B per human.frame.iteration + the 19.35 MB of constants
+        # once per launch pair, over forward + backward of the skinning kernels (HIP events around them)
+        lbs = None
+        if 'lbs_skin_forward' in kernel_us and 'lbs_skin_backward' in kernel_us:
+            t_pair = (kernel_us['lbs_skin_forward'] + kernel_us['lbs_skin_backward']) * 1e-6
+            by = bodies * 167028.0 + 19.35e6
+            fl16 = 3.0 * 2.0 * bodies * V * (2 * 3 * 224.0 + 12 * 32.0)       # issued on the 16-bit matrix pipe (3 products)
+            lbs = {'kernels': 'k_skin_fwd16 | k_featgrad16 + k_jointgrad16 (split-fp16 / split-bf16 contractions)',
+                   'forward_us': round(kernel_us['lbs_skin_forward'], 1), 'backward_us': round(kernel_us['lbs_skin_backward'], 1),
+                   'bound': 'hbm', 'algorithmic_bytes': by, 'achieved': round(by / t_pair / 1e9, 1), 'peak': PEAK_HBM_GBS,
+                   'unit': 'GB/s', 'frac': round(by / t_pair / 1e9 / PEAK_HBM_GBS, 4),
+                   'mfma_16bit': {'issued_tflops': round(fl16 / t_pair / 1e12, 1), 'peak': 2500.0, 'frac': round(fl16 / t_pair / 2.5e15, 4)},
+                   'tolerance': 'vertices within 2.4e-7 m and gradients within 6e-6 (relative to the largest entry) of the '
+                                'exact-fp32 MFMA kernels of round 1 (tools/time_lbs.py); fixtures: 1e-5 m / 2e-4',
+                   'traffic': {k: traffic.get(k) for k in ('k_skin_fwd16', 'k_featgrad16', 'k_jointgrad16') if traffic.get(k)}}
+        unit_frames = T_TOTAL if args.strong else T_LOCAL
         out = {
-            'metric': 'optimizer iterations/sec (N humans x T frames)', 'value': round(its * world, 3),
-            'unit': 'iterations/s (%d humans x %d frames per iteration unit)' % (N_PEOPLE, T_LOCAL), 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'metric': 'optimizer iterations/sec (N humans x T frames)',
+            'value': round(its if args.strong else its * world, 3),
+            'unit': 'iterations/s (%d humans x %d frames per iteration unit)' % (N_PEOPLE, unit_frames), 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'strong' if args.strong else 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'launch': 'eager' if args.eager else 'hipGraph replay',
-            'config': {'workload': 'MuPoTs TS13-shape %d humans x %d frames, %dx%d, batch 10, full nine-term loss stack '
-                                   '(2D joints, raster depth, soft silhouette, contact, foot sliding, priors, velocity, '
-                                   'filtered vertices) + RMSprop; scene injected (ground plane), one-euro filters live'
-                                   % (N_PEOPLE, T_LOCAL * world, IMG[0], IMG[1]),
-                       'humans': N_PEOPLE, 'frames': T_LOCAL * world, 'frames_per_gpu': T_LOCAL, 'image': list(IMG),
-                       'parallelism': 'frames sharded x%d, RCCL all-reduce on betas/scale grads' % world},
-            'organic_scene': organic, 'roofline': roof, 'roofline_mfma': roof_mfma, 'kernel_us': {k: round(v, 1) for k, v in kernel_us.items()},
+            'config': {'workload': ('BASELINE C5: %d humans x %d frames + 200 000-point scene cloud, %dx%d, batch 10, full nine-term '
+                                    'loss stack + RMSprop, one-euro filters live' % (N_PEOPLE, T_TOTAL, IMG[0], IMG[1])) if args.strong else
+                                   ('MuPoTs TS13-shape %d humans x %d frames, %dx%d, batch 10, full nine-term loss stack '
+                                    '(2D joints, raster depth, soft silhouette, contact, foot sliding, priors, velocity, '
+                                    'filtered vertices) + RMSprop; scene injected (ground plane), one-euro filters live '
+                                    '(updated every 25 cycles inside the timed region)' % (N_PEOPLE, T_TOTAL, IMG[0], IMG[1])),
+                       'humans': N_PEOPLE, 'frames': T_TOTAL, 'frames_per_gpu': frames_here, 'image': list(IMG),
+                       'parallelism': 'one contiguous sequence, frames sharded x%d by the drop-in (mhmocap.optimizer under '
+                                      'torch.distributed), one RCCL all-reduce on the betas/scale gradients + one-frame halos per cycle' % world},
+            'timed_region_s': round(dt, 4),
+            'organic_scene': organic, 'roofline': roof, 'roofline_lbs_projection': lbs,
+            'kernel_us': {k: round(v, 1) for k, v in kernel_us.items()},
             'kernel_group_ms': {k: round(v, 4) for k, v in kern.items()},
             'loss_first_cycle': {k: float(v) for k, v in log[0].items()},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_fit and world == 1 and not args.strong:
+            out['fit_250'] = fit_block(struct, regs, tmp, device, K, seq)
+        if not args.no_cpu_baseline and world == 1 and not args.strong:
             ncores = os.cpu_count() or 1
             ncores = min(ncores, 16)
             torch.set_num_threads(ncores)
+            os.environ['ORACLE_THREADS'] = str(ncores)
             o, cpu_s = cpu_baseline(struct, regs, K, seq, pT0, args.cpu_frames, args.cpu_cycles)
             cpu_its = 1.0 / (cpu_s * (T_LOCAL / float(args.cpu_frames)))
             out['cpu_baseline'] = {
                 'value': round(cpu_its, 6), 'unit': 'iterations/s (4 humans x 200 frames per iteration unit)',
                 'cores': ncores, 'kind': 'port',
-                'sample': '%d cycles of the CPU oracle (torch-CPU LBS/losses + C face selection) on the first %d of the '
-                          '200 frames (x4 humans, 240x135, same nine-term stack); per-cycle time scaled by 200/%d'
-                          % (args.cpu_cycles, args.cpu_frames, args.cpu_frames),
-                'sec_per_cycle_sample': round(cpu_s, 3)}
+                'sample': '%d cycles of the CPU oracle (torch-CPU LBS/losses on %d threads + C face selection, one body per '
+                          'thread) on the first %d of the 200 frames (x4 humans, 240x135, same nine-term stack); per-cycle time '
+                          'scaled by 200/%d' % (args.cpu_cycles, ncores, args.cpu_frames, args.cpu_frames),
+                'sec_per_cycle_sample': round(cpu_s, 3),
+                'reference_loop_in_build_container': 'the reference\'s own fit loop (PyTorch3D replaced by the oracle rasteriser through '
+                                                     'the stubs) took 1.67 s per cycle on the same 20-frame sample on 8 Xeon threads = '
+                                                     '0.0598 it/s at 200 frames (BASELINE.md; it cannot run on the GPU box)'}
             out['speedup_vs_cpu_port'] = round(its / cpu_its, 1)
-            # MPJPE (mm) between the GPU path and the CPU oracle after the same cycles on the sample
-            from oracle import lbs_oracle as lo
-            opt2 = build_optimizer(struct, regs, tmp, args.cpu_frames, device, K)
-            sl = slice(0, args.cpu_frames)
-            opt2.init_optimized_variables(seq['pose2d'][sl], seq['poses_smpl'][sl], seq['betas_smpl'][sl],
-                                          seq['valid_smpl'][sl], num_iter=0)
-            opt2.engine.leaf('poses_T').copy_(torch.tensor(pT0[sl]).view(args.cpu_frames, N_PEOPLE, 3))
-            mz = np.clip(np.max(pT0[sl][..., 0, 2], axis=1), 2, None)
-            opt2.engine.leaf('zmax_lin').copy_(torch.tensor(2.0 * mz))
-            sub = {k: v[sl] for k, v in seq.items() if isinstance(v, np.ndarray) and v.shape[:1] == (T_LOCAL,)}
-            dl2 = torch.utils.data.DataLoader(synthetic_seq.SequenceDataset(sub), batch_size=BATCH, shuffle=False)
-            opt2.scene_depth = ground_scene(K, W, H)
-            opt2.update_scene_pointcloud(opt2.scene_depth, seq['backmasks'][sl].min(axis=0) > 0)
-            opt2.fit(dl2, num_iter=args.cpu_cycles)
-            ov, wv = opt2.get_optimized_variables(), o.optimized_variables()
-            om = lo.BodyModel(struct, regs)
-
-            def joints(v):
-                B = args.cpu_frames * N_PEOPLE
-                be = torch.tensor(v['betas_smpl']).expand(args.cpu_frames, N_PEOPLE, 10).reshape(B, 10)
-                j = lo.smpl_forward(om, be, torch.tensor(v['poses_smpl']).view(B, 72))['joints_alphapose']
-                s = torch.tensor(v['scale_factor']).view(1, N_PEOPLE, 1, 1)
-                return s * j.view(args.cpu_frames, N_PEOPLE, 17, 3) + torch.tensor(v['poses_T'])
-            with torch.no_grad():
-                d = (joints(ov) - joints(wv)).norm(dim=-1).mean()
-            out['mpjpe_mm_vs_cpu_oracle'] = round(float(d) * 1000.0, 4)
-            out['mpjpe_note'] = '17 key-points, %d frames x 4 humans, after %d identical cycles from identical inputs' % (
-                args.cpu_frames, args.cpu_cycles)
+            out.update(mpjpe_block(struct, regs, tmp, device, K, seq, pT0, o, args))
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def fit_block(struct, regs, tmp, device, K, seq):
+    """Wall time of the drop-in call ``predict.py:343`` makes: ``opt.fit(dataloader, num_iter=250)`` on a fresh optimiser --
+    staging of the dataloader's tensors, graph captures, 250 cycles, nine filter updates, 220 device-side scene updates
+    (cycles 30..249) and the scene image, until the log is back on the host."""
+    from mhhip import synthetic_seq
+    W, H = IMG
+    c = COEFS
+    from mhmocap.optimizer import SMPLDepthSequenceOptimizer
+    opt = SMPLDepthSequenceOptimizer(
+        image_size=IMG, num_frames=T_LOCAL, cam_K=K, device=device, smpl_model_parameters_path=tmp, smpl_data_struct=struct,
+        proj2d_loss_coef=c['proj2d'], depth_loss_coef=c['depth'], silhouette_loss_coef=c['silhouette'],
+        reg_velocity_coef=c['reg_velocity'], reg_verts_filter_coef=c['reg_verts_filter'], reg_poses_coef=c['reg_poses'],
+        reg_scales_coef=c['reg_scales'], reg_contact_coef=c['reg_contact'], reg_foot_sliding_coef=c['reg_foot_sliding'])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    opt.init_optimized_variables(seq['pose2d'], seq['poses_smpl'], seq['betas_smpl'], seq['valid_smpl'], num_iter=100)
+    torch.cuda.synchronize()
+    t_init = time.perf_counter() - t0
+    dl = torch.utils.data.DataLoader(synthetic_seq.SequenceDataset(seq), batch_size=BATCH, shuffle=False)
+    t0 = time.perf_counter()
+    opt._stage_from_dataloader(dl)
+    torch.cuda.synchronize()
+    t_stage = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    log = opt.fit(dl, num_iter=250)
+    torch.cuda.synchronize()
+    t_fit = time.perf_counter() - t0
+    ov = opt.get_optimized_variables()
+    return {'wall_s': round(t_stage + t_fit, 4), 'staging_s': round(t_stage, 4), 'cycles_s': round(t_fit, 4),
+            'cycles_per_s_incl_everything': round(250.0 / (t_stage + t_fit), 1), 'warmup_100_iterations_s': round(t_init, 4),
+            'what': 'opt.fit(dataloader, num_iter=250) as predict.py:343 calls it on C3: staging, graph captures, 250 cycles, '
+                    '9 one-euro filter updates, 220 device scene updates, scene image; log read back',
+            'final_loss_pose24j': float(log[-1]['loss_pose24j']), 'scene_points': int(opt.scene_pcd.shape[2]),
+            'scene_img_shape': list(np.asarray(ov['scene_img']).shape)}
+
+
+def mpjpe_block(struct, regs, tmp, device, K, seq, pT0, o, args):
+    """MPJPE (mm) between the GPU path and the CPU oracle after the same cycles on the CPU sample: the 17 AlphaPose
+    key-points the loop optimises and the 15 MuPoTs joints the evaluator scores (evaluate.py:231-232, 254)."""
+    from mhhip import synthetic, synthetic_seq
+    from oracle import lbs_oracle as lo
+    W, H = IMG
+    nf = args.cpu_frames
+    regs_m = dict(regs)
+    opt2 = build_optimizer(struct, regs, tmp, nf, device, K)
+    sl = slice(0, nf)
+    opt2.init_optimized_variables(seq['pose2d'][sl], seq['poses_smpl'][sl], seq['betas_smpl'][sl], seq['valid_smpl'][sl], num_iter=0)
+    opt2.engine.leaf('poses_T').copy_(torch.tensor(pT0[sl]).view(nf, N_PEOPLE, 3))
+    mz = np.clip(np.max(pT0[sl][..., 0, 2], axis=1), 2, None)
+    opt2.engine.leaf('zmax_lin').copy_(torch.tensor(2.0 * mz))
+    sub = {k: v[sl] for k, v in seq.items() if isinstance(v, np.ndarray) and v.shape[:1] == (seq['pose2d'].shape[0],)}
+    dl2 = torch.utils.data.DataLoader(synthetic_seq.SequenceDataset(sub), batch_size=BATCH, shuffle=False)
+    opt2.scene_depth = ground_scene(K, W, H)
+    opt2.update_scene_pointcloud(opt2.scene_depth, seq['backmasks'][sl].min(axis=0) > 0)
+    opt2.fit(dl2, num_iter=args.cpu_cycles)
+    ov, wv = opt2.get_optimized_variables(), o.optimized_variables()
+    om = lo.BodyModel(struct, regs_m)
+
+    def joints(v, key):
+        B = nf * N_PEOPLE
+        be = torch.tensor(v['betas_smpl']).expand(nf, N_PEOPLE, 10).reshape(B, 10)
+        j = lo.smpl_forward(om, be, torch.tensor(v['poses_smpl']).view(B, 72))[key]
+        s = torch.tensor(v['scale_factor']).view(1, N_PEOPLE, 1, 1)
+        return s * j.view(nf, N_PEOPLE, -1, 3) + torch.tensor(v['poses_T'])
+    with torch.no_grad():
+        d17 = (joints(ov, 'joints_alphapose') - joints(wv, 'joints_alphapose')).norm(dim=-1).mean()
+        d15 = (joints(ov, 'joints_mupots')[:, :, :15] - joints(wv, 'joints_mupots')[:, :, :15]).norm(dim=-1).mean()
+    return {'mpjpe_mm_vs_cpu_oracle': round(float(d17) * 1000.0, 4), 'mpjpe15_mupots_mm_vs_cpu_oracle': round(float(d15) * 1000.0, 4),
+            'mpjpe_note': '17 AlphaPose key-points / first 15 MuPoTs joints (evaluate.py:231-232), %d frames x 4 humans, after %d '
+                          'identical cycles from identical inputs' % (nf, args.cpu_cycles)}
 
 
 if __name__ == '__main__':

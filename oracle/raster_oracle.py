@@ -63,9 +63,20 @@ def select_faces(verts_ndc, faces, H, W, blur_radius, K):
     out_f = np.empty((v.shape[0], H, W, K), np.int32)
     out_z = np.empty((v.shape[0], H, W, K), np.float32)
     L = _lib()
-    for b in range(v.shape[0]):
+
+    def one(b):
         L.raster_select(v[b].ctypes.data, f.ctypes.data, f.shape[0], H, W, ctypes.c_float(blur_radius), K,
                         out_f[b].ctypes.data, out_z[b].ctypes.data)
+    # the C selection is single-threaded per body; bodies are independent and ctypes releases the GIL, so the bodies of
+    # a batch are spread over ORACLE_THREADS host threads (default: torch's thread count) -- same results, any order
+    nthr = int(os.environ.get('ORACLE_THREADS', '0')) or torch.get_num_threads()
+    if nthr > 1 and v.shape[0] > 1:
+        import concurrent.futures
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(nthr, v.shape[0])) as ex:
+            list(ex.map(one, range(v.shape[0])))
+    else:
+        for b in range(v.shape[0]):
+            one(b)
     return out_f.astype(np.int64), out_z
 
 

@@ -8,11 +8,15 @@ import torch
 from . import engine, raster, synthetic
 
 
-def make_sequence(model, num_people, num_frames, image_size, seed, cam_K=None, chunk=256, z_range=(3.0, 8.0)):
+def make_sequence(model, num_people, num_frames, image_size, seed, cam_K=None, chunk=256, z_range=(3.0, 8.0),
+                  render_frames=None):
     """Returns a dict with the arrays the reference's dataset yields (datautils.py:531-542) for the
     whole sequence, as numpy: pose2d (T,N,17,3), poses_smpl (T,N,72), betas_smpl (T,N,10),
     valid_smpl (T,N,1), seg_mask (T,N,H,W), depths (T,H,W), backmasks (T,H,W), images (T,H,W,3),
-    plus cam_K and the ground-truth parameters."""
+    plus cam_K and the ground-truth parameters.  ``render_frames=(f0, f1)``: the frame-sharded run -- the parameter
+    tracks and key-points of the WHOLE sequence (they are what every rank is handed), images rendered only for the
+    frames this rank owns (``seg_mask`` / ``depths`` / ``images`` / ``backmasks`` then have f1-f0 frames, see
+    ``ShardDataset``)."""
     N, T = num_people, num_frames
     W, H = image_size
     dev = model.device
@@ -21,9 +25,10 @@ def make_sequence(model, num_people, num_frames, image_size, seed, cam_K=None, c
     sp = synthetic.make_sequence_params(N, T, seed, z_range)
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
     betas = t(sp['betas_gt'])
+    r0, r1 = (0, T) if render_frames is None else (int(render_frames[0]), int(render_frames[1]))
     pose2d = np.zeros((T, N, 17, 3), np.float32)
-    seg = np.zeros((T, N, H, W), np.float32)
-    depths = np.zeros((T, H, W), np.float32)
+    seg = np.zeros((r1 - r0, N, H, W), np.float32)
+    depths = np.zeros((r1 - r0, H, W), np.float32)
     # background: ground plane y = 1.15 m (y points down) and a back wall at z = 10 m
     ys = (np.arange(H, dtype=np.float32) + 0.5 - K[1, 2]) / K[1, 1]
     ray_y = np.tile(ys[:, None], (1, W))
@@ -39,6 +44,9 @@ def make_sequence(model, num_people, num_frames, image_size, seed, cam_K=None, c
         verts, _, _, _ = model.lbs_forward(betas, poses, None, tr, want_vposed=False)
         kp = model.joints_regress(engine.REG_ALPHAPOSE, verts, corr=tr)
         uv, _, _ = engine.project_joints_loss(kp, K, None, torch.zeros(nb, 17, 3, device=dev), 0.5, 0, W, H)
+        pose2d[f0:f1, :, :, :2] = uv.view(f1 - f0, N, 17, 2).cpu().numpy()
+        if f1 <= r0 or f0 >= r1:
+            continue
         zbuf, alpha = raster.render(model, verts, K, image_size)
         zb = zbuf.view(f1 - f0, N, H, W)
         al = alpha.view(f1 - f0, N, H, W)
@@ -50,17 +58,17 @@ def make_sequence(model, num_people, num_frames, image_size, seed, cam_K=None, c
         depth = torch.minimum(body_z, bg_t[None])
         disp = 1.0 / depth
         lo, hi = disp.amin(dim=(1, 2), keepdim=True), disp.amax(dim=(1, 2), keepdim=True)
-        depths[f0:f1] = ((disp - lo) / torch.clamp(hi - lo, min=1e-6)).cpu().numpy()
-        seg[f0:f1] = sg.cpu().numpy()
-        pose2d[f0:f1, :, :, :2] = uv.view(f1 - f0, N, 17, 2).cpu().numpy()
+        a, b = max(f0, r0), min(f1, r1)
+        depths[a - r0:b - r0] = ((disp - lo) / torch.clamp(hi - lo, min=1e-6)).cpu().numpy()[a - f0:b - f0]
+        seg[a - r0:b - r0] = sg.cpu().numpy()[a - f0:b - f0]
     pose2d[..., :2] += rng.normal(0, 1.0, (T, N, 17, 2)).astype(np.float32)
     conf = rng.uniform(0.6, 1.0, (T, N, 17)).astype(np.float32)
     conf[rng.rand(T, N, 17) < 0.1] = 0.1
     pose2d[..., 2] = conf
     backmasks = (seg.sum(1) == 0).astype(np.int64)
-    images = rng.randint(0, 255, (T, H, W, 3)).astype(np.uint8)
+    images = rng.randint(0, 255, (r1 - r0, H, W, 3)).astype(np.uint8)
     return dict(pose2d=pose2d, poses_smpl=sp['poses_init'], betas_smpl=sp['betas_init'], valid_smpl=sp['valid'],
-                seg_mask=seg, depths=depths, backmasks=backmasks, images=images, cam_K=K, gt=sp)
+                seg_mask=seg, depths=depths, backmasks=backmasks, images=images, cam_K=K, gt=sp, render_frames=(r0, r1))
 
 
 class SequenceDataset(torch.utils.data.Dataset):
@@ -77,3 +85,24 @@ class SequenceDataset(torch.utils.data.Dataset):
         return dict(images=s['images'][i], depths=s['depths'][i], seg_mask=s['seg_mask'][i], backmasks=s['backmasks'][i],
                     pose2d=s['pose2d'][i], poses_smpl=s['poses_smpl'][i], betas_smpl=s['betas_smpl'][i],
                     valid_smpl=s['valid_smpl'][i], idxs=i)
+
+
+class ShardDataset(torch.utils.data.Dataset):
+    """Whole-sequence dataset of a frame-sharded run built with ``make_sequence(render_frames=(f0, f1))``: every rank
+    iterates all frames (that is what ``predict.py`` does under torchrun), the image tensors of frames this rank does
+    not own are a shared block of zeros (the optimiser only stages its own frames)."""
+
+    def __init__(self, seq):
+        self.s = seq
+        self.r0, self.r1 = seq['render_frames']
+        self._z = {k: np.zeros_like(seq[k][0]) for k in ('images', 'depths', 'seg_mask', 'backmasks')}
+
+    def __len__(self):
+        return self.s['pose2d'].shape[0]
+
+    def __getitem__(self, i):
+        s = self.s
+        own = self.r0 <= i < self.r1
+        g = lambda k: s[k][i - self.r0] if own else self._z[k]
+        return dict(images=g('images'), depths=g('depths'), seg_mask=g('seg_mask'), backmasks=g('backmasks'), pose2d=s['pose2d'][i],
+                    poses_smpl=s['poses_smpl'][i], betas_smpl=s['betas_smpl'][i], valid_smpl=s['valid_smpl'][i], idxs=i)

@@ -107,6 +107,8 @@ def make_inputs(model, T=20, N=2, W=96, H=60, seed=41):
     t = np.arange(T, dtype=np.float32)
     tr[:, 0] = np.stack([-0.40 + 0.03 * t, 0.2 + 0 * t, 2.4 + 0.055 * t], -1)       # walks away, left -> right
     tr[:, 1] = np.stack([0.45 - 0.035 * t, 0.2 + 0 * t, 3.4 - 0.055 * t], -1)         # approaches, right -> left
+    for n in range(2, N):                                                              # (timing tool: more tracks)
+        tr[:, n] = np.stack([-1.2 + 0.8 * (n - 2) + 0.01 * t, 0.2 + 0 * t, 4.0 + 0.5 * (n - 2) + 0 * t], -1)
     cam_K = synthetic.default_cam_K((W, H), 60.0)
     with torch.no_grad():
         out = lbs_oracle.smpl_forward(model, torch.tensor(np.tile(sp['betas_gt'][None], (T, 1, 1))).view(-1, 10),

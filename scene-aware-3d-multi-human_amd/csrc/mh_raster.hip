@@ -816,7 +816,14 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
             T[12] = l12 <= R_KEPS ? 0.f : __builtin_amdgcn_rcpf(l12);
             desc[lane] = (xa - x0) | ((ya - sy0) << 10) | ((xb - xa + 1) << 20);
             fid[lane] = (int)(e_a & 0xfffffu);
-            zbs[lane] = __float_as_uint(fminf(ca[2], fminf(ca[5], ca[8])));
+            {
+              // nearest vertex depth MINUS 16 ulps: the interpolated depth (normalised weights through v_rcp_f32) can fall a
+              // few ulps short of the nearest vertex, and on such a tie the depth cull below dropped a candidate or not
+              // depending on which wave got to the pixel first (round 1: ~20 of 1.2 M pixels differed from run to run in
+              // the face id of their 4th silhouette key).  With the margin the selection is order-independent.
+              const unsigned zq = __float_as_uint(fminf(ca[2], fminf(ca[5], ca[8])));
+              zbs[lane] = zq > 16u ? zq - 16u : 0u;
+            }
           }
         }
         const int incl = r_wave_scan_add(cnt);

@@ -202,17 +202,19 @@ int mh_velocity_term(int T, int N, const float* pT /*(T,N,3)*/, const float* pre
                      const float* next_halo, float coef, float* gpT, float* loss_out, void* stream);
 /* filtered-vertex smoothness: loss = sum ||(v[t]-v[t-1]) - (vf[t]-vf[t-1])||^2,
  * gverts += coef * d loss / d v.  E = N*V*3 floats per frame.  prev_* / next_* (E): the
- * neighbouring ranks' boundary frames (NULL at the sequence ends).                          */
+ * neighbouring ranks' boundary frames (NULL at the sequence ends).  ws: device workspace of
+ * mh_filtered_verts_workspace_bytes(T, E) bytes (per-block partial sums; one per engine).    */
+size_t mh_filtered_verts_workspace_bytes(int T, size_t E);
 int mh_filtered_verts_term(int T, size_t E, const float* verts, const float* verts_filt,
                            const float* prev_v, const float* prev_vf, const float* next_v,
                            const float* next_vf, float coef, float* gverts, float* loss_out,
-                           void* stream);
+                           void* ws, void* stream);
 /* the same, but gverts = coef * d loss / d v (overwrites: the caller starts its vertex-gradient buffer with this
  * term instead of clearing it first) */
 int mh_filtered_verts_term_init(int T, size_t E, const float* verts, const float* verts_filt,
                                 const float* prev_v, const float* prev_vf, const float* next_v,
                                 const float* next_vf, float coef, float* gverts, float* loss_out,
-                                void* stream);
+                                void* ws, void* stream);
 
 /* ---- staging of the constant per-frame inputs (once per sequence; optimizer.py:396-409, 434) --
  * The N float {0,1} instance masks of a frame become ONE 32-bit word per pixel (bit n = person n,

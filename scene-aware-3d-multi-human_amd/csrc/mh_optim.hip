@@ -346,7 +346,7 @@ extern "C" int mh_velocity_term(int T, int N, const float* pT, const float* prev
   return MH_OK;
 }
 
-// VEC = float4 (E divisible by 4: SMPL's N*6890*3 always is) or float.  OVERWRITE: gverts = term (the caller
+// VEC = float4 (E = N*V*3 divisible by 4 and 16-byte aligned buffers: SMPL with an even N) or float (any E).  OVERWRITE: gverts = term (the caller
 // initialises the vertex-gradient buffer with this term instead of clearing it first).
 // Sliding window over time: a workgroup owns FV_TB consecutive frames of a slice of the elements and walks through
 // them with (t-1, t, t+1) in registers, so every vertex and filtered vertex is read once
@@ -430,13 +430,24 @@ __global__ __launch_bounds__(256) void k_sum_partials(const float* partial, int 
   if (threadIdx.x == 0) out[0] = s[0];
 }
 
-static float* g_fv_partial = nullptr;   // per-block partial sums, allocated once per process
-static size_t g_fv_cap = 0;
+// per-block partial sums live in a caller-provided workspace (one per engine: captured graphs bake its address; a
+// process-global buffer would be shared by every engine, stream and device)
+static void fv_grid(int T, size_t E, bool vec, unsigned* gx, unsigned* gy) {
+  const size_t EVh = vec ? E / 4 : E;
+  *gx = (unsigned)std::min<size_t>((EVh + 255) / 256, 1024);
+  *gy = (unsigned)((T + FV_TB - 1) / FV_TB);
+}
+extern "C" size_t mh_filtered_verts_workspace_bytes(int T, size_t E) {
+  unsigned gx, gy;
+  fv_grid(T < 1 ? 1 : T, E < 1 ? 1 : E, false, &gx, &gy);      // the scalar form has the larger grid
+  return ((size_t)gx * gy * sizeof(float) + 255) & ~(size_t)255;
+}
 
 static int filtered_verts_term(int T, size_t E, const float* verts, const float* verts_filt, const float* prev_v,
                                const float* prev_vf, const float* next_v, const float* next_vf, float coef, float* gverts,
-                               float* loss_out, bool overwrite, void* stream) {
-  MH_CHECK(verts && verts_filt && gverts && loss_out, "null argument");
+                               float* loss_out, bool overwrite, void* ws, void* stream) {
+  MH_CHECK(verts && verts_filt && gverts && loss_out && ws, "null argument");
+  float* g_fv_partial = (float*)ws;
   MH_CHECK(T >= 1 && E >= 1, "empty input");
   MH_CHECK((prev_v == nullptr) == (prev_vf == nullptr) && (next_v == nullptr) == (next_vf == nullptr),
            "halo vertices and filtered halo vertices come in pairs");
@@ -444,14 +455,9 @@ static int filtered_verts_term(int T, size_t E, const float* verts, const float*
   auto aligned = [](const void* q) { return q == nullptr || ((uintptr_t)q & 15u) == 0; };
   const bool vec = (E % 4 == 0) && aligned(verts) && aligned(verts_filt) && aligned(prev_v) && aligned(prev_vf) && aligned(next_v) &&
                    aligned(next_vf) && aligned(gverts);
-  const size_t EVh = vec ? E / 4 : E;
-  const unsigned gx = (unsigned)std::min<size_t>((EVh + 255) / 256, 1024), gy = (unsigned)((T + FV_TB - 1) / FV_TB);
+  unsigned gx, gy;
+  fv_grid(T, E, vec, &gx, &gy);
   const size_t nblk = (size_t)gx * gy;
-  if (nblk > g_fv_cap) {
-    if (g_fv_partial) (void)hipFree(g_fv_partial);
-    MH_HIP(hipMalloc((void**)&g_fv_partial, nblk * sizeof(float)));
-    g_fv_cap = nblk;
-  }
   const dim3 grid(gx, gy), blk(256);
 #define FV_KERNEL k_filtered_verts
 #define FV_LAUNCH(VEC, OW)                                                                                       \
@@ -469,14 +475,14 @@ static int filtered_verts_term(int T, size_t E, const float* verts, const float*
 
 extern "C" int mh_filtered_verts_term(int T, size_t E, const float* verts, const float* verts_filt,
                                       const float* prev_v, const float* prev_vf, const float* next_v,
-                                      const float* next_vf, float coef, float* gverts, float* loss_out, void* stream) {
-  return filtered_verts_term(T, E, verts, verts_filt, prev_v, prev_vf, next_v, next_vf, coef, gverts, loss_out, false, stream);
+                                      const float* next_vf, float coef, float* gverts, float* loss_out, void* ws, void* stream) {
+  return filtered_verts_term(T, E, verts, verts_filt, prev_v, prev_vf, next_v, next_vf, coef, gverts, loss_out, false, ws, stream);
 }
 
 extern "C" int mh_filtered_verts_term_init(int T, size_t E, const float* verts, const float* verts_filt,
                                            const float* prev_v, const float* prev_vf, const float* next_v,
-                                           const float* next_vf, float coef, float* gverts, float* loss_out, void* stream) {
-  return filtered_verts_term(T, E, verts, verts_filt, prev_v, prev_vf, next_v, next_vf, coef, gverts, loss_out, true, stream);
+                                           const float* next_vf, float coef, float* gverts, float* loss_out, void* ws, void* stream) {
+  return filtered_verts_term(T, E, verts, verts_filt, prev_v, prev_vf, next_v, next_vf, coef, gverts, loss_out, true, ws, stream);
 }
 
 // =============================================================================================

@@ -73,8 +73,10 @@ def lib():
         L.mh_one_euro_scan.argtypes = [vp, vp, ctypes.c_int, ctypes.c_size_t] + [ctypes.c_float] * 3 + [vp]
         L.mh_one_euro_scan_shard.argtypes = [vp, vp, ctypes.c_int, ctypes.c_size_t] + [ctypes.c_float] * 3 + [ctypes.c_int, ctypes.c_float, vp, vp, vp, vp]
         L.mh_velocity_term.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_float, vp, vp, vp]
-        L.mh_filtered_verts_term.argtypes = [ctypes.c_int, ctypes.c_size_t] + [vp] * 6 + [ctypes.c_float, vp, vp, vp]
-        L.mh_filtered_verts_term_init.argtypes = [ctypes.c_int, ctypes.c_size_t] + [vp] * 6 + [ctypes.c_float, vp, vp, vp]
+        L.mh_filtered_verts_term.argtypes = [ctypes.c_int, ctypes.c_size_t] + [vp] * 6 + [ctypes.c_float, vp, vp, vp, vp]
+        L.mh_filtered_verts_term_init.argtypes = [ctypes.c_int, ctypes.c_size_t] + [vp] * 6 + [ctypes.c_float, vp, vp, vp, vp]
+        L.mh_filtered_verts_workspace_bytes.restype = ctypes.c_size_t
+        L.mh_filtered_verts_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_size_t]
         u32p = vp
         L.mh_warmup_project.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, c_float_p, c_float_p, vp,
                                         ctypes.c_float, ctypes.c_float, vp, vp, vp]
@@ -139,3 +141,25 @@ def stream_ptr(device=None):
 def host_f32(a):
     a = np.ascontiguousarray(a, dtype=np.float32)
     return a, a.ctypes.data_as(c_float_p)
+
+
+def on_own_device(cls):
+    """Class decorator: every public method runs with the object's device current (``self.dev`` / ``self.device``).  The C
+    ABI launches on the stream it is handed and allocates / sets attributes on the CURRENT device, so an engine built for
+    "cuda:1" must not depend on the caller having selected that device (predict.py passes an arbitrary device_name)."""
+    import functools
+    import torch
+
+    def wrap(fn):
+        @functools.wraps(fn)
+        def inner(self, *a, **kw):
+            dev = getattr(self, 'dev', None) or getattr(self, 'device', None)
+            if dev is None or getattr(dev, 'type', 'cpu') != 'cuda' or torch.cuda.current_device() == (dev.index or 0):
+                return fn(self, *a, **kw)
+            with torch.cuda.device(dev):
+                return fn(self, *a, **kw)
+        return inner
+    for name, attr in list(vars(cls).items()):
+        if callable(attr) and not name.startswith('__') and not isinstance(attr, (staticmethod, classmethod, property)):
+            setattr(cls, name, wrap(attr))
+    return cls

@@ -47,6 +47,7 @@ def _dense(a, dtype=np.float32):
     return np.ascontiguousarray(np.array(a, dtype=dtype))
 
 
+@_lib.on_own_device
 class BodyModel(object):
     """Device-resident SMPL constants (an ``mh_model``)."""
 
@@ -231,7 +232,9 @@ def filtered_verts_term(verts, verts_filt, coef, gverts, prev=None, nxt=None):
     loss = torch.empty(1, dtype=torch.float32, device=verts.device)
     pv, pvf = prev if prev is not None else (None, None)
     nv, nvf = nxt if nxt is not None else (None, None)
-    check(_lib.lib().mh_filtered_verts_term(T, verts.numel() // T, ptr(verts), ptr(verts_filt), ptr(pv), ptr(pvf),
-                                            ptr(nv), ptr(nvf), float(coef), ptr(gverts), ptr(loss),
+    E = verts.numel() // T
+    ws = torch.empty(_lib.lib().mh_filtered_verts_workspace_bytes(T, E), dtype=torch.uint8, device=verts.device)
+    check(_lib.lib().mh_filtered_verts_term(T, E, ptr(verts), ptr(verts_filt), ptr(pv), ptr(pvf),
+                                            ptr(nv), ptr(nvf), float(coef), ptr(gverts), ptr(loss), ptr(ws),
                                             _lib.stream_ptr(verts.device)))
     return loss

@@ -6,6 +6,7 @@ from . import _lib
 from ._lib import check, ptr
 
 
+@_lib.on_own_device
 class RasterTerms(object):
     """Callable handed to ``SequenceEngine.cycle``: adds the depth and silhouette terms of all
     local frames (reference optimizer.py:425-477) to ``gverts`` / the depth-range gradients and
@@ -13,6 +14,7 @@ class RasterTerms(object):
 
     def __init__(self, engine, znear=1.0, zfar=100.0):
         e = engine
+        self.dev = e.dev
         self.faces = torch.as_tensor(np.ascontiguousarray(np.asarray(e.m.faces).astype(np.int32))).to(e.dev)
         self.ws = torch.empty(_lib.lib().mh_raster_workspace_bytes(e.T, e.N, e.V, self.faces.shape[0], e.H, e.W), dtype=torch.uint8, device=e.dev)
         self.K = np.ascontiguousarray(e.K.reshape(9))

@@ -30,6 +30,7 @@ def _dev(a, device, dtype=torch.float32):
     return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(device).contiguous()
 
 
+@_lib.on_own_device
 class SequenceEngine(object):
     def __init__(self, model, image_size, num_frames, num_people, cam_K, cam_dist_coef=None, coefs=None,
                  joint_confidence_thr=0.5, eps=1e-3, batch_size=10, max_cycles=1024, joint_weights=None):
@@ -60,6 +61,7 @@ class SequenceEngine(object):
         self.shared_lo = int(self.offs[4])          # betas | xscale: the all-reduced tail
         self.ws = model.workspace(B)
         self.ws2 = model.backward_workspace(B)
+        self.fv_ws = torch.empty(_lib.lib().mh_filtered_verts_workspace_bytes(T, N * self.V * 3), dtype=torch.uint8, device=self.dev)
         self.verts = z(B, self.V, 3)
         self.vposed = z(B, self.V, 3)
         self.gverts = None
@@ -442,7 +444,7 @@ class SequenceEngine(object):
                     ev = self._tic('filtered_verts')
                     check(L.mh_filtered_verts_term_init(T, E, ptr(self.verts), ptr(self.verts_filt), ptr(h.get('v_prev')),
                                                         ptr(h.get('vf_prev')), ptr(h.get('v_next')), ptr(h.get('vf_next')),
-                                                        float(c['reg_verts_filter']), ptr(gv), ptr(log[8:9]), s2))
+                                                        float(c['reg_verts_filter']), ptr(gv), ptr(log[8:9]), ptr(self.fv_ws), s2))
                     self._toc(ev)
                 else:
                     gv.zero_()

@@ -238,3 +238,76 @@ def test_c1_shape_one_human_square_image(smpl_struct, smpl_regs, oracle_model, t
     """C1's shape (MuPoTs TS1: 2048^2 x 0.125 = 256x256, one human, 50 frames, batch 10) on the device"""
     opt, dl, o, batches, seq = _setup(smpl_struct, smpl_regs, oracle_model, tmp_path, 50, 1, 256, 256, 10, 53, True)
     _cycle_vs_oracle(opt, dl, o, batches)
+
+
+def test_c4_shard_of_250_frames_with_halos(smpl_struct, smpl_regs, oracle_model, tmp_path):
+    """One rank's share of BASELINE config C4 (4 humans x 2000 frames over 8 GPUs = 250 frames per GPU): frames
+    [10, 260) of a longer sequence on a ``SequenceEngine`` whose ``first_frame > 0``, with the one-frame halos of the
+    velocity term injected from the neighbouring frames, against the oracle on the WHOLE sequence restricted to the
+    shard's batches (per-frame gradients, and the shard's share of the replicated shape / scale gradients that the
+    all-reduce would sum)."""
+    from mhhip.raster import RasterTerms
+    from mhhip.sequence import SequenceEngine
+    T, N, W, H, batch, f0, f1 = 270, 4, 240, 135, 10, 10, 260
+    opt, dl, o, batches, seq = _setup(smpl_struct, smpl_regs, oracle_model, tmp_path, T, N, W, H, batch, 57, True)
+    full = {n: p.detach().numpy().copy() for n, p in zip(['poses_T', 'poses_smpl', 'betas', 'zmin_lin', 'zmax_lin', 'xscale'], o.leaves())}
+    sl = slice(f0, f1)
+    e = SequenceEngine(opt.SMPLPY.body_model, (W, H), f1 - f0, N, opt.cam_K, None, dict(gi.COEFS), batch_size=batch)
+    e.set_leaves(full['poses_T'][sl], full['poses_smpl'][sl], full['betas'], full['zmin_lin'][sl], full['zmax_lin'][sl], full['xscale'])
+    betas_ref = np.mean(seq['betas_smpl'], axis=0)
+    e.stage(seq['pose2d'][sl], seq['poses_smpl'][sl], (seq['valid_smpl'][sl] > 0.7).astype(np.float32), betas_ref, seq['seg_mask'][sl],
+            seq['depths'][sl])
+    e.scene_from_depth(opt.scene_depth, seq['backmasks'].min(axis=0) > 0)
+    dev = e.dev
+    e.halo = {'pT_prev': torch.tensor(full['poses_T'][f0 - 1]).view(N, 3).to(dev), 'pT_next': torch.tensor(full['poses_T'][f1]).view(N, 3).to(dev)}
+    e.cycle_begin()
+    e.cycle_finish(0, raster=RasterTerms(e))
+    log = e.read_log(1)[0]
+    want = o.cycle_grads(batches[f0 // batch:f1 // batch])          # the shard's 25 batches + the full-sequence temporal term
+    for k in ['loss_pose24j', 'loss_depth', 'loss_silhouette', 'reg_contact', 'reg_foot_sliding']:
+        np.testing.assert_allclose(log[k], want[k], rtol=3e-3, atol=1e-6, err_msg=k)
+    for name, ename in LEAF_MAP:
+        w = _oracle_grad(o, name)
+        if name in ('poses_T', 'poses_smpl', 'zmin_lin', 'zmax_lin'):
+            w = w[sl]
+        g = e.leaf(ename, e.grads).cpu().numpy().reshape(w.shape)
+        scale = max(np.abs(w).max(), 1e-8)
+        err = np.abs(g - w)
+        bad = float((err > 5e-3 * scale).mean())
+        assert bad < 0.01 and np.median(err) < 1e-3 * scale, '%s: %.4f of entries above 5e-3*max, median %.2e' % (name, bad, np.median(err))
+    # the halo matters: the boundary frames' translation gradient contains the pull of frames 9 and 260
+    gT = e.leaf('poses_T', e.grads).cpu().numpy()
+    vel_pull = 2 * gi.COEFS['reg_velocity'] * (full['poses_T'][f0, :, 0] - full['poses_T'][f0 - 1, :, 0])
+    assert np.abs(vel_pull).max() > 1e-4 * np.abs(gT[0]).max()
+
+
+def test_optimized_variables_pickle_round_trip(smpl_struct, smpl_regs, tmp_path):
+    """f4: the dict of ``get_optimized_variables`` written and re-read the way predict.py:333-347 does
+    (``optvar_init.pkl`` / ``optvar_stage1.pkl``), keys, shapes and dtypes as the reference's (optimizer.py:619-636)"""
+    import pickle
+    fin = gi.fit_inputs()
+    opt = _new_opt(smpl_struct, smpl_regs, tmp_path, fin)
+    opt.init_optimized_variables(fin['pose2d'], fin['poses_smpl'], fin['betas_smpl'], fin['valid_smpl'], num_iter=5)
+    T, N, H, W = fin['T'], fin['N'], fin['H'], fin['W']
+    shapes = {'scale_factor': (1, N, 1, 1), 'poses_T': (T, N, 1, 3), 'poses_smpl': (T, N, 72), 'betas_smpl': (1, N, 10),
+              'valid_smpl': (T, N, 1), 'min_z': (T, 1, 1), 'max_z': (T, 1, 1)}
+    for stage, fit in (('optvar_init.pkl', False), ('optvar_stage1.pkl', True)):
+        if fit:
+            opt.scene_update = 'device'
+            opt.fit(torch.utils.data.DataLoader(_DS(fin), batch_size=5, shuffle=False), num_iter=32)
+        ov = opt.get_optimized_variables()
+        path = str(tmp_path / stage)
+        with open(path, 'wb') as fh:
+            pickle.dump(ov, fh)
+        with open(path, 'rb') as fh:
+            back = pickle.load(fh)
+        assert set(back.keys()) == {'scale_factor', 'poses_T', 'poses_smpl', 'betas_smpl', 'valid_smpl', 'min_z', 'max_z',
+                                    'scene_depth', 'scene_img', 'scene_mask'}
+        for k, shp in shapes.items():
+            assert isinstance(back[k], np.ndarray) and back[k].shape == shp and back[k].dtype == np.float32, (k, back[k].shape, back[k].dtype)
+            np.testing.assert_array_equal(back[k], ov[k])
+        if fit:
+            assert back['scene_depth'].shape == (H, W) and back['scene_img'].shape == (H, W, 3) and back['scene_img'].dtype == np.uint8
+            assert back['scene_mask'].shape == (H, W)
+        else:
+            assert back['scene_depth'] is None

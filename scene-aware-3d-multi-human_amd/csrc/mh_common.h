@@ -82,8 +82,8 @@ struct mh_model {
   uint16_t* Dt16;  // [VP/16][3][7][2][64][8] bf16 (hi, lo) terms of the basis, backward B operand of
                    // v_mfma_f32_32x32x16_bf16 (contraction over the 16 vertices of a block): lane l = (basis column
                    // 32 ct + (l&31), vertex half l>>5) holds vertices 16 blk + 8 (l>>5) + 0..7 of component c
-  uint16_t* W16;   // [VP/32][2][2][64][8] bf16 (hi, lo) terms of the dense skinning weights, B operand of
-                   // v_mfma_f32_16x16x32_bf16 (two joint tiles of 16, 24 joints used)
+  uint16_t* W16;   // [VP/16][2][64][8] bf16 (hi, lo) terms of the dense skinning weights, B operand of
+                   // v_mfma_f32_32x32x16_bf16: lane l = (joint l&31 (24 used), vertex half l>>5)
   int* skidx;      // [VP][nw] bones of the <= nw non-zero skinning weights per vertex
   float* skw;      // [VP][nw]
   float* Jt;       // [24][3]     J_regressor . v_template
@@ -95,6 +95,7 @@ struct mh_model {
   int* kpv_ptr;    // [VP+1]
   int* kpv_j;      // [nnz]
   float* kpv_w;    // [nnz]
+  int* kpv_head;   // [VP][4] (first entry, entry count, first joint, first weight bits)
 };
 
 static inline int mh_groups(int B) { return (B + 31) / 32; }

@@ -675,6 +675,7 @@ struct SkinBwdP {
   const int* kpv_ptr;
   const int* kpv_j;
   const float* kpv_w;
+  const int* kpv_head;
   float* pF;   // [CH][GB][224]
   float* pA;   // [CH][GB][12][24]
   float* pS;   // [CH][GB][4]  (gT.xyz, gscale)
@@ -879,15 +880,12 @@ __global__ __launch_bounds__(256, 2) void k_skin_bwd(SkinBwdP p) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // Split-bf16 backward (default).  The two dense adjoints of the skinning pass are contractions over the vertices
-// with a per-lane element-wise operand:
-//     gfeat[b][k]      = sum_{v,c} gv[b][v][c] . D[k][v][c]              gv = T^T (s g)    (k_featgrad16)
-//     gA[b][j][r][c]   = sum_v     W[v][j] . (s g_r)[b][v] . [q;1]_c[b][v]                 (k_jointgrad16)
-// Lane = (body of a group of 32, vertex half): a lane evaluates its body at the 8 vertices 16 blk + 8 half + 0..7, and
-// those eight values, as two bf16 terms, ARE the A operand of v_mfma_f32_32x32x16_bf16; the B operands are the
-// constant tables Dt16 / W16 (two bf16 terms each); three products per operand pair, fp32 accumulation.  Two kernels
-// because the accumulators do not fit one register file (7 x 16 + 12 x 16); the joint kernel needs no bone blend.
-// A workgroup = one body group x one vertex chunk, its four waves take the chunk's 16-vertex blocks round-robin and
-// are summed through LDS in fixed order; chunks are summed in fixed order by k_pose_bwd (deterministic).
+// with a per-(body, vertex) element-wise operand:
+//     gfeat[b][k]      = sum_{v,c} gv[b][v][c] . D[k][v][c]              gv = T^T (s g)
+//     gA[b][j][r][c]   = sum_v     W[v][j] . (s g_r)[b][v] . [q;1]_c[b][v]
+// The element-wise values of 32 bodies x 16 vertices, as two bf16 terms, ARE the A operand of
+// v_mfma_f32_32x32x16_bf16 (lane = (body, vertex half), eight vertices per lane); the B operands are the constant
+// tables Dt16 / W16 (two bf16 terms each); three products per operand pair, fp32 accumulation.
 // ---------------------------------------------------------------------------------------------------------------
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 typedef __bf16 bfx8 __attribute__((ext_vector_type(8)));
@@ -925,199 +923,52 @@ struct Bwd16P {
   const int* kpv_ptr;
   const int* kpv_j;
   const float* kpv_w;
+  const int* kpv_head;
   float* pF;   // [CH][GB][224]
   float* pA;   // [CH][GB][12][24]
   float* pS;   // [CH][GB][4]  (gT.xyz, gscale)
 };
 
-// One wave's (32 bodies x 16 vertices) block of a (B,V,3) array, fetched with row-coalesced 12-byte loads (16 lanes
-// = the 192 contiguous bytes of one body) and transposed through a wave-private LDS buffer into the operand layout:
-// lane (body l&31, half l>>5) receives its eight vertices 8 (l>>5) + 0..7.  (Letting every lane read its own body row
-// straight from memory touches 64 cache lines per instruction and thrashed the 32 KB L1: 6x the bytes from L2.)
-#define BW_TS 20                                   // padded row stride (floats): conflict-free ds_read_b128
-#define BW_TBUF (3 * 32 * BW_TS)                   // floats per wave
-__device__ __forceinline__ void bwd16_fetch(const float* __restrict__ src, int B, int V, int g, int blk, int lane,
-                                            f32x3 r[8]) {
-  if (!src) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) r[k] = (f32x3){0.f, 0.f, 0.f};
-    return;
-  }
-  const int vx = blk * 16 + (lane & 15);
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int b = g * 32 + 4 * k + (lane >> 4);
-    const bool ok = b < B && vx < V;                 // clamped address + select: no divergent branch per load
-    const f32x3 x = *(const f32x3*)(src + ((size_t)(b < B ? b : B - 1) * V + (vx < V ? vx : V - 1)) * 3);
-    r[k] = (f32x3){ok ? x[0] : 0.f, ok ? x[1] : 0.f, ok ? x[2] : 0.f};
-  }
-}
-__device__ __forceinline__ void bwd16_transpose(float* buf, int lane, const f32x3 r[8], float out[8][3]) {
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int k = 0; k < 8; ++k)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) buf[(c * 32 + 4 * k + (lane >> 4)) * BW_TS + (lane & 15)] = r[k][c];
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const f32x4* q = (const f32x4*)(buf + (c * 32 + (lane & 31)) * BW_TS + 8 * (lane >> 5));
-    const f32x4 a = q[0], b = q[1];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) { out[t][c] = a[t]; out[4 + t][c] = b[t]; }
-  }
-  __builtin_amdgcn_wave_barrier();
-}
-// key-point regressor adjoint of the lane's eight vertices: dL/dverts += R^T dL/djoints (~670 entries over the mesh)
-__device__ __forceinline__ void bwd16_kp(const Bwd16P& p, int v0, const float* sGjb, float g[8][3]) {
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    const int ke0 = p.kpv_ptr[v0 + t], ke1 = p.kpv_ptr[v0 + t + 1];
-    for (int e = ke0; e < ke1; ++e) {
-      const float w = p.kpv_w[e];
-      const float* gj = sGjb + p.kpv_j[e] * 3;
-      g[t][0] = fmaf(w, gj[0], g[t][0]);
-      g[t][1] = fmaf(w, gj[1], g[t][1]);
-      g[t][2] = fmaf(w, gj[2], g[t][2]);
-    }
-  }
-}
-
-#ifndef JG_OCC
-#define JG_OCC 2
+#define BW_TS 20                                   // padded body-row stride (floats): conflict-free ds_read_b128
+#ifndef SB_OCC
+#define SB_OCC 2
 #endif
-#ifndef FG_OCC
-#define FG_OCC 1
+#ifndef SB_FENCE2
+#define SB_FENCE2
 #endif
-#define MFMA16_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
-#define JG_TS 36                                   // padded row stride (floats) of the joint kernel's transpose buffer
-#define JG_TBUF (3 * 16 * JG_TS)
-// Joint-transform gradient on 16x16x32 tiles (12 x 2 x 4 accumulator registers for 16 bodies x 24 joints x 12 entries):
-// a wave = 16 bodies of the group (wave & 1) on one of two vertex streams (wave >> 1), blocks of 32 vertices;
-// lane = (body l&15, vertex quarter l>>4) with the vertices 32 blk + 8 (l>>4) + 0..7.
-template <bool HASG, bool KP>
-__global__ __launch_bounds__(256, JG_OCC) void k_jointgrad16(Bwd16P p) {
-  extern __shared__ __attribute__((aligned(16))) float smj[];
-  float* sGj = smj;                    // [32][52]
-  float* sRed = smj + 32 * 52;         // [2][12*2*4][64]; the waves' transpose buffers alias it until the reduction
-  const int g = blockIdx.x, ch = blockIdx.y;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
-  const int bh = wave & 1, vs = wave >> 1;
-  for (int i = tid; i < 32 * 51; i += 256) {
-    const int bb = i / 51, e = i % 51;
-    const int b = g * 32 + bb;
-    sGj[bb * 52 + e] = (p.gjoints && b < p.B) ? p.gjoints[(size_t)b * 51 + e] : 0.f;
-  }
-  __syncthreads();
-  const int b = g * 32 + 16 * bh + li;
-  const bool bvalid = b < p.B;
-  const float sb = bvalid ? p.scale[b] : 0.f;
-  f32x4 acc[12][2];
-#pragma unroll
-  for (int i = 0; i < 12; ++i) acc[i][0] = acc[i][1] = (f32x4){0, 0, 0, 0};
-  const int nblk = p.VP / 32;
-  const int PB32 = (p.PB + 1) / 2;
-  const int bend = min((ch + 1) * PB32, nblk);
-  const bfx8* Wb = (const bfx8*)p.W16 + lane;          // [blk32][joint tile][term][lane]
-  float* tb = sRed + wave * JG_TBUF;
-  for (int blk = ch * PB32 + vs; blk < bend; blk += 2) {
-    const bfx8 wh0 = Wb[(size_t)blk * 256], wl0 = Wb[(size_t)blk * 256 + 64];
-    const bfx8 wh1 = Wb[(size_t)blk * 256 + 128], wl1 = Wb[(size_t)blk * 256 + 192];
-    float gq[8][3], q[8][3];
-    {
-      // row-coalesced fetch (32 lanes = the 384 contiguous bytes of one body), then transpose through LDS
-      const int vx = blk * 32 + (lane & 31);
-      f32x3 rg[8], rq[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int bb = g * 32 + 16 * bh + 2 * k + (lane >> 5);
-        const bool ok = bb < p.B && vx < p.V;
-        const size_t o = ((size_t)(bb < p.B ? bb : p.B - 1) * p.V + (vx < p.V ? vx : p.V - 1)) * 3;
-        const f32x3 xq = *(const f32x3*)(p.vposed + o);
-        f32x3 xg = {0.f, 0.f, 0.f};
-        if (HASG) xg = *(const f32x3*)(p.gverts + o);
-        rq[k] = (f32x3){ok ? xq[0] : 0.f, ok ? xq[1] : 0.f, ok ? xq[2] : 0.f};
-        rg[k] = (f32x3){ok ? xg[0] : 0.f, ok ? xg[1] : 0.f, ok ? xg[2] : 0.f};
-      }
-#pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) tb[(c * 16 + 2 * k + (lane >> 5)) * JG_TS + (lane & 31)] = pass ? rq[k][c] : rg[k][c];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const f32x4* src = (const f32x4*)(tb + (c * 16 + li) * JG_TS + 8 * lq);
-          const f32x4 a = src[0], bq = src[1];
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            if (pass) { q[t][c] = a[t]; q[4 + t][c] = bq[t]; }
-            else { gq[t][c] = a[t]; gq[4 + t][c] = bq[t]; }
-          }
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-    if (KP) bwd16_kp(p, blk * 32 + 8 * lq, sGj + (16 * bh + li) * 52, gq);
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float a[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) a[t] = (c < 3) ? sb * gq[t][r] * q[t][c] : sb * gq[t][r];
-        bfx8 ah, al;
-        mh_split_bf16x8(a, ah, al);
-        const int rc = r * 4 + c;
-        acc[rc][0] = MFMA16_BF16(ah, wh0, acc[rc][0]);
-        acc[rc][1] = MFMA16_BF16(ah, wh1, acc[rc][1]);
-        acc[rc][0] = MFMA16_BF16(ah, wl0, acc[rc][0]);
-        acc[rc][1] = MFMA16_BF16(ah, wl1, acc[rc][1]);
-        acc[rc][0] = MFMA16_BF16(al, wh0, acc[rc][0]);
-        acc[rc][1] = MFMA16_BF16(al, wh1, acc[rc][1]);
-      }
-    }
-  }
-  // sum the two vertex streams of each body half through LDS (fixed order); element (rc, jt, reg) of lane l is
-  // C[body = 4 (l>>4) + reg][joint = 16 jt + (l&15)]
-  __syncthreads();                     // every wave is done with its transpose buffer
-  float* myRed = sRed + bh * (12 * 2 * 4 * 64);
-  for (int w = 0; w < 2; ++w) {
-    if (vs == w) {
-#pragma unroll
-      for (int rc = 0; rc < 12; ++rc)
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float* qd = myRed + ((rc * 2 + jt) * 4 + r) * 64 + lane;
-            *qd = (w == 0) ? acc[rc][jt][r] : (*qd + acc[rc][jt][r]);
-          }
-    }
-    __syncthreads();
-  }
-  const size_t GB = (size_t)p.G * 32;
-  float* oA = p.pA + ((size_t)ch * GB + (size_t)g * 32) * 288;
-  for (int i = tid; i < 2 * 12 * 2 * 4 * 64; i += 256) {
-    const int hb = i / (12 * 2 * 4 * 64), e = i % (12 * 2 * 4 * 64);
-    const int rc = e >> 9, jt = (e >> 8) & 1, r = (e >> 6) & 3, l = e & 63;
-    const int row = 16 * hb + 4 * (l >> 4) + r, joint = 16 * jt + (l & 15);
-    if (joint < MH_NJ) oA[(size_t)row * 288 + rc * MH_NJ + joint] = sRed[i];
-  }
-}
-
-#ifndef FG_RING
-#define FG_RING 8
+#ifndef SB_FENCE
+#define SB_FENCE
 #endif
+#define SB_GS 33                                   // vertex-row stride (floats) of the vertex-major adjoint tile
+#define SB_LDS_FLOATS (32 * BWD_AS + 32 * 52 + 3 * 16 * SB_GS + 7 * 32 * BW_TS + 3 * 2 * 64 * 4 + 8 * 32 * 3)
+// One kernel for both adjoints.  A workgroup = one body group x one vertex chunk, walked in blocks of 16 vertices; its
+// four waves share each block through LDS instead of each owning blocks:
+//   stage   256 threads fetch the block's adjoints and posed vertices row-coalesced (16 lanes = the 192 contiguous
+//           bytes of one body) -- the next block's rows are requested before this block's arithmetic;
+//   blend   thread = (body tid&31, vertex pair tid>>5): bone-blended transform, key-point adjoint, gv = T^T (s g); the
+//           pair's (hi, lo) bf16 terms go to LDS already in A-fragment order (one dword per term and component), s g
+//           goes back body-major.  A half wave shares its vertex, so the skinning rows are broadcast loads;
+//   mfma    every wave reads the SAME A fragments and owns output columns: wave w the basis columns 64 w .. 64 w + 63
+//           (two 32-wide tiles, the fourth wave one) and the joint-gradient entries 3 w .. 3 w + 2 of the twelve; it
+//           alone reads the B fragments of those columns -- one pass over Dt16 per workgroup, not one per wave.
+// 80 accumulator registers per lane instead of 112 / 192: two workgroups per CU (75 KB of LDS each), eight waves to
+// cover the LDS and barrier waits that the one-wave-per-SIMD two-kernel version (r02a) exposed.  No cross-wave
+// reduction: a wave's accumulators cover the chunk's every vertex.  Chunks are summed in fixed order by k_pose_bwd.
 template <bool NW4, bool KP>
-__global__ __launch_bounds__(256, FG_OCC) void k_featgrad16(Bwd16P p) {
-  extern __shared__ __attribute__((aligned(16))) float smf[];
-  float* sA = smf;                        // [32][BWD_AS]
-  float* sGj = sA + 32 * BWD_AS;          // [32][52]
-  float* sRed = sGj + 32 * 52;            // [7*16][64] + [32][4]; the waves' transpose buffers alias it until the reduction
-  const int g = blockIdx.x, ch = blockIdx.y;
+__global__ __launch_bounds__(256, SB_OCC) void k_skinbwd16(Bwd16P p) {
+  extern __shared__ __attribute__((aligned(16))) float smb[];
+  float* sA = smb;                            // [32][BWD_AS]
+  float* sGj = sA + 32 * BWD_AS;              // [32][52]
+  float* sGv = sGj + 32 * 52;                 // [3][16][SB_GS]   adjoints, vertex-major (blend: lanes = bodies)
+  float* sGx = sGv + 3 * 16 * SB_GS;          // [3][32][BW_TS]   s (g + R^T gj), body-major (mfma phase)
+  float* sQ = sGx + 3 * 32 * BW_TS;           // [4][32][BW_TS]   posed vertices, body-major; [3] = ones
+  unsigned* sF = (unsigned*)(sQ + 4 * 32 * BW_TS);   // [3][2][64][4]  bf16 (hi, lo) A fragments of gv
+  float* sTr = (float*)(sF + 3 * 2 * 64 * 4);        // [8][32][3]
+  // Workgroups go to the eight XCDs round-robin; XCD x takes the x-th eighth of the (chunk-major) work list, so a
+  // chunk's slice of Dt16 / W16 is fetched into ~one L2 instead of all eight (measured: 150 MB less HBM-side traffic).
+  const int per = gridDim.x >> 3, item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (item >= p.G * p.CH) return;
+  const int g = item % p.G, ch = item / p.G;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   for (int i = tid; i < 32 * MH_NJ * 12; i += 256) {
     const int bb = i / (MH_NJ * 12), e = i % (MH_NJ * 12);
@@ -1128,86 +979,117 @@ __global__ __launch_bounds__(256, FG_OCC) void k_featgrad16(Bwd16P p) {
     const int b = g * 32 + bb;
     sGj[bb * 52 + e] = (p.gjoints && b < p.B) ? p.gjoints[(size_t)b * 51 + e] : 0.f;
   }
-  __syncthreads();
-  const int b = g * 32 + li;
-  const bool bvalid = b < p.B;
-  const float sb = bvalid ? p.scale[b] : 0.f;
-  f32x16 acc[7];
+  const int bi = tid & 31, vs = tid >> 5;      // blend phase: body, vertex pair
+  const float sb = (g * 32 + bi < p.B) ? p.scale[g * 32 + bi] : 0.f;
+  const float* sAb = sA + bi * BWD_AS;
+  f32x16 accF[2], accA[3];
 #pragma unroll
-  for (int i = 0; i < 7; ++i) acc[i] = (f32x16){0};
+  for (int i = 0; i < 2; ++i) accF[i] = (f32x16){0};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) accA[i] = (f32x16){0};
   float sT0 = 0, sT1 = 0, sT2 = 0;
-  const float sS = 0.f;                // see k_pose_bwd (scale_from_joint_sums)
   const int nblk = p.VP / 16;
-  const int bend = min((ch + 1) * p.PB, nblk);
-  const float* sAb = sA + li * BWD_AS;
-  const bfx8* Db = (const bfx8*)p.Dt16 + lane;     // [blk][c][ct][term][lane] in 16-byte units: 42 x 64 per block
-  const int nw4 = p.nw < 4 ? p.nw : 4;
-  // One wave per SIMD: the 7 x 16 accumulators plus the element-wise phase do not fit 256 registers without spilling
-  // accumulators to scratch (measured: 163 us with 2 waves + spills against 100 us with 1 wave).
-  for (int blk = ch * p.PB + wave; blk < bend; blk += 4) {
-    const bfx8* Dk = Db + (size_t)blk * 42 * 64;
-    const int v0 = blk * 16 + 8 * lh;
-    float gv[3][8];
-    float* tbuf = sRed + wave * BW_TBUF;
-    {
-      // stage the adjoints [component][body][vertex] in the wave's LDS buffer; they are read back four vertices at
-      // a time inside the blend loop
-      f32x3 rg[8];
-      bwd16_fetch(p.gverts, p.B, p.V, g, blk, lane, rg);
-      __builtin_amdgcn_wave_barrier();
+  const int b0 = ch * p.PB, bend = min((ch + 1) * p.PB, nblk);
+  const bool two = wave < 3;                   // the fourth wave owns one basis tile (and repeats it into a second
+  const int ct0 = 2 * wave, ct1 = two ? 2 * wave + 1 : 6;   // accumulator it never writes: no branches in the loop)
+  for (int i = tid; i < 32 * BW_TS; i += 256) sQ[3 * 32 * BW_TS + i] = 1.f;
+  const bfx8* Db = (const bfx8*)p.Dt16 + lane;   // [blk][c][ct][term][lane] in 16-byte units
+  const bfx8* Wb = (const bfx8*)p.W16 + lane;    // [blk][term][lane]
+  // stage: thread = (row tid>>4 (+16), vertex tid&15)
+  const int fvx = tid & 15, fr = tid >> 4;
+  f32x3 rg[2], rq[2];
+  auto fetch = [&](int blk) {
+    const int v = blk * 16 + fvx;
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) tbuf[(c * 32 + 4 * k + (lane >> 4)) * BW_TS + (lane & 15)] = rg[k][c];
-      __builtin_amdgcn_wave_barrier();
+    for (int k = 0; k < 2; ++k) {
+      // Clamped addresses, no masking: a padding body has scale 0 (its s g, gv and products vanish), a padding
+      // vertex has zero rows in Dt16 / W16; only the plain sum of g (the translation gradient) masks them, below.
+      const int b = g * 32 + fr + 16 * k;
+      const size_t o = ((size_t)(b < p.B ? b : p.B - 1) * p.V + (v < p.V ? v : p.V - 1)) * 3;
+      rq[k] = *(const f32x3*)(p.vposed + o);
+      rg[k] = (f32x3){0.f, 0.f, 0.f};
+      if (p.gverts) rg[k] = *(const f32x3*)(p.gverts + o);
     }
-    float gq[4][3];
-    // skinning rows are fetched one vertex ahead (and no further: the scheduler is fenced per vertex, it otherwise
-    // hoists all eight rows and spills)
-    int4 nj4 = {0, 0, 0, 0};
-    f32x4 nw4v = {0.f, 0.f, 0.f, 0.f};
-    if (NW4) { nj4 = *(const int4*)(p.skidx + (size_t)v0 * 4); nw4v = *(const f32x4*)(p.skw + (size_t)v0 * 4); }
+  };
+  // skinning rows and key-point head rows of the thread's vertex pair: requested AHEAD of the block's B operands
+  // (memory returns in order: behind them they would wait for all 14 KB)
+  int4 j4[2], kh[2];
+  f32x4 w4[2];
+  auto fetch_rows = [&](int blk) {
+    const int vp = blk * 16 + 2 * vs;            // padded rows exist up to VP
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const int v = v0 + t;                                       // padded rows of the skinning table exist up to VP
-      if ((t & 3) == 0) {
+    for (int u = 0; u < 2; ++u) {
+      if (NW4) {
+        j4[u] = *(const int4*)(p.skidx + (size_t)(vp + u) * 4);
+        w4[u] = *(const f32x4*)(p.skw + (size_t)(vp + u) * 4);
+      }
+      if (KP) kh[u] = *(const int4*)(p.kpv_head + (size_t)(vp + u) * 4);
+    }
+  };
+  if (b0 < bend) fetch(b0);
+  for (int blk = b0; blk < bend; ++blk) {
+    // ---- stage ----
+    fetch_rows(blk);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const f32x4 a = *(const f32x4*)(tbuf + (c * 32 + li) * BW_TS + 8 * lh + t);
+    for (int k = 0; k < 2; ++k)
 #pragma unroll
-          for (int u = 0; u < 4; ++u) gq[u][c] = a[u];
+      for (int c = 0; c < 3; ++c) sGv[(c * 16 + fvx) * SB_GS + fr + 16 * k] = rg[k][c];
+    // B operands of this block (constant tables, L2 resident): requested here, used after the blend
+    const bfx8* Dk = Db + (size_t)blk * 42 * 64;
+    bfx8 bD[3][2][2], bW[2];
+    auto fetch_b = [&](int c) {
+      bD[c][0][0] = Dk[((c * 7 + ct0) * 2) * 64];
+      bD[c][0][1] = Dk[((c * 7 + ct0) * 2 + 1) * 64];
+      bD[c][1][0] = Dk[((c * 7 + ct1) * 2) * 64];
+      bD[c][1][1] = Dk[((c * 7 + ct1) * 2 + 1) * 64];
+    };
+    fetch_b(0);
+    fetch_b(1);
+    fetch_b(2);
+    const int vp = blk * 16 + 2 * vs;            // first vertex of the thread's pair
+    SB_FENCE;
+    __syncthreads();                             // (A) adjoint tile complete; every wave is past the last mfma phase
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) sQ[(c * 32 + fr + 16 * k) * BW_TS + fvx] = rq[k][c];
+    if (blk + 1 < bend) fetch(blk + 1);
+    // ---- blend ----
+    float gvp[3][2], gxp[3][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int vl = 2 * vs + u, v = vp + u;
+      float g0 = sGv[(0 * 16 + vl) * SB_GS + bi], g1 = sGv[(1 * 16 + vl) * SB_GS + bi], g2 = sGv[(2 * 16 + vl) * SB_GS + bi];
+      if (KP && kh[u].y > 0) {   // key-point regressor adjoint: dL/dverts += R^T dL/djoints (~670 entries over the mesh)
+        {
+          const float w = __builtin_bit_cast(float, kh[u].w);
+          const float* gj = sGj + bi * 52 + kh[u].z * 3;
+          g0 = fmaf(w, gj[0], g0);
+          g1 = fmaf(w, gj[1], g1);
+          g2 = fmaf(w, gj[2], g2);
         }
-        if (KP) {   // key-point regressor adjoint: dL/dverts += R^T dL/djoints (~670 entries over the mesh)
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int ke0 = p.kpv_ptr[v + u], ke1 = p.kpv_ptr[v + u + 1];
-            for (int e = ke0; e < ke1; ++e) {
-              const float w = p.kpv_w[e];
-              const float* gj = sGj + li * 52 + p.kpv_j[e] * 3;
-              gq[u][0] = fmaf(w, gj[0], gq[u][0]);
-              gq[u][1] = fmaf(w, gj[1], gq[u][1]);
-              gq[u][2] = fmaf(w, gj[2], gq[u][2]);
-            }
-          }
+        for (int e = kh[u].x + 1; e < kh[u].x + kh[u].y; ++e) {
+          const float w = p.kpv_w[e];
+          const float* gj = sGj + bi * 52 + p.kpv_j[e] * 3;
+          g0 = fmaf(w, gj[0], g0);
+          g1 = fmaf(w, gj[1], g1);
+          g2 = fmaf(w, gj[2], g2);
         }
       }
       float T[12];
 #pragma unroll
       for (int e = 0; e < 12; ++e) T[e] = 0.f;
       if (NW4) {
-        const int4 j4 = nj4;
-        const f32x4 w4 = nw4v;
-        if (t < 7) { nj4 = *(const int4*)(p.skidx + (size_t)(v + 1) * 4); nw4v = *(const f32x4*)(p.skw + (size_t)(v + 1) * 4); }
-        const int jj[4] = {j4.x, j4.y, j4.z, j4.w};
+        const int jj[4] = {j4[u].x, j4[u].y, j4[u].z, j4[u].w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const f32x4* Aj = (const f32x4*)(sAb + jj[k] * 12);
           const f32x4 a0 = Aj[0], a1 = Aj[1], a2 = Aj[2];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            T[e] = fmaf(w4[k], a0[e], T[e]);
-            T[4 + e] = fmaf(w4[k], a1[e], T[4 + e]);
-            T[8 + e] = fmaf(w4[k], a2[e], T[8 + e]);
+            T[e] = fmaf(w4[u][k], a0[e], T[e]);
+            T[4 + e] = fmaf(w4[u][k], a1[e], T[4 + e]);
+            T[8 + e] = fmaf(w4[u][k], a2[e], T[8 + e]);
           }
           if (k == 1) __builtin_amdgcn_sched_barrier(0);      // two bones (24 registers of LDS data) in flight at a time
         }
@@ -1225,74 +1107,89 @@ __global__ __launch_bounds__(256, FG_OCC) void k_featgrad16(Bwd16P p) {
           }
         }
       }
-      const float g0 = gq[t & 3][0], g1 = gq[t & 3][1], g2 = gq[t & 3][2];
-      sT0 += g0; sT1 += g1; sT2 += g2;
+      if (v < p.V) { sT0 += g0; sT1 += g1; sT2 += g2; }
       // d/d v_posed = R_T^T (s g).  (The scale gradient sum_v g.x needs neither x nor v_posed here: it equals
       // (1/s) sum_j <A_j, dL/dA_j> and is taken from the joint-gradient sums in k_pose_bwd.)
       const float gx0 = sb * g0, gx1 = sb * g1, gx2 = sb * g2;
-      gv[0][t] = fmaf(T[8], gx2, fmaf(T[4], gx1, T[0] * gx0));
-      gv[1][t] = fmaf(T[9], gx2, fmaf(T[5], gx1, T[1] * gx0));
-      gv[2][t] = fmaf(T[10], gx2, fmaf(T[6], gx1, T[2] * gx0));
+      gxp[0][u] = gx0; gxp[1][u] = gx1; gxp[2][u] = gx2;
+      gvp[0][u] = fmaf(T[8], gx2, fmaf(T[4], gx1, T[0] * gx0));
+      gvp[1][u] = fmaf(T[9], gx2, fmaf(T[5], gx1, T[1] * gx0));
+      gvp[2][u] = fmaf(T[10], gx2, fmaf(T[6], gx1, T[2] * gx0));
       __builtin_amdgcn_sched_barrier(0);
     }
-    // B ring: the first FG_RING (component, column tile) steps are requested behind the element-wise phase (their
-    // registers are not free earlier) and land while the operands are being split
-    bfx8 rb[FG_RING][2];
+    bW[0] = Wb[(size_t)blk * 128];               // (their registers were the blend's; used last in the mfma phase)
+    bW[1] = Wb[(size_t)blk * 128 + 64];
+    {
+      // the pair (vertices 2 vs, 2 vs + 1) is one dword of the fragment of lane (body, half vs>>2), dword vs&3
+      const int fl = (vs >> 2) * 32 + bi, fd = vs & 3;
 #pragma unroll
-    for (int i = 0; i < FG_RING; ++i) { rb[i][0] = Dk[(i * 2) * 64]; rb[i][1] = Dk[(i * 2 + 1) * 64]; }
-    bfx8 ah[3], al[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) mh_split_bf16x8(gv[c], ah[c], al[c]);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int st = 0; st < 21; ++st) {
-      const int c = st / 7, ct = st % 7, cur = st % FG_RING;
-      const bfx8 bh = rb[cur][0], bl = rb[cur][1];
-      if (st + FG_RING < 21) {
-        rb[cur][0] = Dk[((st + FG_RING) * 2) * 64];
-        rb[cur][1] = Dk[((st + FG_RING) * 2 + 1) * 64];
-      }
-      acc[ct] = MFMA_BF16(ah[c], bh, acc[ct]);
-      acc[ct] = MFMA_BF16(ah[c], bl, acc[ct]);
-      acc[ct] = MFMA_BF16(al[c], bh, acc[ct]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_wave_barrier();
-  }
-  // ---- reduce: halves of a wave hold different vertices of the same body; then the four waves through LDS ----
-  __syncthreads();                     // every wave is done with its transpose buffer
-  sT0 += __shfl_xor(sT0, 32, 64);
-  sT1 += __shfl_xor(sT1, 32, 64);
-  sT2 += __shfl_xor(sT2, 32, 64);
-  float* sSc = sRed + 7 * 16 * 64;
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
-#pragma unroll
-      for (int ct = 0; ct < 7; ++ct)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float* qd = sRed + (ct * 16 + r) * 64 + lane;
-          *qd = (w == 0) ? acc[ct][r] : (*qd + acc[ct][r]);
-        }
-      if (lh == 0) {
-        float* qd = sSc + li * 4;
-        if (w == 0) { qd[0] = sT0; qd[1] = sT1; qd[2] = sT2; qd[3] = sS; }
-        else { qd[0] += sT0; qd[1] += sT1; qd[2] += sT2; qd[3] += sS; }
+      for (int c = 0; c < 3; ++c) {
+        const f32x2 v2 = {gvp[c][0], gvp[c][1]};
+        const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v2, bfx2));
+        const f32x2 r2 = {v2[0] - __builtin_bit_cast(float, hi << 16), v2[1] - __builtin_bit_cast(float, hi & 0xffff0000u)};
+        sF[((c * 2) * 64 + fl) * 4 + fd] = hi;
+        sF[((c * 2 + 1) * 64 + fl) * 4 + fd] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bfx2));
+        *(f32x2a*)(sGx + (c * 32 + bi) * BW_TS + 2 * vs) = (f32x2a){gxp[c][0], gxp[c][1]};
       }
     }
-    __syncthreads();
+    __syncthreads();                             // (B) fragments, s g and posed vertices of the block are in LDS
+    // ---- mfma ----
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const bfx8 ah = *(const bfx8*)(sF + ((c * 2) * 64 + lane) * 4);
+      const bfx8 al = *(const bfx8*)(sF + ((c * 2 + 1) * 64 + lane) * 4);
+      accF[0] = MFMA_BF16(ah, bD[c][0][0], accF[0]);
+      accF[0] = MFMA_BF16(ah, bD[c][0][1], accF[0]);
+      accF[0] = MFMA_BF16(al, bD[c][0][0], accF[0]);
+      accF[1] = MFMA_BF16(ah, bD[c][1][0], accF[1]);
+      accF[1] = MFMA_BF16(ah, bD[c][1][1], accF[1]);
+      accF[1] = MFMA_BF16(al, bD[c][1][0], accF[1]);
+      SB_FENCE2;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int rc = 3 * wave + k, r = rc >> 2, c = rc & 3;      // wave-uniform
+      const f32x4* gp = (const f32x4*)(sGx + (r * 32 + li) * BW_TS + 8 * lh);
+      const f32x4 ga = gp[0], gb = gp[1];
+      const f32x4* qp = (const f32x4*)(sQ + (c * 32 + li) * BW_TS + 8 * lh);      // c = 3: the row of ones
+      const f32x4 qa = qp[0], qb = qp[1];
+      float a[8];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { a[t] = ga[t] * qa[t]; a[4 + t] = gb[t] * qb[t]; }
+      bfx8 ah, al;
+      mh_split_bf16x8(a, ah, al);
+      accA[k] = MFMA_BF16(ah, bW[0], accA[k]);
+      accA[k] = MFMA_BF16(ah, bW[1], accA[k]);
+      accA[k] = MFMA_BF16(al, bW[0], accA[k]);
+      SB_FENCE2;
+    }
   }
+  // ---- write the chunk's partial sums; element r of lane l is C[body (r&3) + 8 (r>>2) + 4 (l>>5)][column l&31] ----
   const size_t GB = (size_t)p.G * 32;
   const size_t base = (size_t)ch * GB + (size_t)g * 32;
   float* oF = p.pF + base * MH_FS;
-  for (int i = tid; i < 7 * 16 * 64; i += 256) {
-    const int ct = i >> 10, r = (i >> 6) & 15, l = i & 63;
-    const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-    oF[(size_t)row * MH_FS + ct * 32 + (l & 31)] = sRed[i];
+  float* oA = p.pA + base * 288;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+    oF[(size_t)row * MH_FS + (2 * wave) * 32 + li] = accF[0][r];
+    if (two) oF[(size_t)row * MH_FS + (2 * wave + 1) * 32 + li] = accF[1][r];
+    if (li < MH_NJ) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) oA[(size_t)row * 288 + (3 * wave + k) * MH_NJ + li] = accA[k][r];
+    }
   }
-  float* oS = p.pS + base * 4;
-  for (int i = tid; i < 128; i += 256) oS[i] = sSc[i];
+  sTr[(vs * 32 + bi) * 3 + 0] = sT0;
+  sTr[(vs * 32 + bi) * 3 + 1] = sT1;
+  sTr[(vs * 32 + bi) * 3 + 2] = sT2;
+  __syncthreads();
+  if (tid < 128) {
+    const int bb = tid >> 2, c = tid & 3;
+    float s = 0.f;
+    if (c < 3)
+      for (int k = 0; k < 8; ++k) s += sTr[(k * 32 + bb) * 3 + c];
+    p.pS[base * 4 + tid] = s;                    // [3] (the scale term) comes from the joint sums, see k_pose_bwd
+  }
 }
 
 struct PoseBwdP {
@@ -1604,31 +1501,21 @@ extern "C" int mh_lbs_backward(const mh_model* m, int B, int NB, const float* be
     sp.PB = (m->VP / 16 + CH - 1) / CH;
     sp.A = fw.A; sp.scale = fw.scale; sp.vposed = vposed; sp.gverts = gverts; sp.gjoints = gjoints;
     sp.Dt16 = m->Dt16; sp.W16 = m->W16; sp.skidx = m->skidx; sp.skw = m->skw;
-    sp.kpv_ptr = m->kpv_ptr; sp.kpv_j = m->kpv_j; sp.kpv_w = m->kpv_w;
+    sp.kpv_ptr = m->kpv_ptr; sp.kpv_j = m->kpv_j; sp.kpv_w = m->kpv_w; sp.kpv_head = m->kpv_head;
     sp.pF = bw.pF; sp.pA = bw.pA; sp.pS = bw.pS;
-    const size_t ldsF = (size_t)(32 * BWD_AS + 32 * 52 + std::max(7 * 16 * 64 + 128, 4 * BW_TBUF)) * 4;
-    const size_t ldsJ = (size_t)(32 * 52 + std::max(2 * 12 * 2 * 4 * 64, 4 * JG_TBUF)) * 4;
+    const size_t ldsB = (size_t)SB_LDS_FLOATS * 4;
     static bool attr_b16 = false;
     if (!attr_b16) {
-      const void* fk[4] = {(const void*)k_featgrad16<false, false>, (const void*)k_featgrad16<false, true>,
-                           (const void*)k_featgrad16<true, false>, (const void*)k_featgrad16<true, true>};
-      const void* jk[4] = {(const void*)k_jointgrad16<false, false>, (const void*)k_jointgrad16<false, true>,
-                           (const void*)k_jointgrad16<true, false>, (const void*)k_jointgrad16<true, true>};
-      for (int i = 0; i < 4; ++i) {
-        MH_HIP(hipFuncSetAttribute(fk[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsF));
-        MH_HIP(hipFuncSetAttribute(jk[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsJ));
-      }
+      const void* fk[4] = {(const void*)k_skinbwd16<false, false>, (const void*)k_skinbwd16<false, true>,
+                           (const void*)k_skinbwd16<true, false>, (const void*)k_skinbwd16<true, true>};
+      for (int i = 0; i < 4; ++i) MH_HIP(hipFuncSetAttribute(fk[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB));
       attr_b16 = true;
     }
-    const bool nw4 = m->nw == 4, kp = gjoints != nullptr, hasg = gverts != nullptr;
-    auto fkern = nw4 ? (kp ? k_featgrad16<true, true> : k_featgrad16<true, false>)
-                     : (kp ? k_featgrad16<false, true> : k_featgrad16<false, false>);
-    auto jkern = hasg ? (kp ? k_jointgrad16<true, true> : k_jointgrad16<true, false>)
-                      : (kp ? k_jointgrad16<false, true> : k_jointgrad16<false, false>);
+    const bool nw4 = m->nw == 4, kp = gjoints != nullptr;
+    auto kern = nw4 ? (kp ? k_skinbwd16<true, true> : k_skinbwd16<true, false>)
+                    : (kp ? k_skinbwd16<false, true> : k_skinbwd16<false, false>);
     mh_prof_mark(MH_PROF_SKIN_BWD, 0, st);
-    hipLaunchKernelGGL(fkern, dim3(G, CH), dim3(256), ldsF, st, sp);
-    MH_LAUNCH_CHECK();
-    hipLaunchKernelGGL(jkern, dim3(G, CH), dim3(256), ldsJ, st, sp);
+    hipLaunchKernelGGL(kern, dim3(8 * ((G * CH + 7) / 8)), dim3(256), ldsB, st, sp);
     MH_LAUNCH_CHECK();
     mh_prof_mark(MH_PROF_SKIN_BWD, 1, st);
   } else {

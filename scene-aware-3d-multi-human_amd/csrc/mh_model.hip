@@ -210,7 +210,7 @@ extern "C" int mh_model_create(mh_model** out, const mh_model_host* h) {
       return f;
     };
     const int NBLK = VP / 16;
-    std::vector<uint16_t> Dt16((size_t)NBLK * 3 * 7 * 2 * 64 * 8, 0), W16((size_t)(VP / 32) * 2 * 2 * 64 * 8, 0);
+    std::vector<uint16_t> Dt16((size_t)NBLK * 3 * 7 * 2 * 64 * 8, 0), W16((size_t)NBLK * 2 * 64 * 8, 0);
     for (int blk = 0; blk < NBLK; ++blk)
       for (int lane = 0; lane < 64; ++lane)
         for (int t = 0; t < 8; ++t) {
@@ -224,18 +224,17 @@ extern "C" int mh_model_create(mh_model** out, const mh_model_host* h) {
               Dt16[base + 64 * 8 + (size_t)lane * 8 + t] = lo;
             }
         }
-    // W16 [VP/32][joint tile 2][term 2][lane][8]: B operand of v_mfma_f32_16x16x32_bf16, lane l = (joint 16 jt + (l&15),
-    // vertex quarter l>>4) holds vertices 32 blk + 8 (l>>4) + 0..7
-    for (int blk = 0; blk < VP / 32; ++blk)
-      for (int jt = 0; jt < 2; ++jt)
-        for (int lane = 0; lane < 64; ++lane)
-          for (int t = 0; t < 8; ++t) {
-            const int v = blk * 32 + 8 * (lane >> 4) + t, n = 16 * jt + (lane & 15);
-            const float w = (v < V && n < MH_NJ) ? h->lbs_weights[(size_t)v * MH_NJ + n] : 0.f;
-            const uint16_t hi = f2bf(w), lo = f2bf(w - bf2f(hi));
-            W16[(((size_t)blk * 2 + jt) * 2) * 64 * 8 + (size_t)lane * 8 + t] = hi;
-            W16[(((size_t)blk * 2 + jt) * 2 + 1) * 64 * 8 + (size_t)lane * 8 + t] = lo;
-          }
+    // W16 [VP/16][term 2][lane][8]: B operand of v_mfma_f32_32x32x16_bf16, lane l = (joint l&31, vertex half l>>5)
+    // holds vertices 16 blk + 8 (l>>5) + 0..7
+    for (int blk = 0; blk < NBLK; ++blk)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int t = 0; t < 8; ++t) {
+          const int v = blk * 16 + 8 * (lane >> 5) + t, n = lane & 31;
+          const float w = (v < V && n < MH_NJ) ? h->lbs_weights[(size_t)v * MH_NJ + n] : 0.f;
+          const uint16_t hi = f2bf(w), lo = f2bf(w - bf2f(hi));
+          W16[((size_t)blk * 2) * 64 * 8 + (size_t)lane * 8 + t] = hi;
+          W16[((size_t)blk * 2 + 1) * 64 * 8 + (size_t)lane * 8 + t] = lo;
+        }
     if ((rc = upload(&m->Dt16, Dt16))) return rc;
     if ((rc = upload(&m->W16, W16))) return rc;
   }
@@ -299,7 +298,7 @@ extern "C" int mh_model_create(mh_model** out, const mh_model_host* h) {
   if ((rc = build_regressor(&m->reg[MH_REG_MUPOTS], h->reg_mupots, 17, V))) return rc;
   if ((rc = build_regressor(&m->reg[MH_REG_EXTRA9], h->reg_extra9, 9, V))) return rc;
   {
-    std::vector<int> ptr(VP + 1, 0), js;
+    std::vector<int> ptr(VP + 1, 0), js, head((size_t)VP * 4, 0);
     std::vector<float> ws;
     for (int v = 0; v < VP; ++v) {
       if (h->reg_alphapose && v < V)
@@ -311,7 +310,16 @@ extern "C" int mh_model_create(mh_model** out, const mh_model_host* h) {
           }
         }
       ptr[v + 1] = (int)js.size();
+      // head row: (first entry index, entry count, first joint, first weight bits) -- one 16-byte load gives the
+      // backward everything it needs for the common single-entry vertex
+      head[(size_t)v * 4] = ptr[v];
+      head[(size_t)v * 4 + 1] = ptr[v + 1] - ptr[v];
+      if (ptr[v + 1] > ptr[v]) {
+        head[(size_t)v * 4 + 2] = js[ptr[v]];
+        memcpy(&head[(size_t)v * 4 + 3], &ws[ptr[v]], 4);
+      }
     }
+    if ((rc = upload(&m->kpv_head, head))) return rc;
     if ((rc = upload(&m->kpv_ptr, ptr))) return rc;
     if ((rc = upload(&m->kpv_j, js))) return rc;
     if ((rc = upload(&m->kpv_w, ws))) return rc;
@@ -322,7 +330,7 @@ extern "C" int mh_model_create(mh_model** out, const mh_model_host* h) {
 
 extern "C" int mh_model_destroy(mh_model* m) {
   if (!m) return MH_OK;
-  void* ptrs[] = {m->vt, m->D, m->Dt, m->D16, m->Dt16, m->W16, m->skidx, m->skw, m->Jt, m->JS, m->faces, m->kpv_ptr, m->kpv_j, m->kpv_w};
+  void* ptrs[] = {m->vt, m->D, m->Dt, m->D16, m->Dt16, m->W16, m->skidx, m->skw, m->Jt, m->JS, m->faces, m->kpv_ptr, m->kpv_j, m->kpv_w, m->kpv_head};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < 4; ++i) {

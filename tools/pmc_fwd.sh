@@ -19,7 +19,7 @@ for d in sorted(glob.glob('$OUT/s*/')):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             k = r['Kernel_Name'][:40]
-            if any(x in k for x in ("skin", "pose_", "grad16")):
+            if any(x in k for x in ("skin", "pose_", "skinbwd")):
                 acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
         for k, c in acc.items():
             print(k, {n: round(sum(v) / len(v)) for n, v in c.items()}, 'launches', len(next(iter(c.values()))))

@@ -9,6 +9,6 @@ python - <<PY
 import csv, glob
 for f in glob.glob('$OUT/**/*kernel_stats.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        if any(k in r['Name'] for k in ('skin', 'pose', 'grad16', 'person')):
+        if any(k in r['Name'] for k in ('skin', 'pose', 'skinbwd', 'person')):
             print('%-60s calls %5s avg %9.1f us' % (r['Name'][:60], r['Calls'], float(r['AverageNs']) / 1e3))
 PY

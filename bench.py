@@ -71,9 +71,11 @@ def load_pmc_traffic():
 
 def load_pmc_valu(kernel):
     """Vector instructions per launch of `kernel` from the committed SQ counter pass (profiles/README.md)"""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_sq_counters.txt')
-    if not os.path.exists(path):
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc_sq_counters.txt')))
+    if not found:
         return None
+    path = found[-1]                      # the newest round's pass
     cur = None
     with open(path) as f:
         for line in f:

@@ -1,10 +1,10 @@
 """Condense rocprofv3 outputs under gpurun_out/ into the committed profiles/ (developer tool).
-  python tools/make_profiles.py <round-tag> <stats-dir> <fetch-dir> <write-dir>"""
+  python tools/make_profiles.py <round-tag> <stats-dir> <fetch-dir> <write-dir> [out-dir]"""
 import csv, glob, json, os, shutil, sys, collections
 
 tag, dstats, dfetch, dwrite = sys.argv[1:5]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out = os.path.join(ROOT, 'profiles')
+out = sys.argv[5] if len(sys.argv) > 5 else os.path.join(ROOT, 'profiles')
 os.makedirs(out, exist_ok=True)
 st = glob.glob(os.path.join(dstats, '**', '*kernel_stats.csv'), recursive=True)
 if st:
@@ -32,4 +32,4 @@ for k in sorted(set(fetch) | set(write)):
                               'wide (16 B/lane) streaming reads are under-counted by 2x, other widths uncalibrated '
                               '(MI355X_MICROARCH.md, HBM)'}
 json.dump(traffic, open(os.path.join(out, 'pmc_traffic.json'), 'w'), indent=1, sort_keys=True)
-print(json.dumps({k: v for k, v in traffic.items() if k in ('k_raster_strip', 'k_skin_fwd', 'k_skin_bwd', 'k_raster_grads')}, indent=1))
+print(json.dumps({k: v for k, v in traffic.items() if k in ('k_raster_strip', 'k_skin_fwd16', 'k_skinbwd16', 'k_raster_grads')}, indent=1))

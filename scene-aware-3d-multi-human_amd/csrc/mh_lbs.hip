@@ -1233,13 +1233,27 @@ __global__ __launch_bounds__(256) void k_pose_bwd(PoseBwdP p) {
     for (int i = 0; i < 9; ++i) aA[i] = 0.f;
 #pragma unroll
     for (int i = 0; i < 7; ++i) aF[i] = 0.f;
-    for (int c = 0; c < p.CH; ++c) {
-      const float* qa = p.pA + ((size_t)c * GB + b) * 288 + j;
-      const float* qf = p.pF + ((size_t)c * GB + b) * MH_FS + j;
+    // four chunks (64 loads) in flight per round trip; a missing chunk re-reads the last one and adds zero
+    for (int c0 = 0; c0 < p.CH; c0 += 4) {
+      float tA[4][9], tF[4][7];
 #pragma unroll
-      for (int i = 0; i < 9; ++i) aA[i] += qa[32 * i];
+      for (int u = 0; u < 4; ++u) {
+        const int c = min(c0 + u, p.CH - 1);
+        const float* qa = p.pA + ((size_t)c * GB + b) * 288 + j;
+        const float* qf = p.pF + ((size_t)c * GB + b) * MH_FS + j;
 #pragma unroll
-      for (int i = 0; i < 7; ++i) aF[i] += qf[32 * i];
+        for (int i = 0; i < 9; ++i) tA[u][i] = qa[32 * i];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) tF[u][i] = qf[32 * i];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float m = c0 + u < p.CH ? 1.f : 0.f;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) aA[i] = fmaf(m, tA[u][i], aA[i]);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) aF[i] = fmaf(m, tF[u][i], aF[i]);
+      }
     }
 #pragma unroll
     for (int i = 0; i < 9; ++i) sGA[bl][j + 32 * i] = aA[i];

@@ -311,3 +311,35 @@ def test_optimized_variables_pickle_round_trip(smpl_struct, smpl_regs, tmp_path)
             assert back['scene_mask'].shape == (H, W)
         else:
             assert back['scene_depth'] is None
+
+
+def _staged(opt):
+    e = opt.engine
+    return {k: getattr(e, k).cpu().numpy() for k in ('pose2d', 'poses_ref', 'bits', 'ebits', 'depths', 'area', 'p2d_valid')}
+
+
+def test_staging_reads_a_plain_dataset_directly_and_a_custom_loader_through_its_batches(smpl_struct, smpl_regs, tmp_path,
+                                                                                     monkeypatch):
+    """The one-time staging pass takes the frames from ``dataloader.dataset`` when the loader is the stock one (no
+    torch.stack per key and batch), and from the loader's batches otherwise (custom collate, a list of batches, ...):
+    the staged device tensors, the images kept for the scene image and the batch size must be the same either way."""
+    fin = gi.fit_inputs()
+    got = []
+    loaders = [lambda: torch.utils.data.DataLoader(_DS(fin), batch_size=5, shuffle=False),               # direct
+               lambda: torch.utils.data.DataLoader(_DS(fin), batch_size=5, shuffle=False,
+                                                   collate_fn=lambda b: torch.utils.data.default_collate(b)),   # via batches
+               lambda: torch.utils.data.DataLoader(_DS(fin), batch_size=5, shuffle=False)]               # forced via batches
+    for i, mk in enumerate(loaders):
+        monkeypatch.setenv('MHHIP_STAGE_VIA_LOADER', '1' if i == 2 else '0')
+        opt = _new_opt(smpl_struct, smpl_regs, tmp_path, fin)
+        opt.init_optimized_variables(fin['pose2d'], fin['poses_smpl'], fin['betas_smpl'], fin['valid_smpl'], num_iter=0)
+        dl = mk()
+        assert opt._dataset_is_plain(dl, dl.dataset) == (i == 0)
+        opt._stage_from_dataloader(dl)
+        got.append((_staged(opt), np.array(opt._images), np.array(opt._backmasks), opt.engine.batch))
+    for other in got[1:]:
+        for k in got[0][0]:
+            np.testing.assert_array_equal(other[0][k], got[0][0][k], err_msg=k)
+        np.testing.assert_array_equal(other[1], got[0][1])
+        np.testing.assert_array_equal(other[2], got[0][2])
+        assert other[3] == got[0][3] == 5

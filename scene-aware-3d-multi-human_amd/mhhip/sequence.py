@@ -398,8 +398,9 @@ class SequenceEngine(object):
         self._finish_a(use_images, raster)
         self._finish_b(row, use_images, raster)
 
-    def _finish_a(self, use_images=True, raster=None):
-        """Everything between the LBS forward and the scene-dependent part.  The vertex-gradient buffer starts as the
+    def _finish_a(self, use_images=True, raster=None, grads_later=False):
+        """Everything between the LBS forward and the scene-dependent part.  grads_later: stop after the rasteriser's
+        selection half; ``_finish_b(..., raster_grads=True)`` runs its gradient half beside the scene terms.  The vertex-gradient buffer starts as the
         filtered-vertex term (or zero); then the rasterised terms run on the main stream while the small terms that
         need the vertices (key-point regression + 2D joints and -- with a static scene -- contact / foot sliding) run
         on the second stream: in the captured graph they are a parallel branch that fills the tails of the raster
@@ -460,8 +461,9 @@ class SequenceEngine(object):
             if raster is not None:
                 ev = self._tic('raster_terms')
                 raster(self, gv, log, phases=1)
-                main.wait_event(self._ev_gv)
-                raster(self, gv, log, phases=2)
+                if not grads_later:
+                    main.wait_event(self._ev_gv)
+                    raster(self, gv, log, phases=2)
                 self._toc(ev)
             else:
                 # no rasteriser: alpha = 0, zbuf empty -> the mask-only silhouette term (tests only)
@@ -484,9 +486,12 @@ class SequenceEngine(object):
         check(L.mh_reduce_sum(ptr(self.batch_contact), self.nbatches, 1.0, ptr(log[5:6]), st))
         check(L.mh_reduce_sum(ptr(self.batch_foot), self.nbatches, 1.0, ptr(log[6:7]), st))
 
-    def _finish_b(self, row, use_images=True, raster=None):
+    def _finish_b(self, row, use_images=True, raster=None, raster_grads=False):
         """scene terms when the cloud is rebuilt on the device every cycle (they wait for its event), LBS backward,
-        log row"""
+        log row.  raster_grads: the rasteriser's gradient half was left to this part (``_finish_a(grads_later=True)``):
+        it runs on the main stream while the contact / foot-sliding chain runs on the second one -- behind the gradient
+        kernel that chain was 90 us of serial latency per cycle (its vertex gradients are atomics, so the two may
+        interleave)."""
         L = _lib.lib()
         st = _lib.stream_ptr(self.dev)
         T, N, B = self.T, self.N, self.B
@@ -496,13 +501,25 @@ class SequenceEngine(object):
         pT = self.leaf('poses_T')
         filt = self.verts_filt is not None and self.pT_filt is not None
         gv, log = self._gv_cur, self.tmp_log
+        images = use_images and self.has_images and raster is not None
         if self.scene_pts is not None and not self._scene_done:
             ev = self._tic('scene_terms')
             if self._scene_pending:              # the scene of the previous cycle is built on its own stream
                 torch.cuda.current_stream(self.dev).wait_event(self._scene_event)
                 self._scene_pending = False
-            self._scene_terms(st)
+            if raster_grads and images:
+                main = torch.cuda.current_stream(self.dev)
+                side = self._side_stream()
+                side.wait_stream(main)
+                self._scene_terms(side.cuda_stream)
+                raster(self, gv, log, phases=2)
+                main.wait_stream(side)
+                raster_grads = False
+            else:
+                self._scene_terms(st)
             self._toc(ev)
+        if raster_grads and images:
+            raster(self, gv, log, phases=2)
         ev = self._tic('lbs_backward')
         check(L.mh_lbs_backward(self.m.handle, B, N, ptr(self.leaf('betas')), ptr(self.leaf('poses_smpl')),
                                 ptr(self.leaf('xscale')), ptr(pT), ptr(self.vposed), ptr(gv), ptr(self.gj), ptr(gposes),
@@ -568,11 +585,11 @@ class SequenceEngine(object):
             # without waiting for it, only the contact part does
             def part_a():
                 self.cycle_begin()
-                self._finish_a(True, raster)
+                self._finish_a(True, raster, grads_later=True)
             self.replay(('a',) + key, part_a, wait_scene=False)
             if scene_update:
                 self.scene_device_launch()
-            self.replay(('b',) + key, lambda: self._finish_b(None, True, raster))
+            self.replay(('b',) + key, lambda: self._finish_b(None, True, raster, raster_grads=True))
         else:
             def body():
                 self.cycle_begin()

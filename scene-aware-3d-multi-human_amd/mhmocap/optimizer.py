@@ -311,31 +311,49 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
         have_img = True
         store = {}
         keep = {}
+        world, _ = self._world()
+        ds = getattr(dataloader, 'dataset', None)
+        direct = self._dataset_is_plain(dataloader, ds)
+        own = None                      # frame range of the per-pixel inputs kept on this rank (None: the whole sequence)
+        if direct and world > 1:
+            # the batch size is known up front: fix the shard first, keep the big per-pixel inputs of the own frames only
+            if int(bs) != self._engine_batch:
+                self._build_engine(int(bs), leaves=self._global_leaves())
+            own = (self.first_frame, self.last_frame)
+        LOCAL = ('depths', 'seg_mask')
 
         def alloc(k, shape, dtype):
             # page-locked host buffers: the one upload of the sequence then runs at PCIe speed
+            n = T if own is None or k not in LOCAL else own[1] - own[0]
             try:
-                t = torch.zeros((T,) + tuple(shape), dtype=torch.from_numpy(np.zeros(0, dtype)).dtype,
+                t = torch.zeros((n,) + tuple(shape), dtype=torch.from_numpy(np.zeros(0, dtype)).dtype,
                                 pin_memory=torch.cuda.is_available() and os.environ.get('MHHIP_STAGE_PINNED', '1') == '1')
                 keep[k] = t
                 store[k] = t.numpy()
             except (RuntimeError, TypeError):
-                store[k] = np.zeros((T,) + tuple(shape), dtype)
+                store[k] = np.zeros((n,) + tuple(shape), dtype)
 
         def put(idx, data, lead):
             nonlocal have_img
             for k in ['depths', 'seg_mask', 'pose2d', 'poses_smpl', 'images', 'backmasks']:
                 if k not in data:
-                    if k in ('depths', 'seg_mask'):
+                    if k in LOCAL:
                         have_img = False
+                    continue
+                if own is not None and k in LOCAL:
+                    if not own[0] <= idx < own[1]:
+                        continue
+                    a = data[k].numpy() if isinstance(data[k], torch.Tensor) else np.asarray(data[k])
+                    if k not in store:
+                        alloc(k, a.shape[lead:], a.dtype)
+                    store[k][idx - own[0]] = a
                     continue
                 a = data[k].numpy() if isinstance(data[k], torch.Tensor) else np.asarray(data[k])
                 if k not in store:
                     alloc(k, a.shape[lead:], a.dtype)
                 store[k][idx] = a
 
-        ds = getattr(dataloader, 'dataset', None)
-        if self._dataset_is_plain(dataloader, ds):
+        if direct:
             # A plain map-style dataset behind the stock collate function: the frames are read from the dataset itself,
             # straight into the staging buffers.  Going through the loader costs a torch.stack per key and batch plus
             # the profiler hooks of every __next__ (250 of the 350 ms this pass took at C3) for batches that are taken
@@ -350,14 +368,14 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
                     bs = len(idx)
                 put(idx, data, 1)
                 first = False
-        world, _ = self._world()
         if world > 1 and int(bs) != self._engine_batch:
             # block boundaries are multiples of the batch size: re-shard with the dataloader's
             self._build_engine(int(bs), leaves=self._global_leaves())
         self.engine.set_batch_size(int(bs))
         sl = slice(self.first_frame, self.last_frame)
+        loc = (lambda k: store[k]) if own is not None else (lambda k: store[k][sl])
         self.engine.stage(store['pose2d'][sl], store.get('poses_smpl', self._poses_ref)[sl], self._valid[sl], self._betas_ref,
-                          store['seg_mask'][sl] if have_img else None, store['depths'][sl] if have_img else None)
+                          loc('seg_mask') if have_img else None, loc('depths') if have_img else None)
         self._images = store.get('images')          # whole sequence (colour median of the scene image, once per fit)
         self._backmasks = store.get('backmasks')
         self._staged = True

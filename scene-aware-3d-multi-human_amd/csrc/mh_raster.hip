@@ -11,7 +11,7 @@
 //                         (a tile's candidate faces become one contiguous range)
 //   (r_strip_table)       extra workgroup of k_raster_face_sort: windows cut into tiles of <= R_CAP pixels, prefix-summed into a device-side
 //                         work list (no host sync); also the work units of the gradient kernel
-//   k_raster_strip_order  one workgroup: tiles by decreasing candidate-face count (longest first)
+//   (r_strip_order)       end of that workgroup: tiles by decreasing estimated cost (longest first; a schedule only)
 //   k_raster_strip        one workgroup per tile; every wave runs barrier-free rounds of 64 faces (3-deep gather
 //                         pipeline, bbox, pair list / even split, depth cull) and inserts 64-bit (z, face) keys into
 //                         the tile's LDS window with ds_min_u64: slot 0 = nearest face of the blur 1e-4 pass (all
@@ -302,6 +302,62 @@ __device__ __forceinline__ void r_tiling(int ww, int wh, int* tw, int* th, int* 
   *nrow = (wh + *th - 1) / *th;
 }
 
+// Longest-processing-time-first order of the tiles: a tile's cost is estimated from its candidate-face count and its
+// pixel count; counting sort into 64 cost classes, most expensive first (without it the last tiles to start were often
+// among the most expensive and the kernel ended ~40 % later than its work divided by the CU count).  The order is only a
+// schedule -- any permutation gives the same keys -- so it does not wait for this cycle's face sort: it runs at the end
+// of the tile-list workgroup (beside the face sort, not behind it: one single-workgroup kernel of 15 us less on the
+// chain) and reads the candidate counts from whatever row_start / maxh hold at that moment, i.e. mostly the previous
+// cycle's sort -- bodies move a fraction of a pixel per cycle.  Every value read that way is clamped.
+template <int NT>
+__device__ __forceinline__ void r_strip_order(const RasterP& p, int total) {
+  __shared__ int o_hist[64], o_cursor[64];
+  const int tid = threadIdx.x, H = p.H;
+  if (tid < 64) o_hist[tid] = 0;
+  __syncthreads();
+  // measured on C3: a tile takes ~7 ns per candidate face and ~76 ns per window pixel
+  const long long cmax = (long long)p.F + 11ll * R_CAP + 1;
+  auto cost_class = [&](int s) {
+    const int b = p.strip_body[s];
+    const int sy0 = p.strip_row0[s], sy1 = sy0 + p.strip_rows[s] - 1;
+    const int* rs = p.row_start + (size_t)b * (2 * (H + 1) + 1);
+    const int mh = min(max(p.maxh[b], 0), H);
+    const int ra = max(0, sy0 - mh), rb = min(sy1 + 1, H);
+    const long long n = (long long)(rs[rb] - rs[ra]) + (long long)(rs[H + 1 + rb] - rs[H + 1 + ra]);
+    const long long cost = min(max(n, 0ll), (long long)p.F) + 11ll * p.strip_rows[s] * p.strip_cols[s];
+    return 63 - (int)min(63ll, max(0ll, cost * 64 / cmax));       // class 0 = most expensive
+  };
+  // the classes of a thread's first eight tiles stay in registers (a class costs a chain of four dependent loads)
+  int cls[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int s = tid + i * NT;
+    cls[i] = s < total ? cost_class(s) : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (cls[i] >= 0) atomicAdd(&o_hist[cls[i]], 1);
+  // further tiles: the class is computed ONCE and parked (in the per-tile sums, which the strip kernel only writes later)
+  // -- evaluated again for the placement it could differ (the face sort is rewriting row_start meanwhile), and two
+  // passes that disagree do not produce a permutation
+  int* park = (int*)p.partial;
+  for (int s = tid + 8 * NT; s < total; s += NT) {
+    const int c = cost_class(s);
+    park[s] = c;
+    atomicAdd(&o_hist[c], 1);
+  }
+  __syncthreads();
+  if (tid < 64) {           // exclusive scan of the 64 class counts by the first wave
+    const int h = o_hist[tid];
+    o_cursor[tid] = mh_wave_scan_add(h) - h;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (cls[i] >= 0) p.strip_order[atomicAdd(&o_cursor[cls[i]], 1)] = tid + i * NT;
+  for (int s = tid + 8 * NT; s < total; s += NT) p.strip_order[atomicAdd(&o_cursor[park[s]], 1)] = s;
+}
+
 // tile list of all windows + work units of the gradient kernel, by one workgroup of NT threads (the extra workgroup of
 // k_raster_face_sort: it only needs the windows, so it runs beside the face sort instead of in front of it)
 template <int NT>
@@ -413,6 +469,7 @@ __device__ __forceinline__ void r_strip_table(const RasterP& p) {
   }
   __syncthreads();
   if (threadIdx.x == 0) p.gunit_total[0] = c_full + c_part;
+  r_strip_order<NT>(p, carry_ns);          // the tile tables above were written by this workgroup (barriers in between)
 }
 
 // =============================================================================================
@@ -658,48 +715,6 @@ __device__ __forceinline__ void r_tile_depth_sums(const RasterP& p, int s, int b
     float* o = p.partial + (size_t)s * 6;
     o[0] = lA; o[1] = lB; o[2] = lC; o[3] = lS1; o[4] = lS2; o[5] = 0.f;
   }
-}
-
-// Longest-processing-time-first order of the tiles: a tile's cost is estimated from its candidate-face count (known
-// once the faces are sorted by row) and its pixel count.  Counting sort into 64 cost classes, most expensive first; without it the last tiles to start
-// were often among the most expensive and the kernel ended ~40 % later than its work divided by the CU count.
-__global__ __launch_bounds__(1024) void k_raster_strip_order(RasterP p) {
-  __shared__ int hist[64], cursor[64];
-  const int tid = threadIdx.x, total = p.total[0], H = p.H;
-  if (tid < 64) hist[tid] = 0;
-  __syncthreads();
-  // measured on C3: a tile takes ~7 ns per candidate face and ~76 ns per window pixel
-  const long long cmax = (long long)p.F + 11ll * R_CAP + 1;
-  auto cost_class = [&](int s) {
-    const int b = p.strip_body[s];
-    const int sy0 = p.strip_row0[s], sy1 = sy0 + p.strip_rows[s] - 1;
-    const int* rs = p.row_start + (size_t)b * (2 * (H + 1) + 1);
-    const int ra = max(0, sy0 - p.maxh[b]), rb = min(sy1 + 1, H);
-    const int n = (rs[rb] - rs[ra]) + (rs[H + 1 + rb] - rs[H + 1 + ra]);
-    const long long cost = (long long)n + 11ll * p.strip_rows[s] * p.strip_cols[s];
-    return 63 - (int)min(63ll, cost * 64 / cmax);       // class 0 = most expensive
-  };
-  // the classes of a thread's first eight tiles stay in registers (a class costs a chain of four dependent loads)
-  int cls[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int s = tid + i * 1024;
-    cls[i] = s < total ? cost_class(s) : -1;
-  }
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-    if (cls[i] >= 0) atomicAdd(&hist[cls[i]], 1);
-  for (int s = tid + 8 * 1024; s < total; s += 1024) atomicAdd(&hist[cost_class(s)], 1);
-  __syncthreads();
-  if (tid < 64) {           // exclusive scan of the 64 class counts by the first wave
-    const int h = hist[tid];
-    cursor[tid] = mh_wave_scan_add(h) - h;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-    if (cls[i] >= 0) p.strip_order[atomicAdd(&cursor[cls[i]], 1)] = tid + i * 1024;
-  for (int s = tid + 8 * 1024; s < total; s += 1024) p.strip_order[atomicAdd(&cursor[cost_class(s)], 1)] = s;
 }
 
 #define RW (RB / 64)         // waves per tile workgroup
@@ -1391,8 +1406,6 @@ static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const flo
   hipLaunchKernelGGL(k_raster_windows, dim3(p.B), dim3(RWT), 0, st, p);
   MH_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_raster_face_sort, dim3(p.B + 1), dim3(RFS), (size_t)2 * (H + 1) * sizeof(int), st, p);
-  MH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_raster_strip_order, dim3(1), dim3(1024), 0, st, p);
   MH_LAUNCH_CHECK();
   // persistent grids over the device-side work list (the strip count is only known on the device)
   const int grid = 256 * 3 * 4;

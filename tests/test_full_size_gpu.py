@@ -109,3 +109,30 @@ def test_c5_shape_cycle_restricts_to_the_first_batch(smpl_struct, smpl_regs, ora
         assert (err > 5e-3 * scale).mean() < 0.01, (name, err.max(), scale)
         assert np.median(err) < 1e-3 * scale, name
         assert np.abs(w).max() > 0, name
+
+
+def test_selection_does_not_depend_on_what_the_workspace_held(smpl_struct, smpl_regs, oracle_model, tmp_path):
+    """The tile schedule (longest first) is estimated beside the face sort from whatever the previous cycle left in the
+    workspace; a fresh workspace holds anything.  ~7000 tiles at C3 (more than the order's register-resident part): the
+    per-body depth sums, which come out of the selection in fixed order, must be bit-identical whether the workspace
+    held zeros, random bits or the previous cycle's tables."""
+    T, N, W, H, batch = 200, 4, 240, 135, 50
+    opt, dl, o, batches, seq = _setup(smpl_struct, smpl_regs, oracle_model, tmp_path, T, N, W, H, batch, 41, True)
+    opt._stage_from_dataloader(dl)
+    from mhhip.raster import RasterTerms
+    e = opt.engine
+    raster = RasterTerms(e)
+    outs = []
+    for fill in ('zeros', 'random', 'previous', 'random'):
+        if fill == 'zeros':
+            raster.ws.zero_()
+        elif fill == 'random':
+            raster.ws.copy_(torch.randint(0, 256, raster.ws.shape, dtype=torch.uint8, device=raster.ws.device))
+        e.cycle(0, raster=raster)
+        torch.cuda.synchronize()
+        outs.append((e.depth_body.clone(), e.sil_body.clone(), e.leaf('poses_T', e.grads).clone()))
+    for d, s_, g in outs[1:]:
+        assert torch.equal(d, outs[0][0])
+        torch.testing.assert_close(s_, outs[0][1], rtol=1e-5, atol=1e-7)
+        scale = float(outs[0][2].abs().max())
+        assert float((g - outs[0][2]).abs().max()) <= 2e-3 * scale        # float atomics in the gradient scatter

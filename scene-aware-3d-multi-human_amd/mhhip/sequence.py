@@ -13,6 +13,7 @@ instance masks of a frame packed into one 32-bit word per pixel (raw and twice-e
 import ctypes
 
 import numpy as np
+import os
 import torch
 
 from . import _lib, engine
@@ -457,19 +458,26 @@ class SequenceEngine(object):
             self._scene_terms(s2)
             self._scene_done = True
         # ---- main branch: rasterised depth / silhouette terms ----------------------------------------------------------
+        joined = False
         if images:
             if raster is not None:
                 ev = self._tic('raster_terms')
                 raster(self, gv, log, phases=1)
                 if not grads_later:
-                    main.wait_event(self._ev_gv)
+                    # the whole side branch ends long before the selection does: ONE join here instead of a wait for the
+                    # buffer initialisation here and a second join in front of the backward (every cross-stream edge of
+                    # the replayed graph costs several us of idle time on the chain, even when its event has long been
+                    # signalled: +0.5 % same-box)
+                    main.wait_stream(side)
+                    joined = True
                     raster(self, gv, log, phases=2)
                 self._toc(ev)
             else:
                 # no rasteriser: alpha = 0, zbuf empty -> the mask-only silhouette term (tests only)
                 self.sil_body.copy_(self.sil_apply * self.sil_S / (self.sil_D + 1.0))
                 check(L.mh_reduce_sum(ptr(self.sil_body), B, 1.0, ptr(log[2:3]), st))
-        main.wait_stream(side)
+        if not joined:
+            main.wait_stream(side)
 
     def _scene_terms(self, st):
         """contact + in-batch foot sliding (optimizer.py:485-518) on stream st; gradients by atomics / disjoint writes"""

@@ -1278,20 +1278,57 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
         lcorr += alpha * alpha - 2.f * alpha * seg;                        // losses.py:35-38 through 1 - acc (value only)
         const float galpha = gAlphaScale * (alpha - seg);
         if (galpha != 0.f) {
+          // Every selected face contributes to the two end points of its nearest edge.  The (up to) eight end points
+          // of a pixel are gathered in registers (picked with selects, mapped to camera space) and contributions to the
+          // same vertex are merged before they go to the LDS table: neighbouring faces share contour vertices, and an
+          // LDS float atomic costs ~4 cycles per active LANE on gfx950 whatever the addresses (SQ_LDS_IDX_ACTIVE:
+          // 26 M cycles for the 7 M lane-atomics this scatter issued unmerged -- a third of the kernel; unique
+          // addresses, fewer instructions under the same masks or de-correlated lanes changed nothing), while the vector
+          // instructions of the merge are nearly free here (VALU 23 % busy).  113 -> 90 us.  (Merging the three
+          // vertices of the depth term's face as well costs 45 spilled registers at 1024 threads: 139 us.)
+          int eid[8];
+          float egx[8], egy[8], egz[8];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
+            eid[2 * k] = eid[2 * k + 1] = -1;
+            egx[2 * k] = egy[2 * k] = egz[2 * k] = egx[2 * k + 1] = egy[2 * k + 1] = egz[2 * k + 1] = 0.f;
             if (!have[k]) continue;
             // d alpha / d sd_k = -(1/sigma) p_k prod_j (1 - p_j)
             const float gd = galpha * (-(1.f / SIGMA_S)) * pk[k] * qprod * sgn[k];
             if (gd == 0.f) continue;
-            // vertex picks without dynamic register indexing
             const Tri& tr = trs[k];
-#pragma unroll
-            for (int v = 0; v < 3; ++v) {
-              const float w = (v == ea[k] ? wa[k] : 0.f) + (v == eb[k] ? wb_[k] : 0.f);
-              if (w != 0.f) r_scatter<TAB>(p, gvb, tr, v, gd * w * 2.f * gqx[k], gd * w * 2.f * gqy[k], 0.f);
+            const bool a0 = ea[k] == 0, b1 = eb[k] == 1;       // a in {0,1}, b in {1,2}
+            const int ia_ = a0 ? tr.idx[0] : tr.idx[1], ib_ = b1 ? tr.idx[1] : tr.idx[2];
+            const float xa = a0 ? tr.x[0] : tr.x[1], ya = a0 ? tr.y[0] : tr.y[1], za = a0 ? tr.z[0] : tr.z[1];
+            const float xb = b1 ? tr.x[1] : tr.x[2], yb = b1 ? tr.y[1] : tr.y[2], zb = b1 ? tr.z[1] : tr.z[2];
+            const float gxn = gd * 2.f * gqx[k], gyn = gd * 2.f * gqy[k];
+            if (wa[k] != 0.f) {
+              const float rz = r_rcp(za), ux = wa[k] * gxn, uy = wa[k] * gyn;
+              eid[2 * k] = ia_;
+              egx[2 * k] = -p.s * rz * ux; egy[2 * k] = -p.s * rz * uy; egz[2 * k] = -((xa - p.w1) * ux + (ya - p.h1) * uy) * rz;
+            }
+            if (wb_[k] != 0.f) {
+              const float rz = r_rcp(zb), ux = wb_[k] * gxn, uy = wb_[k] * gyn;
+              eid[2 * k + 1] = ib_;
+              egx[2 * k + 1] = -p.s * rz * ux; egy[2 * k + 1] = -p.s * rz * uy; egz[2 * k + 1] = -((xb - p.w1) * ux + (yb - p.h1) * uy) * rz;
             }
           }
+#pragma unroll
+          for (int i = 1; i < 8; ++i) {
+            bool merged = false;
+#pragma unroll
+            for (int j = 0; j < i; ++j) {
+              const bool hit = !merged && eid[i] >= 0 && eid[j] == eid[i];
+              egx[j] += hit ? egx[i] : 0.f;
+              egy[j] += hit ? egy[i] : 0.f;
+              egz[j] += hit ? egz[i] : 0.f;
+              merged = merged || hit;
+            }
+            if (merged) eid[i] = -1;
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if (eid[i] >= 0) r_acc_add<TAB>(gvb, eid[i], egx[i], egy[i], egz[i]);
         }
       }
     }

@@ -733,7 +733,6 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
   __shared__ int wDesc[RW][64];             // xa | ya << 10 | nx << 20 (tile-relative)
   __shared__ int wFid[RW][64];
   __shared__ int wMark[RW][64];
-  __shared__ unsigned wZb[RW][64];          // bits of the nearest vertex depth of the staged faces
   __shared__ unsigned short wPl[RW][RPL];   // pair list of the sub-pixel path: face slot | pair index << 6
   __shared__ float s_sums[RB / 64];
   __shared__ float sXf[R_CAP];              // NDC x of the tile columns
@@ -752,7 +751,6 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
   int* desc = wDesc[wave];
   int* fid = wFid[wave];
   int* mark = wMark[wave];
-  unsigned* zbs = wZb[wave];
   unsigned short* pl = wPl[wave];
   for (int si = blockIdx.x; si < total; si += gridDim.x) {
     const int s = p.strip_order[si];
@@ -801,6 +799,8 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
         }
         // ---- this round: bbox against the tile, candidate count, staging -----------------------------------
         int cnt = 0;
+        int f_pix = 0, f_nx = 1;                 // first window pixel (tile-relative index) and width of the face's pixel box
+        unsigned f_zb = 0u;                      // bits of its nearest vertex depth (minus the margin below)
         if (idx < i1 && (int)(e_a >> 20) >= sy0) {
           const float bxmin = fminf(ca[0], fminf(ca[3], ca[6])) - blur_d, bxmax = fmaxf(ca[0], fmaxf(ca[3], ca[6])) + blur_d;
           const float bymin = fminf(ca[1], fminf(ca[4], ca[7])) - blur_d, bymax = fmaxf(ca[1], fmaxf(ca[4], ca[7])) + blur_d;
@@ -830,6 +830,8 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
             T[11] = l02 <= R_KEPS ? 0.f : __builtin_amdgcn_rcpf(l02);
             T[12] = l12 <= R_KEPS ? 0.f : __builtin_amdgcn_rcpf(l12);
             desc[lane] = (xa - x0) | ((ya - sy0) << 10) | ((xb - xa + 1) << 20);
+            f_pix = (ya - sy0) * tw + (xa - x0);
+            f_nx = xb - xa + 1;
             fid[lane] = (int)(e_a & 0xfffffu);
             {
               // nearest vertex depth MINUS 16 ulps: the interpolated depth (normalised weights through v_rcp_f32) can fall a
@@ -837,7 +839,7 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
               // depending on which wave got to the pixel first (round 1: ~20 of 1.2 M pixels differed from run to run in
               // the face id of their 4th silhouette key).  With the margin the selection is order-independent.
               const unsigned zq = __float_as_uint(fminf(ca[2], fminf(ca[5], ca[8])));
-              zbs[lane] = zq > 16u ? zq - 16u : 0u;
+              f_zb = zq > 16u ? zq - 16u : 0u;
             }
           }
         }
@@ -845,33 +847,38 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
         const int npairs = __builtin_amdgcn_readlane(incl, 63);
         const int excl = incl - cnt;
         if (npairs > 0 && npairs <= RPL && __ballot(cnt > 16) == 0ull) {
-          // ---- sub-pixel faces (a few candidates each): every face writes its pair descriptors, then the pairs are
-          // evaluated with full lanes straight from the list
-          for (int i = 0; i < cnt; ++i) pl[excl + i] = (unsigned short)(lane | (i << 6));
-          __builtin_amdgcn_wave_barrier();
-          // depth cull, compacting the list in place: the clipped-barycentric depth of a face is never below its
-          // nearest vertex, so a pair whose face lies entirely behind both the pixel's current nearest key and its
-          // current 4th silhouette key cannot change the window (the keys only ever decrease)
-          int nkeep = 0;
-          for (int base = 0; base < npairs; base += 64) {
-            const int i = base + lane;
-            bool keep = false;
-            unsigned short e16 = 0;
-            if (i < npairs) {
-              e16 = pl[i];
-              const int lo = e16 & 63, k = e16 >> 6;
-              const int d = desc[lo];
-              const int nx = d >> 20;
-              const int ky_ = (int)(((float)k + 0.5f) * __builtin_amdgcn_rcpf((float)nx)), kx_ = k - ky_ * nx;
-              const int xi = (d & 1023) + kx_, yi = ((d >> 10) & 1023) + ky_;
-              const unsigned* qh = (const unsigned*)(keys + (size_t)(yi * tw + xi) * 5);
-              const unsigned zb = zbs[lo];
-              keep = !(zb > qh[1] && zb > qh[9]);
+          // ---- sub-pixel faces (a few candidates each).  Depth cull first, per face lane: the clipped-barycentric depth
+          // of a face is never below its nearest vertex, so a pair whose face lies entirely behind both the pixel's current
+          // nearest key and its current 4th silhouette key cannot change the window (the keys only ever decrease).  A lane
+          // walks the <= 16 pixels of its own face (box position, width and depth bound are its registers) and keeps a bit
+          // per survivor; only the survivors are written to the pair list, behind a wave prefix sum of the counts, and
+          // evaluated with full lanes.  (Round 1 listed every pair, then culled the list 64 pairs at a time with a decode
+          // per pair: 324 vector instructions per round against ~220 now, the kernel is bound by their issue.)
+          unsigned keepm = 0u;
+          if (cnt > 0) {
+            int kx = 0, pix = f_pix;
+            for (int k0 = 0; k0 < cnt; k0 += 4) {          // four pixels per trip: their eight key words are in flight together
+              unsigned q1[4], q9[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const unsigned* qh = (const unsigned*)(keys + (size_t)(k0 + u < cnt ? pix : f_pix) * 5);
+                q1[u] = qh[1]; q9[u] = qh[9];
+                ++pix;
+                if (++kx == f_nx) { kx = 0; pix += tw - f_nx; }
+              }
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const bool keep = k0 + u < cnt && !(f_zb > q1[u] && f_zb > q9[u]);
+                keepm |= (keep ? 1u : 0u) << (k0 + u);
+              }
             }
-            const unsigned long long m = __ballot(keep);
-            __builtin_amdgcn_wave_barrier();
-            if (keep) pl[nkeep + __popcll(m & ((1ull << lane) - 1ull))] = e16;
-            nkeep += __popcll(m);
+          }
+          const int nk = __popc(keepm);
+          const int kincl = r_wave_scan_add(nk);
+          const int nkeep = __builtin_amdgcn_readlane(kincl, 63);
+          {
+            int pos = kincl - nk;
+            for (unsigned m = keepm; m; m &= m - 1u) pl[pos++] = (unsigned short)(lane | ((__ffs((int)m) - 1) << 6));
           }
           __builtin_amdgcn_wave_barrier();
           for (int i = lane; i < nkeep; i += 64) {

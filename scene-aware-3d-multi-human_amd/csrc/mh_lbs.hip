@@ -338,6 +338,9 @@ struct SkinFwd16P {
 #ifndef FWD16_WAVES
 #define FWD16_WAVES 8
 #endif
+#ifndef FWD16_TPW
+#define FWD16_TPW 2            // vertex tiles per wave: the staged panels serve two tiles (338 workgroups instead of 675; 1 / 2 / 3: 69.8 / 67.4 / 67.4 us)
+#endif
 #define FWD16_SF_BYTES ((MH_FS / 16) * 2 * 64 * 16)       // 28672: feature terms
 #define FWD16_SA_BYTES (32 * MH_NJ * 12 * 4)              // 36864: bone transforms
 #define FWD16_LDS_BYTES (FWD16_SF_BYTES + FWD16_SA_BYTES + 32 * 16)   // + (scale, translation) per body
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, 2 * FWD16_WAVES / 4) void k_skin_
   const int li = lane & 31, lh = lane >> 5;
   const int g = blockIdx.y;
   const int ntiles = p.VP / 32;
-  if ((int)blockIdx.x * FWD16_WAVES >= ntiles) return;
+  if ((int)blockIdx.x * FWD16_WAVES * FWD16_TPW >= ntiles) return;
   {
     const f32x4* srcF = (const f32x4*)(p.F16 + (size_t)g * (MH_FS / 16) * 2 * 64 * 8);
     for (int i = threadIdx.x; i < FWD16_SF_BYTES / 16; i += FWD16_WAVES * 64) ((f32x4*)sF)[i] = srcF[i];
@@ -375,7 +378,8 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, 2 * FWD16_WAVES / 4) void k_skin_
     }
   }
   __syncthreads();
-  const int tile = blockIdx.x * FWD16_WAVES + wave;
+  for (int rep_ = 0; rep_ < FWD16_TPW; ++rep_) {
+  const int tile = (blockIdx.x * FWD16_WAVES + wave) * FWD16_TPW + rep_;
   if (tile >= ntiles) return;
   const int v = tile * 32 + li;
   // this lane's vertex constants: issued before the matrix phase, consumed after it
@@ -430,7 +434,7 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, 2 * FWD16_WAVES / 4) void k_skin_
     az = MFMA_F16(al, bq[cur][4], az);
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (!vok) return;
+  if (!vok) continue;
   const float us = p.unscale;
   // per-lane LDS bases (bytes): the row part (r&3)+8(r>>2) is a compile-time offset, the half-wave part 4*lh is here
   const unsigned char* aB[4];
@@ -482,6 +486,7 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, 2 * FWD16_WAVES / 4) void k_skin_
       }
     }
   }
+  }   // tiles of this wave
 }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -581,7 +586,7 @@ static int lbs_forward_impl(const mh_model* m, int B, int NB, const float* betas
       attr16[ki] = true;
     }
     mh_prof_mark(MH_PROF_SKIN_FWD, 0, st);
-    hipLaunchKernelGGL(kern, dim3(((m->VP / 32 + FWD16_WAVES - 1) / FWD16_WAVES + 7) / 8 * 8, G), dim3(FWD16_WAVES * 64), lds, st, sp);
+    hipLaunchKernelGGL(kern, dim3(((m->VP / 32 + FWD16_WAVES * FWD16_TPW - 1) / (FWD16_WAVES * FWD16_TPW) + 7) / 8 * 8, G), dim3(FWD16_WAVES * 64), lds, st, sp);
     MH_LAUNCH_CHECK();
     mh_prof_mark(MH_PROF_SKIN_FWD, 1, st);
     return MH_OK;

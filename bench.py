@@ -116,7 +116,7 @@ def cpu_baseline(struct, regs, K, seq, pT0, frames, cycles):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=250)      # 250 cycles (= one fit): >= 0.2 s timed, ten filter updates inside
+    ap.add_argument('--steps', type=int, default=300)      # a fit and a bit: 0.25 s timed at 1200 it/s, twelve filter updates inside
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fit', action='store_true', help='skip the fit_250 block (wall time of the drop-in fit call)')

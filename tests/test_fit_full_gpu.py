@@ -86,7 +86,8 @@ def test_full_cycle_gradients_and_log(smpl_struct, smpl_regs, oracle_model, tmp_
         scale = max(np.abs(w).max(), 1e-8)
         err = np.abs(g - w)
         # rasteriser terms: float atomics and last-ulp selection flips -> tight on (almost) all entries
-        assert (err > 5e-3 * scale).mean() < 0.01, (name, err.max(), scale)
+        frac = float((err > 5e-3 * scale).mean())
+        assert frac < 0.01, '%s: %.4f of the entries above 5e-3*max (max err %.2e, scale %.2e)' % (name, frac, err.max(), scale)
         assert np.median(err) < 1e-3 * scale, name
 
 

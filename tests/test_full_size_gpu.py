@@ -30,7 +30,8 @@ def _compare_grads(e, o, frac=0.01, tight=5e-3, med=1e-3):
         assert np.isfinite(g).all(), name
         scale = max(np.abs(w).max(), 1e-8)
         err = np.abs(g - w)
-        assert (err > tight * scale).mean() < frac, (name, err.max(), scale)
+        off = float((err > tight * scale).mean())
+        assert off < frac, '%s: %.4f of the entries above %g*max (max err %.2e, scale %.2e)' % (name, off, tight, err.max(), scale)
         assert np.median(err) < med * scale, name
 
 
@@ -106,7 +107,8 @@ def test_c5_shape_cycle_restricts_to_the_first_batch(smpl_struct, smpl_regs, ora
         w, g = w[:batch], g[:batch]
         scale = max(np.abs(w).max(), 1e-8)
         err = np.abs(g - w)
-        assert (err > 5e-3 * scale).mean() < 0.01, (name, err.max(), scale)
+        off = float((err > 5e-3 * scale).mean())
+        assert off < 0.01, '%s: %.4f of the entries above 5e-3*max (max err %.2e, scale %.2e)' % (name, off, err.max(), scale)
         assert np.median(err) < 1e-3 * scale, name
         assert np.abs(w).max() > 0, name
 

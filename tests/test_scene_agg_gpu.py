@@ -87,7 +87,7 @@ def test_postprocess_depthmap(H, W, bilateral):
     assert np.isfinite(got).all() and (got > 0).all()
     bad = np.abs(got - want) > 1e-4 * np.maximum(1.0, np.abs(want))
     # the edge threshold (3 x mean of float32 statistics) may flip a borderline pixel; everything else must agree
-    assert bad.mean() < 0.005, bad.sum()
+    assert bad.mean() < 0.005, '%.4f of the pixels differ (%d)' % (float(bad.mean()), int(bad.sum()))
 
 
 def test_points_are_compacted_in_row_major_order():
@@ -153,7 +153,7 @@ def test_fit_builds_the_scene_on_the_device(smpl_struct, smpl_regs, tmp_path):
     got, got_mask, pts = e.scene_device_result()
     np.testing.assert_array_equal(got_mask, ma_mask)
     bad = np.abs(got - want) > 1e-5 * np.maximum(1.0, np.abs(want))
-    assert bad.mean() < 0.005, bad.sum()
+    assert bad.mean() < 0.005, '%.4f of the pixels differ (%d)' % (float(bad.mean()), int(bad.sum()))
     assert pts.shape[0] == int(ma_mask.sum())
 
     opt, log = _fit(smpl_struct, smpl_regs, tmp_path, 'device', 36)

@@ -176,7 +176,7 @@ def test_two_ranks_on_the_device_match_one(tmp_path):
     for k in range(2):
         np.testing.assert_array_equal(r[k]['scene_mask'], mask)
         bad = np.abs(r[k]['scene_depth'] - depth) > 2e-3 * np.maximum(1.0, np.abs(depth))
-        assert bad.mean() < 0.01, bad.sum()
+        assert bad.mean() < 0.01, '%.4f of the pixels differ (%d)' % (float(bad.mean()), int(bad.sum()))
         assert abs(r[k]['npts'] - pts.shape[0]) == 0
 
 

@@ -25,6 +25,23 @@ COEF_KEYS = ['proj2d', 'depth', 'silhouette', 'reg_velocity', 'reg_verts_filter'
              'reg_contact', 'reg_foot_sliding']
 
 
+# The two extra streams of an engine (side branch of the cycle, scene update) are shared by all engines of a device:
+# how streams land on the hardware queues decides whether the scene update really runs beside the cycle or in its
+# queue, and a process that builds one optimiser per sequence would otherwise hand every new engine two
+# fresh streams on whatever queues are next (measured: the same fit 0.25 s or 0.34 s depending on how many engines the
+# process had built before).
+_SHARED_STREAMS = {}
+
+
+def _shared_stream(device, role):
+    key = (torch.device(device).index or 0, role)
+    st = _SHARED_STREAMS.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _SHARED_STREAMS[key] = st
+    return st
+
+
 def _dev(a, device, dtype=torch.float32):
     if isinstance(a, torch.Tensor):
         return a.to(device=device, dtype=dtype).contiguous()
@@ -215,7 +232,7 @@ class SequenceEngine(object):
         d['ma_depth'] = torch.zeros(H, W, device=self.dev)
         d['ma_mask'] = torch.zeros(H, W, device=self.dev)
         d['depth'] = torch.zeros(H, W, device=self.dev)
-        d['stream'] = torch.cuda.Stream(device=self.dev)
+        d['stream'] = _shared_stream(self.dev, 'scene')
         d['ev_main'] = torch.cuda.Event()
         d['ev_snap'] = torch.cuda.Event()
         with torch.cuda.stream(d['stream']):      # first submission now: the stream gets its hardware queue before any
@@ -356,7 +373,7 @@ class SequenceEngine(object):
 
     def _side_stream(self):
         if not hasattr(self, '_side'):
-            self._side = torch.cuda.Stream(device=self.dev)
+            self._side = _shared_stream(self.dev, 'side')
         return self._side
 
     # -- one optimisation cycle (optimizer.py:375-575), gradients accumulated into self.grads -----
@@ -395,13 +412,14 @@ class SequenceEngine(object):
         self.forward(regress=False)
         main.wait_stream(side)
 
-    def cycle_finish(self, row, use_images=True, raster=None):
-        self._finish_a(use_images, raster)
+    def cycle_finish(self, row, use_images=True, raster=None, scene_ready=False):
+        self._finish_a(use_images, raster, scene_ready=scene_ready)
         self._finish_b(row, use_images, raster)
 
-    def _finish_a(self, use_images=True, raster=None, grads_later=False):
-        """Everything between the LBS forward and the scene-dependent part.  grads_later: stop after the rasteriser's
-        selection half; ``_finish_b(..., raster_grads=True)`` runs its gradient half beside the scene terms.  The vertex-gradient buffer starts as the
+    def _finish_a(self, use_images=True, raster=None, scene_ready=False):
+        """Everything between the LBS forward and the scene-dependent part.  scene_ready: the caller has already made
+        the stream wait for the device-side scene update whose cloud this cycle reads, so the contact chain runs in the
+        side branch as with a static scene.  The vertex-gradient buffer starts as the
         filtered-vertex term (or zero); then the rasterised terms run on the main stream while the small terms that
         need the vertices (key-point regression + 2D joints and -- with a static scene -- contact / foot sliding) run
         on the second stream: in the captured graph they are a parallel branch that fills the tails of the raster
@@ -454,7 +472,7 @@ class SequenceEngine(object):
                 self._ev_gv = torch.cuda.Event()
             self._ev_gv.record(side)
         self._scene_done = False
-        if scene and self._scene_dev is None:          # static scene: no cross-stream event to wait for
+        if scene and (self._scene_dev is None or scene_ready):     # static scene, or its event already waited for
             self._scene_terms(s2)
             self._scene_done = True
         # ---- main branch: rasterised depth / silhouette terms ----------------------------------------------------------
@@ -463,14 +481,13 @@ class SequenceEngine(object):
             if raster is not None:
                 ev = self._tic('raster_terms')
                 raster(self, gv, log, phases=1)
-                if not grads_later:
-                    # the whole side branch ends long before the selection does: ONE join here instead of a wait for the
-                    # buffer initialisation here and a second join in front of the backward (every cross-stream edge of
-                    # the replayed graph costs several us of idle time on the chain, even when its event has long been
-                    # signalled: +0.5 % same-box)
-                    main.wait_stream(side)
-                    joined = True
-                    raster(self, gv, log, phases=2)
+                # the whole side branch ends long before the selection does: ONE join here instead of a wait for the
+                # buffer initialisation here and a second join in front of the backward (every cross-stream edge of
+                # the replayed graph costs several us of idle time on the chain, even when its event has long been
+                # signalled: +0.5 % same-box)
+                main.wait_stream(side)
+                joined = True
+                raster(self, gv, log, phases=2)
                 self._toc(ev)
             else:
                 # no rasteriser: alpha = 0, zbuf empty -> the mask-only silhouette term (tests only)
@@ -494,12 +511,9 @@ class SequenceEngine(object):
         check(L.mh_reduce_sum(ptr(self.batch_contact), self.nbatches, 1.0, ptr(log[5:6]), st))
         check(L.mh_reduce_sum(ptr(self.batch_foot), self.nbatches, 1.0, ptr(log[6:7]), st))
 
-    def _finish_b(self, row, use_images=True, raster=None, raster_grads=False):
-        """scene terms when the cloud is rebuilt on the device every cycle (they wait for its event), LBS backward,
-        log row.  raster_grads: the rasteriser's gradient half was left to this part (``_finish_a(grads_later=True)``):
-        it runs on the main stream while the contact / foot-sliding chain runs on the second one -- behind the gradient
-        kernel that chain was 90 us of serial latency per cycle (its vertex gradients are atomics, so the two may
-        interleave)."""
+    def _finish_b(self, row, use_images=True, raster=None):
+        """scene terms when they could not run in the side branch (eager launches with the cloud rebuilt on the device
+        every cycle: they wait for its event here), LBS backward, log row"""
         L = _lib.lib()
         st = _lib.stream_ptr(self.dev)
         T, N, B = self.T, self.N, self.B
@@ -509,25 +523,13 @@ class SequenceEngine(object):
         pT = self.leaf('poses_T')
         filt = self.verts_filt is not None and self.pT_filt is not None
         gv, log = self._gv_cur, self.tmp_log
-        images = use_images and self.has_images and raster is not None
         if self.scene_pts is not None and not self._scene_done:
             ev = self._tic('scene_terms')
             if self._scene_pending:              # the scene of the previous cycle is built on its own stream
                 torch.cuda.current_stream(self.dev).wait_event(self._scene_event)
                 self._scene_pending = False
-            if raster_grads and images:
-                main = torch.cuda.current_stream(self.dev)
-                side = self._side_stream()
-                side.wait_stream(main)
-                self._scene_terms(side.cuda_stream)
-                raster(self, gv, log, phases=2)
-                main.wait_stream(side)
-                raster_grads = False
-            else:
-                self._scene_terms(st)
+            self._scene_terms(st)
             self._toc(ev)
-        if raster_grads and images:
-            raster(self, gv, log, phases=2)
         ev = self._tic('lbs_backward')
         check(L.mh_lbs_backward(self.m.handle, B, N, ptr(self.leaf('betas')), ptr(self.leaf('poses_smpl')),
                                 ptr(self.leaf('xscale')), ptr(pT), ptr(self.vposed), ptr(gv), ptr(self.gj), ptr(gposes),
@@ -589,15 +591,18 @@ class SequenceEngine(object):
         if scene_update:
             self.scene_device_mark()
         if self._scene_dev is not None:
-            # the scene cloud is rebuilt every cycle on its own stream: everything up to the rasteriser replays
-            # without waiting for it, only the contact part does
-            def part_a():
+            # The scene cloud is rebuilt every cycle on its own stream; the update this cycle's contact term reads was
+            # launched a whole cycle ago (and takes less than half of one), so the wait for its event is hoisted to the
+            # start of the cycle (replay() issues it in front of the graph: it never stalls in practice) and the cycle
+            # stays ONE graph with the contact chain in the side branch, hidden under the selection kernel as with a
+            # static scene.  (Until late in round 2 the cycle was split in two graphs at the contact chain: a graph
+            # boundary of ~30 us and the chain on the critical path.)
+            def body_org():
                 self.cycle_begin()
-                self._finish_a(True, raster, grads_later=True)
-            self.replay(('a',) + key, part_a, wait_scene=False)
+                self.cycle_finish(None, raster=raster, scene_ready=True)
+            self.replay(('full+scene',) + key, body_org)
             if scene_update:
                 self.scene_device_launch()
-            self.replay(('b',) + key, lambda: self._finish_b(None, True, raster, raster_grads=True))
         else:
             def body():
                 self.cycle_begin()

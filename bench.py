@@ -197,8 +197,12 @@ def main():
     sh.update_filters()                                                                # filtered-vertex term live
     nstep = [0]
 
+    # one-euro filter updates every 25 cycles as in fit (optimizer.py:383-392); the phase is chosen so that the first one
+    # falls inside the timed region whatever --steps is (the driver's 20 steps: at step 10)
+    upd_at = args.warmup + min(10, max(args.steps // 2, 1))
+
     def one_cycle(c, graphs, scene=False):
-        if c % 25 == 0 and c > 0:
+        if c >= upd_at and (c - upd_at) % 25 == 0:
             sh.update_filters()
         # scene: the organic path of fit (cycle >= 30): scene rebuilt from the sequence every cycle, on its own stream, from
         # the leaves as they are before this cycle's step
@@ -342,6 +346,8 @@ def main():
                        'parallelism': 'one contiguous sequence, frames sharded x%d by the drop-in (mhmocap.optimizer under '
                                       'torch.distributed), one RCCL all-reduce on the betas/scale gradients + one-frame halos per cycle' % world},
             'timed_region_s': round(dt, 4),
+            'filter_updates_in_timed_region': sum(1 for c in range(args.warmup, args.warmup + args.steps)
+                                                  if c >= upd_at and (c - upd_at) % 25 == 0),
             'organic_scene': organic, 'roofline': roof, 'roofline_lbs_projection': lbs,
             'kernel_us': {k: round(v, 1) for k, v in kernel_us.items()},
             'kernel_group_ms': {k: round(v, 4) for k, v in kern.items()},

@@ -47,7 +47,7 @@ def build_optimizer(struct, regs, tmp, num_frames, device, K):
     c = COEFS
     return SMPLDepthSequenceOptimizer(
         image_size=IMG, num_frames=num_frames, cam_K=K, device=device, smpl_model_parameters_path=tmp,
-        smpl_data_struct=struct, scene_update='none', proj2d_loss_coef=c['proj2d'], depth_loss_coef=c['depth'],
+        smpl_data_struct=struct, scene_update='none', shard_frames=True, proj2d_loss_coef=c['proj2d'], depth_loss_coef=c['depth'],
         silhouette_loss_coef=c['silhouette'], reg_velocity_coef=c['reg_velocity'],
         reg_verts_filter_coef=c['reg_verts_filter'], reg_poses_coef=c['reg_poses'], reg_scales_coef=c['reg_scales'],
         reg_contact_coef=c['reg_contact'], reg_foot_sliding_coef=c['reg_foot_sliding'])

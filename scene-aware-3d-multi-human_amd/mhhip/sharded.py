@@ -37,11 +37,13 @@ def shard_bounds(num_frames, world, batch_size):
 
 
 class ShardedSequence(object):
-    def __init__(self, engine, first_frame, total_frames, group=None):
+    def __init__(self, engine, first_frame, total_frames, group=None, enabled=True):
+        """enabled=False: single-process behaviour even when torch.distributed is initialised (sharding is opt-in)"""
         self.e = engine
         self.group = group
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        on = enabled and dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if on else 0
+        self.world = dist.get_world_size(group) if on else 1
         self.first_frame = int(first_frame)
         self.total_frames = int(total_frames)
         self.is_first = self.first_frame == 0
@@ -52,6 +54,10 @@ class ShardedSequence(object):
     # -- neighbour exchange: the last frame goes to the next rank, the first frame to the previous one -------------------
     # (point-to-point over xGMI: an all_gather of the boundary vertices would move world x 660 KB to every rank for the two
     # rows it needs)
+    def _peer(self, r):
+        """group-local rank -> the GLOBAL rank the point-to-point calls address"""
+        return dist.get_global_rank(self.group, r) if self.group is not None else r
+
     def _gather_boundaries(self, x):
         """x (T_local, E...) -> (prev_rank_last, next_rank_first) or None at the sequence ends."""
         if self.world == 1:
@@ -61,9 +67,11 @@ class ShardedSequence(object):
         nxt = None if self.is_last else torch.empty_like(first)
         ops = []
         if not self.is_first:
-            ops += [dist.P2POp(dist.isend, first, self.rank - 1, self.group), dist.P2POp(dist.irecv, prev, self.rank - 1, self.group)]
+            p = self._peer(self.rank - 1)
+            ops += [dist.P2POp(dist.isend, first, p, self.group), dist.P2POp(dist.irecv, prev, p, self.group)]
         if not self.is_last:
-            ops += [dist.P2POp(dist.isend, last, self.rank + 1, self.group), dist.P2POp(dist.irecv, nxt, self.rank + 1, self.group)]
+            p = self._peer(self.rank + 1)
+            ops += [dist.P2POp(dist.isend, last, p, self.group), dist.P2POp(dist.irecv, nxt, p, self.group)]
         for req in dist.batch_isend_irecv(ops):
             req.wait()
         return prev, nxt
@@ -128,13 +136,13 @@ class ShardedSequence(object):
             E = x.numel() // x.shape[0]
             xp = torch.empty(E, dtype=torch.float32, device=x.device)
             dxp = torch.empty(E, dtype=torch.float32, device=x.device)
-            dist.recv(xp, src=self.rank - 1, group=self.group)
-            dist.recv(dxp, src=self.rank - 1, group=self.group)
+            dist.recv(xp, src=self._peer(self.rank - 1), group=self.group)
+            dist.recv(dxp, src=self._peer(self.rank - 1), group=self.group)
             state = (xp, dxp)
         y, out = e.one_euro_shard(x, c, b, self.first_frame, state)
         if not self.is_last:
-            dist.send(out[0], dst=self.rank + 1, group=self.group)
-            dist.send(out[1], dst=self.rank + 1, group=self.group)
+            dist.send(out[0], dst=self._peer(self.rank + 1), group=self.group)
+            dist.send(out[1], dst=self._peer(self.rank + 1), group=self.group)
         return y
 
     def update_filters(self, c1=0.01, b1=0.02, c2=0.001, b2=0.5):

@@ -85,9 +85,16 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
         self.use_rasteriser = kargs.pop('use_rasteriser', True)
         self.scene_update = kargs.pop('scene_update', 'device')      # 'device' | 'host' (numpy, like the reference) | 'none'
         self.use_graphs = kargs.pop('use_graphs', True)              # replay each cycle as a captured hipGraph
-        # frame sharding: when torch.distributed is initialised with more than one rank, every rank is
-        # handed the SAME full-sequence inputs (predict.py under torchrun) and keeps the frames of its contiguous block
+        # frame sharding is OPT-IN: ``shard_frames=True``, a ``process_group=``, or MHHIP_SHARD_FRAMES=1 in
+        # the environment (for an unmodified predict.py under torchrun).  Every rank is then handed the SAME
+        # full-sequence inputs and keeps the frames of its contiguous block.  Without the opt-in an initialised
+        # torch.distributed changes nothing: every process optimises its own sequence, no collective is issued.
         self.process_group = kargs.pop('process_group', None)
+        shard = kargs.pop('shard_frames', None)
+        if shard is None:
+            shard = self.process_group is not None or os.environ.get('MHHIP_SHARD_FRAMES') == '1'
+        self.shard_frames = bool(shard)
+        self._global_cache = None
         super().__init__(**kargs)
         if focal_length is None:
             focal_length = get_focal(min(image_size), fov)
@@ -145,7 +152,7 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
 
     # -- frame sharding ---------------------------------------------------------------------------------
     def _world(self):
-        if dist.is_available() and dist.is_initialized():
+        if self.shard_frames and dist.is_available() and dist.is_initialized():
             return dist.get_world_size(self.process_group), dist.get_rank(self.process_group)
         return 1, 0
 
@@ -171,6 +178,11 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
         outs = [torch.empty_like(pad) for _ in range(world)]
         dist.all_gather(outs, pad, group=self.process_group)
         return torch.cat([o[:b - a] for o, (a, b) in zip(outs, self._bounds)]).cpu().numpy()
+
+    def refresh_global_leaves(self):
+        """collective: re-gather the whole-sequence leaves get_optimized_variables() serves (frame-sharded run only)"""
+        self._global_cache = None
+        return self._global_leaves()
 
     def check_replicas(self):
         """Debug aid (MHHIP_CHECK_REPLICAS=1 runs it every 25 cycles): the shared leaves betas | xscale and their
@@ -217,6 +229,7 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
         while self._world()[0] > 1 and bs0 > 1 and (T + bs0 - 1) // bs0 < self._world()[0]:
             bs0 -= 1
         self._build_engine(batch_size=bs0)
+        self._global_leaves()                     # sharded: gathered once here, served locally until fit() ends
         self.scene_depth = None
         self.scene_pcd = None
         self.poses_T_filtered = None
@@ -246,12 +259,25 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
                                betas=self._bcast(np.asarray(leaves['betas'], np.float32)),
                                zmin_lin=np.asarray(leaves['zmin_lin'])[sl], zmax_lin=np.asarray(leaves['zmax_lin'])[sl],
                                xscale=self._bcast(np.asarray(leaves['xscale'], np.float32)))
-        self.sh = sharded.ShardedSequence(self.engine, self.first_frame, self.num_frames, group=self.process_group)
+        self.sh = sharded.ShardedSequence(self.engine, self.first_frame, self.num_frames, group=self.process_group,
+                                          enabled=self.shard_frames)
+        self._global_cache = None
         self._engine_batch = int(batch_size)
         self.valid_smpl = torch.tensor(self._valid, device=self.device)
         self._staged = False
 
-    def _global_leaves(self):
+    def _global_leaves(self, cached=False):
+        """Whole-sequence leaves.  In a frame-sharded run this is a COLLECTIVE (all_gather over the group): ``fit`` and
+        ``init_optimized_variables`` call it on every rank and keep the result, so that ``get_optimized_variables()``
+        (``cached=True``) is a local read -- the usual ``if rank == 0: save(opt.get_optimized_variables())`` works."""
+        if cached and self._world()[0] > 1 and self._global_cache is not None:
+            return self._global_cache
+        g = self._gather_global()
+        if self._world()[0] > 1:
+            self._global_cache = g
+        return g
+
+    def _gather_global(self):
         e = self.engine
         return dict(poses_T=self._gather_frames(e.leaf('poses_T')).reshape(self.num_frames, self.num_people, 1, 3),
                     poses_smpl=self._gather_frames(e.leaf('poses_smpl')), betas=e.leaf('betas').cpu().numpy().copy(),
@@ -455,6 +481,8 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
             if check_every and cycle % check_every == 0:
                 self.check_replicas()
         self._finish_scene()
+        self._global_cache = None
+        self._global_leaves()                     # sharded: the one gather of the result (collective, every rank is here)
         return sh.read_log(num_iter)
 
     def _host_scene_update(self):
@@ -497,7 +525,9 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
     def get_optimized_variables(self):
         e = self.engine
         T, N = self.num_frames, self.num_people
-        g = self._global_leaves()             # frame-sharded run: the whole sequence, gathered on every rank
+        # frame-sharded run: the whole sequence as gathered at the end of init_optimized_variables() / fit() -- a local
+        # read, NOT a collective (leaves edited by hand in between: call refresh_global_leaves() on every rank)
+        g = self._global_leaves(cached=True)
         zmin, zmax = g['zmin_lin'].reshape(T, 1, 1), g['zmax_lin'].reshape(T, 1, 1)
         min_z = softplus_np(zmin)
         max_z = min_z + self.min_delta_z + softplus_np(zmax)

@@ -72,21 +72,24 @@ def camera_inverse_projection(ptsuvd, K):
     return np.concatenate([xy, ptsuvd[:, 2:3]], axis=-1)
 
 
-def _shadowed(name):
-    m = globals().get('__shadowed__')
-    return getattr(m, name, None) if m is not None else None
+def _on_device(t):
+    """Host tensors are uploaded to the current HIP device, pushed through the same kernel and downloaded again: the
+    overlay has ONE arithmetic path (the HIP library) and never executes the module it shadows."""
+    import torch
+    if t.is_cuda:
+        return t, None
+    if not torch.cuda.is_available():
+        raise RuntimeError('mhmocap.transforms (MI355X build) needs a HIP device: there is no CPU path')
+    return t.to('cuda'), t.device
 
 
 def camera_projection_torch(pts3d, K, return_depth=False, Kd=None):
     """pts3d (N,M,3), K (N,3,3) device tensors -> (N,M,2) pixels (reference :57-95); forward only (the optimiser's
-    differentiable projection is fused into ``mh_project_joints_loss``).  Host tensors are not part of the
-    accelerated path: they go to the shadowed reference function when the overlay runs over a reference tree."""
+    differentiable projection is fused into ``mh_project_joints_loss``).  Host tensors make the round trip over the
+    device (same kernel, result returned on the host)."""
     import torch
-    if not pts3d.is_cuda:
-        ref = _shadowed('camera_projection_torch')
-        if ref is None:
-            raise RuntimeError('camera_projection_torch (MI355X build) needs device tensors: no CPU path')
-        return ref(pts3d, K, return_depth=return_depth, Kd=Kd)
+    pts3d, home = _on_device(pts3d)
+    K = K.to(pts3d.device)
     L = _hip()
     p = pts3d.contiguous().float()
     Kc = K.contiguous().float()
@@ -95,23 +98,20 @@ def camera_projection_torch(pts3d, K, return_depth=False, Kd=None):
     kd = None if Kd is None else np.ascontiguousarray(np.asarray(Kd, np.float32).reshape(5))
     L.check(L.lib().mh_project_points(N, M, L.ptr(p), L.ptr(Kc), None if kd is None else kd.ctypes.data_as(L.c_float_p),
                                       1 if return_depth else 0, L.ptr(out), L.stream_ptr(p.device)))
-    return out
+    return out if home is None else out.to(home)
 
 
 def camera_inverse_projection_torch(ptsuvd, K):
     """ptsuvd (N,M,3) pixels + depth, K (N,3,3) -> camera-space points (reference :114-130)."""
     import torch
-    if not ptsuvd.is_cuda:
-        ref = _shadowed('camera_inverse_projection_torch')
-        if ref is None:
-            raise RuntimeError('camera_inverse_projection_torch (MI355X build) needs device tensors: no CPU path')
-        return ref(ptsuvd, K)
+    ptsuvd, home = _on_device(ptsuvd)
+    K = K.to(ptsuvd.device)
     L = _hip()
     p = ptsuvd.contiguous().float()
     Kc = K.contiguous().float()
     out = torch.empty_like(p)
     L.check(L.lib().mh_unproject_points(p.shape[0], p.shape[1], L.ptr(p), L.ptr(Kc), L.ptr(out), L.stream_ptr(p.device)))
-    return out
+    return out if home is None else out.to(home)
 
 
 def softplus(x):

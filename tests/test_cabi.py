@@ -55,6 +55,20 @@ def test_product_path_never_imports_the_oracle():
                 assert 'import oracle' not in src and 'from oracle' not in src and 'oracle.' not in src, os.path.join(dirpath, f)
 
 
+def test_overlay_never_calls_into_the_module_it_shadows():
+    """An overlay module may RE-EXPORT names of the reference module it shadows (mhhip/_overlay.inherit) but no function
+    body of the product may execute one: the only place that touches ``__shadowed__`` is mhhip/_overlay.py."""
+    import re
+    pkg = os.path.join(ROOT, 'scene-aware-3d-multi-human_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            path = os.path.join(dirpath, f)
+            if not f.endswith('.py') or path.endswith(os.path.join('mhhip', '_overlay.py')):
+                continue
+            code = re.sub(r'#.*', '', open(path).read())
+            assert '__shadowed__' not in code and not re.search(r'\b_shadowed\s*\(', code), path
+
+
 def test_overlay_signatures_match_the_reference_call_sites():
     """predict.py:290-306 / 332-344 call these with these keywords."""
     from mhmocap.optimizer import SMPLDepthSequenceOptimizer

@@ -66,10 +66,11 @@ def _run_fit(tmp):
     model = lo.BodyModel(st, regs)
     opt = SMPLDepthSequenceOptimizer(image_size=(W, H), num_frames=T, cam_K=K, device='cpu', smpl_model_parameters_path=tmp,
                                      smpl_data_struct=st, engine_factory=CpuShardEngine.factory(model), use_rasteriser=False,
-                                     scene_update='none', use_graphs=False, **COEFS)
+                                     scene_update='none', use_graphs=False, shard_frames=True, **COEFS)
     opt.init_optimized_variables(pose2d, sp['poses_init'], sp['betas_init'], sp['valid'], num_iter=0)
     # a start away from the [0,0,1] of a skipped warm-up: the ground-truth translations, local slice per rank
     opt.engine.leaf('poses_T').copy_(torch.tensor(sp['trans_gt'][opt.first_frame:opt.last_frame]))
+    opt.refresh_global_leaves()        # leaves edited by hand: re-gather what get_optimized_variables() serves (collective)
     ov0 = opt.get_optimized_variables()
     dl = torch.utils.data.DataLoader(_DS(sp, pose2d), batch_size=BATCH, shuffle=False)
     log = opt.fit(dl, num_iter=CYCLES, update_filters_every=31)

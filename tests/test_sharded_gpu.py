@@ -200,7 +200,8 @@ def _fit_run(tmp, world):
         image_size=(W, H), num_frames=FT, cam_K=K, device='cuda:0', smpl_model_parameters_path=tmp, smpl_data_struct=struct,
         proj2d_loss_coef=c['proj2d'], depth_loss_coef=c['depth'], silhouette_loss_coef=c['silhouette'],
         reg_velocity_coef=c['reg_velocity'], reg_verts_filter_coef=c['reg_verts_filter'], reg_poses_coef=c['reg_poses'],
-        reg_scales_coef=c['reg_scales'], reg_contact_coef=c['reg_contact'], reg_foot_sliding_coef=c['reg_foot_sliding'])
+        reg_scales_coef=c['reg_scales'], reg_contact_coef=c['reg_contact'], reg_foot_sliding_coef=c['reg_foot_sliding'],
+        shard_frames=True)
     seq = synthetic_seq.make_sequence(opt.SMPLPY.body_model, N, FT, (W, H), 45, cam_K=K, z_range=(2.6, 3.6))
     opt.init_optimized_variables(seq['pose2d'], seq['poses_smpl'], seq['betas_smpl'], seq['valid_smpl'], num_iter=30)
     dl = torch.utils.data.DataLoader(synthetic_seq.SequenceDataset(seq), batch_size=BATCH, shuffle=False)

@@ -1,8 +1,14 @@
-"""Host side of the scene update (reference optimizer.py:578-584, 595-600; fhsog.py:180-202;
-utils.py:91-135, 174-209).  The reference runs this part in numpy / OpenCV on the host once per
-cycle >= 30; it is SURVEY row f1 ("next": to be moved to the GPU).  OpenCV is not available in the
-build image, so the bilateral / Sobel / erode steps are restated in numpy following OpenCV's
-documented semantics (BORDER_REFLECT_101) -- this part is unpinned (no reference output exists)."""
+"""TEST INFRASTRUCTURE ONLY (checker of the device scene aggregation, csrc/mh_sceneagg.hip): numpy restatement of the
+reference's host-side scene update -- optimizer.py:578-584, 595-600; fhsog.py:180-202 (``aggegrate_scene_geometry_median``);
+utils.py:91-135 (``fillin_values``), 174-209 (``postprocess_depthmap``).  Nothing under scene-aware-3d-multi-human_amd/
+imports this file (tests/test_cabi.py).
+
+Pinning: ``aggregate_scene_median`` is pinned to the reference's own output (tests/golden/reference_cpu.npz,
+tests/test_scene_median_golden.py).  OpenCV is absent from the image, so ``cv2.bilateralFilter`` / ``cv2.Sobel`` /
+``cv2.erode`` are restated from their documented semantics (BORDER_REFLECT_101, circular bilateral support, +inf border
+for erode) -- **parity unpinned** against cv2 itself (its 32F bilateral uses an interpolated exp table: expect ~1e-5
+relative differences); pinned analytically by tests/test_scene_oracle.py (constant image, step edge, ramp, single-pixel
+erosion, hole filling)."""
 import numpy as np
 import torch
 

@@ -55,6 +55,16 @@ void mh_prof_mark(int which, int edge, hipStream_t st);
     }                                                            \
   } while (0)
 
+// hipFuncSetAttribute is per DEVICE: latch "done" per (call site, device), not per process
+#define MH_MAX_DEVICES 64
+static inline bool mh_first_on_device(unsigned char* flags /*[MH_MAX_DEVICES], zero-initialised static*/) {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MH_MAX_DEVICES) return true;
+  if (flags[d]) return false;
+  flags[d] = 1;
+  return true;
+}
+
 struct mh_tree {
   int parent[MH_NJ];
   int level[MH_NJ];

@@ -579,12 +579,10 @@ static int lbs_forward_impl(const mh_model* m, int B, int NB, const float* betas
     const bool full = (B % 32) == 0, nw4 = m->nw <= 4;
     auto kern = full ? (nw4 ? k_skin_fwd16<true, true> : k_skin_fwd16<true, false>)
                      : (nw4 ? k_skin_fwd16<false, true> : k_skin_fwd16<false, false>);
-    static bool attr16[4] = {false, false, false, false};
+    static unsigned char attr16[4][MH_MAX_DEVICES];
     const int ki = (full ? 2 : 0) + (nw4 ? 1 : 0);
-    if (!attr16[ki]) {
+    if (mh_first_on_device(attr16[ki]))
       MH_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr16[ki] = true;
-    }
     mh_prof_mark(MH_PROF_SKIN_FWD, 0, st);
     hipLaunchKernelGGL(kern, dim3(((m->VP / 32 + FWD16_WAVES * FWD16_TPW - 1) / (FWD16_WAVES * FWD16_TPW) + 7) / 8 * 8, G), dim3(FWD16_WAVES * 64), lds, st, sp);
     MH_LAUNCH_CHECK();
@@ -1523,12 +1521,11 @@ extern "C" int mh_lbs_backward(const mh_model* m, int B, int NB, const float* be
     sp.kpv_ptr = m->kpv_ptr; sp.kpv_j = m->kpv_j; sp.kpv_w = m->kpv_w; sp.kpv_head = m->kpv_head;
     sp.pF = bw.pF; sp.pA = bw.pA; sp.pS = bw.pS;
     const size_t ldsB = (size_t)SB_LDS_FLOATS * 4;
-    static bool attr_b16 = false;
-    if (!attr_b16) {
+    static unsigned char attr_b16[MH_MAX_DEVICES];
+    if (mh_first_on_device(attr_b16)) {
       const void* fk[4] = {(const void*)k_skinbwd16<false, false>, (const void*)k_skinbwd16<false, true>,
                            (const void*)k_skinbwd16<true, false>, (const void*)k_skinbwd16<true, true>};
       for (int i = 0; i < 4; ++i) MH_HIP(hipFuncSetAttribute(fk[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB));
-      attr_b16 = true;
     }
     const bool nw4 = m->nw == 4, kp = gjoints != nullptr;
     auto kern = nw4 ? (kp ? k_skinbwd16<true, true> : k_skinbwd16<true, false>)
@@ -1538,12 +1535,10 @@ extern "C" int mh_lbs_backward(const mh_model* m, int B, int NB, const float* be
     MH_LAUNCH_CHECK();
     mh_prof_mark(MH_PROF_SKIN_BWD, 1, st);
   } else {
-  static bool attr_set = false;
+  static unsigned char attr_set[MH_MAX_DEVICES];
   const size_t lds = (size_t)(16 * BWD_AS + 16 * 52 + BWD_NACC * 4 * 64 + 64) * 4;
-  if (!attr_set) {
+  if (mh_first_on_device(attr_set))
     MH_HIP(hipFuncSetAttribute((const void*)k_skin_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
   SkinBwdP sp;
   sp.B = B; sp.G16 = G16; sp.GB = G * 32; sp.V = m->V; sp.VP = m->VP; sp.nw = m->nw; sp.CH = CH;
   sp.PQ = (m->VP / 4 + CH - 1) / CH;

@@ -1470,11 +1470,9 @@ static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const flo
   if (gverts) {
     const bool use_tab = V <= RG_MAXV;
     const size_t tab = (use_tab ? (size_t)V * 3 * sizeof(float) : 0) + (RG_LIST + 1) * sizeof(int);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned char attr_set[MH_MAX_DEVICES];
+    if (mh_first_on_device(attr_set))
       MH_HIP(hipFuncSetAttribute((const void*)k_raster_grads<true>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_MAXV * 3 * 4 + (RG_LIST + 1) * 4));
-      attr_set = true;
-    }
     // sil_corr is zero here: cleared by k_raster_body_out (phase 1) and again by k_raster_finish after every use
     mh_prof_mark(MH_PROF_RASTER_GRADS, 0, st);
     // one workgroup per CU is resident (LDS table); the work-unit count is only known on the device

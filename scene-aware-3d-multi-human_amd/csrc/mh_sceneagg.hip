@@ -5,7 +5,7 @@
 //   ->  iterative 7x7 median fill of the masked pixels  ->  un-projection of the valid pixels (compacted on the device,
 //   the count stays in device memory so nothing synchronises with the host).
 // OpenCV is not available offline; bilateral / Sobel / erode follow its documented semantics (BORDER_REFLECT_101,
-// circular bilateral support, constant +inf border for erode) exactly as mhmocap/scene_host.py restates them.
+// circular bilateral support, constant +inf border for erode); the checker is oracle/scene_oracle.py + analytic pins.
 #include "mh_common.h"
 
 // ---- per-frame depth range (optimizer.py:683-688): inv_min = 1/min_z, inv_max = 1/max_z ------------------------------
@@ -32,6 +32,7 @@ __global__ __launch_bounds__(64) void k_scene_median(int T, int P, const float* 
   const bool live = p < P;
   auto value = [&](int t) -> unsigned {
     if (!live || backmask[(size_t)t * P + p] == 0) return SM_INVALID;
+    if (!invz) return __float_as_uint(depths[(size_t)t * P + p]);                      // raw non-negative values (colour planes)
     const float inv_min = invz[2 * t], inv_max = invz[2 * t + 1];
     const float disp = depths[(size_t)t * P + p] * (inv_min - inv_max) + inv_max;      // optimizer.py:425
     return __float_as_uint(1.0f / disp);                                               // :426
@@ -458,24 +459,26 @@ extern "C" size_t mh_scene_workspace_bytes(int T, int H, int W) {
 
 extern "C" int mh_scene_median(int T, int H, int W, const float* depths, const uint8_t* backmask, const float* zmin_lin,
                                const float* zmax_lin, float* ma_depth, float* ma_mask, void* ws, void* stream) {
-  MH_CHECK(depths && backmask && zmin_lin && zmax_lin && ma_depth && ma_mask && ws, "null argument");
+  MH_CHECK(depths && backmask && ma_depth && ma_mask && ws, "null argument");
+  MH_CHECK((zmin_lin == nullptr) == (zmax_lin == nullptr), "depth-range leaves come in pairs (both NULL: median of the raw values)");
   MH_CHECK(T > 0 && H > 0 && W > 0, "empty input");
   const int P = H * W;
   SceneWs s = scene_carve(ws, P);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_scene_ranges, dim3((T + 127) / 128), dim3(128), 0, st, T, zmin_lin, zmax_lin, s.invz);
-  MH_LAUNCH_CHECK();
+  if (zmin_lin) {
+    hipLaunchKernelGGL(k_scene_ranges, dim3((T + 127) / 128), dim3(128), 0, st, T, zmin_lin, zmax_lin, s.invz);
+    MH_LAUNCH_CHECK();
+  }
+  const float* invz = zmin_lin ? (const float*)s.invz : (const float*)nullptr;
   const size_t lds = (size_t)T * 64 * sizeof(unsigned);
   if (lds <= 150 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned char attr_set[MH_MAX_DEVICES];
+    if (mh_first_on_device(attr_set))
       MH_HIP(hipFuncSetAttribute((const void*)k_scene_median<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(k_scene_median<true>, dim3((P + 63) / 64), dim3(64), lds, st, T, P, depths, backmask, (const float*)s.invz,
+    hipLaunchKernelGGL(k_scene_median<true>, dim3((P + 63) / 64), dim3(64), lds, st, T, P, depths, backmask, invz,
                        ma_depth, ma_mask);
   } else {     // very long sequences: the values are recomputed from HBM/L2 in every pass
-    hipLaunchKernelGGL(k_scene_median<false>, dim3((P + 63) / 64), dim3(64), 0, st, T, P, depths, backmask, (const float*)s.invz,
+    hipLaunchKernelGGL(k_scene_median<false>, dim3((P + 63) / 64), dim3(64), 0, st, T, P, depths, backmask, invz,
                        ma_depth, ma_mask);
   }
   MH_LAUNCH_CHECK();

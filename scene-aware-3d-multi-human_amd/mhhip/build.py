@@ -45,8 +45,28 @@ def _stale(target, deps):
     return any(os.path.getmtime(f) > t for f in deps)
 
 
+def _flags(src, extra=None):
+    extra = os.environ.get('MHHIP_CXXFLAGS', '').split() if extra is None else extra
+    return COMMON + PER_FILE.get(os.path.basename(src), []) + list(extra)
+
+
+def _stamp(src):
+    return _obj(src) + '.flags'
+
+
+def _flags_changed(src, extra=None):
+    """an object is only reused when it was compiled with exactly the flags this build would use (experiments through
+    MHHIP_CXXFLAGS must not leave objects behind that a later plain build links silently -- mh_lbs.hip without
+    -fno-slp-vectorize computes wrong vertices)"""
+    try:
+        with open(_stamp(src)) as f:
+            return f.read() != ' '.join(_flags(src, extra))
+    except OSError:
+        return True
+
+
 def is_stale():
-    return _stale(LIB, sources() + _headers())
+    return _stale(LIB, sources() + _headers()) or any(_flags_changed(s) for s in sources())
 
 
 def build(force=False, verbose=False):
@@ -59,16 +79,24 @@ def build(force=False, verbose=False):
     hdrs = _headers()
     jobs = []
     for src in sources():
-        if force or extra or _stale(_obj(src), [src] + hdrs):
-            jobs.append([hipcc] + COMMON + PER_FILE.get(os.path.basename(src), []) + extra + ['-c', src, '-o', _obj(src)])
+        if force or _stale(_obj(src), [src] + hdrs) or _flags_changed(src, extra):
+            jobs.append((src, [hipcc] + _flags(src, extra) + ['-c', src, '-o', _obj(src)]))
 
     def run(cmd):
         if verbose:
             print(' '.join(cmd))
         subprocess.run(cmd, check=True)
 
+    def compile_one(job):
+        src, cmd = job
+        if os.path.exists(_stamp(src)):
+            os.remove(_stamp(src))
+        run(cmd)
+        with open(_stamp(src), 'w') as f:
+            f.write(' '.join(_flags(src, extra)))
+
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
-        list(ex.map(run, jobs))
+        list(ex.map(compile_one, jobs))
     run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + [_obj(s) for s in sources()] + ['-o', LIB + '.tmp'])
     os.replace(LIB + '.tmp', LIB)
     return LIB

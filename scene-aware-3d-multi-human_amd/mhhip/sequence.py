@@ -316,22 +316,45 @@ class SequenceEngine(object):
         self._scene_event = s['ev']
         self._scene_pending = True
 
+    # -- hooks of the frame-sharded driver (mhhip/sharded.py; the CPU stand-in of the tests implements the same) -----
+    def main_stream(self):
+        return torch.cuda.current_stream(self.dev)
+
+    def stream_ctx(self, stream):
+        return torch.cuda.stream(stream)
+
+    def scene_median_rows(self, depths_t, back_t, zmin, zmax, med, msk, stream):
+        """masked median over the frame axis of pixel-major rows (rows, frames); zmin = zmax = None: raw values"""
+        rows, frames = depths_t.shape
+        check(_lib.lib().mh_scene_median_t(frames, 1, rows, ptr(depths_t), ptr(back_t), ptr(zmin), ptr(zmax), ptr(med), ptr(msk),
+                                           ptr(self._scene_dev['ws']), stream.cuda_stream))
+
+    def scene_fill_plane(self, val, mask, ksize, stream):
+        """looped ksize x ksize median fill of an integer-valued (H,W) plane, in place (optimizer.py:595-600)"""
+        check(_lib.lib().mh_scene_fill(self.H, self.W, int(ksize), 1, ptr(val), ptr(mask), ptr(self._scene_dev['ws']), stream.cuda_stream))
+
     def scene_device_image(self, images):
         """images (T,H,W,3) uint8 -> (H,W,3) uint8 masked median over time of the background colour, holes filled with
         the 11x11 median like optimizer.py:595-600 (the colour median does not depend on the optimised variables: once
-        per fit).  Returns (scene_img, scene_mask)."""
+        per fit).  Returns (scene_img, scene_mask).  Up to 2048 frames: pixel-major register form of the median; longer
+        sequences: the frame-major form (any T)."""
         d, L = self._scene_dev, _lib.lib()
         T, H, W = self.T, self.H, self.W
         P = H * W
         st = _lib.stream_ptr(self.dev)
         img = torch.as_tensor(np.ascontiguousarray(images)).to(self.dev)
-        back_t = d['back_t'] if 'back_t' in d else d['back'].view(T, P).t().contiguous()
+        if T <= 2048:
+            back_t = d['back_t'] if 'back_t' in d else d['back'].view(T, P).t().contiguous()
         out = torch.empty(H, W, 3, device=self.dev)
         mask = torch.empty(H, W, device=self.dev)
         for ch in range(3):
-            plane_t = img[..., ch].reshape(T, P).t().contiguous().float()
             val = torch.empty(H, W, device=self.dev)
-            check(L.mh_scene_median_t(T, H, W, ptr(plane_t), ptr(back_t), None, None, ptr(val), ptr(mask), ptr(d['ws']), st))
+            if T <= 2048:
+                plane_t = img[..., ch].reshape(T, P).t().contiguous().float()
+                check(L.mh_scene_median_t(T, H, W, ptr(plane_t), ptr(back_t), None, None, ptr(val), ptr(mask), ptr(d['ws']), st))
+            else:
+                plane = img[..., ch].float().contiguous()
+                check(L.mh_scene_median(T, H, W, ptr(plane), ptr(d['back']), None, None, ptr(val), ptr(mask), ptr(d['ws']), st))
             val.floor_()                                        # .astype(np.uint8) of the reference
             m = mask.clone()
             check(L.mh_scene_fill(H, W, 11, 1, ptr(val), ptr(m), ptr(d['ws']), st))

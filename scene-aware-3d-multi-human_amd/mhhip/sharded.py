@@ -180,63 +180,91 @@ class ShardedSequence(object):
         Pmax = (P + G - 1) // G
         p0 = min(self.rank * Pmax, P)
         p1 = min(p0 + Pmax, P)
-
-        def gather_padded(x, fill):
-            buf = torch.full((Tmax, P), fill, dtype=x.dtype, device=e.dev)
-            buf[:T] = x.view(T, P)
-            outs = [torch.empty_like(buf) for _ in range(G)]
-            dist.all_gather(outs, buf, group=self.group)
-            full = torch.cat(outs, 0)                                  # (G*Tmax, P), rank-major frame order
-            sl = torch.zeros(Pmax, G * Tmax, dtype=x.dtype, device=e.dev)
-            sl[:p1 - p0] = full[:, p0:p1].t()
-            return sl.contiguous()
         d = e._scene_dev
-        self._sc = dict(Tmax=Tmax, Tall=G * Tmax, Pmax=Pmax, p0=p0, p1=p1,
-                        depths_t=gather_padded(e.depths, 0.0), back_t=gather_padded(d['back'], 0),
+        self._sc = dict(Tmax=Tmax, Tall=G * Tmax, Pmax=Pmax, p0=p0, p1=p1)
+        assert self._sc['Tall'] <= 2048, 'pixel-sharded median: at most 2048 (padded) frames in total'
+        self._sc.update(depths_t=self._gather_padded(e.depths, 0.0), back_t=self._gather_padded(d['back'], 0),
                         z=[torch.zeros(2 * Tmax, device=e.dev) for _ in range(2)], med=torch.zeros(Pmax, device=e.dev),
                         msk=torch.zeros(Pmax, device=e.dev))
-        assert self._sc['Tall'] <= 2048, 'pixel-sharded median: at most 2048 (padded) frames in total'
+
+    def _gather_padded(self, x, fill):
+        """(T_local, P) frames of this rank -> (Pmax, G*Tmax): ALL frames (rank-major, padded with `fill`) of this
+        rank's slice of the pixels, pixel-major"""
+        e, sc, G = self.e, self._sc, self.world
+        T, P = e.T, e.H * e.W
+        Tmax, Pmax, p0, p1 = sc['Tmax'], sc['Pmax'], sc['p0'], sc['p1']
+        buf = torch.full((Tmax, P), fill, dtype=x.dtype, device=e.dev)
+        buf[:T] = x.view(T, P)
+        outs = [torch.empty_like(buf) for _ in range(G)]
+        dist.all_gather(outs, buf, group=self.group)
+        full = torch.cat(outs, 0)                                  # (G*Tmax, P), rank-major frame order
+        sl = torch.zeros(Pmax, G * Tmax, dtype=x.dtype, device=e.dev)
+        sl[:p1 - p0] = full[:, p0:p1].t()
+        return sl.contiguous()
+
+    def _gather_pixels(self, rows):
+        """(k, Pmax) per-rank pixel slices -> (k, H*W) on every rank"""
+        outs = [torch.empty_like(rows) for _ in range(self.world)]
+        dist.all_gather(outs, rows.contiguous(), group=self.group)
+        return torch.cat(outs, 1)[:, :self.e.H * self.e.W], outs          # slices are Pmax wide, in rank order
 
     def scene_update(self):
         """One scene update (call at the start of a cycle >= 30, like SequenceEngine.scene_device_update)."""
         e = self.e
         if self.world == 1:
             return e.scene_device_update()
-        from . import _lib
-        from ._lib import check, ptr
-        L = _lib.lib()
         sc, d = self._sc, e._scene_dev
-        T, H, W, G = e.T, e.H, e.W, self.world
-        Tmax, Tall, Pmax = sc['Tmax'], sc['Tall'], sc['Pmax']
+        T, G = e.T, self.world
+        Tmax = sc['Tmax']
         k = d['next']
         s = d['sets'][k]
         z = sc['z'][k]                # one snapshot buffer per set: the previous update's all_gather (other stream) may
         z.fill_(1.0)                  # still be reading the other one
         z[:T].copy_(e.leaf('zmin_lin').view(-1))
         z[Tmax:Tmax + T].copy_(e.leaf('zmax_lin').view(-1))
-        main = torch.cuda.current_stream(e.dev)
-        d['ev_main'].record(main)
+        d['ev_main'].record(e.main_stream())
         side = d['stream']
         side.wait_event(d['ev_main'])
-        with torch.cuda.stream(side):
+        with e.stream_ctx(side):
             zs = [torch.empty_like(z) for _ in range(G)]
             dist.all_gather(zs, z, group=self.group)
             zmin_all = torch.cat([z[:Tmax] for z in zs]).contiguous()
             zmax_all = torch.cat([z[Tmax:] for z in zs]).contiguous()
-            st = side.cuda_stream
-            check(L.mh_scene_median_t(Tall, 1, Pmax, ptr(sc['depths_t']), ptr(sc['back_t']), ptr(zmin_all), ptr(zmax_all),
-                                      ptr(sc['med']), ptr(sc['msk']), ptr(d['ws']), st))
+            e.scene_median_rows(sc['depths_t'], sc['back_t'], zmin_all, zmax_all, sc['med'], sc['msk'], side)
             both = torch.stack([sc['med'], sc['msk']])
-            outs = [torch.empty_like(both) for _ in range(G)]
-            dist.all_gather(outs, both, group=self.group)
-            full = torch.cat(outs, 1)[:, :H * W]                         # slices are Pmax wide, in rank order
+            full, outs = self._gather_pixels(both)
             d['ma_depth'].view(-1).copy_(full[0])
             d['ma_mask'].view(-1).copy_(full[1])
-            e._scene_finish(s, st)
+            e._scene_finish(s, side.cuda_stream)
             s['ev'].record(side)
             self._keep = (zs, zmin_all, zmax_all, both, outs, full)      # alive until the stream has consumed them
         d['ready'] = k
         d['next'] = 1 - k
+
+    def scene_image(self, images_local):
+        """images (T_local,H,W,3) uint8 of this rank's frames -> (scene_img (H,W,3) uint8, scene_mask (H,W)): masked
+        median over ALL frames of the background colour + looped 11x11 fill (optimizer.py:595-600), once per fit.
+        Frame-sharded: the same pixel sharding as the depth median (each colour plane gathered pixel-major for the own
+        slice of the pixels, medians all-gathered, the fill redundantly on every rank)."""
+        e = self.e
+        if self.world == 1:
+            return e.scene_device_image(images_local)
+        sc, d = self._sc, e._scene_dev
+        H, W = e.H, e.W
+        main = e.main_stream()
+        img = torch.as_tensor(np.ascontiguousarray(images_local)).to(e.dev)
+        out = torch.empty(H, W, 3, device=e.dev)
+        med, msk = torch.zeros(sc['Pmax'], device=e.dev), torch.zeros(sc['Pmax'], device=e.dev)
+        m = None
+        for ch in range(3):
+            plane_t = self._gather_padded(img[..., ch].float().reshape(e.T, H * W), 0.0)
+            e.scene_median_rows(plane_t, sc['back_t'], None, None, med, msk, main)
+            full, _ = self._gather_pixels(torch.stack([med, msk]))
+            val = full[0].floor().view(H, W).contiguous()             # .astype(np.uint8) of the reference
+            m = full[1].view(H, W).contiguous().clone()
+            e.scene_fill_plane(val, m, 11, main)
+            out[..., ch] = val
+        return out.clamp_(0, 255).to(torch.uint8).cpu().numpy(), m.cpu().numpy()
 
     def scene_swap(self):
         self.e.scene_device_swap()

@@ -83,7 +83,10 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
                  reg_velocity_coef=1.0, reg_verts_filter_coef=1.0, reg_poses_coef=1.0, reg_scales_coef=1.0,
                  reg_contact_coef=1.0, reg_foot_sliding_coef=1.0, joint_confidence_thr=0.5, eps=1e-3, **kargs):
         self.use_rasteriser = kargs.pop('use_rasteriser', True)
-        self.scene_update = kargs.pop('scene_update', 'device')      # 'device' | 'host' (numpy, like the reference) | 'none'
+        self.scene_update = kargs.pop('scene_update', 'device')      # 'device' | 'none'
+        if self.scene_update not in ('device', 'none'):
+            raise ValueError("scene_update must be 'device' or 'none' (the numpy restatement of the reference's host path "
+                             "lives with the test infrastructure, not in the product), got %r" % (self.scene_update,))
         self.use_graphs = kargs.pop('use_graphs', True)              # replay each cycle as a captured hipGraph
         # frame sharding is OPT-IN: ``shard_frames=True``, a ``process_group=``, or MHHIP_SHARD_FRAMES=1 in
         # the environment (for an unmodified predict.py under torchrun).  Every rank is then handed the SAME
@@ -346,24 +349,32 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
             if int(bs) != self._engine_batch:
                 self._build_engine(int(bs), leaves=self._global_leaves())
             own = (self.first_frame, self.last_frame)
-        LOCAL = ('depths', 'seg_mask')
+        LOCAL = ('depths', 'seg_mask', 'images', 'backmasks')     # per-pixel inputs: only the own frames are kept
+        PINNED = ('depths', 'seg_mask')          # uploaded once at PCIe speed; images / backmasks stay pageable (they are
+        # only read again for the scene update's set-up and the scene image) -- and never more than this many bytes
+        pin_budget = [int(float(os.environ.get('MHHIP_STAGE_PINNED_MAX_GB', '8')) * (1 << 30))]
 
         def alloc(k, shape, dtype):
-            # page-locked host buffers: the one upload of the sequence then runs at PCIe speed
             n = T if own is None or k not in LOCAL else own[1] - own[0]
-            try:
-                t = torch.zeros((n,) + tuple(shape), dtype=torch.from_numpy(np.zeros(0, dtype)).dtype,
-                                pin_memory=torch.cuda.is_available() and os.environ.get('MHHIP_STAGE_PINNED', '1') == '1')
-                keep[k] = t
-                store[k] = t.numpy()
-            except (RuntimeError, TypeError):
-                store[k] = np.zeros((n,) + tuple(shape), dtype)
+            nbytes = int(np.prod((n,) + tuple(shape))) * np.dtype(dtype).itemsize
+            pin = (k in PINNED and torch.cuda.is_available() and os.environ.get('MHHIP_STAGE_PINNED', '1') == '1'
+                   and nbytes <= pin_budget[0])
+            if pin:
+                try:
+                    t = torch.zeros((n,) + tuple(shape), dtype=torch.from_numpy(np.zeros(0, dtype)).dtype, pin_memory=True)
+                    pin_budget[0] -= nbytes
+                    keep[k] = t
+                    store[k] = t.numpy()
+                    return
+                except (RuntimeError, TypeError):
+                    pass
+            store[k] = np.zeros((n,) + tuple(shape), dtype)
 
         def put(idx, data, lead):
             nonlocal have_img
             for k in ['depths', 'seg_mask', 'pose2d', 'poses_smpl', 'images', 'backmasks']:
                 if k not in data:
-                    if k in LOCAL:
+                    if k in ('depths', 'seg_mask'):
                         have_img = False
                     continue
                 if own is not None and k in LOCAL:
@@ -402,8 +413,11 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
         loc = (lambda k: store[k]) if own is not None else (lambda k: store[k][sl])
         self.engine.stage(store['pose2d'][sl], store.get('poses_smpl', self._poses_ref)[sl], self._valid[sl], self._betas_ref,
                           loc('seg_mask') if have_img else None, loc('depths') if have_img else None)
-        self._images = store.get('images')          # whole sequence (colour median of the scene image, once per fit)
-        self._backmasks = store.get('backmasks')
+        # own frames only (scene update set-up, colour median of the scene image once per fit); copied out of the staging
+        # buffers so that no page-locked memory outlives this call
+        self._images = None if 'images' not in store else np.array(loc('images'))
+        self._backmasks = None if 'backmasks' not in store else np.array(loc('backmasks'))
+        keep.clear()
         self._staged = True
 
     @staticmethod
@@ -438,8 +452,6 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
         if self.use_rasteriser and e.has_images:
             raster = e.raster_terms(self.znear, self.zfar)        # one per engine: captured graphs bake its addresses
         scene_mode = self.scene_update
-        if world > 1 and scene_mode == 'host':
-            raise RuntimeError("scene_update='host' is a single-process path; the frame-sharded run aggregates on the device")
         check_every = 25 if os.environ.get('MHHIP_CHECK_REPLICAS') == '1' else 0
         lr = 0.01                                                             # a new RMSprop + ExponentialLR per fit (:355-356)
         cycles = range(num_iter)
@@ -458,7 +470,7 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
             if dev_scene and e._scene_dev is None:
                 # the update only reads the depth-range leaves as they are before this cycle's step and is first used by
                 # the NEXT cycle's contact term: launched on its own stream during this cycle, swapped in after it
-                sh.scene_setup(self._backmasks[self.first_frame:self.last_frame])
+                sh.scene_setup(self._backmasks)
             if world > 1:
                 # frame-sharded: halos + ONE all-reduce of the betas|xscale gradient tail per cycle (mhhip/sharded.py);
                 # the median of the scene update runs pixel-sharded over all ranks' frames
@@ -466,13 +478,9 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
                     sh.scene_update()
                 sh.cycle(cycle, raster=raster, graphs=self.use_graphs)
             else:
-                # single process: one captured graph per cycle (the device scene update is issued after the first
-                # replay); the host scene path hands over a new cloud every cycle, so it launches eagerly
-                sh.cycle(cycle, raster=raster, graphs=self.use_graphs and not (scene_now and scene_mode == 'host'),
-                         scene_update=dev_scene)
-            if scene_now and scene_mode == 'host':
-                self._host_scene_update()
-            elif dev_scene:
+                # single process: one captured graph per cycle (the device scene update is issued after the first replay)
+                sh.cycle(cycle, raster=raster, graphs=self.use_graphs, scene_update=dev_scene)
+            if dev_scene:
                 e.scene_device_swap()
             if not self.optim_scale_factor:
                 e.leaf('xscale', e.grads).zero_()
@@ -485,36 +493,17 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
         self._global_leaves()                     # sharded: the one gather of the result (collective, every rank is here)
         return sh.read_log(num_iter)
 
-    def _host_scene_update(self):
-        from . import scene_host
-        e = self.engine
-        depths = scene_host.target_depths(e)                                  # (T,H,W) = 1/target_disp, :425-426
-        ma_image, ma_depth, ma_mask = scene_host.aggregate_scene_median(depths, self._images, self._backmasks)
-        self.scene_depth = scene_host.postprocess_depthmap(ma_depth, ma_mask, use_bilateral_filter=True)
-        self._ma = (ma_image, ma_mask)
-        self.update_scene_pointcloud(self.scene_depth, ma_mask)
-
     def _finish_scene(self):
+        """results of the device scene aggregation back on the host + the scene image (optimizer.py:595-600), once per fit"""
         e = self.engine
-        if self.scene_update == 'device' and e._scene_dev is not None:
-            from . import scene_host
-            self.scene_depth, ma_mask, pts = e.scene_device_result()
-            self.scene_pcd = pts.unsqueeze(0).unsqueeze(0)
-            self._ma = None
-            if self._images is not None and self.num_frames <= 512 and self._world()[0] == 1:
-                # colour median + 11x11 fill on the device (independent of the optimised variables: once per fit)
-                self.scene_img, self.scene_mask = e.scene_device_image(self._images)
-                return
-            if self._images is not None:
-                ma_image = scene_host.aggregate_scene_median(None, self._images, self._backmasks, images_only=True)[0]
-                self._ma = (ma_image, ma_mask)
-        if getattr(self, '_ma', None) is None or self._ma[0] is None:
+        if self.scene_update != 'device' or e._scene_dev is None:
             return
-        from . import scene_host
-        scene_img, scene_mask = self._ma[0].copy(), self._ma[1].astype(np.float32).copy()
-        while scene_mask.min() == 0:                                          # :595-600
-            scene_img, scene_mask = scene_host.fillin_values(scene_img, scene_mask, filter_size=11)
-        self.scene_img, self.scene_mask = scene_img, scene_mask
+        self.scene_depth, ma_mask, pts = e.scene_device_result()
+        self.scene_pcd = pts.unsqueeze(0).unsqueeze(0)
+        if self._images is not None:
+            # colour median + looped 11x11 fill on the device (independent of the optimised variables: once per fit);
+            # frame-sharded: pixel-sharded over the ranks like the depth median
+            self.scene_img, self.scene_mask = self.sh.scene_image(self._images)
 
     # -- reference optimizer.py:605-616 ---------------------------------------------------------------
     def update_scene_pointcloud(self, scene_depth, scene_mask):

@@ -1,5 +1,5 @@
 """Scene aggregation on the device (row a24/f1) against the numpy restatement of the reference's host pipeline
-(mhmocap/scene_host.py; its median is pinned to the reference through tests/golden): masked median over time,
+(oracle/scene_oracle.py; its median is pinned to the reference through tests/golden): masked median over time,
 bilateral + Sobel edge mask + erode + iterative median fill, compaction/un-projection."""
 import numpy as np
 import pytest
@@ -21,7 +21,7 @@ def _ranges(zmin, zmax):
 
 @pytest.mark.parametrize('T,H,W', [(23, 12, 20), (200, 9, 70), (8, 16, 16)])
 def test_masked_median_over_time(T, H, W):
-    from mhmocap import scene_host
+    from oracle import scene_oracle as scene_host
     _l, L = _lib()
     rng = np.random.RandomState(T)
     dn = rng.uniform(0, 1, (T, H, W)).astype(np.float32)
@@ -73,7 +73,7 @@ def _scene(H, W, seed):
 
 @pytest.mark.parametrize('H,W,bilateral', [(68, 120, 1), (45, 37, 1), (68, 120, 0)])
 def test_postprocess_depthmap(H, W, bilateral):
-    from mhmocap import scene_host
+    from oracle import scene_oracle as scene_host
     _l, L = _lib()
     depth, mask = _scene(H, W, H + W)
     want = scene_host.postprocess_depthmap(depth, mask, use_bilateral_filter=bool(bilateral))
@@ -141,7 +141,7 @@ def _fit(smpl_struct, smpl_regs, tmp_path, mode, num_iter):
 def test_fit_builds_the_scene_on_the_device(smpl_struct, smpl_regs, tmp_path):
     """same optimiser state -> the device pipeline must reproduce the host one (numpy, as the reference does it); then
     the organic path of `fit` (first scene update at cycle 30) runs with the contact term live"""
-    from mhmocap import scene_host
+    from oracle import scene_oracle as scene_host
     opt, _ = _fit(smpl_struct, smpl_regs, tmp_path, 'none', 3)
     e = opt.engine
     depths = scene_host.target_depths(e)
@@ -164,7 +164,7 @@ def test_fit_builds_the_scene_on_the_device(smpl_struct, smpl_regs, tmp_path):
 
 def test_scene_image_median_and_fill_on_the_device(smpl_struct, smpl_regs, tmp_path):
     """optimizer.py:595-600: colour median over time (background pixels only) + looped 11x11 median fill of the holes"""
-    from mhmocap import scene_host
+    from oracle import scene_oracle as scene_host
     opt, _ = _fit(smpl_struct, smpl_regs, tmp_path, 'none', 1)
     e = opt.engine
     T, H, W = e.T, e.H, e.W
@@ -182,3 +182,70 @@ def test_scene_image_median_and_fill_on_the_device(smpl_struct, smpl_regs, tmp_p
     assert got_img.dtype == np.uint8 and got_img.shape == (H, W, 3)
     np.testing.assert_array_equal(got_mask, np.ones((H, W), np.float32))
     np.testing.assert_array_equal(got_img, want_img)
+
+
+# ---- known answers (tests/test_scene_oracle.py pins the numpy checker with the same cases) -----------------------------------
+def _known_cases():
+    import test_scene_oracle as tso
+    return tso.scene_known_answer_cases()
+
+
+@pytest.mark.parametrize('case', _known_cases(), ids=lambda c: c[0])
+def test_postprocess_known_answers_on_the_device(case):
+    """constant image with a hole / clean depth step / step on a ramp: outputs that follow from the definitions of the
+    bilateral filter, Sobel, two 3x3 erosions and the looped 7x7 median fill (utils.py:174-209, 91-135) -- no checker"""
+    _l, L = _lib()
+    _, depth, mask, bil, want, rtol = case
+    H, W = depth.shape
+    dev = torch.device('cuda:0')
+    ws = torch.empty(L.mh_scene_workspace_bytes(1, H, W), dtype=torch.uint8, device=dev)
+    out = torch.empty(H, W, device=dev)
+    tdepth, tmask = torch.tensor(depth, device=dev), torch.tensor(mask, device=dev)
+    _l.check(L.mh_scene_postprocess(H, W, _l.ptr(tdepth), _l.ptr(tmask), int(bil), 7, _l.ptr(out), _l.ptr(ws), _l.stream_ptr(dev)))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=max(rtol, 2e-6))
+
+
+def test_fill_sweeps_known_answer_on_the_device():
+    """value = column index with nine masked columns: medians of the valid window values, the second sweep reading the
+    first sweep's results (and never a value written in the same sweep)"""
+    import test_scene_oracle as tso
+    _l, L = _lib()
+    x, mask, filled = tso.column_hole_case()
+    H, W = x.shape
+    dev = torch.device('cuda:0')
+    ws = torch.empty(L.mh_scene_workspace_bytes(1, H, W), dtype=torch.uint8, device=dev)
+    tv, tm = torch.tensor(x, device=dev), torch.tensor(mask, device=dev)
+    _l.check(L.mh_scene_fill(H, W, 7, 0, _l.ptr(tv), _l.ptr(tm), _l.ptr(ws), _l.stream_ptr(dev)))
+    torch.cuda.synchronize()
+    got = tv.cpu().numpy()
+    np.testing.assert_array_equal(tm.cpu().numpy(), np.ones((H, W), np.float32))
+    np.testing.assert_allclose(got[:, 10:19], filled[None, :].repeat(H, 0), rtol=1e-6)
+    np.testing.assert_array_equal(got[:, :10], x[:, :10])
+    np.testing.assert_array_equal(got[:, 19:], x[:, 19:])
+
+
+def test_raw_value_median_frame_major_equals_pixel_major():
+    """colour planes of sequences longer than the register form's 2048 frames go through mh_scene_median with
+    zmin = zmax = NULL (raw values); same result as the pixel-major form and as numpy"""
+    _l, L = _lib()
+    T, H, W = 37, 10, 23
+    rng = np.random.RandomState(3)
+    vals = rng.randint(0, 256, (T, H, W)).astype(np.float32)
+    back = (rng.uniform(0, 1, (T, H, W)) > 0.5).astype(np.uint8)
+    back[:, 0, 0] = 0
+    dev = torch.device('cuda:0')
+    ws = torch.empty(L.mh_scene_workspace_bytes(T, H, W), dtype=torch.uint8, device=dev)
+    tv, tb = torch.tensor(vals, device=dev), torch.tensor(back, device=dev)
+    a, am = torch.empty(H, W, device=dev), torch.empty(H, W, device=dev)
+    b, bm = torch.empty(H, W, device=dev), torch.empty(H, W, device=dev)
+    _l.check(L.mh_scene_median(T, H, W, _l.ptr(tv), _l.ptr(tb), None, None, _l.ptr(a), _l.ptr(am), _l.ptr(ws), _l.stream_ptr(dev)))
+    tvt, tbt = tv.view(T, H * W).t().contiguous(), tb.view(T, H * W).t().contiguous()
+    _l.check(L.mh_scene_median_t(T, H, W, _l.ptr(tvt), _l.ptr(tbt), None, None, _l.ptr(b), _l.ptr(bm), _l.ptr(ws), _l.stream_ptr(dev)))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())
+    np.testing.assert_array_equal(am.cpu().numpy(), bm.cpu().numpy())
+    want = np.ma.median(np.ma.array(vals, mask=back == 0), axis=0)
+    seen = back.max(axis=0) > 0
+    np.testing.assert_allclose(a.cpu().numpy()[seen], want.data[seen], rtol=1e-6)
+    assert not seen[0, 0] and float(am[0, 0]) == 0.0

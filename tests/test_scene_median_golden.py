@@ -1,7 +1,7 @@
 """The per-pixel masked median over time of the scene update (reference fhsog.py:180-202, called from
 optimizer.py:579-582) against the reference's own output (tests/golden: ``median_*`` on the T=20 fit inputs, where
-every pixel is seen; ``median2_*`` with ties, never-seen pixels and pixels seen by 1 / 2 / 4 frames): the numpy host
-path of the product (non-default ``scene_update='host'``) on the CPU, and the two device kernels
+every pixel is seen; ``median2_*`` with ties, never-seen pixels and pixels seen by 1 / 2 / 4 frames): the numpy
+checker (oracle/scene_oracle.py) on the CPU, and the two device kernels
 (``mh_scene_median`` / ``mh_scene_median_t``) on the GPU."""
 import numpy as np
 import pytest
@@ -20,7 +20,7 @@ def _case(which, golden, golden_raster):
 
 @pytest.mark.parametrize('which', [1, 2])
 def test_host_median_matches_reference(golden, golden_raster, which):
-    from mhmocap import scene_host
+    from oracle import scene_oracle as scene_host
     dn, back, imgs, wimg, wdep, wmask = _case(which, golden, golden_raster)
     img, dep, msk = scene_host.aggregate_scene_median((1.0 / (dn + 0.5)).astype(np.float32), imgs, back)
     np.testing.assert_array_equal(msk, wmask)

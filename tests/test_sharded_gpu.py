@@ -277,4 +277,10 @@ def test_fit_of_the_drop_in_on_two_ranks(tmp_path):
         tol = 5e-2 * max(1.0, float(np.median(np.abs(ov[k]))))
         assert np.median(err) <= tol and np.isfinite(r[0]['ov'][k]).all(), (k, float(np.median(err)), float(np.percentile(err, 90)), tol)
     assert log[33]['reg_filter_verts'] > 0 and log[33]['reg_contact'] > 0 and r[0]['log'][33]['reg_contact'] > 0
+    # the scene image (optimizer.py:595-600) does not depend on the optimised variables: the pixel-sharded colour median
+    # + fill of the two-rank run must be EXACTLY the single-process one, on every rank
+    for k in ('scene_img', 'scene_mask'):
+        assert ov[k] is not None and np.asarray(ov[k]).shape[:2] == (H, W)
+        np.testing.assert_array_equal(r[0]['ov'][k], ov[k], err_msg=k)
+        np.testing.assert_array_equal(r[1]['ov'][k], ov[k], err_msg=k)
     assert r[0]['ov']['scene_depth'].shape == (H, W) and np.isfinite(r[0]['ov']['scene_depth']).all()

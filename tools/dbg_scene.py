@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'scene-aware-3d-multi-human_amd'), os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'tests', 'golden')]
 from mhhip import synthetic, synthetic_seq
 from mhmocap.optimizer import SMPLDepthSequenceOptimizer
-from mhmocap import scene_host
+from oracle import scene_oracle as scene_host
 import golden_inputs as gi
 struct = synthetic.make_smpl_struct(1); regs = synthetic.make_extra_regressors(1, struct)
 tmp = tempfile.mkdtemp()

@@ -131,6 +131,12 @@ def main():
     ap.add_argument('--humans', type=int, default=None)
     ap.add_argument('--frames', type=int, default=None)
     ap.add_argument('--image', type=str, default=None)
+    ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl', help='nccl = RCCL over xGMI (the measured '
+                    'configuration).  gloo: DRY RUN of the multi-rank path -- every collective staged through host memory '
+                    '(mhhip/hostdist.py); with --one-device all ranks share cuda:0, so the N-rank orchestration (halos, '
+                    'all-reduce, filter hand-off) can be executed on a 1-GPU box.  Its numbers are not scaling results.')
+    ap.add_argument('--one-device', action='store_true', help='every rank uses cuda:0 (only with --backend gloo)')
+    ap.add_argument('--presteps', type=int, default=300, help='untimed steady-state cycles before the warm-up')
     args = ap.parse_args()
     global N_PEOPLE, T_LOCAL, IMG
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -146,16 +152,23 @@ def main():
         T_LOCAL = args.frames
     if args.image:
         IMG = tuple(int(x) for x in args.image.split('x'))
-    T_TOTAL = 500 if args.strong else T_LOCAL * world
+    T_TOTAL = (args.frames or 500) if args.strong else T_LOCAL * world
 
     import torch.distributed as dist
+    assert args.backend == 'gloo' or not args.one_device, '--one-device needs --backend gloo (RCCL refuses two ranks per device)'
+    dev_index = 0 if args.one_device else local_rank
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    device = 'cuda:%d' % local_rank
-    torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(dev_index)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
+        else:
+            dist.init_process_group('gloo')
+            from mhhip import hostdist
+            dist = hostdist.install()          # host-staged collectives for the driver, the drop-in and this file
+    device = 'cuda:%d' % dev_index
+    torch.cuda.set_device(dev_index)
 
     import tempfile
     from mhhip import build as mhbuild, synthetic, synthetic_seq, sharded
@@ -216,7 +229,7 @@ def main():
     # bring the device to its steady state before the W warm-up steps: graph capture, lazy allocations, and enough
     # back-to-back work for the clocks to ramp (a fresh box that idled through the CPU-side set-up was once measured
     # at 0.57x for the first tens of milliseconds)
-    for c_pre in range(300):            # a fixed count: every rank must issue the same collectives
+    for c_pre in range(args.presteps):  # a fixed count: every rank must issue the same collectives
         one_cycle(1 + c_pre % 20, use_graphs)
         if c_pre % 10 == 9:
             torch.cuda.synchronize()
@@ -336,6 +349,8 @@ def main():
             'unit': 'iterations/s (%d humans x %d frames per iteration unit)' % (N_PEOPLE, unit_frames), 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'strong' if args.strong else 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'launch': 'eager' if args.eager else 'hipGraph replay',
+            'backend': ('RCCL (nccl)' if args.backend == 'nccl' else 'DRY RUN: gloo, collectives staged through the host%s -- not a '
+                        'scaling measurement' % (', all ranks on one device' if args.one_device else '')) if world > 1 else None,
             'config': {'workload': ('BASELINE C5: %d humans x %d frames + 200 000-point scene cloud, %dx%d, batch 10, full nine-term '
                                     'loss stack + RMSprop, one-euro filters live' % (N_PEOPLE, T_TOTAL, IMG[0], IMG[1])) if args.strong else
                                    ('MuPoTs TS13-shape %d humans x %d frames, %dx%d, batch 10, full nine-term loss stack '

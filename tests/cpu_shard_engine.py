@@ -2,6 +2,7 @@
 that the frame-sharded driver (mhhip/sharded.py: halo exchange, shared-gradient all-reduce, one-euro
 state hand-off) can be exercised with world_size > 1 on the gloo backend without a GPU.  The maths
 comes from the oracle (tests may use it); only the raster-free terms are modelled."""
+import contextlib
 import math
 
 import numpy as np
@@ -9,6 +10,23 @@ import torch
 
 from oracle import fit_oracle as fo
 from oracle import lbs_oracle as lo
+from oracle import scene_oracle as so
+
+
+class _NullStream(object):
+    """what the sharded driver needs of a stream on a host without one"""
+    cuda_stream = None
+
+    def wait_event(self, ev):
+        pass
+
+    def synchronize(self):
+        pass
+
+
+class _NullEvent(object):
+    def record(self, stream=None):
+        pass
 
 
 def one_euro_shard_np(x, min_cutoff, beta, first_frame, state, frame_rate=25):
@@ -177,6 +195,92 @@ class CpuShardEngine(object):
 
     def step(self, lr):
         fo.rmsprop_step(self.params, self.grads, self.sq, self.buf, lr)
+
+    # -- scene aggregation hooks (same contract as SequenceEngine; arithmetic from oracle/scene_oracle.py) ------------
+    def main_stream(self):
+        return _NullStream()
+
+    def stream_ctx(self, stream):
+        return contextlib.nullcontext()
+
+    def set_images(self, depths):
+        self.depths = torch.tensor(np.asarray(depths, np.float32))
+        self.has_images = True
+
+    def scene_device_setup(self, backmasks):
+        H, W, T = self.H, self.W, self.T
+        z = lambda *s: torch.zeros(*s)
+        self._scene_dev = dict(back=torch.tensor((np.asarray(backmasks) != 0).astype(np.uint8)), ws=None, ma_depth=z(H, W),
+                               ma_mask=z(H, W), depth=z(H, W), stream=_NullStream(), ev_main=_NullEvent(),
+                               sets=[dict(pts=z(H * W, 3), count=torch.zeros(1, dtype=torch.int32), grid=None,
+                                          zsnap=z(2 * T), ev=_NullEvent()) for _ in range(2)],
+                               next=0, ready=None, front=None)
+
+    def scene_median_rows(self, depths_t, back_t, zmin, zmax, med, msk, stream):
+        d = depths_t.numpy().astype(np.float32)
+        if zmin is not None:
+            zmin, zmax = zmin.numpy().astype(np.float32), zmax.numpy().astype(np.float32)
+            min_z = np.log(np.float32(1) + np.exp(zmin)).astype(np.float32)
+            max_z = (min_z + np.float32(1) + np.log(np.float32(1) + np.exp(zmax))).astype(np.float32)
+            inv_min, inv_max = (np.float32(1) / min_z)[None], (np.float32(1) / max_z)[None]
+            d = (np.float32(1) / (d * (inv_min - inv_max) + inv_max)).astype(np.float32)
+        m = np.ma.median(np.ma.array(d, mask=back_t.numpy() == 0), axis=1)
+        seen = back_t.numpy().max(axis=1) > 0
+        med.copy_(torch.tensor(np.where(seen, np.ma.filled(m, 0.0), 0.0).astype(np.float32)))
+        msk.copy_(torch.tensor(seen.astype(np.float32)))
+
+    def _scene_finish(self, s, st):
+        d = self._scene_dev
+        ma_depth, ma_mask = d['ma_depth'].numpy(), d['ma_mask'].numpy()
+        with np.errstate(invalid='ignore', divide='ignore'):
+            depth = so.postprocess_depthmap(ma_depth, ma_mask, use_bilateral_filter=True)
+        d['depth'].copy_(torch.tensor(depth))
+        H, W = self.H, self.W
+        K = self.K[0].numpy()
+        u = (np.arange(W, dtype=np.float32) + 0.5 - K[0, 2]) / K[0, 0]
+        v = (np.arange(H, dtype=np.float32) + 0.5 - K[1, 2]) / K[1, 1]
+        pts = np.stack([depth * u[None, :], depth * v[:, None], depth], -1)[ma_mask > 0.5].astype(np.float32)
+        s['pts'][:len(pts)] = torch.tensor(pts)
+        s['count'][0] = len(pts)
+
+    def scene_device_update(self):
+        d = self._scene_dev
+        T, P = self.T, self.H * self.W
+        k = d['next']
+        med, msk = torch.zeros(P), torch.zeros(P)
+        self.scene_median_rows(self.depths.view(T, P).t().contiguous(), d['back'].view(T, P).t().contiguous(),
+                               self.leaf('zmin_lin').clone(), self.leaf('zmax_lin').clone(), med, msk, None)
+        d['ma_depth'].view(-1).copy_(med)
+        d['ma_mask'].view(-1).copy_(msk)
+        self._scene_finish(d['sets'][k], None)
+        d['ready'], d['next'] = k, 1 - k
+
+    def scene_device_swap(self):
+        d = self._scene_dev
+        if d['ready'] is not None:
+            d['front'], d['ready'] = d['sets'][d['ready']], None
+
+    def scene_device_result(self):
+        d = self._scene_dev
+        s = d['front'] if d['ready'] is None else d['sets'][d['ready']]
+        n = int(s['count'].item())
+        return d['depth'].numpy().copy(), d['ma_mask'].numpy() > 0.5, s['pts'][:n].clone()
+
+    def scene_fill_plane(self, val, mask, ksize, stream):
+        x, m = val.numpy().astype(np.uint8), mask.numpy().copy()      # integer plane: every sweep stores floor(median)
+        while m.min() == 0:
+            x, m = so.fillin_values(x, m, filter_size=ksize)
+        val.copy_(torch.tensor(x.astype(np.float32)))
+        mask.copy_(torch.tensor(m))
+
+    def scene_device_image(self, images):
+        T, H, W = self.T, self.H, self.W
+        back = self._scene_dev['back'].numpy()
+        img, _, _ = so.aggregate_scene_median(None, np.asarray(images), back, images_only=True)
+        mask = (back.max(axis=0) > 0).astype(np.float32)
+        while mask.min() == 0:
+            img, mask = so.fillin_values(img, mask, filter_size=11)
+        return img, mask
 
     def one_euro_shard(self, x, min_cutoff, beta, first_frame, state_in=None):
         st = None if state_in is None else (state_in[0].numpy(), state_in[1].numpy())

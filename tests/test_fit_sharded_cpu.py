@@ -1,4 +1,4 @@
-"""world_size-2 (gloo, CPU) run of the DROP-IN's ``fit`` (mhmocap/optimizer.py) against the single-process run: the
+"""world_size-2 and -3 (gloo, CPU; 3 ranks: uneven blocks 6/3/3, a middle rank) run of the DROP-IN's ``fit`` (mhmocap/optimizer.py) against the single-process run: the
 orchestration the 8-GPU run of ``predict_mupots.py`` under torchrun goes through -- every rank is handed the same
 whole-sequence inputs, keeps its contiguous block of frames (block boundaries at batch multiples), the replicated
 shape / scale leaves are broadcast from rank 0, each cycle exchanges the halos and all-reduces the shared gradient
@@ -92,20 +92,22 @@ def _worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(900)
-def test_fit_on_two_ranks_matches_one(tmp_path):
-    port = 31500 + os.getpid() % 2000
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+@pytest.mark.parametrize('world,bounds', [(2, [(0, 6), (6, 12)]), (3, [(0, 6), (6, 9), (9, 12)])])
+def test_fit_on_several_ranks_matches_one(tmp_path, world, bounds):
+    port = 31500 + os.getpid() % 2000 + 7 * world
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     one = os.path.join(str(tmp_path), 'one')
     os.makedirs(one)
     opt, ov0, log, ov = _run_fit(one)
     assert (opt.first_frame, opt.last_frame) == (0, T)
-    r = [torch.load(os.path.join(str(tmp_path), 'rank%d.pt' % k), weights_only=False) for k in range(2)]
-    assert (r[0]['first'], r[0]['last'], r[1]['first'], r[1]['last']) == (0, 6, 6, 12) and r[0]['local_T'] == 6
+    r = [torch.load(os.path.join(str(tmp_path), 'rank%d.pt' % k), weights_only=False) for k in range(world)]
+    assert [(x['first'], x['last']) for x in r] == bounds and r[0]['local_T'] == 6
     keys = ['scale_factor', 'poses_T', 'poses_smpl', 'betas_smpl', 'valid_smpl', 'min_z', 'max_z']
     for k in keys:
         # every rank returns the WHOLE sequence, identical across ranks ...
-        np.testing.assert_array_equal(r[0]['ov'][k], r[1]['ov'][k], err_msg=k)
-        np.testing.assert_array_equal(r[0]['ov0'][k], r[1]['ov0'][k], err_msg=k)
+        for x in r[1:]:
+            np.testing.assert_array_equal(r[0]['ov'][k], x['ov'][k], err_msg=k)
+            np.testing.assert_array_equal(r[0]['ov0'][k], x['ov0'][k], err_msg=k)
         assert r[0]['ov'][k].shape == ov[k].shape, k
         # ... and equal to the single-process run (33 RMSprop steps incl. two with the filtered-vertex term)
         np.testing.assert_allclose(r[0]['ov0'][k], ov0[k], atol=1e-7, err_msg=k)
@@ -115,5 +117,5 @@ def test_fit_on_two_ranks_matches_one(tmp_path):
     for c in range(CYCLES):
         for key in log[c]:
             np.testing.assert_allclose(r[0]['log'][c][key], log[c][key], rtol=2e-4, atol=1e-7, err_msg='%s cycle %d' % (key, c))
-            np.testing.assert_allclose(r[1]['log'][c][key], log[c][key], rtol=2e-4, atol=1e-7)
+            np.testing.assert_allclose(r[-1]['log'][c][key], log[c][key], rtol=2e-4, atol=1e-7)
     assert log[32]['reg_filter_verts'] > 0 and log[30]['reg_filter_verts'] == 0

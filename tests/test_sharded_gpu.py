@@ -4,7 +4,6 @@ nine-term cycle -- halos, shared-gradient all-reduce, one-euro hand-off, capture
 between them.  The NCCL/RCCL transport itself is exercised by `bench.py --gpus N`."""
 import os
 import sys
-import types
 
 import numpy as np
 import pytest
@@ -25,53 +24,9 @@ def _paths():
 
 def _host_staged_dist():
     """torch.distributed with the tensor ops going through the host (gloo has no GPU all_gather / send / recv)"""
-    shim = types.SimpleNamespace(**{k: getattr(dist, k) for k in dir(dist) if not k.startswith('__')})
-
-    def all_gather(outs, t, group=None):
-        tmp = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
-        dist.all_gather(tmp, t.detach().cpu(), group=group)
-        for o, c in zip(outs, tmp):
-            o.copy_(c)
-
-    def all_reduce(t, op=dist.ReduceOp.SUM, group=None):
-        c = t.detach().cpu()
-        dist.all_reduce(c, op=op, group=group)
-        t.copy_(c)
-
-    def send(t, dst, group=None):
-        dist.send(t.detach().cpu(), dst=dst, group=group)
-
-    def recv(t, src, group=None):
-        c = torch.empty(t.shape, dtype=t.dtype)
-        dist.recv(c, src=src, group=group)
-        t.copy_(c)
-
-    class P2POp(object):
-        def __init__(self, op, tensor, peer, group=None):
-            self.op, self.tensor, self.peer, self.group = op, tensor, peer, group
-
-    def batch_isend_irecv(ops):
-        staged, reqs = [], []
-        for o in ops:
-            c = o.tensor.detach().cpu() if o.op is shim.isend else torch.empty(o.tensor.shape, dtype=o.tensor.dtype)
-            staged.append(c)
-            reqs.append((dist.isend if o.op is shim.isend else dist.irecv)(c, o.peer, group=o.group))
-        for r in reqs:
-            r.wait()
-        for o, c in zip(ops, staged):
-            if o.op is shim.irecv:
-                o.tensor.copy_(c)
-        return []
-
-    shim.isend, shim.irecv = object(), object()
-    shim.P2POp, shim.batch_isend_irecv = P2POp, batch_isend_irecv
-    def broadcast(t, src, group=None):
-        c = t.detach().cpu()
-        dist.broadcast(c, src=src, group=group)
-        t.copy_(c)
-
-    shim.all_gather, shim.all_reduce, shim.send, shim.recv, shim.broadcast = all_gather, all_reduce, send, recv, broadcast
-    return shim
+    _paths()
+    from mhhip import hostdist
+    return hostdist.host_staged()
 
 
 def _build(f0, f1):

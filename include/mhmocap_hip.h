@@ -277,6 +277,15 @@ int mh_contact_foot_terms(int T, int N, int V, int batch, const float* verts, co
                           const float* low_xyz, const float* dy, float coef_contact, float coef_foot,
                           float* gpT, float* gverts, float* batch_contact, float* batch_foot,
                           void* stream);
+/* the same with an explicit batch table: batch_frames[bt * batch + k] = frame at position k of batch bt (-1 = empty
+ * position of a shorter batch); position k is paired with position k-1 of the same batch exactly like the reference does
+ * with whatever its dataloader delivered -- with the shipped `shuffle: True` (configs/predict_mupots.yml:14,
+ * predict.py:273-277) random frames of a random batch (optimizer.py:394, 512-518).  Every frame must appear at most
+ * once in the table. */
+int mh_contact_foot_terms_idx(int T, int N, int V, int batch, int nbatches, const int32_t* batch_frames /*(nbatches,batch)*/,
+                              const float* verts, const int32_t* low_idx, const float* low_xyz, const float* dy,
+                              float coef_contact, float coef_foot, float* gpT, float* gverts, float* batch_contact,
+                              float* batch_foot, void* stream);
 /* a21: pixel centres + depth -> camera-space points (H*W,3) (optimizer.py:605-612,
  * transforms.py:114-130).  K_host: HOST 3x3 intrinsics.                                       */
 int mh_scene_unproject(const float* depth /*(H,W)*/, int H, int W, const float* K_host,

@@ -398,7 +398,9 @@ class SequenceOracle(object):
         return log
 
     def fit(self, batches, num_iter, update_filters_every=25, scene_update=None, cpu_alias_quirk=False):
-        """optimizer.py:324-602 (scene update delegated to ``scene_update(self, cycle)``)."""
+        """optimizer.py:324-602 (scene update delegated to ``scene_update(self, cycle)``).  ``batches``: the list of
+        batch dicts every cycle sees, or a callable cycle -> list (a shuffling dataloader delivers different batches
+        every cycle, configs/predict_mupots.yml:14)."""
         leaves = self.leaves()
         sq = [torch.zeros_like(p) for p in leaves]
         buf = [torch.zeros_like(p) for p in leaves]
@@ -407,7 +409,7 @@ class SequenceOracle(object):
         for cycle in range(num_iter):
             if cycle >= 30 and cycle % update_filters_every == 0:
                 self.update_filters(cpu_alias_quirk=cpu_alias_quirk)
-            out.append(self.cycle_grads(batches))
+            out.append(self.cycle_grads(batches(cycle) if callable(batches) else batches))
             if scene_update is not None and cycle >= 30:
                 scene_update(self, cycle)
             with torch.no_grad():

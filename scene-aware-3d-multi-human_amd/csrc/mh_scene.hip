@@ -184,9 +184,15 @@ extern "C" int mh_contact_knn(const float* points, int M, const float* low_xyz, 
 
 // ---------------------------------------------------------------------------------------------
 // contact residual + foot sliding (optimizer.py:502-518).  One block per batch of `batch` frames.
+// The reference pairs IN-BATCH neighbours: position k of a batch with position k-1 (:512-517).  With a sequential
+// dataloader those are consecutive frames; with the shipped `shuffle: True` (configs/predict_mupots.yml:14) a batch
+// is a random set of frames in random order.  `frames` (optional) is the batch table of this cycle:
+// frames[bt * batch + k] = frame at position k of batch bt, -1 = empty position (a shorter last batch);
+// NULL = contiguous batches.  Every frame appears once, so the per-frame writes need no atomics.
 // ---------------------------------------------------------------------------------------------
 struct ContactP {
   int T, N, V, batch;
+  const int* frames;      // [nbatches][batch] or NULL
   const float* verts;
   const int* low_idx;
   const float* low_xyz;
@@ -200,17 +206,24 @@ struct ContactP {
 
 __global__ __launch_bounds__(256) void k_contact_foot(ContactP p) {
   const int bt = blockIdx.x;
-  const int t0 = bt * p.batch, t1 = min(t0 + p.batch, p.T);
+  const int pos0 = bt * p.batch;
   __shared__ float s[256];
   __shared__ float scnt;
+  auto frame_at = [&](int k) -> int {      // frame at position k of this batch, -1 = none
+    const int t = p.frames ? p.frames[pos0 + k] : pos0 + k;
+    return t < p.T ? t : -1;
+  };
   // contact: L1(pT, detach(pT) + [0, dy + 0.02, 0])  ->  |dy + 0.02|, gradient -sign on pT.y only
   float lc = 0.f, cnt = 0.f;
-  for (int i = t0 * p.N + threadIdx.x; i < t1 * p.N; i += 256) {
+  for (int j = threadIdx.x; j < p.batch * p.N; j += 256) {
+    const int k = j / p.N, t = frame_at(k);
+    if (t < 0) continue;
+    const int i = t * p.N + (j - k * p.N);
     const float r = -(p.dy[i] + 0.02f);
     lc += fabsf(r);
     const float sg = r > 0.f ? 1.f : (r < 0.f ? -1.f : 0.f);
     if (p.gpT) p.gpT[(size_t)i * 3 + 1] += p.cc * sg;
-    if (i >= (t0 + 1) * p.N) cnt += (p.dy[i] > -0.20f) ? 1.f : 0.f;   // gate of the in-batch pairs, :510-513
+    if (k >= 1 && frame_at(k - 1) >= 0) cnt += (p.dy[i] > -0.20f) ? 1.f : 0.f;   // gate of the in-batch pairs, :510-513
   }
   s[threadIdx.x] = lc;
   __syncthreads();
@@ -230,10 +243,14 @@ __global__ __launch_bounds__(256) void k_contact_foot(ContactP p) {
   __syncthreads();
   const float inv = 1.f / scnt;
   float lf = 0.f;
-  for (int i = (t0 + 1) * p.N + threadIdx.x; i < t1 * p.N; i += 256) {
+  for (int j = p.N + threadIdx.x; j < p.batch * p.N; j += 256) {
+    const int k = j / p.N, t = frame_at(k), tp = frame_at(k - 1);
+    if (t < 0 || tp < 0) continue;
+    const int n = j - k * p.N;
+    const int i = t * p.N + n, ip = tp * p.N + n;
     if (!(p.dy[i] > -0.20f)) continue;
     const int vi = p.low_idx[i];
-    const size_t cur = ((size_t)i * p.V + vi) * 3, prv = ((size_t)(i - p.N) * p.V + vi) * 3;
+    const size_t cur = ((size_t)i * p.V + vi) * 3, prv = ((size_t)ip * p.V + vi) * 3;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float d = p.low_xyz[(size_t)i * 3 + c] - p.verts[prv + c];   // :514-517
@@ -254,20 +271,39 @@ __global__ __launch_bounds__(256) void k_contact_foot(ContactP p) {
   if (threadIdx.x == 0) p.batch_foot[bt] = s[0] * inv;
 }
 
+static int contact_foot_launch(int T, int N, int V, int batch, int nbatches, const int32_t* frames, const float* verts,
+                               const int32_t* low_idx, const float* low_xyz, const float* dy, float coef_contact,
+                               float coef_foot, float* gpT, float* gverts, float* batch_contact, float* batch_foot,
+                               void* stream) {
+  MH_CHECK(verts && low_idx && low_xyz && dy && batch_contact && batch_foot, "null argument");
+  MH_CHECK(T > 0 && N > 0 && V > 0 && batch > 0, "empty input");
+  ContactP p;
+  p.T = T; p.N = N; p.V = V; p.batch = batch; p.frames = frames;
+  p.verts = verts; p.low_idx = low_idx; p.low_xyz = low_xyz; p.dy = dy;
+  p.cc = coef_contact; p.cf = coef_foot; p.gpT = gpT; p.gverts = gverts;
+  p.batch_contact = batch_contact; p.batch_foot = batch_foot;
+  hipLaunchKernelGGL(k_contact_foot, dim3(nbatches), dim3(256), 0, (hipStream_t)stream, p);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
 extern "C" int mh_contact_foot_terms(int T, int N, int V, int batch, const float* verts, const int32_t* low_idx,
                                      const float* low_xyz, const float* dy, float coef_contact, float coef_foot,
                                      float* gpT, float* gverts, float* batch_contact, float* batch_foot,
                                      void* stream) {
-  MH_CHECK(verts && low_idx && low_xyz && dy && batch_contact && batch_foot, "null argument");
-  MH_CHECK(T > 0 && N > 0 && V > 0 && batch > 0, "empty input");
-  ContactP p;
-  p.T = T; p.N = N; p.V = V; p.batch = batch;
-  p.verts = verts; p.low_idx = low_idx; p.low_xyz = low_xyz; p.dy = dy;
-  p.cc = coef_contact; p.cf = coef_foot; p.gpT = gpT; p.gverts = gverts;
-  p.batch_contact = batch_contact; p.batch_foot = batch_foot;
-  hipLaunchKernelGGL(k_contact_foot, dim3((T + batch - 1) / batch), dim3(256), 0, (hipStream_t)stream, p);
-  MH_LAUNCH_CHECK();
-  return MH_OK;
+  MH_CHECK(T > 0 && batch > 0, "empty input");
+  return contact_foot_launch(T, N, V, batch, (T + batch - 1) / batch, nullptr, verts, low_idx, low_xyz, dy, coef_contact,
+                             coef_foot, gpT, gverts, batch_contact, batch_foot, stream);
+}
+
+extern "C" int mh_contact_foot_terms_idx(int T, int N, int V, int batch, int nbatches, const int32_t* batch_frames,
+                                         const float* verts, const int32_t* low_idx, const float* low_xyz, const float* dy,
+                                         float coef_contact, float coef_foot, float* gpT, float* gverts,
+                                         float* batch_contact, float* batch_foot, void* stream) {
+  MH_CHECK(batch_frames, "null argument");
+  MH_CHECK(nbatches > 0, "empty input");
+  return contact_foot_launch(T, N, V, batch, nbatches, batch_frames, verts, low_idx, low_xyz, dy, coef_contact, coef_foot,
+                             gpT, gverts, batch_contact, batch_foot, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -104,6 +104,7 @@ def lib():
         L.mh_scene_grid_build_dev.argtypes = [vp, vp, ctypes.c_int, vp, vp]
         L.mh_contact_knn_grid.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp]
         L.mh_contact_foot_terms.argtypes = [ctypes.c_int] * 4 + [vp] * 4 + [ctypes.c_float] * 2 + [vp] * 5
+        L.mh_contact_foot_terms_idx.argtypes = [ctypes.c_int] * 5 + [vp] * 5 + [ctypes.c_float] * 2 + [vp] * 5
         L.mh_scene_unproject.argtypes = [vp, ctypes.c_int, ctypes.c_int, c_float_p, vp, vp]
         L.mh_raster_workspace_bytes.restype = ctypes.c_size_t
         L.mh_raster_workspace_bytes.argtypes = [ctypes.c_int] * 6

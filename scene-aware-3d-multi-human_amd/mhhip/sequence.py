@@ -102,6 +102,7 @@ class SequenceEngine(object):
         self.pT_filt = None
         self.has_images = False
         self.halo = None              # filled by the frame-sharded driver
+        self.batch_frames = None      # batch table of the current cycle (set_batch_table); None = contiguous batches
         self.timing = None            # {name: [(start_event, end_event), ...]} when enabled by bench.py
 
     def enable_timing(self, on=True):
@@ -131,6 +132,24 @@ class SequenceEngine(object):
         the number of per-batch regulariser additions (optimizer.py:512-518, 531-539)."""
         self.batch = int(batch_size)
         self.nbatches = (self.T + self.batch - 1) // self.batch
+        self.batch_frames = None
+
+    def set_batch_table(self, table):
+        """The batch composition of THIS cycle: table (nbatches, batch) int32, table[b, k] = frame at position k of
+        batch b, -1 = empty (what a shuffling dataloader delivered, configs/predict_mupots.yml:14; the foot-sliding
+        term pairs position k with position k-1, optimizer.py:512-518).  ``table`` may be a device tensor (a row of
+        the per-fit table uploaded once) or a host array; None = contiguous batches.  The device buffer keeps its
+        address: captured cycle graphs read it."""
+        if table is None:
+            self.batch_frames = None
+            return
+        n = self.nbatches * self.batch
+        if getattr(self, 'batch_frames', None) is None or self.batch_frames.numel() != n:
+            self.batch_frames = torch.full((n,), -1, dtype=torch.int32, device=self.dev)
+        if isinstance(table, torch.Tensor):
+            self.batch_frames.copy_(table.reshape(-1), non_blocking=True)
+        else:
+            self.batch_frames.copy_(torch.as_tensor(np.ascontiguousarray(table, dtype=np.int32).reshape(-1)))
 
     # -- leaves as views -------------------------------------------------------------------------
     def _view(self, buf, i, shape):
@@ -528,9 +547,15 @@ class SequenceEngine(object):
         gv, log = self._gv_cur, self.tmp_log
         check(L.mh_lowest_vertex(ptr(self.verts), B, self.V, ptr(self.low_idx), ptr(self.low_xyz), st))
         check(L.mh_contact_knn_grid(ptr(self.scene_grid), self.scene_M, ptr(self.low_xyz), B, 32, ptr(self.dy), st))
-        check(L.mh_contact_foot_terms(T, N, self.V, self.batch, ptr(self.verts), ptr(self.low_idx), ptr(self.low_xyz),
-                                      ptr(self.dy), float(c['reg_contact']), float(c['reg_foot_sliding']), ptr(gpT),
-                                      ptr(gv), ptr(self.batch_contact), ptr(self.batch_foot), st))
+        if getattr(self, 'batch_frames', None) is not None:
+            check(L.mh_contact_foot_terms_idx(T, N, self.V, self.batch, self.nbatches, ptr(self.batch_frames), ptr(self.verts),
+                                              ptr(self.low_idx), ptr(self.low_xyz), ptr(self.dy), float(c['reg_contact']),
+                                              float(c['reg_foot_sliding']), ptr(gpT), ptr(gv), ptr(self.batch_contact),
+                                              ptr(self.batch_foot), st))
+        else:
+            check(L.mh_contact_foot_terms(T, N, self.V, self.batch, ptr(self.verts), ptr(self.low_idx), ptr(self.low_xyz),
+                                          ptr(self.dy), float(c['reg_contact']), float(c['reg_foot_sliding']), ptr(gpT),
+                                          ptr(gv), ptr(self.batch_contact), ptr(self.batch_foot), st))
         check(L.mh_reduce_sum(ptr(self.batch_contact), self.nbatches, 1.0, ptr(log[5:6]), st))
         check(L.mh_reduce_sum(ptr(self.batch_foot), self.nbatches, 1.0, ptr(log[6:7]), st))
 
@@ -577,7 +602,8 @@ class SequenceEngine(object):
         if self.scene_pts is not None:
             scene = (self.scene_pts.data_ptr(), self.scene_grid.data_ptr(), self.scene_M)
         rast = None if raster is None else (raster.ws.data_ptr(), raster.faces.data_ptr())
-        return (rast, scene, self.verts_filt is not None and self.pT_filt is not None, self.halo is None)
+        bt = None if getattr(self, 'batch_frames', None) is None else self.batch_frames.data_ptr()
+        return (rast, scene, self.verts_filt is not None and self.pT_filt is not None, self.halo is None, bt)
 
     def raster_terms(self, znear=1.0, zfar=100.0):
         """The engine's rasteriser binding (workspace + face table), created once and kept alive with the engine:

@@ -329,13 +329,12 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
         T, N = self.num_frames, self.num_people
         H, W = self.img_h, self.img_w
         bs = getattr(dataloader, 'batch_size', None)
-        sampler = getattr(dataloader, 'sampler', None)
-        if sampler is not None and type(sampler).__name__ == 'RandomSampler':
+        if self._is_shuffled(dataloader) and self._world()[0] > 1:
             import warnings
-            warnings.warn('dataloader has shuffle=True (configs/predict_mupots.yml:14): the reference then pairs RANDOM '
-                          'in-batch neighbours for the foot-sliding term (optimizer.py:512-518); this build stages the '
-                          'frames once and pairs CONSECUTIVE frames inside contiguous batches of %s frames '
-                          '(shuffle=False semantics).  Every other term is independent of the batch order.' % bs)
+            warnings.warn('dataloader has shuffle=True (configs/predict_mupots.yml:14) in a FRAME-SHARDED run: a random batch '
+                          'mixes frames of different ranks, so the foot-sliding term (optimizer.py:512-518) pairs CONSECUTIVE '
+                          'frames inside contiguous batches of %s frames instead (shuffle=False semantics; the single-process '
+                          'run reproduces the shuffled pairing).  Every other term is independent of the batch order.' % bs)
         first = True
         have_img = True
         store = {}
@@ -390,6 +389,7 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
                     alloc(k, a.shape[lead:], a.dtype)
                 store[k][idx] = a
 
+        rng_state = None if direct else torch.get_rng_state()     # this extra pass must not advance the shuffle of cycle 0
         if direct:
             # A plain map-style dataset behind the stock collate function: the frames are read from the dataset itself,
             # straight into the staging buffers.  Going through the loader costs a torch.stack per key and batch plus
@@ -405,6 +405,8 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
                     bs = len(idx)
                 put(idx, data, 1)
                 first = False
+        if rng_state is not None:
+            torch.set_rng_state(rng_state)
         if world > 1 and int(bs) != self._engine_batch:
             # block boundaries are multiples of the batch size: re-shard with the dataloader's
             self._build_engine(int(bs), leaves=self._global_leaves())
@@ -419,6 +421,36 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
         self._backmasks = None if 'backmasks' not in store else np.array(loc('backmasks'))
         keep.clear()
         self._staged = True
+
+    @staticmethod
+    def _is_shuffled(dataloader):
+        """does the loader deliver anything but contiguous batches in order?"""
+        sampler = getattr(dataloader, 'sampler', None)
+        return (getattr(dataloader, 'batch_sampler', None) is not None and sampler is not None
+                and type(sampler).__name__ != 'SequentialSampler')
+
+    def _cycle_batch_tables(self, dataloader, num_iter):
+        """The index batches of ``num_iter`` passes over a shuffling dataloader, as a (num_iter, nbatches * batch) int32
+        device table (-1 = empty position).  Indices only -- the inputs stay staged.  Consumes the random number
+        generators exactly like the reference's ``for data in dataloader`` (optimizer.py:394) does once per cycle: the
+        ``_base_seed`` draw of ``DataLoader.__iter__`` from the loader's generator, then whatever the batch sampler
+        draws (RandomSampler: one seed from the global generator) -- so under one ``torch.manual_seed`` both sides see
+        the same batches.  Nothing else on this path draws random numbers, so drawing all cycles up front is the same
+        sequence."""
+        e = self.engine
+        nb, bs = e.nbatches, e.batch
+        tab = np.full((num_iter, nb, bs), -1, np.int32)
+        for c in range(num_iter):
+            torch.empty((), dtype=torch.int64).random_(generator=getattr(dataloader, 'generator', None))
+            seen = 0
+            for b, idx in enumerate(dataloader.batch_sampler):
+                idx = [int(i) for i in idx]
+                assert b < nb and len(idx) <= bs, 'batch sampler delivers more / larger batches than len(dataset) / batch_size'
+                tab[c, b, :len(idx)] = idx
+                seen += len(idx)
+            assert seen == self.num_frames and len(np.unique(tab[c][tab[c] >= 0])) == seen, \
+                'every frame must appear exactly once per pass over the dataloader'
+        return torch.as_tensor(tab.reshape(num_iter, nb * bs)).to(self.device)
 
     @staticmethod
     def _dataset_is_plain(dataloader, ds):
@@ -452,6 +484,13 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
         if self.use_rasteriser and e.has_images:
             raster = e.raster_terms(self.znear, self.zfar)        # one per engine: captured graphs bake its addresses
         scene_mode = self.scene_update
+        # shuffle: True (the shipped config): the in-batch pairs of the foot-sliding term follow the loader's batches
+        tables = None
+        if world == 1 and self._is_shuffled(dataloader):
+            tables = self._cycle_batch_tables(dataloader, num_iter)
+        else:
+            e.set_batch_table(None)
+        self.batch_tables = tables
         check_every = 25 if os.environ.get('MHHIP_CHECK_REPLICAS') == '1' else 0
         lr = 0.01                                                             # a new RMSprop + ExponentialLR per fit (:355-356)
         cycles = range(num_iter)
@@ -465,6 +504,8 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
                     e.update_filters(min_cutoff1, beta1, min_cutoff2, beta2)
                 self.poses_T_filtered = e.pT_filt.view(e.T, self.num_people, 1, 3)
                 self.verts_filtered = e.verts_filt
+            if tables is not None:
+                e.set_batch_table(tables[cycle])
             scene_now = cycle >= 30 and e.has_images and self._backmasks is not None      # :578-584
             dev_scene = scene_now and scene_mode == 'device'
             if dev_scene and e._scene_dev is None:

@@ -115,6 +115,9 @@ class CpuShardEngine(object):
         self.batch = int(batch_size)
         self.nbatches = (self.T + self.batch - 1) // self.batch
 
+    def set_batch_table(self, table):
+        assert table is None, 'the stand-in models the raster-free terms: no foot sliding, no batch table'
+
     def stage(self, pose2d, poses_ref, valid, betas_ref, seg_mask=None, depths=None):
         B, N = self.B, self.N
         self.pose2d = torch.tensor(np.asarray(pose2d, np.float32)).view(B, 17, 3)

@@ -356,6 +356,13 @@ int mh_raster_terms_phase(int T, int N, int V, int F, int H, int W, const float*
                           float coef_depth, float coef_sil, float eps, float* gverts, float* gzmin,
                           float* gzmax, float* depth_body, float* sil_body, void* ws,
                           float* zbuf_out, float* alpha_out, int phases, void* stream);
+/* Deterministic gradient scatter (default off; MHHIP_DETERMINISTIC=1 in the environment switches it on at first use).
+ * The production kernel sums the per-pixel vertex gradients of the rasterised terms with fp32 atomics (LDS table,
+ * then global): the summation order, hence the last bits, vary from run to run.  on != 0: one workgroup per body,
+ * 64-bit fixed-point integer accumulation (exact, order-free), one writer per element -- dL/dverts and all six
+ * gradient leaves are bit-identical between runs, ~4-5x slower for this kernel. */
+int mh_raster_set_deterministic(int on);
+int mh_raster_get_deterministic(void);
 
 /* ---- stand-alone forms of losses.py:19-40 and morphology.py:6-41 (call compatibility of
  * mhmocap.losses / mhmocap.morphology; the optimiser uses the fused kernels above) --------------

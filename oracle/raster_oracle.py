@@ -132,15 +132,21 @@ def fragments(verts_ndc, faces, pix_to_face, H, W):
     return zout, dout, valid
 
 
-def render(verts, faces, cam_K, image_size, znear=1.0, zfar=100.0, sigma=1e-4):
-    """verts (B,V,3) camera space -> zbuf0 (B,H,W) [-1 where empty], alpha (B,H,W)."""
+def render(verts, faces, cam_K, image_size, znear=1.0, zfar=100.0, sigma=1e-4, selection=None):
+    """verts (B,V,3) camera space -> zbuf0 (B,H,W) [-1 where empty], alpha (B,H,W).  selection: (f1 (B,H,W,1), f4
+    (B,H,W,4)) pix_to_face arrays to use INSTEAD of the brute-force selection (tests hand in the selection of the HIP
+    kernel to separate "which faces" from "what comes out of them")."""
     W, H = image_size
     ndc = to_ndc(verts, cam_K, image_size, znear, zfar)
     ndc_np = ndc.detach().numpy().astype(np.float32)
-    f8, _ = select_faces(ndc_np, faces, H, W, 1e-4, 8)                          # optimizer.py:211-215
+    if selection is not None:
+        f8, f4 = np.asarray(selection[0], np.int64), np.asarray(selection[1], np.int64)
+    else:
+        f8, _ = select_faces(ndc_np, faces, H, W, 1e-4, 8)                      # optimizer.py:211-215
     z8, _, _ = fragments(ndc, faces, f8[..., :1], H, W)
     zbuf0 = z8[..., 0]                                                          # optimizer.py:430
-    f4, _ = select_faces(ndc_np, faces, H, W, 2e-5, 4)                          # optimizer.py:221-225
+    if selection is None:
+        f4, _ = select_faces(ndc_np, faces, H, W, 2e-5, 4)                      # optimizer.py:221-225
     _, sd, valid = fragments(ndc, faces, f4, H, W)
     prob = torch.sigmoid(-sd / sigma) * valid.to(sd.dtype)                      # SoftSilhouetteShader / sigmoid_alpha_blend
     alpha = 1.0 - torch.prod(1.0 - prob, dim=-1)

@@ -165,9 +165,28 @@ __device__ __forceinline__ float r_seg_rcp(float px, float py, float ax, float a
 // goes through this symbol (not through a pointer chosen at run time) so that the compiler emits ds_add_f32 rather
 // than flat atomics.
 extern __shared__ __attribute__((aligned(16))) float rg_tab[];
-template <bool TAB>
-__device__ __forceinline__ void r_acc_add(float* gvb, int vid, float gx, float gy, float gz) {
-  if (TAB) {
+// MODE 0: global float atomics (V > RG_MAXV); 1: LDS float table (production); 2: DETERMINISTIC -- the contributions of
+// one body go into an LDS table of 64-bit fixed-point integers (integer addition is associative: any order of the
+// atomics gives the same bits), in three passes over the body's pixels: pass 0 finds the largest contribution (the
+// block exponent), passes 1 / 2 accumulate the lower / upper half of the vertices (the int64 table of all 6890 vertices
+// is 1.5 KB larger than the LDS).  MHHIP_DETERMINISTIC=1 / mh_raster_set_deterministic(1).
+struct RgDet {
+  int pass, shift, v0, v1;
+  float umax;
+};
+template <int MODE>
+__device__ __forceinline__ void r_acc_add(float* gvb, int vid, float gx, float gy, float gz, RgDet& dc) {
+  if (MODE == 2) {
+    if (dc.pass == 0) {
+      dc.umax = fmaxf(dc.umax, fmaxf(fabsf(gx), fmaxf(fabsf(gy), fabsf(gz))));
+      return;
+    }
+    if (vid < dc.v0 || vid >= dc.v1) return;
+    unsigned long long* o = (unsigned long long*)rg_tab + (size_t)(vid - dc.v0) * 3;
+    atomicAdd(o, (unsigned long long)__double2ll_rn(ldexp((double)gx, dc.shift)));
+    atomicAdd(o + 1, (unsigned long long)__double2ll_rn(ldexp((double)gy, dc.shift)));
+    atomicAdd(o + 2, (unsigned long long)__double2ll_rn(ldexp((double)gz, dc.shift)));
+  } else if (MODE == 1) {
     atomicAdd(&rg_tab[vid * 3], gx);
     atomicAdd(&rg_tab[vid * 3 + 1], gy);
     atomicAdd(&rg_tab[vid * 3 + 2], gz);
@@ -180,12 +199,12 @@ __device__ __forceinline__ void r_acc_add(float* gvb, int vid, float gx, float g
 }
 // scatter d/d(ndc x, ndc y, z) of one vertex to camera space: x_ndc = -s X / Z + w1, so d x_ndc / dX = -s / Z and
 // d x_ndc / dZ = s X / Z^2 = -(x_ndc - w1) / Z
-template <bool TAB>
-__device__ __forceinline__ void r_scatter(const RasterP& p, float* gvb, const Tri& t, int k, float gxn, float gyn, float gz) {
+template <int MODE>
+__device__ __forceinline__ void r_scatter(const RasterP& p, float* gvb, const Tri& t, int k, float gxn, float gyn, float gz, RgDet& dc) {
   const float rz = r_rcp(t.z[k]);
   const float gx = -p.s * rz * gxn, gy = -p.s * rz * gyn;
   const float gzz = gz - ((t.x[k] - p.w1) * gxn + (t.y[k] - p.h1) * gyn) * rz;
-  r_acc_add<TAB>(gvb, t.idx[k], gx, gy, gzz);
+  r_acc_add<MODE>(gvb, t.idx[k], gx, gy, gzz, dc);
 }
 
 __device__ __forceinline__ float r_block_sum(float v, float* sh) {
@@ -1092,6 +1111,203 @@ __global__ void k_raster_finish(RasterP p, int T, int do_sil, const float* zmin_
   }
 }
 
+// per-body constants of the gradient kernels
+struct RgBody {
+  int t, n, x0, sy0, ww;
+  const float* vb;                   // projected vertices of the body
+  float* gvb;                        // dL/dverts of the body
+  const unsigned long long* gk;      // the body's window of selection keys
+  float gA, gAlphaScale, pvalid;
+  bool sil_on;
+  uint32_t fr;
+};
+
+// gradient contributions of window pixel i of a body (PyTorch3D's rasteriser backward through the SELECTED faces:
+// clip Jacobian, barycentric Jacobian, PointLineDistanceBackward with the clamped parameter held constant) into the
+// accumulator MODE selects; lcorr accumulates the silhouette value term
+template <int MODE>
+__device__ __forceinline__ void rg_pixel(const RasterP& p, const RgBody& bd, const int i, float& lcorr, RgDet& dc) {
+  const int H = p.H, W = p.W, P = H * W;
+  const int t = bd.t, n = bd.n, x0 = bd.x0, sy0 = bd.sy0, ww = bd.ww;
+  const float* vb = bd.vb;
+  float* gvb = bd.gvb;
+  const unsigned long long* gk = bd.gk;
+  const float gA = bd.gA, gAlphaScale = bd.gAlphaScale, pvalid = bd.pvalid;
+  const bool sil_on = bd.sil_on;
+  const uint32_t fr = bd.fr;
+  const int yi = sy0 + i / ww, xi = x0 + i % ww;
+  const size_t gp = (size_t)t * P + (size_t)yi * W + xi;
+  const float yf = r_pix_to_ndc(H - 1 - yi, H, W), xf = r_pix_to_ndc(W - 1 - xi, W, H);
+  const unsigned long long* q = gk + (size_t)i * 5;
+  const unsigned long long k0 = q[0];
+  if (k0 != RS_EMPTY && gA != 0.f) {
+    const float z = __uint_as_float((unsigned)(k0 >> 32));
+    const float m = (z > 0.f ? 1.f : 0.f) * (float)((p.ebits[gp] >> n) & 1u) * pvalid;
+    const float zc = z + 0.2f;
+    if (m != 0.f && zc > p.eps && 1.f / zc > 1e-3f) {
+      const float gpz = -gA * r_rcp(zc);
+      Tri tr;
+      r_load_tri_ndc(p, vb, (int)(k0 & 0xffffffffu), tr);
+      const float area = r_edge(tr.x[2], tr.y[2], tr.x[0], tr.y[0], tr.x[1], tr.y[1]) + R_KEPS;
+      const float ia = r_rcp(area);
+      float w[3] = {r_edge(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2]) * ia,
+                    r_edge(xf, yf, tr.x[2], tr.y[2], tr.x[0], tr.y[0]) * ia,
+                    r_edge(xf, yf, tr.x[0], tr.y[0], tr.x[1], tr.y[1]) * ia};
+      const float c[3] = {fmaxf(w[0], 0.f), fmaxf(w[1], 0.f), fmaxf(w[2], 0.f)};
+      const float craw = c[0] + c[1] + c[2];
+      const float cs = fmaxf(craw, 1e-5f);
+      const float ics = r_rcp(cs);
+      // pz = sum (c_i/cs) z_i.  The normalised weights n_i = c_i / cs are IEEE divisions: outside the triangle one or
+      // two of the clipped weights are zero, and with a single survivor n is EXACTLY 1, so that the Jacobian of the
+      // normalisation, (g_k - sum_j g_j n_j) / cs, cancels exactly as it does in the reference's autograd.  With the
+      // 1-ulp reciprocal the residue g (1 - c rcp(c)) ~ 1e-7 g survived and was then multiplied by 1/area ~ 1e6 of a
+      // sub-pixel face: the largest error of the whole gradient (4e-4 of the largest entry, found with the
+      // deterministic scatter, round 3).
+      float gwc[3], gz[3], nw[3];
+      float dotn = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        nw[k] = c[k] / cs;
+        gz[k] = gpz * nw[k];
+        gwc[k] = gpz * tr.z[k];          // d/d(normalised clipped weight)
+        dotn += gwc[k] * nw[k];
+      }
+      float gw[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float gc = (gwc[k] - (craw > 1e-5f ? dotn : 0.f)) * ics;
+        gw[k] = w[k] > 0.f ? gc : 0.f;
+      }
+      // w_i = e_i / area
+      const float ge[3] = {gw[0] * ia, gw[1] * ia, gw[2] * ia};
+      const float garea = -(gw[0] * w[0] + gw[1] * w[1] + gw[2] * w[2]) * ia;
+      float gx[3] = {0, 0, 0}, gy[3] = {0, 0, 0};
+      // e0 = edge(p; v1, v2), e1 = edge(p; v2, v0), e2 = edge(p; v0, v1); area = edge(v2; v0, v1)
+#define EDGE_ADJ(gE, A, Bv)                                           \
+  gx[A] += (gE) * (yf - tr.y[Bv]);  gy[A] += (gE) * (tr.x[Bv] - xf);  \
+  gx[Bv] += (gE) * (-(yf - tr.y[A])); gy[Bv] += (gE) * (xf - tr.x[A]);
+      EDGE_ADJ(ge[0], 1, 2)
+      EDGE_ADJ(ge[1], 2, 0)
+      EDGE_ADJ(ge[2], 0, 1)
+#undef EDGE_ADJ
+      // area = (x2-x0)(y1-y0) - (y2-y0)(x1-x0)
+      gx[2] += garea * (tr.y[1] - tr.y[0]);  gy[2] += garea * (-(tr.x[1] - tr.x[0]));
+      gx[0] += garea * (tr.y[2] - tr.y[1]);  gy[0] += garea * (tr.x[1] - tr.x[2]);
+      gx[1] += garea * (-(tr.y[2] - tr.y[0])); gy[1] += garea * (tr.x[2] - tr.x[0]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) r_scatter<MODE>(p, gvb, tr, k, gx[k], gy[k], gz[k], dc);
+    }
+  }
+  // silhouette: the (up to) four selected faces are fetched together (independent gathers in
+  // flight), evaluated, and scattered from registers
+  const uint32_t wb = p.bits[gp];
+  if (sil_on && (wb & fr) == 0u && q[1] != RS_EMPTY) {
+    Tri trs[4];
+    bool have[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned long long kk = q[k + 1];
+      have[k] = kk != RS_EMPTY;
+      if (have[k]) r_load_tri_ndc(p, vb, (int)(kk & 0xffffffffu), trs[k]);
+    }
+    float pk[4], sgn[4], gqx[4], gqy[4], wa[4], wb_[4];
+    int ea[4], eb[4];
+    float qprod = 1.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      pk[k] = 0.f; sgn[k] = 0.f; gqx[k] = gqy[k] = wa[k] = wb_[k] = 0.f; ea[k] = 0; eb[k] = 1;
+      if (!have[k]) continue;
+      const Tri& tr = trs[k];
+      const float area = r_edge(tr.x[2], tr.y[2], tr.x[0], tr.y[0], tr.x[1], tr.y[1]) + R_KEPS;
+      const float ia = r_rcp(area);
+      const bool inside = r_edge(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2]) * ia > 0.f &&
+                          r_edge(xf, yf, tr.x[2], tr.y[2], tr.x[0], tr.y[0]) * ia > 0.f &&
+                          r_edge(xf, yf, tr.x[0], tr.y[0], tr.x[1], tr.y[1]) * ia > 0.f;
+      float t01, t02, t12;
+      bool g01, g02, g12;
+      const float d01 = r_seg_rcp(xf, yf, tr.x[0], tr.y[0], tr.x[1], tr.y[1], &t01, &g01);
+      const float d02 = r_seg_rcp(xf, yf, tr.x[0], tr.y[0], tr.x[2], tr.y[2], &t02, &g02);
+      const float d12 = r_seg_rcp(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2], &t12, &g12);
+      float d, tt;
+      bool dg;
+      int a, bb;
+      if (d01 <= d02 && d01 <= d12) { d = d01; a = 0; bb = 1; tt = t01; dg = g01; }
+      else if (d02 <= d01 && d02 <= d12) { d = d02; a = 0; bb = 2; tt = t02; dg = g02; }
+      else { d = d12; a = 1; bb = 2; tt = t12; dg = g12; }
+      const float xa_ = a == 0 ? tr.x[0] : tr.x[1], ya_ = a == 0 ? tr.y[0] : tr.y[1];
+      const float xb_ = bb == 1 ? tr.x[1] : tr.x[2], yb_ = bb == 1 ? tr.y[1] : tr.y[2];
+      if (dg) { gqx[k] = xb_ - xf; gqy[k] = yb_ - yf; wa[k] = 0.f; wb_[k] = 1.f; }
+      else {
+        gqx[k] = xa_ + tt * (xb_ - xa_) - xf;
+        gqy[k] = ya_ + tt * (yb_ - ya_) - yf;
+        wa[k] = 1.f - tt; wb_[k] = tt;
+      }
+      ea[k] = a; eb[k] = bb;
+      const float sd = inside ? -d : d;
+      pk[k] = r_rcp(1.f + expf(sd * (1.f / SIGMA_S)));
+      sgn[k] = inside ? -1.f : 1.f;
+      qprod *= 1.f - pk[k];
+    }
+    const float alpha = 1.f - qprod;
+    const float seg = (float)((wb >> n) & 1u);
+    lcorr += alpha * alpha - 2.f * alpha * seg;                        // losses.py:35-38 through 1 - acc (value only)
+    const float galpha = gAlphaScale * (alpha - seg);
+    if (galpha != 0.f) {
+      // Every selected face contributes to the two end points of its nearest edge.  The (up to) eight end points
+      // of a pixel are gathered in registers (picked with selects, mapped to camera space) and contributions to the
+      // same vertex are merged before they go to the LDS table: neighbouring faces share contour vertices, and an
+      // LDS float atomic costs ~4 cycles per active LANE on gfx950 whatever the addresses (SQ_LDS_IDX_ACTIVE:
+      // 26 M cycles for the 7 M lane-atomics this scatter issued unmerged -- a third of the kernel; unique
+      // addresses, fewer instructions under the same masks or de-correlated lanes changed nothing), while the vector
+      // instructions of the merge are nearly free here (VALU 23 % busy).  113 -> 90 us.  (Merging the three
+      // vertices of the depth term's face as well costs 45 spilled registers at 1024 threads: 139 us.)
+      int eid[8];
+      float egx[8], egy[8], egz[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        eid[2 * k] = eid[2 * k + 1] = -1;
+        egx[2 * k] = egy[2 * k] = egz[2 * k] = egx[2 * k + 1] = egy[2 * k + 1] = egz[2 * k + 1] = 0.f;
+        if (!have[k]) continue;
+        // d alpha / d sd_k = -(1/sigma) p_k prod_j (1 - p_j)
+        const float gd = galpha * (-(1.f / SIGMA_S)) * pk[k] * qprod * sgn[k];
+        if (gd == 0.f) continue;
+        const Tri& tr = trs[k];
+        const bool a0 = ea[k] == 0, b1 = eb[k] == 1;       // a in {0,1}, b in {1,2}
+        const int ia_ = a0 ? tr.idx[0] : tr.idx[1], ib_ = b1 ? tr.idx[1] : tr.idx[2];
+        const float xa = a0 ? tr.x[0] : tr.x[1], ya = a0 ? tr.y[0] : tr.y[1], za = a0 ? tr.z[0] : tr.z[1];
+        const float xb = b1 ? tr.x[1] : tr.x[2], yb = b1 ? tr.y[1] : tr.y[2], zb = b1 ? tr.z[1] : tr.z[2];
+        const float gxn = gd * 2.f * gqx[k], gyn = gd * 2.f * gqy[k];
+        if (wa[k] != 0.f) {
+          const float rz = r_rcp(za), ux = wa[k] * gxn, uy = wa[k] * gyn;
+          eid[2 * k] = ia_;
+          egx[2 * k] = -p.s * rz * ux; egy[2 * k] = -p.s * rz * uy; egz[2 * k] = -((xa - p.w1) * ux + (ya - p.h1) * uy) * rz;
+        }
+        if (wb_[k] != 0.f) {
+          const float rz = r_rcp(zb), ux = wb_[k] * gxn, uy = wb_[k] * gyn;
+          eid[2 * k + 1] = ib_;
+          egx[2 * k + 1] = -p.s * rz * ux; egy[2 * k + 1] = -p.s * rz * uy; egz[2 * k + 1] = -((xb - p.w1) * ux + (yb - p.h1) * uy) * rz;
+        }
+      }
+#pragma unroll
+      for (int i = 1; i < 8; ++i) {
+        bool merged = false;
+#pragma unroll
+        for (int j = 0; j < i; ++j) {
+          const bool hit = !merged && eid[i] >= 0 && eid[j] == eid[i];
+          egx[j] += hit ? egx[i] : 0.f;
+          egy[j] += hit ? egy[i] : 0.f;
+          egz[j] += hit ? egz[i] : 0.f;
+          merged = merged || hit;
+        }
+        if (merged) eid[i] = -1;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (eid[i] >= 0) r_acc_add<MODE>(gvb, eid[i], egx[i], egy[i], egz[i], dc);
+    }
+  }
+}
+
 // =============================================================================================
 // gradients per strip
 // =============================================================================================
@@ -1128,6 +1344,10 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
     float lcorr = 0.f;
     const float pvalid = p.p2d_valid[b];
     const uint32_t fr = p.front[b];
+    RgBody bd;
+    bd.t = t; bd.n = n; bd.x0 = x0; bd.sy0 = sy0; bd.ww = ww; bd.vb = vb; bd.gvb = gvb; bd.gk = gk;
+    bd.gA = gA; bd.gAlphaScale = gAlphaScale; bd.pvalid = pvalid; bd.sil_on = sil_on; bd.fr = fr;
+    RgDet dc;
     // most window pixels carry no gradient (outside the blur band, masked out, occluded by a nearer person's mask):
     // classify RG_LIST pixels at a time, compact the live ones into an LDS list and evaluate those with full waves.
     // The classification loads of all of a thread's pixels are issued first, and the table is cleared while they
@@ -1173,171 +1393,7 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
     const int nlive = *s_n;
     for (int li_ = tid; li_ < nlive; li_ += RGB) {
       const int i = plist[li_];
-      const int yi = sy0 + i / ww, xi = x0 + i % ww;
-      const size_t gp = (size_t)t * P + (size_t)yi * W + xi;
-      const float yf = r_pix_to_ndc(H - 1 - yi, H, W), xf = r_pix_to_ndc(W - 1 - xi, W, H);
-      const unsigned long long* q = gk + (size_t)i * 5;
-      const unsigned long long k0 = q[0];
-      if (k0 != RS_EMPTY && gA != 0.f) {
-        const float z = __uint_as_float((unsigned)(k0 >> 32));
-        const float m = (z > 0.f ? 1.f : 0.f) * (float)((p.ebits[gp] >> n) & 1u) * pvalid;
-        const float zc = z + 0.2f;
-        if (m != 0.f && zc > p.eps && 1.f / zc > 1e-3f) {
-          const float gpz = -gA * r_rcp(zc);
-          Tri tr;
-          r_load_tri_ndc(p, vb, (int)(k0 & 0xffffffffu), tr);
-          const float area = r_edge(tr.x[2], tr.y[2], tr.x[0], tr.y[0], tr.x[1], tr.y[1]) + R_KEPS;
-          const float ia = r_rcp(area);
-          float w[3] = {r_edge(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2]) * ia,
-                        r_edge(xf, yf, tr.x[2], tr.y[2], tr.x[0], tr.y[0]) * ia,
-                        r_edge(xf, yf, tr.x[0], tr.y[0], tr.x[1], tr.y[1]) * ia};
-          const float c[3] = {fmaxf(w[0], 0.f), fmaxf(w[1], 0.f), fmaxf(w[2], 0.f)};
-          const float craw = c[0] + c[1] + c[2];
-          const float cs = fmaxf(craw, 1e-5f);
-          const float ics = r_rcp(cs);
-          // pz = sum (c_i/cs) z_i
-          float gwc[3], gz[3];
-          float dotg = 0.f;
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            gz[k] = gpz * c[k] * ics;
-            gwc[k] = gpz * tr.z[k];          // d/d(normalised clipped weight)
-            dotg += gwc[k] * c[k];
-          }
-          float gw[3];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const float gc = gwc[k] * ics - (craw > 1e-5f ? dotg * ics * ics : 0.f);
-            gw[k] = w[k] > 0.f ? gc : 0.f;
-          }
-          // w_i = e_i / area
-          const float ge[3] = {gw[0] * ia, gw[1] * ia, gw[2] * ia};
-          const float garea = -(gw[0] * w[0] + gw[1] * w[1] + gw[2] * w[2]) * ia;
-          float gx[3] = {0, 0, 0}, gy[3] = {0, 0, 0};
-          // e0 = edge(p; v1, v2), e1 = edge(p; v2, v0), e2 = edge(p; v0, v1); area = edge(v2; v0, v1)
-#define EDGE_ADJ(gE, A, Bv)                                           \
-  gx[A] += (gE) * (yf - tr.y[Bv]);  gy[A] += (gE) * (tr.x[Bv] - xf);  \
-  gx[Bv] += (gE) * (-(yf - tr.y[A])); gy[Bv] += (gE) * (xf - tr.x[A]);
-          EDGE_ADJ(ge[0], 1, 2)
-          EDGE_ADJ(ge[1], 2, 0)
-          EDGE_ADJ(ge[2], 0, 1)
-#undef EDGE_ADJ
-          // area = (x2-x0)(y1-y0) - (y2-y0)(x1-x0)
-          gx[2] += garea * (tr.y[1] - tr.y[0]);  gy[2] += garea * (-(tr.x[1] - tr.x[0]));
-          gx[0] += garea * (tr.y[2] - tr.y[1]);  gy[0] += garea * (tr.x[1] - tr.x[2]);
-          gx[1] += garea * (-(tr.y[2] - tr.y[0])); gy[1] += garea * (tr.x[2] - tr.x[0]);
-#pragma unroll
-          for (int k = 0; k < 3; ++k) r_scatter<TAB>(p, gvb, tr, k, gx[k], gy[k], gz[k]);
-        }
-      }
-      // silhouette: the (up to) four selected faces are fetched together (independent gathers in
-      // flight), evaluated, and scattered from registers
-      const uint32_t wb = p.bits[gp];
-      if (sil_on && (wb & fr) == 0u && q[1] != RS_EMPTY) {
-        Tri trs[4];
-        bool have[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const unsigned long long kk = q[k + 1];
-          have[k] = kk != RS_EMPTY;
-          if (have[k]) r_load_tri_ndc(p, vb, (int)(kk & 0xffffffffu), trs[k]);
-        }
-        float pk[4], sgn[4], gqx[4], gqy[4], wa[4], wb_[4];
-        int ea[4], eb[4];
-        float qprod = 1.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          pk[k] = 0.f; sgn[k] = 0.f; gqx[k] = gqy[k] = wa[k] = wb_[k] = 0.f; ea[k] = 0; eb[k] = 1;
-          if (!have[k]) continue;
-          const Tri& tr = trs[k];
-          const float area = r_edge(tr.x[2], tr.y[2], tr.x[0], tr.y[0], tr.x[1], tr.y[1]) + R_KEPS;
-          const float ia = r_rcp(area);
-          const bool inside = r_edge(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2]) * ia > 0.f &&
-                              r_edge(xf, yf, tr.x[2], tr.y[2], tr.x[0], tr.y[0]) * ia > 0.f &&
-                              r_edge(xf, yf, tr.x[0], tr.y[0], tr.x[1], tr.y[1]) * ia > 0.f;
-          float t01, t02, t12;
-          bool g01, g02, g12;
-          const float d01 = r_seg_rcp(xf, yf, tr.x[0], tr.y[0], tr.x[1], tr.y[1], &t01, &g01);
-          const float d02 = r_seg_rcp(xf, yf, tr.x[0], tr.y[0], tr.x[2], tr.y[2], &t02, &g02);
-          const float d12 = r_seg_rcp(xf, yf, tr.x[1], tr.y[1], tr.x[2], tr.y[2], &t12, &g12);
-          float d, tt;
-          bool dg;
-          int a, bb;
-          if (d01 <= d02 && d01 <= d12) { d = d01; a = 0; bb = 1; tt = t01; dg = g01; }
-          else if (d02 <= d01 && d02 <= d12) { d = d02; a = 0; bb = 2; tt = t02; dg = g02; }
-          else { d = d12; a = 1; bb = 2; tt = t12; dg = g12; }
-          const float xa_ = a == 0 ? tr.x[0] : tr.x[1], ya_ = a == 0 ? tr.y[0] : tr.y[1];
-          const float xb_ = bb == 1 ? tr.x[1] : tr.x[2], yb_ = bb == 1 ? tr.y[1] : tr.y[2];
-          if (dg) { gqx[k] = xb_ - xf; gqy[k] = yb_ - yf; wa[k] = 0.f; wb_[k] = 1.f; }
-          else {
-            gqx[k] = xa_ + tt * (xb_ - xa_) - xf;
-            gqy[k] = ya_ + tt * (yb_ - ya_) - yf;
-            wa[k] = 1.f - tt; wb_[k] = tt;
-          }
-          ea[k] = a; eb[k] = bb;
-          const float sd = inside ? -d : d;
-          pk[k] = r_rcp(1.f + expf(sd * (1.f / SIGMA_S)));
-          sgn[k] = inside ? -1.f : 1.f;
-          qprod *= 1.f - pk[k];
-        }
-        const float alpha = 1.f - qprod;
-        const float seg = (float)((wb >> n) & 1u);
-        lcorr += alpha * alpha - 2.f * alpha * seg;                        // losses.py:35-38 through 1 - acc (value only)
-        const float galpha = gAlphaScale * (alpha - seg);
-        if (galpha != 0.f) {
-          // Every selected face contributes to the two end points of its nearest edge.  The (up to) eight end points
-          // of a pixel are gathered in registers (picked with selects, mapped to camera space) and contributions to the
-          // same vertex are merged before they go to the LDS table: neighbouring faces share contour vertices, and an
-          // LDS float atomic costs ~4 cycles per active LANE on gfx950 whatever the addresses (SQ_LDS_IDX_ACTIVE:
-          // 26 M cycles for the 7 M lane-atomics this scatter issued unmerged -- a third of the kernel; unique
-          // addresses, fewer instructions under the same masks or de-correlated lanes changed nothing), while the vector
-          // instructions of the merge are nearly free here (VALU 23 % busy).  113 -> 90 us.  (Merging the three
-          // vertices of the depth term's face as well costs 45 spilled registers at 1024 threads: 139 us.)
-          int eid[8];
-          float egx[8], egy[8], egz[8];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            eid[2 * k] = eid[2 * k + 1] = -1;
-            egx[2 * k] = egy[2 * k] = egz[2 * k] = egx[2 * k + 1] = egy[2 * k + 1] = egz[2 * k + 1] = 0.f;
-            if (!have[k]) continue;
-            // d alpha / d sd_k = -(1/sigma) p_k prod_j (1 - p_j)
-            const float gd = galpha * (-(1.f / SIGMA_S)) * pk[k] * qprod * sgn[k];
-            if (gd == 0.f) continue;
-            const Tri& tr = trs[k];
-            const bool a0 = ea[k] == 0, b1 = eb[k] == 1;       // a in {0,1}, b in {1,2}
-            const int ia_ = a0 ? tr.idx[0] : tr.idx[1], ib_ = b1 ? tr.idx[1] : tr.idx[2];
-            const float xa = a0 ? tr.x[0] : tr.x[1], ya = a0 ? tr.y[0] : tr.y[1], za = a0 ? tr.z[0] : tr.z[1];
-            const float xb = b1 ? tr.x[1] : tr.x[2], yb = b1 ? tr.y[1] : tr.y[2], zb = b1 ? tr.z[1] : tr.z[2];
-            const float gxn = gd * 2.f * gqx[k], gyn = gd * 2.f * gqy[k];
-            if (wa[k] != 0.f) {
-              const float rz = r_rcp(za), ux = wa[k] * gxn, uy = wa[k] * gyn;
-              eid[2 * k] = ia_;
-              egx[2 * k] = -p.s * rz * ux; egy[2 * k] = -p.s * rz * uy; egz[2 * k] = -((xa - p.w1) * ux + (ya - p.h1) * uy) * rz;
-            }
-            if (wb_[k] != 0.f) {
-              const float rz = r_rcp(zb), ux = wb_[k] * gxn, uy = wb_[k] * gyn;
-              eid[2 * k + 1] = ib_;
-              egx[2 * k + 1] = -p.s * rz * ux; egy[2 * k + 1] = -p.s * rz * uy; egz[2 * k + 1] = -((xb - p.w1) * ux + (yb - p.h1) * uy) * rz;
-            }
-          }
-#pragma unroll
-          for (int i = 1; i < 8; ++i) {
-            bool merged = false;
-#pragma unroll
-            for (int j = 0; j < i; ++j) {
-              const bool hit = !merged && eid[i] >= 0 && eid[j] == eid[i];
-              egx[j] += hit ? egx[i] : 0.f;
-              egy[j] += hit ? egy[i] : 0.f;
-              egz[j] += hit ? egz[i] : 0.f;
-              merged = merged || hit;
-            }
-            if (merged) eid[i] = -1;
-          }
-#pragma unroll
-          for (int i = 0; i < 8; ++i)
-            if (eid[i] >= 0) r_acc_add<TAB>(gvb, eid[i], egx[i], egy[i], egz[i]);
-        }
-      }
+      rg_pixel<TAB ? 1 : 0>(p, bd, i, lcorr, dc);
     }
     __syncthreads();
     }   // classification pass
@@ -1351,9 +1407,108 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
   }
 }
 
+// Deterministic form of the gradient scatter (mh_raster_set_deterministic / MHHIP_DETERMINISTIC=1): one workgroup per
+// BODY, every window pixel evaluated by a fixed thread, contributions summed as 64-bit fixed-point integers in LDS
+// (integer atomics commute exactly), one plain read-modify-write of dL/dverts per element -- the result is the same
+// bits from run to run whatever the wave schedule.  Three passes over the body's pixels (see RgDet): ~4-5x the time of
+// the production kernel; a verification mode, not a fast path.  The fixed-point step is 2^-46 of the body's largest
+// contribution, i.e. 2^22 times finer than the fp32 sums of the production kernel.
+__global__ __launch_bounds__(RGB) void k_raster_grads_det(RasterP p) {
+  __shared__ float s_red[RGB / 64];
+  __shared__ int s_shift;
+  unsigned long long* tab = (unsigned long long*)rg_tab;
+  const int tid = threadIdx.x;
+  const int H = p.H, W = p.W, P = H * W;
+  const int VH = (p.V + 1) / 2;
+  for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
+    const int t = b / p.N, n = b % p.N;
+    const int x0 = p.win[b * 4], ww = p.win[b * 4 + 2], y0 = p.win[b * 4 + 1], wh = p.win[b * 4 + 3];
+    if (ww <= 0 || wh <= 0) continue;
+    const int npx = ww * wh;
+    float S[6];
+    r_body_sums(p, b, S);
+    const float cnt = S[2] + 1.f;
+    const float diff = S[0] / cnt - S[1] / cnt;
+    RgBody bd;
+    bd.t = t; bd.n = n; bd.x0 = x0; bd.sy0 = y0; bd.ww = ww;
+    bd.vb = p.ndc + (size_t)b * p.V * 3;
+    bd.gvb = p.gverts + (size_t)b * p.V * 3;
+    bd.gk = p.gkeys + (size_t)p.body_koff[b] * 5;
+    bd.gA = p.coef_depth * 2.f * diff / cnt;
+    bd.gAlphaScale = p.coef_sil * p.sil_apply[b] * 2.f / (p.sil_D[b] + 1.f);
+    bd.sil_on = p.sil_apply[b] != 0.f;
+    bd.pvalid = p.p2d_valid[b];
+    bd.fr = p.front[b];
+    RgDet dc;
+    dc.umax = 0.f; dc.shift = 0;
+    float lcorr = 0.f;
+    for (int pass = 0; pass < 3; ++pass) {
+      dc.pass = pass;
+      dc.v0 = pass == 2 ? VH : 0;
+      dc.v1 = pass == 1 ? VH : p.V;
+      __syncthreads();
+      if (pass > 0) {
+        dc.shift = s_shift;
+        for (int i = tid; i < VH * 3; i += RGB) tab[i] = 0ull;
+        __syncthreads();
+      }
+      float lc = 0.f;
+      for (int i = tid; i < npx; i += RGB) {
+        const int yi = y0 + i / ww, xi = x0 + i % ww;
+        const size_t gp = (size_t)t * P + (size_t)yi * W + xi;
+        const unsigned long long* q = bd.gk + (size_t)i * 5;
+        const bool dep = bd.gA != 0.f && bd.pvalid != 0.f && q[0] != RS_EMPTY && ((p.ebits[gp] >> n) & 1u);
+        const bool sil = bd.sil_on && q[1] != RS_EMPTY && (p.bits[gp] & bd.fr) == 0u;
+        if (dep || sil) rg_pixel<2>(p, bd, i, lc, dc);
+      }
+      if (pass == 0) {
+        lcorr = r_block_sum(lc, s_red);                     // fixed thread -> pixel map, fixed tree: deterministic
+        float m = dc.umax;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        __syncthreads();
+        if ((tid & 63) == 0) s_red[tid >> 6] = m;
+        __syncthreads();
+        if (tid == 0) {
+          float mm = 0.f;
+          for (int w = 0; w < RGB / 64; ++w) mm = fmaxf(mm, s_red[w]);
+          int e = 0;
+          if (mm > 0.f && mm < INFINITY) (void)frexpf(mm, &e);   // mm < 2^e
+          s_shift = 46 - e;                                      // |contribution| 2^shift < 2^46; < 2^16 of them per vertex
+        }
+      } else {
+        __syncthreads();
+        const int nv = (dc.v1 - dc.v0) * 3;
+        float* o = bd.gvb + (size_t)dc.v0 * 3;
+        for (int i = tid; i < nv; i += RGB) {
+          const long long a = (long long)tab[i];
+          if (a != 0) o[i] += (float)ldexp((double)a, -dc.shift);   // the only writer of this element in this kernel
+        }
+      }
+    }
+    if (tid == 0 && lcorr != 0.f) p.sil_corr[b] += lcorr;
+  }
+}
+
 __global__ void k_fill(float* x, size_t n, float v) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] = v;
 }
+
+// 0 (default): float atomics in the gradient scatter (fast, summation order varies from run to run);
+// 1: k_raster_grads_det (bit-reproducible)
+static int g_raster_det = -1;
+static bool raster_deterministic() {
+  if (g_raster_det < 0) {
+    const char* e = getenv("MHHIP_DETERMINISTIC");
+    g_raster_det = (e && e[0] == '1') ? 1 : 0;
+  }
+  return g_raster_det != 0;
+}
+extern "C" int mh_raster_set_deterministic(int on) {
+  g_raster_det = on ? 1 : 0;
+  return MH_OK;
+}
+extern "C" int mh_raster_get_deterministic(void) { return raster_deterministic() ? 1 : 0; }
 
 static size_t r_align(size_t x) { return (x + 255) & ~(size_t)255; }
 static size_t r_max_units(size_t B, int H, int W) { return B + B * (size_t)H * W / RG_UNIT + 1; }
@@ -1477,7 +1632,13 @@ static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const flo
     mh_prof_mark(MH_PROF_RASTER_GRADS, 0, st);
     // one workgroup per CU is resident (LDS table); the work-unit count is only known on the device
     const int ggrid = 256 * 6;
-    if (use_tab) hipLaunchKernelGGL(k_raster_grads<true>, dim3(ggrid), dim3(RGB), tab, st, p);
+    if (raster_deterministic()) {
+      MH_CHECK(V <= RG_MAXV, "deterministic gradient scatter: model too large for the LDS table");
+      static unsigned char attr_det[MH_MAX_DEVICES];
+      if (mh_first_on_device(attr_det))
+        MH_HIP(hipFuncSetAttribute((const void*)k_raster_grads_det, hipFuncAttributeMaxDynamicSharedMemorySize, ((RG_MAXV + 1) / 2) * 3 * 8));
+      hipLaunchKernelGGL(k_raster_grads_det, dim3(p.B < 4096 ? p.B : 4096), dim3(RGB), (size_t)((V + 1) / 2) * 3 * 8, st, p);
+    } else if (use_tab) hipLaunchKernelGGL(k_raster_grads<true>, dim3(ggrid), dim3(RGB), tab, st, p);
     else hipLaunchKernelGGL(k_raster_grads<false>, dim3(ggrid), dim3(RGB), tab, st, p);
     MH_LAUNCH_CHECK();
     mh_prof_mark(MH_PROF_RASTER_GRADS, 1, st);

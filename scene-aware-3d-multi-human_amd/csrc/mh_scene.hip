@@ -243,24 +243,33 @@ __global__ __launch_bounds__(256) void k_contact_foot(ContactP p) {
   __syncthreads();
   const float inv = 1.f / scnt;
   float lf = 0.f;
-  for (int j = p.N + threadIdx.x; j < p.batch * p.N; j += 256) {
-    const int k = j / p.N, t = frame_at(k), tp = frame_at(k - 1);
-    if (t < 0 || tp < 0) continue;
-    const int n = j - k * p.N;
-    const int i = t * p.N + n, ip = tp * p.N + n;
-    if (!(p.dy[i] > -0.20f)) continue;
-    const int vi = p.low_idx[i];
-    const size_t cur = ((size_t)i * p.V + vi) * 3, prv = ((size_t)ip * p.V + vi) * 3;
+  // Every frame sits at exactly one position of exactly one batch, so element (frame, person, vertex) of dL/dverts is
+  // touched by at most two pairs of this block: as the CURRENT frame of pair (k, k-1) and as the PREVIOUS frame of pair
+  // (k+1, k).  Two sweeps separated by a barrier -- all current-frame adds, then all previous-frame adds -- make every
+  // add the only writer of its element in its sweep: plain read-modify-writes in a fixed order instead of float
+  // atomics (whose order, hence the last bit of a + x + y, would vary from run to run).
+  for (int sweep = 0; sweep < 2; ++sweep) {
+    for (int j = p.N + threadIdx.x; j < p.batch * p.N; j += 256) {
+      const int k = j / p.N, t = frame_at(k), tp = frame_at(k - 1);
+      if (t < 0 || tp < 0) continue;
+      const int n = j - k * p.N;
+      const int i = t * p.N + n, ip = tp * p.N + n;
+      if (!(p.dy[i] > -0.20f)) continue;
+      const int vi = p.low_idx[i];
+      const size_t cur = ((size_t)i * p.V + vi) * 3, prv = ((size_t)ip * p.V + vi) * 3;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float d = p.low_xyz[(size_t)i * 3 + c] - p.verts[prv + c];   // :514-517
-      lf += fabsf(d);
-      const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-      if (p.gverts) {
-        atomicAdd(&p.gverts[cur + c], p.cf * sg * inv);
-        atomicAdd(&p.gverts[prv + c], -p.cf * sg * inv);
+      for (int c = 0; c < 3; ++c) {
+        const float d = p.low_xyz[(size_t)i * 3 + c] - p.verts[prv + c];   // :514-517
+        const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        if (sweep == 0) {
+          lf += fabsf(d);
+          if (p.gverts) p.gverts[cur + c] += p.cf * sg * inv;
+        } else if (p.gverts) {
+          p.gverts[prv + c] -= p.cf * sg * inv;
+        }
       }
     }
+    __syncthreads();
   }
   s[threadIdx.x] = lf;
   __syncthreads();

@@ -36,6 +36,30 @@ class RasterTerms(object):
             check(L.mh_reduce_sum2(ptr(e.depth_body), ptr(e.sil_body), e.B, 1.0, ptr(log[1:2]), ptr(log[2:3]), st))
 
 
+    def selection(self, e):
+        """Inspection aid: what the last selection pass left in the workspace -- (win (B,4) int32: x0, y0, width, height of
+        every body's screen window; koff (B+1,): first window pixel of every body; keys (window pixels, 5) uint64: per
+        pixel, row-major inside the window, slot 0 = nearest face of the blur-1e-4 pass, slots 1-4 = the K=4 list of the
+        blur-2e-5 pass, ascending; key = float bits of z << 32 | face, all ones = empty)."""
+        B, H, W = e.B, e.H, e.W
+        win = self.ws[:B * 16].view(torch.int32).view(B, 4).cpu().numpy()
+        gk_bytes = ((B * H * W * 40) + 255) // 256 * 256
+        npix = np.maximum(win[:, 2], 0).astype(np.int64) * np.maximum(win[:, 3], 0)
+        koff = np.concatenate([[0], np.cumsum(npix)])
+        gk = self.ws[self.ws.numel() - gk_bytes:]
+        keys = gk[:int(koff[-1]) * 40].cpu().numpy().view(np.uint64).reshape(-1, 5)
+        return win, koff, keys
+
+
+def set_deterministic(on):
+    """mh_raster_set_deterministic: bit-reproducible gradient scatter (64-bit fixed-point accumulation, one workgroup per
+    body) instead of fp32 atomics; returns the previous setting"""
+    L = _lib.lib()
+    old = L.mh_raster_get_deterministic()
+    check(L.mh_raster_set_deterministic(1 if on else 0))
+    return bool(old)
+
+
 def render(model, verts, cam_K, image_size):
     """Nearest-face depth (-1 = empty) and soft-silhouette images of B bodies: (B,H,W) each.
     Inspection / synthetic-data helper on top of ``mh_raster_terms`` (losses disabled)."""

@@ -69,13 +69,28 @@ def test_warmup_lands_on_the_reference_start(golden_raster, smpl_struct, smpl_re
 
 
 @pytest.mark.parametrize('scene', [False, True])
-def test_first_cycle_gradients_with_live_raster(golden_raster, smpl_struct, smpl_regs, tmp_path, scene):
-    from mhhip.raster import RasterTerms
+@pytest.mark.parametrize('det', [False, True])
+def test_first_cycle_gradients_with_live_raster(golden_raster, smpl_struct, smpl_regs, tmp_path, scene, det):
+    """Every entry of every leaf gradient of cycle 1 against the reference's own loop.  Measured (both modes alike):
+    worst entry 7.8e-4 of the leaf's largest (poses_T), 99 % of poses_smpl within 2.2e-5, medians 1e-7..2e-6 -- the
+    worst entries are blur-band flips of single pixels (tests/test_raster_gpu.py enumerates them), not summation order:
+    the deterministic scatter differs from the atomics one by 1.2e-7."""
+    from mhhip.raster import RasterTerms, set_deterministic
     gr = golden_raster
-    fin, opt, dl = _start(smpl_struct, smpl_regs, tmp_path, gr, scene)
-    opt._stage_from_dataloader(dl)
-    e = opt.engine
-    e.cycle(0, raster=RasterTerms(e))
+    old = set_deterministic(det)
+    try:
+        runs = []
+        for rep in range(2 if det else 1):
+            fin, opt, dl = _start(smpl_struct, smpl_regs, tmp_path, gr, scene)
+            opt._stage_from_dataloader(dl)
+            e = opt.engine
+            e.cycle(0, raster=RasterTerms(e))
+            torch.cuda.synchronize()
+            runs.append(e.grads.clone())
+    finally:
+        set_deterministic(old)
+    if det:
+        assert torch.equal(runs[0], runs[1]), 'deterministic mode: the six gradient leaves must be bit-identical between runs'
     log = e.read_log(1, nbatches_total=None)[0]
     pre = 'scene_k1_grad_' if scene else 'k1_grad_'
     for n in LEAVES:
@@ -83,10 +98,9 @@ def test_first_cycle_gradients_with_live_raster(golden_raster, smpl_struct, smpl
         got = _leaf(opt, n, e.grads).reshape(g.shape)
         scale = max(np.abs(g).max(), 1e-8)
         err = np.abs(got - g)
-        frac = float((err > 2e-3 * scale).mean())
-        # float atomics in the raster scatter + last-ulp blur-band flips: tight on (almost) every entry
-        assert frac < 0.01 and np.median(err) < 3e-4 * scale, \
-            '%s: %.4f of entries above 2e-3*max, median %.2e, max %.2e (scale %.2e)' % (n, frac, np.median(err), err.max(), scale)
+        np.testing.assert_allclose(got, g, atol=1.5e-3 * scale, rtol=0, err_msg=n)          # EVERY entry
+        assert np.median(err) < 3e-4 * scale and np.percentile(err, 99) < 6e-4 * scale, \
+            '%s: median %.2e, p99 %.2e, max %.2e (scale %.2e)' % (n, np.median(err), np.percentile(err, 99), err.max(), scale)
     if not scene:
         # the log holds the per-batch mean like the reference's optim_log (:588-590)
         np.testing.assert_allclose(log['loss_depth'], gr['k1_loss_depth_per_batch'].mean(), rtol=2e-3)

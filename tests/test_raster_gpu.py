@@ -25,7 +25,7 @@ def _scene(T, N, W, H, seed, zlo, zhi):
     return sp, pT.astype(np.float32), rng
 
 
-def _run_case(smpl_struct, smpl_regs, T, N, W, H, seed, zlo=3.0, zhi=6.0, fov=60.0):
+def _run_case(smpl_struct, smpl_regs, T, N, W, H, seed, zlo=3.0, zhi=6.0, fov=60.0, hip_selection=False):
     from mhhip import engine
     from mhhip.sequence import SequenceEngine
     from mhhip.raster import RasterTerms
@@ -63,14 +63,17 @@ def _run_case(smpl_struct, smpl_regs, T, N, W, H, seed, zlo=3.0, zhi=6.0, fov=60
     gv = torch.zeros_like(e.verts)
     e.grads.zero_()
     log = torch.zeros(16, device=e.dev)
-    RasterTerms(e)(e, gv, log)
+    rt = RasterTerms(e)
+    rt(e, gv, log)
     torch.cuda.synchronize()
+    sel = rt.selection(e)
 
     # ---- oracle -----------------------------------------------------------------------------------
     verts = e.verts.cpu().clone().requires_grad_(True)
     tzmin = torch.tensor(zmin, requires_grad=True)
     tzmax = torch.tensor(zmax, requires_grad=True)
-    zbuf, alpha = ro.render(verts, faces, K, (W, H))
+    got_sel = _hip_selection(sel, T * N, H, W)
+    zbuf, alpha = ro.render(verts, faces, K, (W, H), selection=(got_sel[..., :1], got_sel[..., 1:]) if hip_selection else None)
     zbuf, alpha = zbuf.view(T, N, H, W), alpha.view(T, N, H, W)
     tseg = torch.tensor(seg)
     conf = (torch.tensor(pose2d[..., 2:3]) >= 0.5).float()
@@ -104,7 +107,21 @@ def _run_case(smpl_struct, smpl_regs, T, N, W, H, seed, zlo=3.0, zhi=6.0, fov=60
                 want_depth=depth_tn.detach().numpy(), sil=e.sil_body.cpu().numpy().reshape(T, N), want_sil=want_sil,
                 gzmin=e.leaf('zmin_lin', e.grads).cpu().numpy(), gzmax=e.leaf('zmax_lin', e.grads).cpu().numpy(),
                 want_gzmin=tzmin.grad.numpy(), want_gzmax=tzmax.grad.numpy(), log=log.cpu().numpy(),
-                zbuf=zbuf.detach().numpy())
+                zbuf=zbuf.detach().numpy(), sel=sel, faces=faces, K=K, verts=e.verts.cpu().numpy(), shape=(T, N, H, W))
+
+
+def _hip_selection(sel, B, H, W):
+    """(B,H,W,5) face ids of the HIP selection pass (-1 = empty): slot 0 = nearest face of the blur-1e-4 pass, 1..4 = the
+    K=4 list of the blur-2e-5 pass"""
+    win, koff, keys = sel
+    EMPTY = np.uint64(0xffffffffffffffff)
+    got = np.full((B, H, W, 5), -1, np.int64)
+    for b in range(B):
+        x0, y0, ww, wh = [int(v) for v in win[b]]
+        if ww > 0 and wh > 0:
+            k = keys[koff[b]:koff[b + 1]].reshape(wh, ww, 5)
+            got[b, y0:y0 + wh, x0:x0 + ww] = np.where(k == EMPTY, -1, (k & np.uint64(0xffffffff)).astype(np.int64))
+    return got
 
 
 def _check(r):
@@ -186,3 +203,103 @@ def test_bodies_behind_or_off_camera_contribute_nothing(smpl_struct, smpl_regs):
     assert (zbuf[0] < 0).all() and (zbuf[1] < 0).all()          # nothing rasterised for the first two bodies
     assert np.abs(g[0]).max() == 0 and np.abs(g[1]).max() == 0
     assert (zbuf[2] > 0).sum() > 20 and np.abs(g[2]).max() > 0
+
+
+def _face_eval64(ndc, faces, b, f, xf, yf):
+    """float64 (pz, inside, d2) of face f of body b at the pixel centre (xf, yf) -- CheckPixelInsideFace"""
+    v = ndc[b][faces[f]].astype(np.float64)
+    (x0, y0, z0), (x1, y1, z1), (x2, y2, z2) = v
+    edge = lambda px, py, ax, ay, bx, by: (px - ax) * (by - ay) - (py - ay) * (bx - ax)
+    area = edge(x2, y2, x0, y0, x1, y1) + 1e-8
+    w = np.array([edge(xf, yf, x1, y1, x2, y2), edge(xf, yf, x2, y2, x0, y0), edge(xf, yf, x0, y0, x1, y1)]) / area
+    c = np.maximum(w, 0)
+    pz = float((c / max(c.sum(), 1e-5)) @ np.array([z0, z1, z2]))
+
+    def seg(ax, ay, bx, by):
+        bax, bay = bx - ax, by - ay
+        l2 = bax * bax + bay * bay
+        if l2 <= 1e-8:
+            return (xf - bx) ** 2 + (yf - by) ** 2
+        t = min(max((bax * (xf - ax) + bay * (yf - ay)) / l2, 0.0), 1.0)
+        return (ax + t * bax - xf) ** 2 + (ay + t * bay - yf) ** 2
+    return pz, bool((w > 0).all()), min(seg(x0, y0, x1, y1), seg(x0, y0, x2, y2), seg(x1, y1, x2, y2))
+
+
+def _selection_differences(r):
+    """Pixels where the HIP selection and the oracle's brute-force selection (same vertices) pick different faces, each
+    checked to be a NEAR-TIE in float64: the face that differs either reaches the pixel centre to within 1e-4 of the blur
+    radius (in / out of the band) or its depth is within 1e-5 of the depth at the cut of the K-nearest list."""
+    T, N, H, W = r['shape']
+    B = T * N
+    faces = r['faces']
+    ndc = ro.to_ndc(torch.tensor(r['verts']), r['K'], (W, H)).numpy().astype(np.float32)
+    got = _hip_selection(r['sel'], B, H, W)
+    f8, _ = ro.select_faces(ndc, faces, H, W, 1e-4, 8)
+    f4, _ = ro.select_faces(ndc, faces, H, W, 2e-5, 4)
+    want = np.concatenate([f8[..., :1], f4], axis=-1)
+    xs, ys = ro.pixel_centres_ndc(H, W)
+    live = int((want[..., 0] >= 0).sum() + (want[..., 1] >= 0).sum())
+    ndiff, not_ties = 0, []
+    d0 = got[..., 0] != want[..., 0]
+    d4 = (np.sort(got[..., 1:], -1) != np.sort(want[..., 1:], -1)).any(-1)    # alpha is a product: the K=4 list is a set
+    for b, y, x in zip(*np.nonzero(d0 | d4)):
+        ndiff += 1
+        xf, yf = float(xs[x]), float(ys[y])
+        for lo, hi, blur in ((0, 1, 1e-4), (1, 5, 2e-5)):
+            A, Bset = set(got[b, y, x, lo:hi]) - {-1}, set(want[b, y, x, lo:hi]) - {-1}
+            if A == Bset:
+                continue
+            ev = {f: _face_eval64(ndc, faces, b, f, xf, yf) for f in A | Bset}
+            zcut = max(ev[f][0] for f in A | Bset)                  # depth of the farthest face either side kept
+            for f in A ^ Bset:
+                pz, inside, d2 = ev[f]
+                band_tie = (not inside) and abs(d2 - blur) <= 1e-4 * blur
+                depth_tie = any(abs(pz - ev[g][0]) <= 1e-5 * max(abs(pz), 1e-6) for g in (A | Bset) if g != f) or abs(pz - zcut) <= 1e-5 * zcut
+                if not (band_tie or depth_tie):
+                    not_ties.append((int(b), int(y), int(x), int(f), pz, inside, d2))
+    return ndiff, live, not_ties
+
+
+@pytest.mark.parametrize('case', [dict(T=3, N=2, W=60, H=34, seed=5), dict(T=2, N=3, W=120, H=68, seed=11, zlo=2.2, zhi=4.0)])
+def test_deterministic_scatter_and_where_the_gradient_errors_come_from(smpl_struct, smpl_regs, case):
+    """MHHIP_DETERMINISTIC / mh_raster_set_deterministic(1):
+    (a) dL/dverts is bit-identical from run to run (the production scatter is not: fp32 atomics) and differs from the
+        production result by rounding only;
+    (b) SELECTION: the K nearest faces of a pixel are a discontinuous function of fp32 depths and distances -- a pixel
+        centre sees ~50 sub-pixel faces inside the blur radius, the kernel interpolates with v_rcp_f32 where the oracle
+        divides.  The two selections differ on ~1 % of the live pixels, and EVERY differing face is verified in float64 to
+        be a near-tie (depth within 1e-5 of the cut of the list, or distance within 1e-4 of the blur radius);
+    (c) GRADIENTS: with the oracle evaluating the faces the HIP kernel selected, EVERY entry of dL/dverts agrees to 5e-4
+        of the largest entry (measured worst 2.3e-4; the depth-range gradients to 2e-4) -- no percentile, no outlier
+        allowance.  What is left is the fp32 noise floor of the barycentric Jacobian itself: its terms cancel to
+        translation invariance and are multiplied by 1/area ~ 1e6 of a sub-pixel face, in the kernel and in the oracle's
+        fp32 autograd alike.  (This test found a real defect on the way: the normalised clipped weights went through
+        v_rcp_f32, whose 1-ulp residue survived that amplification -- 6.6e-4; they are IEEE divisions now.)"""
+    from mhhip.raster import set_deterministic
+    old = set_deterministic(True)
+    try:
+        r = _run_case(smpl_struct, smpl_regs, hip_selection=True, **case)
+        r2 = _run_case(smpl_struct, smpl_regs, hip_selection=True, **case)
+        np.testing.assert_array_equal(r['gv'], r2['gv'])
+        np.testing.assert_array_equal(r['gzmin'], r2['gzmin'])
+        np.testing.assert_array_equal(r['gzmax'], r2['gzmax'])
+        set_deterministic(False)
+        rp = _run_case(smpl_struct, smpl_regs, hip_selection=True, **case)
+    finally:
+        set_deterministic(old)
+    g, w = r['gv'], r['want_gv']
+    scale = np.abs(w).max()
+    assert scale > 0 and np.abs(rp['gv'] - g).max() <= 2e-6 * scale              # atomics noise of the production scatter
+    # (c) same faces -> same numbers, everywhere
+    np.testing.assert_allclose(g, w, atol=5e-4 * scale, rtol=0)
+    np.testing.assert_allclose(rp['gv'], w, atol=5e-4 * scale, rtol=0)
+    assert (np.abs(g - w) > 2e-4 * scale).sum() <= 3
+    np.testing.assert_allclose(r['depth'], r['want_depth'], rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(r['sil'], r['want_sil'], rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(r['gzmin'], r['want_gzmin'], atol=2e-4 * max(np.abs(r['want_gzmin']).max(), 1e-8), rtol=0)
+    np.testing.assert_allclose(r['gzmax'], r['want_gzmax'], atol=2e-4 * max(np.abs(r['want_gzmax']).max(), 1e-8), rtol=0)
+    # (b) the selections
+    ndiff, live, not_ties = _selection_differences(r)
+    print('selection differs on %d of %d live (pixel, pass) entries; not explained as near-ties: %d' % (ndiff, live, len(not_ties)))
+    assert live > 300 and ndiff <= 3e-2 * live + 3, (ndiff, live)
+    assert not not_ties, not_ties[:5]

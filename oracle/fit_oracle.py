@@ -298,7 +298,12 @@ class SequenceOracle(object):
         loss_sil = torch.zeros(())
         tgt_disp = data['depths'] * (1.0 / v['min_z'] - 1.0 / v['max_z']) + 1.0 / v['max_z']   # :425
         if self.rasteriser is not None:
-            zbuf, alpha = self.rasteriser(v['verts'].view(b * N, -1, 3))
+            # (a rasteriser with ``wants_frames`` is also told which frames these bodies belong to: tests hand in the face
+            # selection of the kernel under test, per frame)
+            if getattr(self.rasteriser, 'wants_frames', False):
+                zbuf, alpha = self.rasteriser(v['verts'].view(b * N, -1, 3), frames=idx)
+            else:
+                zbuf, alpha = self.rasteriser(v['verts'].view(b * N, -1, 3))
             zbuf = zbuf.view(b, N, H, W)
             alpha = alpha.view(b, N, H, W)
             er = erode3x3(erode3x3(data['seg_mask']))                             # :434

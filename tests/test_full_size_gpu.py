@@ -35,33 +35,74 @@ def _compare_grads(e, o, frac=0.01, tight=5e-3, med=1e-3):
         assert np.median(err) < med * scale, name
 
 
+class _HipSelectionRasteriser(object):
+    """the oracle's differentiable rendering on the faces the HIP selection pass picked (per frame): separates "which
+    faces" (tests/test_raster_gpu.py enumerates the differences and verifies them as near-ties) from "what comes out
+    of them", so that the gradients can be compared on EVERY entry"""
+    wants_frames = True
+
+    def __init__(self, faces, K, image_size, N):
+        self.faces, self.K, self.size, self.N, self.sel = faces, K, image_size, N, None
+
+    def take(self, raster, e):
+        from test_raster_gpu import _hip_selection
+        self.sel = _hip_selection(raster.selection(e), e.B, e.H, e.W).reshape(e.T, self.N, e.H, e.W, 5)
+
+    def __call__(self, verts, frames):
+        s = self.sel[np.asarray(frames)].reshape(-1, *self.sel.shape[2:])
+        return ro.render(verts, self.faces, self.K, self.size, selection=(s[..., :1], s[..., 1:]))
+
+
 def test_c3_full_size_cycle_matches_oracle(smpl_struct, smpl_regs, oracle_model, tmp_path):
-    T, N, W, H, batch = 200, 4, 240, 135, 50
+    """BASELINE C3 exactly as the bench runs it: 4 humans x 200 frames at 240x135 in batches of TEN (the batch size fixes
+    the in-batch foot-sliding pairs and the per-batch regularisers), deterministic gradient scatter, the oracle
+    rendering the faces the kernel selected: loss log and EVERY entry of EVERY leaf gradient."""
+    from mhhip import synthetic
+    from mhhip.raster import RasterTerms, set_deterministic
+    T, N, W, H, batch = 200, 4, 240, 135, 10
     opt, dl, o, batches, seq = _setup(smpl_struct, smpl_regs, oracle_model, tmp_path, T, N, W, H, batch, 41, True)
+    assert len(batches) == 20
     opt._stage_from_dataloader(dl)
-    from mhhip.raster import RasterTerms
     e = opt.engine
     raster = RasterTerms(e)
-    e.cycle(0, raster=raster)
-    log = e.read_log(1)[0]
-    want = o.cycle_grads(batches)
-    for k in LOG_KEYS:
-        np.testing.assert_allclose(log[k], want[k], rtol=3e-3, atol=1e-6, err_msg=k)
-    for k in ['loss_pose24j', 'loss_depth', 'loss_silhouette', 'reg_contact', 'reg_vel']:
-        assert want[k] > 0, k
-    _compare_grads(e, o)
-    # filters over the 200-frame sequence (optimizer.py:664-675), then the filtered-vertex term (:571-573)
-    e.update_filters()
-    o.update_filters()
-    np.testing.assert_allclose(e.verts_filt.cpu().numpy().reshape(T, -1), o.v_filt.numpy().reshape(T, -1), atol=2e-5)
-    np.testing.assert_allclose(e.pT_filt.cpu().numpy().reshape(T, -1), o.pT_filt.numpy().reshape(T, -1), atol=2e-6)
-    e.cycle(1, raster=raster)
-    log = e.read_log(2)[1]
-    want = o.cycle_grads(batches)
-    for k in LOG_KEYS + ['reg_filter_verts']:
-        np.testing.assert_allclose(log[k], want[k], rtol=3e-3, atol=1e-6, err_msg=k)
-    assert want['reg_filter_verts'] >= 0
-    _compare_grads(e, o)
+    hsel = _HipSelectionRasteriser(np.asarray(smpl_struct.f).astype(np.int64), synthetic.default_cam_K((W, H), 60.0), (W, H), N)
+    o.rasteriser = hsel
+    old = set_deterministic(True)
+    try:
+        e.cycle(0, raster=raster)
+        hsel.take(raster, e)
+        log = e.read_log(1)[0]
+        want = o.cycle_grads(batches)
+        for k in LOG_KEYS:
+            np.testing.assert_allclose(log[k], want[k], rtol=1e-3, atol=1e-6, err_msg=k)
+        for k in ['loss_pose24j', 'loss_depth', 'loss_silhouette', 'reg_contact', 'reg_foot_sliding', 'reg_vel']:
+            assert want[k] > 0, k
+        _compare_grads_everywhere(e, o)
+        # filters over the 200-frame sequence (optimizer.py:664-675), then the filtered-vertex term (:571-573)
+        e.update_filters()
+        o.update_filters()
+        np.testing.assert_allclose(e.verts_filt.cpu().numpy().reshape(T, -1), o.v_filt.numpy().reshape(T, -1), atol=2e-5)
+        np.testing.assert_allclose(e.pT_filt.cpu().numpy().reshape(T, -1), o.pT_filt.numpy().reshape(T, -1), atol=2e-6)
+        e.cycle(1, raster=raster)
+        hsel.take(raster, e)
+        log = e.read_log(2)[1]
+        want = o.cycle_grads(batches)
+        for k in LOG_KEYS + ['reg_filter_verts']:
+            np.testing.assert_allclose(log[k], want[k], rtol=1e-3, atol=1e-6, err_msg=k)
+        assert want['reg_filter_verts'] >= 0
+        _compare_grads_everywhere(e, o)
+    finally:
+        set_deterministic(old)
+
+
+def _compare_grads_everywhere(e, o, tol=1e-3):
+    for name, ename in LEAF_MAP:
+        w = _oracle_grad(o, name)
+        g = e.leaf(ename, e.grads).cpu().numpy().reshape(w.shape)
+        scale = max(np.abs(w).max(), 1e-8)
+        err = np.abs(g - w)
+        print('%-10s max %.2e  p99 %.2e  median %.2e (x largest entry)' % (name, err.max() / scale, np.percentile(err, 99) / scale, np.median(err) / scale))
+        np.testing.assert_allclose(g, w, atol=tol * scale, rtol=0, err_msg=name)
 
 
 def test_c5_cloud_of_200k_points():
@@ -81,6 +122,7 @@ def test_c5_cloud_of_200k_points():
 
 
 def test_c5_shape_cycle_restricts_to_the_first_batch(smpl_struct, smpl_regs, oracle_model, tmp_path, monkeypatch):
+    """8 humans x 500 frames with the 200 000-point cloud INSIDE the cycle (set_scene_points -> grid -> contact term)"""
     T, N, W, H, batch = 500, 8, 240, 135, 25
     coefs = dict(gi.COEFS)
     coefs.update(reg_velocity=0.0, reg_verts_filter=0.0, reg_foot_sliding=0.0)
@@ -89,7 +131,27 @@ def test_c5_shape_cycle_restricts_to_the_first_batch(smpl_struct, smpl_regs, ora
     opt._stage_from_dataloader(dl)
     from mhhip.raster import RasterTerms
     e = opt.engine
-    e.cycle(0, raster=RasterTerms(e))
+    # BASELINE C5's scene: 200 000 points injected directly (the reference ties the cloud to the image, optimizer.py:609-613;
+    # 600x338 px is the equivalent image) -- the same relief + boxes as the stand-alone neighbour-search test above
+    rng = np.random.RandomState(11)
+    M = 200000
+    pts = np.stack([rng.uniform(-6, 6, M), 1.2 + 0.03 * rng.randn(M) + 0.1 * np.sin(rng.uniform(0, 6, M)),
+                    rng.uniform(2, 14, M)], 1).astype(np.float32)
+    box = rng.rand(M) < 0.15
+    pts[box, 1] -= rng.uniform(0.2, 0.9, box.sum()).astype(np.float32)
+    e.set_scene_points(torch.tensor(pts))
+    o_full.scene_pcd = torch.tensor(pts).view(1, 1, M, 3)
+    from mhhip import synthetic
+    from mhhip.raster import set_deterministic
+    raster = RasterTerms(e)
+    hsel = _HipSelectionRasteriser(np.asarray(smpl_struct.f).astype(np.int64), synthetic.default_cam_K((W, H), 60.0), (W, H), N)
+    o_full.rasteriser = hsel
+    old = set_deterministic(True)
+    try:
+        e.cycle(0, raster=raster)
+    finally:
+        set_deterministic(old)
+    hsel.take(raster, e)
     log = e.read_log(1)[0]
     g_all = {ename: e.leaf(ename, e.grads).cpu().numpy() for _, ename in LEAF_MAP}
     for v in g_all.values():
@@ -107,10 +169,11 @@ def test_c5_shape_cycle_restricts_to_the_first_batch(smpl_struct, smpl_regs, ora
         w, g = w[:batch], g[:batch]
         scale = max(np.abs(w).max(), 1e-8)
         err = np.abs(g - w)
-        off = float((err > 5e-3 * scale).mean())
-        assert off < 0.01, '%s: %.4f of the entries above 5e-3*max (max err %.2e, scale %.2e)' % (name, off, err.max(), scale)
-        assert np.median(err) < 1e-3 * scale, name
+        print('%-10s max %.2e  median %.2e (x largest entry)' % (name, err.max() / scale, np.median(err) / scale))
+        np.testing.assert_allclose(g, w, atol=1e-3 * scale, rtol=0, err_msg=name)        # EVERY entry of the first batch
         assert np.abs(w).max() > 0, name
+    # the contact term of the first batch against the oracle's full argsort over the 200 000 points
+    np.testing.assert_allclose(float(e.batch_contact[0]), want['reg_contact'], rtol=1e-4)
 
 
 def test_selection_does_not_depend_on_what_the_workspace_held(smpl_struct, smpl_regs, oracle_model, tmp_path):

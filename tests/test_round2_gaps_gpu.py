@@ -4,6 +4,8 @@ coefficients through ``fit``, models with more than four bones per vertex, BASEL
 (1 human, 256x256), and one 250-frame shard of C4 with its halos taken from the neighbouring frames."""
 import warnings
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -138,18 +140,26 @@ def test_lbs_with_rotation_matrices(oracle_model, smpl_struct):
     np.testing.assert_allclose(v_rot.cpu().numpy(), v_aa.detach().cpu().numpy(), atol=2e-6)
 
 
-def test_shuffled_dataloader_warns_and_stages_in_frame_order(smpl_struct, smpl_regs, tmp_path):
+def test_shuffled_dataloader_stages_in_frame_order_without_touching_the_rng(smpl_struct, smpl_regs, tmp_path):
+    """shuffle=True (the shipped config): the frames are staged once, in FRAME order, whatever order the loader would
+    deliver them in; the staging pass must not advance the random number generators (the shuffle of cycle 0 has to be
+    the one the reference draws, tests/test_shuffle_gpu.py); no warning any more (round 2 paired contiguous frames)."""
     fin = gi.fit_inputs()
-    opt = _new_opt(smpl_struct, smpl_regs, tmp_path, fin)
-    opt.init_optimized_variables(fin['pose2d'], fin['poses_smpl'], fin['betas_smpl'], fin['valid_smpl'], num_iter=0)
-    with pytest.warns(UserWarning, match='shuffle=True'):
-        opt._stage_from_dataloader(torch.utils.data.DataLoader(_DS(fin), batch_size=5, shuffle=True))
-    np.testing.assert_array_equal(opt.engine.pose2d.cpu().numpy().reshape(fin['pose2d'].shape), fin['pose2d'])
-    with warnings.catch_warnings():
-        warnings.simplefilter('error')
-        opt2 = _new_opt(smpl_struct, smpl_regs, tmp_path, fin)
-        opt2.init_optimized_variables(fin['pose2d'], fin['poses_smpl'], fin['betas_smpl'], fin['valid_smpl'], num_iter=0)
-        opt2._stage_from_dataloader(torch.utils.data.DataLoader(_DS(fin), batch_size=5, shuffle=False))
+    for via_loader in ('0', '1'):
+        os.environ['MHHIP_STAGE_VIA_LOADER'] = via_loader          # 1: the route of custom loaders (iterates the loader)
+        try:
+            opt = _new_opt(smpl_struct, smpl_regs, tmp_path, fin)
+            opt.init_optimized_variables(fin['pose2d'], fin['poses_smpl'], fin['betas_smpl'], fin['valid_smpl'], num_iter=0)
+            torch.manual_seed(77)
+            state = torch.get_rng_state()
+            with warnings.catch_warnings():
+                warnings.simplefilter('error')
+                opt._stage_from_dataloader(torch.utils.data.DataLoader(_DS(fin), batch_size=5, shuffle=True))
+            assert torch.equal(torch.get_rng_state(), state)
+        finally:
+            os.environ.pop('MHHIP_STAGE_VIA_LOADER', None)
+        np.testing.assert_array_equal(opt.engine.pose2d.cpu().numpy().reshape(fin['pose2d'].shape), fin['pose2d'])
+        np.testing.assert_array_equal(opt._backmasks, fin['backmasks'])
 
 
 def test_distortion_coefficients_through_fit(smpl_struct, smpl_regs, oracle_model, tmp_path):

@@ -269,8 +269,16 @@ class SequenceOracle(object):
         verts = out['verts'].view(b, N, -1, 3)
         j17 = out['joints_alphapose'].view(b, N, 17, 3)
         pT = self.poses_T[idx]
+        verts_abs = scale * verts + pT
+        ov = getattr(self, 'verts_value_override', None)
+        if ov is not None:
+            # test aid: evaluate everything downstream AT the vertices of the kernel under test (values replaced, the
+            # gradient still flows through this oracle's own LBS).  The rasterised terms are ill-conditioned at sliver
+            # faces seen edge-on (gradient ~ 1/area): a 1e-7 m difference between two fp32 LBS evaluations moves such a
+            # body's gradient by percents, which says nothing about either implementation.
+            verts_abs = verts_abs + (ov[idx].to(verts_abs.dtype) - verts_abs).detach()
         return dict(scale=scale, min_z=min_z, max_z=max_z, pT=pT,
-                    verts=scale * verts + pT, joints=scale * j17 + pT, poses=self.poses_smpl[idx])
+                    verts=verts_abs, joints=scale * j17 + pT, poses=self.poses_smpl[idx])
 
     def full_sequence_verts(self):
         T, N = self.T, self.N

@@ -14,6 +14,7 @@ import pytest
 import torch
 
 import golden_inputs as gi
+from oracle import raster_oracle as ro
 from test_fit_full_gpu import LEAF_MAP, _oracle_grad, _setup
 from test_scene_knn_gpu import _dy_reference, _run
 
@@ -44,9 +45,14 @@ class _HipSelectionRasteriser(object):
     def __init__(self, faces, K, image_size, N):
         self.faces, self.K, self.size, self.N, self.sel = faces, K, image_size, N, None
 
-    def take(self, raster, e):
+    def take(self, raster, e, oracle=None):
+        """the selection of the cycle the engine just ran; oracle: also evaluate the oracle's terms AT the engine's vertices
+        (oracle/fit_oracle.py verts_value_override: sliver faces make the rasterised gradients ill-conditioned in the
+        vertices, and the LBS forward has its own parity tests at 1e-5 m)"""
         from test_raster_gpu import _hip_selection
         self.sel = _hip_selection(raster.selection(e), e.B, e.H, e.W).reshape(e.T, self.N, e.H, e.W, 5)
+        if oracle is not None:
+            oracle.verts_value_override = e.verts.view(e.T, self.N, -1, 3).cpu().clone()
 
     def __call__(self, verts, frames):
         s = self.sel[np.asarray(frames)].reshape(-1, *self.sel.shape[2:])
@@ -56,7 +62,8 @@ class _HipSelectionRasteriser(object):
 def test_c3_full_size_cycle_matches_oracle(smpl_struct, smpl_regs, oracle_model, tmp_path):
     """BASELINE C3 exactly as the bench runs it: 4 humans x 200 frames at 240x135 in batches of TEN (the batch size fixes
     the in-batch foot-sliding pairs and the per-batch regularisers), deterministic gradient scatter, the oracle
-    rendering the faces the kernel selected: loss log and EVERY entry of EVERY leaf gradient."""
+    rendering the faces the kernel selected at the vertices the kernel produced: loss log and EVERY entry of EVERY
+    leaf gradient (no percentiles, no outlier allowance)."""
     from mhhip import synthetic
     from mhhip.raster import RasterTerms, set_deterministic
     T, N, W, H, batch = 200, 4, 240, 135, 10
@@ -70,7 +77,7 @@ def test_c3_full_size_cycle_matches_oracle(smpl_struct, smpl_regs, oracle_model,
     old = set_deterministic(True)
     try:
         e.cycle(0, raster=raster)
-        hsel.take(raster, e)
+        hsel.take(raster, e, oracle=o)
         log = e.read_log(1)[0]
         want = o.cycle_grads(batches)
         for k in LOG_KEYS:
@@ -84,7 +91,7 @@ def test_c3_full_size_cycle_matches_oracle(smpl_struct, smpl_regs, oracle_model,
         np.testing.assert_allclose(e.verts_filt.cpu().numpy().reshape(T, -1), o.v_filt.numpy().reshape(T, -1), atol=2e-5)
         np.testing.assert_allclose(e.pT_filt.cpu().numpy().reshape(T, -1), o.pT_filt.numpy().reshape(T, -1), atol=2e-6)
         e.cycle(1, raster=raster)
-        hsel.take(raster, e)
+        hsel.take(raster, e, oracle=o)
         log = e.read_log(2)[1]
         want = o.cycle_grads(batches)
         for k in LOG_KEYS + ['reg_filter_verts']:
@@ -95,7 +102,7 @@ def test_c3_full_size_cycle_matches_oracle(smpl_struct, smpl_regs, oracle_model,
         set_deterministic(old)
 
 
-def _compare_grads_everywhere(e, o, tol=1e-3):
+def _compare_grads_everywhere(e, o, tol=2e-4):       # measured worst entry at C3: 3.1e-5 of the leaf's largest
     for name, ename in LEAF_MAP:
         w = _oracle_grad(o, name)
         g = e.leaf(ename, e.grads).cpu().numpy().reshape(w.shape)
@@ -151,7 +158,7 @@ def test_c5_shape_cycle_restricts_to_the_first_batch(smpl_struct, smpl_regs, ora
         e.cycle(0, raster=raster)
     finally:
         set_deterministic(old)
-    hsel.take(raster, e)
+    hsel.take(raster, e, oracle=o_full)
     log = e.read_log(1)[0]
     g_all = {ename: e.leaf(ename, e.grads).cpu().numpy() for _, ename in LEAF_MAP}
     for v in g_all.values():
@@ -170,7 +177,7 @@ def test_c5_shape_cycle_restricts_to_the_first_batch(smpl_struct, smpl_regs, ora
         scale = max(np.abs(w).max(), 1e-8)
         err = np.abs(g - w)
         print('%-10s max %.2e  median %.2e (x largest entry)' % (name, err.max() / scale, np.median(err) / scale))
-        np.testing.assert_allclose(g, w, atol=1e-3 * scale, rtol=0, err_msg=name)        # EVERY entry of the first batch
+        np.testing.assert_allclose(g, w, atol=2e-4 * scale, rtol=0, err_msg=name)        # EVERY entry of the first batch (measured 6.6e-6)
         assert np.abs(w).max() > 0, name
     # the contact term of the first batch against the oracle's full argsort over the 200 000 points
     np.testing.assert_allclose(float(e.batch_contact[0]), want['reg_contact'], rtol=1e-4)

@@ -361,6 +361,15 @@ int mh_raster_terms_phase(int T, int N, int V, int F, int H, int W, const float*
  * then global): the summation order, hence the last bits, vary from run to run.  on != 0: one workgroup per body,
  * 64-bit fixed-point integer accumulation (exact, order-free), one writer per element -- dL/dverts and all six
  * gradient leaves are bit-identical between runs, ~4-5x slower for this kernel. */
+/* Temporal coherence of the rasteriser's preparation: the per-body face lists (sorted by first pixel
+ * row) are kept across launches and rebuilt for a body only when one of its vertices has moved `rows` pixel rows since the
+ * body's last sort; tiles read their candidates `rows` further out and every face is decided from the current
+ * coordinates, so the selection is bit-identical to a fresh sort.  Default 1 (MHHIP_RASTER_SORT_MARGIN overrides at
+ * first use); 0 = sort every launch.  mh_raster_sort_counters: {bodies seen, bodies re-sorted}, cumulative over the
+ * launches on this workspace (synchronises the stream). */
+int mh_raster_set_sort_margin(int rows);
+int mh_raster_get_sort_margin(void);
+int mh_raster_sort_counters(int T, int N, int V, int F, int H, int W, void* ws, unsigned long long* out_host /*[2]*/, void* stream);
 int mh_raster_set_deterministic(int on);
 int mh_raster_get_deterministic(void);
 

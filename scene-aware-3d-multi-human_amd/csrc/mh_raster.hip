@@ -81,7 +81,15 @@ struct RasterP {
   int* gunit_total;          // [1]
   int* strip_order;          // [max_strips] tiles by decreasing candidate-face count (longest first)
   float* sil_corr;           // [B] sum over the silhouette pixels of alpha^2 - 2 alpha seg (accumulated by k_raster_grads)
+  // temporal coherence of the face sort (see k_raster_face_sort): the sorted lists of a body are kept until one of its
+  // vertices has moved `margin` pixel rows away from where it was when the lists were built
+  int margin;                // rows (0: rebuild every launch)
+  float* rowb;               // [B][V] continuous pixel-row coordinate of every vertex at the body's last sort
+  unsigned long long* sort_tag;   // [B] validity tag of the body's lists (a fresh workspace holds anything)
+  int* stale;                // [B] set by k_raster_windows: 1 = the lists must be rebuilt this launch
+  unsigned long long* sort_count;  // [2] launches x bodies seen, bodies rebuilt (cumulative)
 };
+#define RS_TAG(b, m) (0x5bd1e995c0ffee00ull ^ ((unsigned long long)(b) * 0x9E3779B97F4A7C15ull) ^ (unsigned long long)(m))
 
 __device__ __forceinline__ float r_pix_to_ndc(int i, int S1, int S2) {
   float range = 2.0f;
@@ -252,6 +260,15 @@ __device__ __forceinline__ void r_insert(unsigned long long* q, float pz, bool i
   }
 }
 
+// continuous row coordinate of an NDC y as one fused multiply-add: row = ra - y * rk (r_ndc_to_pix spelled out costs two
+// IEEE divisions per call; the difference is ~1e-5 px, inside the 1e-3 px guard of the face row ranges)
+__device__ __forceinline__ void r_row_affine(const RasterP& p, float* ra, float* rk) {
+  float range = 2.0f;
+  if (p.H > p.W) range = ((float)p.H * range) / (float)p.W;
+  *rk = (float)p.H / range;
+  *ra = (float)p.H - 0.5f - 0.5f * (float)p.H;
+}
+
 // =============================================================================================
 // windows and strips
 // =============================================================================================
@@ -264,11 +281,20 @@ __global__ __launch_bounds__(RWT) void k_raster_windows(RasterP p) {
   const float* vb = p.verts + (size_t)b * p.V * 3;
   // extremes in NDC; the (monotonically decreasing) NDC -> pixel map is applied once to the four results
   float mnx = 1e30f, mny = 1e30f, mxx = -1e30f, mxy = -1e30f;
+  // how far (in pixel rows) the vertices have moved since this body's face lists were sorted: below the margin the lists
+  // are still a superset of every tile's candidates (k_raster_face_sort), and the sort is skipped
+  float ra, rk;
+  r_row_affine(p, &ra, &rk);
+  const float* rowb = p.rowb + (size_t)b * p.V;
+  const bool tagged = p.margin > 0 && p.sort_tag[b] == RS_TAG(b, p.margin);
+  bool moved = !tagged;
+  const float thr = (float)p.margin - 0.02f;
   for (int v = tid; v < p.V; v += RWT) {
     const float X = vb[(size_t)v * 3], Y = vb[(size_t)v * 3 + 1], Z = vb[(size_t)v * 3 + 2];
     const float xn = p.s * (-X) / Z + p.w1, yn = p.s * (-Y) / Z + p.h1;
     float* o = p.ndc + ((size_t)b * p.V + v) * 3;
     o[0] = xn; o[1] = yn; o[2] = Z;
+    if (tagged) moved = moved || !(fabsf(fmaf(-yn, rk, ra) - rowb[v]) < thr);      // NaN-safe: anything odd rebuilds
     if (Z > R_KEPS) {
       mnx = fminf(mnx, xn); mxx = fmaxf(mxx, xn);
       mny = fminf(mny, yn); mxy = fmaxf(mxy, yn);
@@ -279,11 +305,15 @@ __global__ __launch_bounds__(RWT) void k_raster_windows(RasterP p) {
     mnx = fminf(mnx, __shfl_xor(mnx, o, 64)); mny = fminf(mny, __shfl_xor(mny, o, 64));
     mxx = fmaxf(mxx, __shfl_xor(mxx, o, 64)); mxy = fmaxf(mxy, __shfl_xor(mxy, o, 64));
   }
+  const int any_moved = __syncthreads_or(moved ? 1 : 0);
   if ((tid & 63) == 0) {
     sbb[tid >> 6][0] = mnx; sbb[tid >> 6][1] = mny; sbb[tid >> 6][2] = mxx; sbb[tid >> 6][3] = mxy;
   }
   __syncthreads();
   if (tid == 0) {
+    p.stale[b] = any_moved;
+    atomicAdd(&p.sort_count[0], 1ull);
+    if (any_moved) atomicAdd(&p.sort_count[1], 1ull);
     for (int w = 1; w < RWT / 64; ++w) {
       mnx = fminf(mnx, sbb[w][0]); mny = fminf(mny, sbb[w][1]);
       mxx = fmaxf(mxx, sbb[w][2]); mxy = fmaxf(mxy, sbb[w][3]);
@@ -341,7 +371,7 @@ __device__ __forceinline__ void r_strip_order(const RasterP& p, int total) {
     const int sy0 = p.strip_row0[s], sy1 = sy0 + p.strip_rows[s] - 1;
     const int* rs = p.row_start + (size_t)b * (2 * (H + 1) + 1);
     const int mh = min(max(p.maxh[b], 0), H);
-    const int ra = max(0, sy0 - mh), rb = min(sy1 + 1, H);
+    const int ra = max(0, sy0 - mh - p.margin), rb = min(sy1 + 1 + p.margin, H);
     const long long n = (long long)(rs[rb] - rs[ra]) + (long long)(rs[H + 1 + rb] - rs[H + 1 + ra]);
     const long long cost = min(max(n, 0ll), (long long)p.F) + 11ll * p.strip_rows[s] * p.strip_cols[s];
     return 63 - (int)min(63ll, max(0ll, cost * 64 / cmax));       // class 0 = most expensive
@@ -559,27 +589,25 @@ __device__ __forceinline__ int r_wave_scan_max(int x) {              // values >
 #endif
 #define RFS_V 7              // row words fetched together (second pass)
 // lo | hi << 16 with bit 15 = sign of the screen-space area (which side of the face looks at the camera)
-// continuous row coordinate of an NDC y as one fused multiply-add: row = ra - y * rk (r_ndc_to_pix spelled out costs two
-// IEEE divisions per call; the difference is ~1e-5 px, inside the 1e-3 px guard below)
-__device__ __forceinline__ void r_row_affine(const RasterP& p, float* ra, float* rk) {
-  float range = 2.0f;
-  if (p.H > p.W) range = ((float)p.H * range) / (float)p.W;
-  *rk = (float)p.H / range;
-  *ra = (float)p.H - 0.5f - 0.5f * (float)p.H;
-}
 __device__ __forceinline__ unsigned r_face_rows_xyz(const RasterP& p, float ra, float rk, const float (&x)[3], const float (&y)[3],
                                                      const float (&z)[3], float* zmin_out) {
   const float farea = r_edge(x[0], y[0], x[1], y[1], x[2], y[2]);
   unsigned out = 1u;                                     // lo = 1 > hi = 0: skipped
-  if (fminf(z[0], fminf(z[1], z[2])) >= R_KEPS && !(farea <= R_KEPS && farea >= -R_KEPS)) {
+  // With kept lists (margin > 0) the two exclusions of the rasteriser -- a vertex behind the camera, a degenerate
+  // screen-space area -- are decided by k_raster_strip from the CURRENT coordinates (a sliver seen edge-on crosses the
+  // 1e-8 area threshold under the smallest motion): the list must hold every face that can be on screen within the
+  // margin.  Rebuilding every launch (margin 0) they can be dropped here, as in rounds 1-2.
+  const bool ok = p.margin > 0 || (fminf(z[0], fminf(z[1], z[2])) >= R_KEPS && !(farea <= R_KEPS && farea >= -R_KEPS));
+  if (ok) {
     const float blur_d = sqrtf(BLUR_D);
     const float bymin = fminf(y[0], fminf(y[1], y[2])) - blur_d, bymax = fmaxf(y[0], fmaxf(y[1], y[2])) + blur_d;
     // rows whose pixel centre lies inside the blurred bbox (centres at the integers of the row coordinate), 1e-3 px
     // absorbs the rounding.  A tight range matters: the tallest face of a body sets how far above a tile its
     // candidate range starts
     const float lo = ceilf(fmaf(-bymax, rk, ra) - 1e-3f), hi = floorf(fmaf(-bymin, rk, ra) + 1e-3f);
-    if (hi >= lo && hi >= 0.f && lo <= (float)(p.H - 1)) {
-      const unsigned ulo = (unsigned)fmaxf(lo, 0.f), uhi = (unsigned)fminf(hi, (float)(p.H - 1));
+    const float mg = (float)p.margin;
+    if (hi >= lo && hi >= -mg && lo <= (float)(p.H - 1) + mg) {          // (false for NaN rows)
+      const unsigned ulo = (unsigned)fminf(fmaxf(lo, 0.f), (float)(p.H - 1)), uhi = (unsigned)fminf(fmaxf(hi, 0.f), (float)(p.H - 1));
       out = ulo | (uhi << 16) | (farea > 0.f ? 0x8000u : 0u);
     }
   }
@@ -599,6 +627,13 @@ __global__ __launch_bounds__(RFS, 8) void k_raster_face_sort(RasterP p) {
     return;
   }
   const int b = blockIdx.x - 1, tid = threadIdx.x, H = p.H, HB = H + 1;
+  // Temporal coherence: the optimiser moves a body by a small fraction of a pixel per cycle, and this kernel -- one
+  // workgroup per body, a latency chain of gathers, histogram atomics and a scan -- was 100 us of every cycle's critical
+  // path.  The lists of a body stay valid as a SUPERSET of every tile's candidates while no vertex has moved `margin`
+  // rows from where it was at the sort (k_raster_windows checks that against rowb and sets stale[b]): a tile then reads
+  // the rows [first - tallest - margin, last + margin] and k_raster_strip decides every face from the current
+  // coordinates, so the selection keys are bit-identical to those of a fresh sort (tests/test_full_size_gpu.py).
+  if (p.margin > 0 && !p.stale[b]) return;
   const float* nb = p.ndc + (size_t)b * p.V * 3;
   unsigned* fr = p.frows + (size_t)b * p.F;
   unsigned* fs = p.fsort + (size_t)b * p.F;
@@ -609,6 +644,13 @@ __global__ __launch_bounds__(RFS, 8) void k_raster_face_sort(RasterP p) {
   int mh = 0, n0 = 0, n1 = 0;
   float z0 = 0.f, z1 = 0.f, ra, rk;
   r_row_affine(p, &ra, &rk);
+  if (p.margin > 0) {                      // where the vertices are now = what the next launches measure their motion from
+    float* rowb = p.rowb + (size_t)b * p.V;
+    for (int v = tid; v < p.V; v += RFS) rowb[v] = fmaf(-nb[(size_t)v * 3 + 1], rk, ra);
+    if (tid == 0) p.sort_tag[b] = RS_TAG(b, p.margin);
+  } else if (tid == 0) {
+    p.sort_tag[b] = 0ull;                  // lists without the margin's slack: never to be kept by a later launch
+  }
   auto tally = [&](unsigned r, float zm, bool live) {
     const int lo = (int)(r & 0x7fffu), hi = (int)(r >> 16), cls = (int)((r >> 15) & 1u);
     if (live && lo <= hi) {
@@ -785,7 +827,8 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
     for (int i = tid; i < tw; i += RB) sXf[i] = r_pix_to_ndc(W - 1 - (x0 + i), W, H);
     for (int i = tid; i < nrows; i += RB) sYf[i] = r_pix_to_ndc(H - 1 - (sy0 + i), H, W);
     // candidate faces: the near class of the rows first, then the far class (two contiguous ranges of fsort)
-    const int ra_ = max(0, sy0 - p.maxh[b]), rb_ = min(sy1 + 1, H);
+    // kept lists: a face's first row may have moved by up to `margin` rows either way since the sort
+    const int ra_ = max(0, sy0 - p.maxh[b] - p.margin), rb_ = min(sy1 + 1 + p.margin, H);
     const int a0 = rs[ra_], na = rs[rb_] - a0, b0 = rs[H + 1 + ra_], nbk = rs[H + 1 + rb_] - b0;
     const int i1 = na + nbk;
     auto fs_at = [&](int j) { return fs[j < na ? a0 + j : b0 + (j - na)]; };
@@ -820,7 +863,7 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
         int cnt = 0;
         int f_pix = 0, f_nx = 1;                 // first window pixel (tile-relative index) and width of the face's pixel box
         unsigned f_zb = 0u;                      // bits of its nearest vertex depth (minus the margin below)
-        if (idx < i1 && (int)(e_a >> 20) >= sy0) {
+        if (idx < i1 && (int)(e_a >> 20) + p.margin >= sy0) {
           const float bxmin = fminf(ca[0], fminf(ca[3], ca[6])) - blur_d, bxmax = fmaxf(ca[0], fmaxf(ca[3], ca[6])) + blur_d;
           const float bymin = fminf(ca[1], fminf(ca[4], ca[7])) - blur_d, bymax = fmaxf(ca[1], fmaxf(ca[4], ca[7])) + blur_d;
           // pixel range of the blurred bbox: the continuous pixel coordinate of each bound, widened by 1e-3 px (its
@@ -837,11 +880,19 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
             yb -= sYf[yb - sy0] < bymin ? 1 : 0;
           }
           cnt = max(0, xb - xa + 1) * max(0, yb - ya + 1);
+          const float farea = r_edge(ca[6], ca[7], ca[0], ca[1], ca[3], ca[4]);
+          if (p.margin > 0) {
+            // the rasteriser's exclusions, from the current coordinates (with kept lists the sort does not apply them):
+            // a vertex behind the camera, a degenerate screen-space area (the edge function is antisymmetric:
+            // edge(v2; v0, v1) = edge(v0; v1, v2) up to the rounding of the products, same test as r_face_rows_xyz)
+            const float fa = r_edge(ca[0], ca[1], ca[3], ca[4], ca[6], ca[7]);
+            if (!(fminf(ca[2], fminf(ca[5], ca[8])) >= R_KEPS) || (fa <= R_KEPS && fa >= -R_KEPS)) cnt = 0;
+          }
           if (cnt > 0) {
             float* T = T_ + lane * RT;
 #pragma unroll
             for (int k = 0; k < 9; ++k) T[k] = ca[k];
-            T[9] = __builtin_amdgcn_rcpf(r_edge(ca[6], ca[7], ca[0], ca[1], ca[3], ca[4]) + R_KEPS);
+            T[9] = __builtin_amdgcn_rcpf(farea + R_KEPS);
             const float l01 = (ca[3] - ca[0]) * (ca[3] - ca[0]) + (ca[4] - ca[1]) * (ca[4] - ca[1]);
             const float l02 = (ca[6] - ca[0]) * (ca[6] - ca[0]) + (ca[7] - ca[1]) * (ca[7] - ca[1]);
             const float l12 = (ca[6] - ca[3]) * (ca[6] - ca[3]) + (ca[7] - ca[4]) * (ca[7] - ca[4]);
@@ -1510,10 +1561,28 @@ extern "C" int mh_raster_set_deterministic(int on) {
 }
 extern "C" int mh_raster_get_deterministic(void) { return raster_deterministic() ? 1 : 0; }
 
+// rows a vertex may move before its body's face lists are sorted again (0 = sort every launch, the round-2 behaviour)
+static int g_raster_margin = -1;
+static int raster_sort_margin() {
+  if (g_raster_margin < 0) {
+    const char* e = getenv("MHHIP_RASTER_SORT_MARGIN");
+    g_raster_margin = e ? atoi(e) : 1;
+    if (g_raster_margin < 0 || g_raster_margin > 8) g_raster_margin = 1;
+  }
+  return g_raster_margin;
+}
+extern "C" int mh_raster_set_sort_margin(int rows) {
+  MH_CHECK(rows >= 0 && rows <= 8, "margin must be 0..8 rows");
+  g_raster_margin = rows;
+  return MH_OK;
+}
+extern "C" int mh_raster_get_sort_margin(void) { return raster_sort_margin(); }
+
 static size_t r_align(size_t x) { return (x + 255) & ~(size_t)255; }
 static size_t r_max_units(size_t B, int H, int W) { return B + B * (size_t)H * W / RG_UNIT + 1; }
 static size_t r_ws_extra(size_t B, int V, int F, int H) {
-  return r_align(B * V * 3 * 4) + 2 * r_align(B * F * 4) + r_align(B * (size_t)(2 * (H + 1) + 1) * 4) + 2 * r_align(B * 4) + r_align(B * 8);
+  return r_align(B * V * 3 * 4) + 2 * r_align(B * F * 4) + r_align(B * (size_t)(2 * (H + 1) + 1) * 4) + 2 * r_align(B * 4) + r_align(B * 8) +
+         r_align(B * V * 4) + r_align(B * 8) + r_align(B * 4) + r_align(16);     // rowb, sort_tag, stale, sort_count
 }
 static int r_max_strips(int B, int H, int W) {
   // full-width windows give the most tiles per body
@@ -1529,6 +1598,53 @@ extern "C" size_t mh_raster_workspace_bytes(int T, int N, int V, int F, int H, i
          r_align(B * 2 * 4) + r_align(B * (size_t)H * W * 5 * 8);
 }
 
+
+static void r_carve(RasterP& p, void* ws) {
+  const size_t B = (size_t)p.B;
+  const int V = p.V, F = p.F, H = p.H, W = p.W;
+  p.max_strips = r_max_strips(p.B, H, W);
+  const size_t ms = (size_t)p.max_strips;
+  char* c = (char*)ws;
+  p.win = (int*)c; c += r_align(B * 4 * 4);
+  p.body_first = (int*)c; c += r_align(B * 4);
+  p.body_ns = (int*)c; c += r_align(B * 4);
+  p.total = (int*)c; c += r_align(4);
+  p.strip_body = (int*)c; c += r_align(ms * 4);
+  p.strip_row0 = (int*)c; c += r_align(ms * 4);
+  p.strip_rows = (int*)c; c += r_align(ms * 4);
+  p.strip_col0 = (int*)c; c += r_align(ms * 4);
+  p.strip_cols = (int*)c; c += r_align(ms * 4);
+  p.strip_order = (int*)c; c += r_align(ms * 4);
+  p.partial = (float*)c; c += r_align(ms * 6 * 4);
+  p.dinv = (float*)c; c += r_align(B * 2 * 4);
+  p.ndc = (float*)c; c += r_align(B * V * 3 * 4);
+  p.frows = (unsigned*)c; c += r_align(B * F * 4);
+  p.fsort = (unsigned*)c; c += r_align(B * F * 4);
+  p.row_start = (int*)c; c += r_align(B * (size_t)(2 * (H + 1) + 1) * 4);
+  p.maxh = (int*)c; c += r_align(B * 4);
+  p.sil_corr = (float*)c; c += r_align(B * 4);
+  p.body_koff = (long long*)c; c += r_align(B * 8);
+  p.rowb = (float*)c; c += r_align(B * V * 4);
+  p.sort_tag = (unsigned long long*)c; c += r_align(B * 8);
+  p.stale = (int*)c; c += r_align(B * 4);
+  p.sort_count = (unsigned long long*)c; c += r_align(16);
+  p.margin = raster_sort_margin();
+  p.gunit_body = (int*)c; c += r_align(r_max_units(B, H, W) * 4);
+  p.gunit_p0 = (int*)c; c += r_align(r_max_units(B, H, W) * 4);
+  p.gunit_total = (int*)c; c += r_align(4);
+  p.gkeys = (unsigned long long*)c;
+}
+
+extern "C" int mh_raster_sort_counters(int T, int N, int V, int F, int H, int W, void* ws, unsigned long long* out_host, void* stream) {
+  MH_CHECK(ws && out_host, "null argument");
+  MH_CHECK(T > 0 && N > 0 && V > 0 && F > 0 && H > 0 && W > 0, "empty input");
+  RasterP p;
+  p.B = T * N; p.N = N; p.V = V; p.F = F; p.H = H; p.W = W;
+  r_carve(p, ws);
+  MH_HIP(hipMemcpyAsync(out_host, p.sort_count, 16, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  MH_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return MH_OK;
+}
 
 static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const float* cam_K_host, const float* verts,
                              const int32_t* faces, const uint32_t* bits, const uint32_t* ebits, const float* depths,
@@ -1567,34 +1683,7 @@ static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const flo
   p.coef_depth = coef_depth; p.coef_sil = coef_sil; p.eps = eps;
   p.gverts = gverts; p.depth_body = depth_body; p.sil_body = sil_body;
   p.zbuf_out = zbuf_out; p.alpha_out = alpha_out;
-  // carve the workspace
-  const size_t B = (size_t)p.B;
-  p.max_strips = r_max_strips(p.B, H, W);
-  const size_t ms = (size_t)p.max_strips;
-  char* c = (char*)ws;
-  p.win = (int*)c; c += r_align(B * 4 * 4);
-  p.body_first = (int*)c; c += r_align(B * 4);
-  p.body_ns = (int*)c; c += r_align(B * 4);
-  p.total = (int*)c; c += r_align(4);
-  p.strip_body = (int*)c; c += r_align(ms * 4);
-  p.strip_row0 = (int*)c; c += r_align(ms * 4);
-  p.strip_rows = (int*)c; c += r_align(ms * 4);
-  p.strip_col0 = (int*)c; c += r_align(ms * 4);
-  p.strip_cols = (int*)c; c += r_align(ms * 4);
-  p.strip_order = (int*)c; c += r_align(ms * 4);
-  p.partial = (float*)c; c += r_align(ms * 6 * 4);
-  p.dinv = (float*)c; c += r_align(B * 2 * 4);
-  p.ndc = (float*)c; c += r_align(B * V * 3 * 4);
-  p.frows = (unsigned*)c; c += r_align(B * F * 4);
-  p.fsort = (unsigned*)c; c += r_align(B * F * 4);
-  p.row_start = (int*)c; c += r_align(B * (size_t)(2 * (H + 1) + 1) * 4);
-  p.maxh = (int*)c; c += r_align(B * 4);
-  p.sil_corr = (float*)c; c += r_align(B * 4);
-  p.body_koff = (long long*)c; c += r_align(B * 8);
-  p.gunit_body = (int*)c; c += r_align(r_max_units(B, H, W) * 4);
-  p.gunit_p0 = (int*)c; c += r_align(r_max_units(B, H, W) * 4);
-  p.gunit_total = (int*)c; c += r_align(4);
-  p.gkeys = (unsigned long long*)c;
+  r_carve(p, ws);
   hipStream_t st = (hipStream_t)stream;
   if (phases & 1) {
   if (zbuf_out) {   // -1 = empty, like fragments.zbuf

@@ -36,6 +36,13 @@ class RasterTerms(object):
             check(L.mh_reduce_sum2(ptr(e.depth_body), ptr(e.sil_body), e.B, 1.0, ptr(log[1:2]), ptr(log[2:3]), st))
 
 
+    def sort_counters(self, e):
+        """(bodies seen, bodies whose face lists were re-sorted), cumulative over the launches on this workspace"""
+        import ctypes
+        out = (ctypes.c_ulonglong * 2)()
+        check(_lib.lib().mh_raster_sort_counters(e.T, e.N, e.V, self.faces.shape[0], e.H, e.W, ptr(self.ws), out, _lib.stream_ptr(e.dev)))
+        return int(out[0]), int(out[1])
+
     def selection(self, e):
         """Inspection aid: what the last selection pass left in the workspace -- (win (B,4) int32: x0, y0, width, height of
         every body's screen window; koff (B+1,): first window pixel of every body; keys (window pixels, 5) uint64: per
@@ -49,6 +56,14 @@ class RasterTerms(object):
         gk = self.ws[self.ws.numel() - gk_bytes:]
         keys = gk[:int(koff[-1]) * 40].cpu().numpy().view(np.uint64).reshape(-1, 5)
         return win, koff, keys
+
+
+def set_sort_margin(rows):
+    """mh_raster_set_sort_margin (0 = sort the face lists every launch); returns the previous setting"""
+    L = _lib.lib()
+    old = L.mh_raster_get_sort_margin()
+    check(L.mh_raster_set_sort_margin(int(rows)))
+    return int(old)
 
 
 def set_deterministic(on):

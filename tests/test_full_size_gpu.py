@@ -208,3 +208,42 @@ def test_selection_does_not_depend_on_what_the_workspace_held(smpl_struct, smpl_
         torch.testing.assert_close(s_, outs[0][1], rtol=1e-5, atol=1e-7)
         scale = float(outs[0][2].abs().max())
         assert float((g - outs[0][2]).abs().max()) <= 2e-3 * scale        # float atomics in the gradient scatter
+
+
+def test_kept_face_lists_give_the_same_selection_as_a_fresh_sort(smpl_struct, smpl_regs, oracle_model, tmp_path):
+    """Temporal coherence of the rasteriser's preparation (mh_raster_set_sort_margin, default 1 row): over 40 optimisation
+    cycles at the C3 shape -- RMSprop's first, largest steps included -- the selection keys (40 B per window pixel: z and
+    face of the nearest face and of the K=4 list) of the launch that KEEPS its face lists must equal, bit for bit, those
+    of a launch that sorts afresh on a second workspace; the lists must actually be kept (most bodies, most cycles) and
+    must be rebuilt when a body moves by more than the margin."""
+    from mhhip.raster import RasterTerms, set_sort_margin
+    T, N, W, H, batch = 100, 4, 240, 135, 10
+    opt, dl, o, batches, seq = _setup(smpl_struct, smpl_regs, oracle_model, tmp_path, T, N, W, H, batch, 47, True)
+    opt._stage_from_dataloader(dl)
+    e = opt.engine
+    kept, fresh = RasterTerms(e), RasterTerms(e)
+    kept.ws.copy_(torch.randint(0, 256, kept.ws.shape, dtype=torch.uint8, device=kept.ws.device))     # a workspace holds anything
+    gv, log = torch.zeros_like(e.verts), torch.zeros(16, device=e.dev)
+    old = set_sort_margin(1)
+    try:
+        lr, seen0 = 0.01, None
+        for c in range(40):
+            e.cycle(c, raster=kept)                              # full cycle on the kept lists (selection + gradients)
+            torch.cuda.synchronize()
+            _, _, k1 = kept.selection(e)
+            set_sort_margin(0)
+            fresh(e, gv, log, phases=1)                          # same vertices, lists sorted now
+            torch.cuda.synchronize()
+            _, _, k0 = fresh.selection(e)
+            set_sort_margin(1)
+            assert k1.shape == k0.shape and (k1 == k0).all(), 'cycle %d: %d window pixels differ' % (c, int((k1 != k0).any(axis=1).sum()))
+            e.step(lr)
+            lr *= 0.99
+            if c == 19:                                          # a jump of a few pixels for every fourth frame
+                e.leaf('poses_T')[::4, :, 1] += 0.08
+        seen, rebuilt = kept.sort_counters(e)
+    finally:
+        set_sort_margin(old)
+    assert seen == 40 * e.B
+    print('face lists rebuilt for %d of %d (body, cycle) pairs' % (rebuilt, seen))
+    assert e.B <= rebuilt < 0.6 * seen                            # everything once, the jump, the early large steps -- not every cycle

@@ -356,6 +356,16 @@ int mh_raster_terms_phase(int T, int N, int V, int F, int H, int W, const float*
                           float coef_depth, float coef_sil, float eps, float* gverts, float* gzmin,
                           float* gzmax, float* depth_body, float* sil_body, void* ws,
                           float* zbuf_out, float* alpha_out, int phases, void* stream);
+/* the same; phase 2 also writes the sums over the bodies of the depth / silhouette loss values (one float each, device
+ * memory, may be NULL) -- the two entries of a cycle's log row (optimizer.py:546-554) without a reduction launch */
+int mh_raster_terms_phase_log(int T, int N, int V, int F, int H, int W, const float* cam_K_host,
+                          const float* verts, const int32_t* faces, const uint32_t* bits,
+                          const uint32_t* ebits, const float* depths, const float* zmin_lin,
+                          const float* zmax_lin, const float* pose2d_valid, const uint32_t* front,
+                          const float* sil_apply, const float* sil_D, const float* sil_S,
+                          float coef_depth, float coef_sil, float eps, float* gverts, float* gzmin,
+                          float* gzmax, float* depth_body, float* sil_body, void* ws,
+                          float* zbuf_out, float* alpha_out, int phases, float* log_depth, float* log_sil, void* stream);
 /* Deterministic gradient scatter (default off; MHHIP_DETERMINISTIC=1 in the environment switches it on at first use).
  * The production kernel sums the per-pixel vertex gradients of the rasterised terms with fp32 atomics (LDS table,
  * then global): the summation order, hence the last bits, vary from run to run.  on != 0: one workgroup per body,
@@ -366,7 +376,13 @@ int mh_raster_terms_phase(int T, int N, int V, int F, int H, int W, const float*
  * body's last sort; tiles read their candidates `rows` further out and every face is decided from the current
  * coordinates, so the selection is bit-identical to a fresh sort.  Default 1 (MHHIP_RASTER_SORT_MARGIN overrides at
  * first use); 0 = sort every launch.  mh_raster_sort_counters: {bodies seen, bodies re-sorted}, cumulative over the
- * launches on this workspace (synchronises the stream). */
+ * launches on this workspace (synchronises the stream); out_host NULL resets them (stream-ordered). */
+/* A workspace must be initialised ONCE before its first launch (stream-ordered; again if its bytes were overwritten):
+ * clears the control words (work-list epoch and counters, face-list tags, silhouette accumulator).
+ * mh_raster_workspace_offsets: byte offsets of {window table (B x 4 int32), first key of every body (B x int64, in
+ * window pixels), key array (5 x uint64 per window pixel)} for inspection tools. */
+int mh_raster_workspace_init(int T, int N, int V, int F, int H, int W, void* ws, void* stream);
+int mh_raster_workspace_offsets(int T, int N, int V, int F, int H, int W, size_t* out /*[3]*/);
 int mh_raster_set_sort_margin(int rows);
 int mh_raster_get_sort_margin(void);
 int mh_raster_sort_counters(int T, int N, int V, int F, int H, int W, void* ws, unsigned long long* out_host /*[2]*/, void* stream);

@@ -6,12 +6,11 @@
 // MI355X design.  SMPL triangles are sub-pixel at MuPoTs resolution (13776 faces on a few
 // hundred pixels, blur radius larger than a face), so rasterisation is FACE-parallel with the per-pixel K-nearest
 // lists kept in LDS:
-//   k_raster_windows      one workgroup per body: NDC projection of the vertices + screen window
-//   k_raster_face_sort    one workgroup per body: pixel-row range of every face, counting sort by first row
-//                         (a tile's candidate faces become one contiguous range)
-//   (r_strip_table)       extra workgroup of k_raster_face_sort: windows cut into tiles of <= R_CAP pixels, prefix-summed into a device-side
-//                         work list (no host sync); also the work units of the gradient kernel
-//   (r_strip_order)       end of that workgroup: tiles by decreasing estimated cost (longest first; a schedule only)
+//   k_raster_prepare      one workgroup per body: NDC projection of the vertices + screen window; pixel-row range of every
+//                         face and counting sort by first row (a tile's candidate faces become contiguous ranges) -- only
+//                         when a vertex has moved more than `margin` rows since the body's last sort (temporal coherence);
+//                         the body's tiles of <= R_CAP pixels and gradient work units appended to per-cost-class lists
+//                         (longest first; no serial pass, no host sync)
 //   k_raster_strip        one workgroup per tile; every wave runs barrier-free rounds of 64 faces (3-deep gather
 //                         pipeline, bbox, pair list / even split, depth cull) and inserts 64-bit (z, face) keys into
 //                         the tile's LDS window with ds_min_u64: slot 0 = nearest face of the blur 1e-4 pass (all
@@ -19,7 +18,7 @@
 //                         nearest of the blur 2e-5 silhouette pass (atomic-min cascade: the displaced key moves on).
 //                         The finished window is written to HBM once (40 B per window pixel).
 //   k_raster_sums         per tile: residual sums of the depth and silhouette terms
-//   k_raster_finish       silhouette value per body + chain of the depth-range leaves per frame
+//   k_raster_finish       per frame: per-body loss values from the tile sums, chain of the depth-range leaves, log sums
 //   k_raster_grads        per work unit (2048 window pixels of one body): live-pixel compaction, exact re-evaluation
 //                         of the selected faces, gradients scattered to an LDS vertex table, flushed with atomics
 // No (b,N,H,W,K) fragment tensor, z-buffer or alpha image is materialised (the reference builds
@@ -59,9 +58,8 @@ struct RasterP {
   // workspace
   int max_strips;
   int* win;                  // [B][4] x0,y0,ww,wh (ww <= 0: nothing on screen)
-  int* body_first;           // [B] first strip of the body
-  int* body_ns;              // [B] strips of the body
-  int* total;                // [1] number of strips
+  int* body_first;           // [B] first tile slot of the body (b * max_strips / B)
+  int* body_ns;              // [B] tiles of the body
   int* strip_body;           // [max_strips]
   int* strip_row0;           // [max_strips] first image row of the tile
   int* strip_rows;           // [max_strips]
@@ -76,17 +74,21 @@ struct RasterP {
   unsigned* fsort;           // [B][F] faces ordered by their first row: hi << 20 | face
   int* row_start;            // [B][2][H+1] (+1): per class (near class first), first entry of fsort with lo >= row
   int* maxh;                 // [B] tallest face (rows) of the body
-  int* gunit_body;           // [max_units] gradient work units: RG_UNIT window pixels of one body, full units first
-  int* gunit_p0;             // [max_units] first window pixel of the unit
-  int* gunit_total;          // [1]
-  int* strip_order;          // [max_strips] tiles by decreasing candidate-face count (longest first)
+  // work lists (see k_raster_prepare): per cost class, append-only, counters double-buffered by the epoch's parity
+  int max_units;
+  unsigned* ctl;             // [0] epoch, [1] ticket of the preparation kernel
+  int* cls_count;            // [2][R_NCLS] tiles per cost class
+  int* cls_list;             // [R_NCLS][max_strips] tile slots
+  int* gcls_count;           // [2][R_NGCLS] gradient work units per class
+  unsigned long long* gcls_list;   // [R_NGCLS][max_units] body << 32 | piece
+  long long* px_total;       // [2] window pixels handed out in gkeys
   float* sil_corr;           // [B] sum over the silhouette pixels of alpha^2 - 2 alpha seg (accumulated by k_raster_grads)
   // temporal coherence of the face sort (see k_raster_face_sort): the sorted lists of a body are kept until one of its
   // vertices has moved `margin` pixel rows away from where it was when the lists were built
   int margin;                // rows (0: rebuild every launch)
   float* rowb;               // [B][V] continuous pixel-row coordinate of every vertex at the body's last sort
   unsigned long long* sort_tag;   // [B] validity tag of the body's lists (a fresh workspace holds anything)
-  int* stale;                // [B] set by k_raster_windows: 1 = the lists must be rebuilt this launch
+  char* ctl_end;             // (host) end of the control words
   unsigned long long* sort_count;  // [2] launches x bodies seen, bodies rebuilt (cumulative)
 };
 #define RS_TAG(b, m) (0x5bd1e995c0ffee00ull ^ ((unsigned long long)(b) * 0x9E3779B97F4A7C15ull) ^ (unsigned long long)(m))
@@ -272,70 +274,6 @@ __device__ __forceinline__ void r_row_affine(const RasterP& p, float* ra, float*
 // =============================================================================================
 // windows and strips
 // =============================================================================================
-#ifndef RWT
-#define RWT 1024             // threads of the window kernel (16 waves per body keep enough loads in flight)
-#endif
-__global__ __launch_bounds__(RWT) void k_raster_windows(RasterP p) {
-  __shared__ float sbb[RWT / 64][4];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const float* vb = p.verts + (size_t)b * p.V * 3;
-  // extremes in NDC; the (monotonically decreasing) NDC -> pixel map is applied once to the four results
-  float mnx = 1e30f, mny = 1e30f, mxx = -1e30f, mxy = -1e30f;
-  // how far (in pixel rows) the vertices have moved since this body's face lists were sorted: below the margin the lists
-  // are still a superset of every tile's candidates (k_raster_face_sort), and the sort is skipped
-  float ra, rk;
-  r_row_affine(p, &ra, &rk);
-  const float* rowb = p.rowb + (size_t)b * p.V;
-  const bool tagged = p.margin > 0 && p.sort_tag[b] == RS_TAG(b, p.margin);
-  bool moved = !tagged;
-  const float thr = (float)p.margin - 0.02f;
-  for (int v = tid; v < p.V; v += RWT) {
-    const float X = vb[(size_t)v * 3], Y = vb[(size_t)v * 3 + 1], Z = vb[(size_t)v * 3 + 2];
-    const float xn = p.s * (-X) / Z + p.w1, yn = p.s * (-Y) / Z + p.h1;
-    float* o = p.ndc + ((size_t)b * p.V + v) * 3;
-    o[0] = xn; o[1] = yn; o[2] = Z;
-    if (tagged) moved = moved || !(fabsf(fmaf(-yn, rk, ra) - rowb[v]) < thr);      // NaN-safe: anything odd rebuilds
-    if (Z > R_KEPS) {
-      mnx = fminf(mnx, xn); mxx = fmaxf(mxx, xn);
-      mny = fminf(mny, yn); mxy = fmaxf(mxy, yn);
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    mnx = fminf(mnx, __shfl_xor(mnx, o, 64)); mny = fminf(mny, __shfl_xor(mny, o, 64));
-    mxx = fmaxf(mxx, __shfl_xor(mxx, o, 64)); mxy = fmaxf(mxy, __shfl_xor(mxy, o, 64));
-  }
-  const int any_moved = __syncthreads_or(moved ? 1 : 0);
-  if ((tid & 63) == 0) {
-    sbb[tid >> 6][0] = mnx; sbb[tid >> 6][1] = mny; sbb[tid >> 6][2] = mxx; sbb[tid >> 6][3] = mxy;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    p.stale[b] = any_moved;
-    atomicAdd(&p.sort_count[0], 1ull);
-    if (any_moved) atomicAdd(&p.sort_count[1], 1ull);
-    for (int w = 1; w < RWT / 64; ++w) {
-      mnx = fminf(mnx, sbb[w][0]); mny = fminf(mny, sbb[w][1]);
-      mxx = fmaxf(mxx, sbb[w][2]); mxy = fmaxf(mxy, sbb[w][3]);
-    }
-    if (mnx <= mxx) {       // at least one vertex in front of the camera
-      const float px0 = r_ndc_to_pix(mxx, p.W, p.H), px1 = r_ndc_to_pix(mnx, p.W, p.H);
-      const float py0 = r_ndc_to_pix(mxy, p.H, p.W), py1 = r_ndc_to_pix(mny, p.H, p.W);
-      mnx = px0; mxx = px1; mny = py0; mxy = py1;
-    }
-    // clamp in float first: a body far outside the image must not overflow the int conversion
-    const float big = 1e6f;
-    mnx = fminf(fmaxf(mnx, -big), big); mxx = fminf(fmaxf(mxx, -big), big);
-    mny = fminf(fmaxf(mny, -big), big); mxy = fminf(fmaxf(mxy, -big), big);
-    const int x0 = max(0, (int)floorf(mnx) - 2), y0 = max(0, (int)floorf(mny) - 2);
-    const int x1 = min(p.W - 1, (int)ceilf(mxx) + 2), y1 = min(p.H - 1, (int)ceilf(mxy) + 2);
-    p.win[b * 4] = x0;
-    p.win[b * 4 + 1] = y0;
-    p.win[b * 4 + 2] = x1 - x0 + 1;
-    p.win[b * 4 + 3] = y1 - y0 + 1;
-  }
-}
-
 #define R_TILE_W 64          // tile width for windows wider than one LDS strip
 
 // tile geometry of a window: full-width row strips while a row fits into LDS, column tiles otherwise
@@ -349,176 +287,6 @@ __device__ __forceinline__ void r_tiling(int ww, int wh, int* tw, int* th, int* 
   }
   *ncol = (ww + *tw - 1) / *tw;
   *nrow = (wh + *th - 1) / *th;
-}
-
-// Longest-processing-time-first order of the tiles: a tile's cost is estimated from its candidate-face count and its
-// pixel count; counting sort into 64 cost classes, most expensive first (without it the last tiles to start were often
-// among the most expensive and the kernel ended ~40 % later than its work divided by the CU count).  The order is only a
-// schedule -- any permutation gives the same keys -- so it does not wait for this cycle's face sort: it runs at the end
-// of the tile-list workgroup (beside the face sort, not behind it: one single-workgroup kernel of 15 us less on the
-// chain) and reads the candidate counts from whatever row_start / maxh hold at that moment, i.e. mostly the previous
-// cycle's sort -- bodies move a fraction of a pixel per cycle.  Every value read that way is clamped.
-template <int NT>
-__device__ __forceinline__ void r_strip_order(const RasterP& p, int total) {
-  __shared__ int o_hist[64], o_cursor[64];
-  const int tid = threadIdx.x, H = p.H;
-  if (tid < 64) o_hist[tid] = 0;
-  __syncthreads();
-  // measured on C3: a tile takes ~7 ns per candidate face and ~76 ns per window pixel
-  const long long cmax = (long long)p.F + 11ll * R_CAP + 1;
-  auto cost_class = [&](int s) {
-    const int b = p.strip_body[s];
-    const int sy0 = p.strip_row0[s], sy1 = sy0 + p.strip_rows[s] - 1;
-    const int* rs = p.row_start + (size_t)b * (2 * (H + 1) + 1);
-    const int mh = min(max(p.maxh[b], 0), H);
-    const int ra = max(0, sy0 - mh - p.margin), rb = min(sy1 + 1 + p.margin, H);
-    const long long n = (long long)(rs[rb] - rs[ra]) + (long long)(rs[H + 1 + rb] - rs[H + 1 + ra]);
-    const long long cost = min(max(n, 0ll), (long long)p.F) + 11ll * p.strip_rows[s] * p.strip_cols[s];
-    return 63 - (int)min(63ll, max(0ll, cost * 64 / cmax));       // class 0 = most expensive
-  };
-  // the classes of a thread's first eight tiles stay in registers (a class costs a chain of four dependent loads)
-  int cls[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int s = tid + i * NT;
-    cls[i] = s < total ? cost_class(s) : -1;
-  }
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-    if (cls[i] >= 0) atomicAdd(&o_hist[cls[i]], 1);
-  // further tiles: the class is computed ONCE and parked (in the per-tile sums, which the strip kernel only writes later)
-  // -- evaluated again for the placement it could differ (the face sort is rewriting row_start meanwhile), and two
-  // passes that disagree do not produce a permutation
-  int* park = (int*)p.partial;
-  for (int s = tid + 8 * NT; s < total; s += NT) {
-    const int c = cost_class(s);
-    park[s] = c;
-    atomicAdd(&o_hist[c], 1);
-  }
-  __syncthreads();
-  if (tid < 64) {           // exclusive scan of the 64 class counts by the first wave
-    const int h = o_hist[tid];
-    o_cursor[tid] = mh_wave_scan_add(h) - h;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-    if (cls[i] >= 0) p.strip_order[atomicAdd(&o_cursor[cls[i]], 1)] = tid + i * NT;
-  for (int s = tid + 8 * NT; s < total; s += NT) p.strip_order[atomicAdd(&o_cursor[park[s]], 1)] = s;
-}
-
-// tile list of all windows + work units of the gradient kernel, by one workgroup of NT threads (the extra workgroup of
-// k_raster_face_sort: it only needs the windows, so it runs beside the face sort instead of in front of it)
-template <int NT>
-__device__ __forceinline__ void r_strip_table(const RasterP& p) {
-  __shared__ int s_ns[NT];
-  __shared__ long long s_px[NT];
-  __shared__ int carry_ns;
-  __shared__ long long carry_px;
-  if (threadIdx.x == 0) {
-    carry_ns = 0;
-    carry_px = 0;
-  }
-  __syncthreads();
-  for (int base = 0; base < p.B; base += NT) {
-    const int b = base + threadIdx.x;
-    int ww = 0, wh = 0, tw = 1, th = 1, ncol = 0, nrow = 0, ns = 0;
-    if (b < p.B) {
-      ww = p.win[b * 4 + 2];
-      wh = p.win[b * 4 + 3];
-      if (ww > 0 && wh > 0) {
-        r_tiling(ww, wh, &tw, &th, &ncol, &nrow);
-        ns = ncol * nrow;
-      } else {
-        ww = wh = 0;
-      }
-    }
-    s_ns[threadIdx.x] = ns;
-    s_px[threadIdx.x] = (long long)ww * wh;
-    __syncthreads();
-    // inclusive scan (Hillis-Steele)
-    for (int o = 1; o < NT; o <<= 1) {
-      int a = 0;
-      long long c = 0;
-      if ((int)threadIdx.x >= o) {
-        a = s_ns[threadIdx.x - o];
-        c = s_px[threadIdx.x - o];
-      }
-      __syncthreads();
-      s_ns[threadIdx.x] += a;
-      s_px[threadIdx.x] += c;
-      __syncthreads();
-    }
-    const int first = carry_ns + s_ns[threadIdx.x] - ns;
-    const long long koff = carry_px + s_px[threadIdx.x] - (long long)ww * wh;
-    if (b < p.B) {
-      p.body_first[b] = first;
-      p.body_ns[b] = ns;
-      p.body_koff[b] = koff;
-      const int x0 = p.win[b * 4], y0 = p.win[b * 4 + 1];
-      for (int k = 0; k < ns; ++k) {
-        const int tr = k / ncol, tc = k - tr * ncol;
-        p.strip_body[first + k] = b;
-        p.strip_row0[first + k] = y0 + tr * th;
-        p.strip_rows[first + k] = min(th, wh - tr * th);
-        p.strip_col0[first + k] = x0 + tc * tw;
-        p.strip_cols[first + k] = min(tw, ww - tc * tw);
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x == NT - 1) {
-      carry_ns += s_ns[NT - 1];
-      carry_px += s_px[NT - 1];
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) p.total[0] = carry_ns;
-  // work units of the gradient kernel: a body's window in pieces of RG_UNIT pixels, the full pieces first so that
-  // the long units start early and the partial ones fill the tail (the per-body version finished 2x later than
-  // its work divided by the CU count: the largest bodies happened to start last)
-  __shared__ int c_full, c_part;
-  if (threadIdx.x == 0) c_full = c_part = 0;
-  __syncthreads();
-  for (int b = threadIdx.x; b < p.B; b += NT) {
-    const int ww = p.win[b * 4 + 2], wh = p.win[b * 4 + 3];
-    const int npx = (ww > 0 && wh > 0) ? ww * wh : 0;
-    const int nfull = npx / RG_UNIT;
-    if (nfull) {
-      const int pos = atomicAdd(&c_full, nfull);
-      for (int k = 0; k < nfull; ++k) { p.gunit_body[pos + k] = b; p.gunit_p0[pos + k] = k * RG_UNIT; }
-    }
-  }
-  __syncthreads();
-  // the partial pieces by decreasing size (32 classes): the largest of them start first as well
-  __shared__ int p_hist[32], p_cur[32];
-  if (threadIdx.x < 32) p_hist[threadIdx.x] = 0;
-  __syncthreads();
-  const int nf = c_full;
-  auto part_class = [&](int rem) { return 31 - min(31, rem * 32 / RG_UNIT); };
-  for (int b = threadIdx.x; b < p.B; b += NT) {
-    const int ww = p.win[b * 4 + 2], wh = p.win[b * 4 + 3];
-    const int npx = (ww > 0 && wh > 0) ? ww * wh : 0;
-    if (npx % RG_UNIT) atomicAdd(&p_hist[part_class(npx % RG_UNIT)], 1);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int a = 0;
-    for (int k = 0; k < 32; ++k) { p_cur[k] = a; a += p_hist[k]; }
-    c_part = a;
-  }
-  __syncthreads();
-  for (int b = threadIdx.x; b < p.B; b += NT) {
-    const int ww = p.win[b * 4 + 2], wh = p.win[b * 4 + 3];
-    const int npx = (ww > 0 && wh > 0) ? ww * wh : 0;
-    if (npx % RG_UNIT) {
-      const int pos = nf + atomicAdd(&p_cur[part_class(npx % RG_UNIT)], 1);
-      p.gunit_body[pos] = b;
-      p.gunit_p0[pos] = (npx / RG_UNIT) * RG_UNIT;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) p.gunit_total[0] = c_full + c_part;
-  r_strip_order<NT>(p, carry_ns);          // the tile tables above were written by this workgroup (barriers in between)
 }
 
 // =============================================================================================
@@ -581,9 +349,6 @@ __device__ __forceinline__ int r_wave_scan_max(int x) {              // values >
 // conservative pixel-row range of every face + counting sort of the body's visible faces by their first row (one
 // workgroup per body): a tile's candidate faces are then one contiguous range of fsort (first row in
 // [tile_row0 - tallest_face, tile_last_row]); entries are hi << 20 | face.
-#ifndef RFS
-#define RFS 512
-#endif
 #ifndef RFS_U
 #define RFS_U 4              // faces whose gathers are in flight together (first pass)
 #endif
@@ -614,31 +379,74 @@ __device__ __forceinline__ unsigned r_face_rows_xyz(const RasterP& p, float ra, 
   *zmin_out = fminf(z[0], fminf(z[1], z[2]));
   return out;
 }
-// Two classes per row: the faces whose class is nearer to the camera on average (for a closed mesh: the ones looking at
-// it) come first in fsort, so that a tile rasterises them first and the depth cull of k_raster_strip then removes most
-// of the far-side candidates.  row_start: [2][H+1] (+ total), class-major in that order.
-__global__ __launch_bounds__(RFS, 8) void k_raster_face_sort(RasterP p) {
-  extern __shared__ int hist[];                     // [2][H + 1]: sign class, row
+// ---------------------------------------------------------------------------------------------------------------------
+// Work lists without a serial pass.  Every body owns a fixed range of tile slots (s = b * cap + k), so the per-body sums
+// over a body's tiles keep their fixed order; the ORDER in which tiles (and the work units of the gradient kernel) are
+// processed is a schedule only -- any permutation yields the same keys -- and is kept as one append-only list per cost
+// class (longest-processing-time first: without it the last tiles to start were often among the most expensive and the
+// selection ended ~40 % later than its work divided by the CU count).  The lists are filled with atomics by the per-body
+// workgroups of k_raster_prepare; the consumers map a running index to (class, position) through a 64-entry prefix.
+// The counters are double-buffered by the parity of an epoch word: the workgroup that finishes the preparation LAST
+// (ticket) clears the other parity for the next launch and advances the epoch -- no memset node, no host state, so the
+// sequence replays from a captured graph.  (Rounds 1-2 built dense tables in ONE extra workgroup: prefix sums over the
+// bodies, then a counting sort of ~7000 tiles by cost -- 45 us of serial work that the face sort used to hide and the
+// kept face lists exposed.)
+#define R_NCLS 64            // cost classes of the tiles (0 = most expensive)
+#define R_NGCLS 33           // gradient work units: class 0 = full units, 1..32 = partial units by decreasing size
+struct RLists {
+  int par;                   // parity the consumers of this launch read
+  int total;
+  int pre[R_NCLS + 1];
+};
+__device__ __forceinline__ int r_cap(const RasterP& p) { return p.max_strips / p.B; }
+// (to be called by all threads of a workgroup) tiles of the launch that just prepared: LDS prefix over the classes
+__device__ __forceinline__ void r_lists_load(const RasterP& p, int* sh_pre /*[R_NCLS+1]*/, const int* counts, int ncls, int cap_total) {
+  if ((int)threadIdx.x == 0) {
+    const int par = (int)((p.ctl[0] - 1u) & 1u);
+    int a = 0;
+    for (int c = 0; c < ncls; ++c) {
+      sh_pre[c] = a;
+      a += min(max(counts[par * ncls + c], 0), cap_total);
+    }
+    sh_pre[ncls] = a;
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ int r_list_class(const int* sh_pre, int ncls, int i) {
+  int c = 0;
+  while (c + 1 < ncls && sh_pre[c + 1] <= i) ++c;          // <= 64 LDS reads per tile; a tile is thousands of cycles
+  return c;
+}
+
+// cost class of a tile from the body's face lists: ~7 ns per candidate face and ~76 ns per window pixel (measured, C3)
+__device__ __forceinline__ int r_tile_class(const RasterP& p, const int* rs, int mh, int sy0, int nrows, int ncols) {
+  const int H = p.H;
+  const long long cmax = (long long)p.F + 11ll * R_CAP + 1;
+  const int sy1 = sy0 + nrows - 1;
+  mh = min(max(mh, 0), H);
+  const int ra = max(0, sy0 - mh - p.margin), rb = min(sy1 + 1 + p.margin, H);
+  const long long n = (long long)(rs[rb] - rs[ra]) + (long long)(rs[H + 1 + rb] - rs[H + 1 + ra]);
+  const long long cost = min(max(n, 0ll), (long long)p.F) + 11ll * nrows * ncols;
+  return R_NCLS - 1 - (int)min((long long)(R_NCLS - 1), max(0ll, cost * R_NCLS / cmax));
+}
+
+// conservative pixel-row range of every face + counting sort of the body's faces by their first row, by the NT threads
+// of the body's workgroup: a tile's candidate faces are then contiguous ranges of fsort (first row in
+// [tile_row0 - tallest_face - margin, tile_last_row + margin]); entries are hi << 20 | face.
+// Two classes per row: the faces whose class (sign of the screen-space area) is nearer to the camera on average (for a
+// closed mesh: the ones looking at it) come first in fsort, so that a tile rasterises them first and the depth cull of
+// k_raster_strip then removes most of the far-side candidates.  row_start: [2][H+1] (+ total), class-major in that order.
+template <int NT>
+__device__ __forceinline__ void r_face_sort(const RasterP& p, int b, int* hist /*LDS [2][H+1]*/) {
   __shared__ int s_maxh, s_flip;
   __shared__ float s_z[2];
   __shared__ int s_n[2];
-  if (blockIdx.x == 0) {               // one extra workgroup (dispatched first): the tile list
-    r_strip_table<RFS>(p);
-    return;
-  }
-  const int b = blockIdx.x - 1, tid = threadIdx.x, H = p.H, HB = H + 1;
-  // Temporal coherence: the optimiser moves a body by a small fraction of a pixel per cycle, and this kernel -- one
-  // workgroup per body, a latency chain of gathers, histogram atomics and a scan -- was 100 us of every cycle's critical
-  // path.  The lists of a body stay valid as a SUPERSET of every tile's candidates while no vertex has moved `margin`
-  // rows from where it was at the sort (k_raster_windows checks that against rowb and sets stale[b]): a tile then reads
-  // the rows [first - tallest - margin, last + margin] and k_raster_strip decides every face from the current
-  // coordinates, so the selection keys are bit-identical to those of a fresh sort (tests/test_full_size_gpu.py).
-  if (p.margin > 0 && !p.stale[b]) return;
+  const int tid = threadIdx.x, H = p.H, HB = H + 1;
   const float* nb = p.ndc + (size_t)b * p.V * 3;
   unsigned* fr = p.frows + (size_t)b * p.F;
   unsigned* fs = p.fsort + (size_t)b * p.F;
   int* rs = p.row_start + (size_t)b * (2 * HB + 1);
-  for (int i = tid; i < 2 * HB; i += RFS) hist[i] = 0;
+  for (int i = tid; i < 2 * HB; i += NT) hist[i] = 0;
   if (tid == 0) { s_maxh = 0; s_z[0] = s_z[1] = 0.f; s_n[0] = s_n[1] = 0; }
   __syncthreads();
   int mh = 0, n0 = 0, n1 = 0;
@@ -646,7 +454,7 @@ __global__ __launch_bounds__(RFS, 8) void k_raster_face_sort(RasterP p) {
   r_row_affine(p, &ra, &rk);
   if (p.margin > 0) {                      // where the vertices are now = what the next launches measure their motion from
     float* rowb = p.rowb + (size_t)b * p.V;
-    for (int v = tid; v < p.V; v += RFS) rowb[v] = fmaf(-nb[(size_t)v * 3 + 1], rk, ra);
+    for (int v = tid; v < p.V; v += NT) rowb[v] = fmaf(-nb[(size_t)v * 3 + 1], rk, ra);
     if (tid == 0) p.sort_tag[b] = RS_TAG(b, p.margin);
   } else if (tid == 0) {
     p.sort_tag[b] = 0ull;                  // lists without the margin's slack: never to be kept by a later launch
@@ -659,15 +467,14 @@ __global__ __launch_bounds__(RFS, 8) void k_raster_face_sort(RasterP p) {
       if (cls) { z1 += zm; ++n1; } else { z0 += zm; ++n0; }
     }
   };
-  // The gathers of RFS_U faces are in flight together: the kernel is one workgroup per body and was bound by the
-  // chain index load -> vertex gather -> histogram of one face after the other (27 chains per thread for SMPL).
-  // (Measured: the kernel stays at the rate of its 12-byte gathers, ~9 cycles per wave-wide gather per CU; combining
+  // The gathers of RFS_U faces are in flight together: the sort is bound by the chain index load -> vertex gather ->
+  // histogram of one face after the other.  (Measured in round 2: it stays at the rate of its 12-byte gathers; combining
   // the histogram atomics of a wave by ballot was 4x slower -- a wave's 64 faces fall into too many distinct bins.)
-  for (int f0 = tid; f0 < p.F; f0 += RFS_U * RFS) {
+  for (int f0 = tid; f0 < p.F; f0 += RFS_U * NT) {
     int vi[RFS_U][3];
 #pragma unroll
     for (int u = 0; u < RFS_U; ++u) {
-      const int f = min(f0 + u * RFS, p.F - 1);
+      const int f = min(f0 + u * NT, p.F - 1);
 #pragma unroll
       for (int k = 0; k < 3; ++k) vi[u][k] = p.faces[3 * f + k];
     }
@@ -681,7 +488,7 @@ __global__ __launch_bounds__(RFS, 8) void k_raster_face_sort(RasterP p) {
       }
 #pragma unroll
     for (int u = 0; u < RFS_U; ++u) {
-      const int f = f0 + u * RFS;
+      const int f = f0 + u * NT;
       float zm;
       const unsigned r = r_face_rows_xyz(p, ra, rk, x[u], y[u], z[u], &zm);
       if (f < p.F) fr[f] = r;
@@ -728,12 +535,135 @@ __global__ __launch_bounds__(RFS, 8) void k_raster_face_sort(RasterP p) {
     const int lo = (int)(r & 0x7fffu), hi = (int)(r >> 16), cls = (int)((r >> 15) & 1u);
     if (live && lo <= hi) fs[atomicAdd(&hist[cls * HB + lo], 1)] = ((unsigned)hi << 20) | (unsigned)f;
   };
-  for (int f0 = tid; f0 < p.F; f0 += RFS_V * RFS) {       // the row words of RFS_V faces are fetched together
+  for (int f0 = tid; f0 < p.F; f0 += RFS_V * NT) {        // the row words of RFS_V faces are fetched together
     unsigned r[RFS_V];
 #pragma unroll
-    for (int u = 0; u < RFS_V; ++u) r[u] = fr[min(f0 + u * RFS, p.F - 1)];
+    for (int u = 0; u < RFS_V; ++u) r[u] = fr[min(f0 + u * NT, p.F - 1)];
 #pragma unroll
-    for (int u = 0; u < RFS_V; ++u) place(r[u], f0 + u * RFS, f0 + u * RFS < p.F);
+    for (int u = 0; u < RFS_V; ++u) place(r[u], f0 + u * NT, f0 + u * NT < p.F);
+  }
+  __syncthreads();             // rs / maxh of this body are read by the tile classes below (same workgroup: L2-coherent stores + barrier)
+}
+
+// One workgroup per body: NDC projection of the vertices (kept in HBM, 12 B per vertex) + screen window, how far the
+// vertices have moved since the body's face lists were sorted, the sort itself when they moved too far (temporal
+// coherence: the optimiser moves a body by a small fraction of a pixel per cycle; the lists stay a SUPERSET of every
+// tile's candidates while no vertex has moved `margin` rows, tiles read `margin` rows further out and k_raster_strip
+// decides every face from the current coordinates, so the keys are bit-identical to those of a fresh sort), and the
+// body's tiles and gradient work units appended to the cost-class lists.
+#ifndef RPREP
+#define RPREP 1024
+#endif
+__global__ __launch_bounds__(RPREP) void k_raster_prepare(RasterP p) {
+  extern __shared__ int hist[];                     // [2][H + 1] of the sort
+  __shared__ float sbb[RPREP / 64][4];
+  __shared__ int s_win[4];
+  __shared__ long long s_koff;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const unsigned epoch = p.ctl[0];                  // constant while this kernel runs: advanced by its last workgroup
+  const int par = (int)(epoch & 1u);
+  const float* vb = p.verts + (size_t)b * p.V * 3;
+  // extremes in NDC; the (monotonically decreasing) NDC -> pixel map is applied once to the four results
+  float mnx = 1e30f, mny = 1e30f, mxx = -1e30f, mxy = -1e30f;
+  float ra, rk;
+  r_row_affine(p, &ra, &rk);
+  const float* rowb = p.rowb + (size_t)b * p.V;
+  const bool tagged = p.margin > 0 && p.sort_tag[b] == RS_TAG(b, p.margin);
+  bool moved = !tagged;
+  const float thr = (float)p.margin - 0.02f;
+  for (int v = tid; v < p.V; v += RPREP) {
+    const float X = vb[(size_t)v * 3], Y = vb[(size_t)v * 3 + 1], Z = vb[(size_t)v * 3 + 2];
+    const float xn = p.s * (-X) / Z + p.w1, yn = p.s * (-Y) / Z + p.h1;
+    float* o = p.ndc + ((size_t)b * p.V + v) * 3;
+    o[0] = xn; o[1] = yn; o[2] = Z;
+    if (tagged) moved = moved || !(fabsf(fmaf(-yn, rk, ra) - rowb[v]) < thr);      // NaN-safe: anything odd rebuilds
+    if (Z > R_KEPS) {
+      mnx = fminf(mnx, xn); mxx = fmaxf(mxx, xn);
+      mny = fminf(mny, yn); mxy = fmaxf(mxy, yn);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mnx = fminf(mnx, __shfl_xor(mnx, o, 64)); mny = fminf(mny, __shfl_xor(mny, o, 64));
+    mxx = fmaxf(mxx, __shfl_xor(mxx, o, 64)); mxy = fmaxf(mxy, __shfl_xor(mxy, o, 64));
+  }
+  const int any_moved = __syncthreads_or(moved ? 1 : 0);
+  if ((tid & 63) == 0) {
+    sbb[tid >> 6][0] = mnx; sbb[tid >> 6][1] = mny; sbb[tid >> 6][2] = mxx; sbb[tid >> 6][3] = mxy;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    atomicAdd(&p.sort_count[0], 1ull);
+    if (any_moved) atomicAdd(&p.sort_count[1], 1ull);
+    for (int w = 1; w < RPREP / 64; ++w) {
+      mnx = fminf(mnx, sbb[w][0]); mny = fminf(mny, sbb[w][1]);
+      mxx = fmaxf(mxx, sbb[w][2]); mxy = fmaxf(mxy, sbb[w][3]);
+    }
+    if (mnx <= mxx) {       // at least one vertex in front of the camera
+      const float px0 = r_ndc_to_pix(mxx, p.W, p.H), px1 = r_ndc_to_pix(mnx, p.W, p.H);
+      const float py0 = r_ndc_to_pix(mxy, p.H, p.W), py1 = r_ndc_to_pix(mny, p.H, p.W);
+      mnx = px0; mxx = px1; mny = py0; mxy = py1;
+    }
+    // clamp in float first: a body far outside the image must not overflow the int conversion
+    const float big = 1e6f;
+    mnx = fminf(fmaxf(mnx, -big), big); mxx = fminf(fmaxf(mxx, -big), big);
+    mny = fminf(fmaxf(mny, -big), big); mxy = fminf(fmaxf(mxy, -big), big);
+    const int x0 = max(0, (int)floorf(mnx) - 2), y0 = max(0, (int)floorf(mny) - 2);
+    const int x1 = min(p.W - 1, (int)ceilf(mxx) + 2), y1 = min(p.H - 1, (int)ceilf(mxy) + 2);
+    int ww = x1 - x0 + 1, wh = y1 - y0 + 1;
+    p.win[b * 4] = x0;
+    p.win[b * 4 + 1] = y0;
+    p.win[b * 4 + 2] = ww;
+    p.win[b * 4 + 3] = wh;
+    if (ww <= 0 || wh <= 0) ww = wh = 0;
+    s_win[0] = x0; s_win[1] = y0; s_win[2] = ww; s_win[3] = wh;
+    // the body's window of selection keys: dense in gkeys, in whatever order the bodies get here (only an address)
+    s_koff = (long long)atomicAdd((unsigned long long*)&p.px_total[par], (unsigned long long)((long long)ww * wh));
+    p.body_koff[b] = s_koff;
+  }
+  if (p.margin == 0 || any_moved) r_face_sort<RPREP>(p, b, hist);       // (ends with a barrier)
+  else __syncthreads();
+  // ---- tiles of the window -> the cost-class lists ------------------------------------------------------------------
+  const int x0 = s_win[0], y0 = s_win[1], ww = s_win[2], wh = s_win[3];
+  int tw = 1, th = 1, ncol = 0, nrow = 0;
+  if (ww > 0) r_tiling(ww, wh, &tw, &th, &ncol, &nrow);
+  const int cap = r_cap(p), ns = min(ncol * nrow, cap), first = b * cap;
+  if (tid == 0) { p.body_first[b] = first; p.body_ns[b] = ns; }
+  const int* rs = p.row_start + (size_t)b * (2 * (p.H + 1) + 1);
+  const int mh = p.maxh[b];
+  for (int k = tid; k < ns; k += RPREP) {
+    const int tr = k / ncol, tc = k - tr * ncol, s = first + k;
+    const int r0 = y0 + tr * th, nr = min(th, wh - tr * th), c0 = x0 + tc * tw, nc = min(tw, ww - tc * tw);
+    p.strip_body[s] = b;
+    p.strip_row0[s] = r0; p.strip_rows[s] = nr;
+    p.strip_col0[s] = c0; p.strip_cols[s] = nc;
+    const int c = r_tile_class(p, rs, mh, r0, nr, nc);
+    const int pos = atomicAdd(&p.cls_count[par * R_NCLS + c], 1);
+    if (pos < p.max_strips) p.cls_list[(size_t)c * p.max_strips + pos] = s;
+  }
+  // ---- work units of the gradient kernel: the window in pieces of RG_UNIT pixels; the full pieces first so that the long
+  // units start early, the partial ones by decreasing size behind them (the per-body version finished 2x later than its
+  // work divided by the CU count: the largest bodies happened to start last)
+  const long long npx = (long long)ww * wh;
+  const int nfull = (int)(npx / RG_UNIT), rem = (int)(npx % RG_UNIT);
+  for (int k = tid; k < nfull + (rem ? 1 : 0); k += RPREP) {
+    const int c = k < nfull ? 0 : 1 + (31 - min(31, rem * 32 / RG_UNIT));
+    const int pos = atomicAdd(&p.gcls_count[par * R_NGCLS + c], 1);
+    if (pos < p.max_units) p.gcls_list[(size_t)c * p.max_units + pos] = ((unsigned long long)(unsigned)b << 32) | (unsigned)k;
+  }
+  // ---- ticket: the last workgroup clears the other parity for the next launch and advances the epoch ------------------
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();
+    const unsigned t = atomicAdd(&p.ctl[1], 1u);
+    if (t == (unsigned)p.B - 1u) {
+      for (int c = 0; c < R_NCLS; ++c) p.cls_count[(par ^ 1) * R_NCLS + c] = 0;
+      for (int c = 0; c < R_NGCLS; ++c) p.gcls_count[(par ^ 1) * R_NGCLS + c] = 0;
+      p.px_total[par ^ 1] = 0;
+      p.ctl[1] = 0u;
+      __threadfence();
+      p.ctl[0] = epoch + 1u;
+    }
   }
 }
 
@@ -801,7 +731,9 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = p.H, W = p.W;
   const float blur_d = sqrtf(BLUR_D);
-  const int total = p.total[0];
+  __shared__ int s_pre[R_NCLS + 1];
+  r_lists_load(p, s_pre, p.cls_count, R_NCLS, p.max_strips);
+  const int total = s_pre[R_NCLS];
   const float rx = W > H ? 2.f * (float)W / (float)H : 2.f, ry = H > W ? 2.f * (float)H / (float)W : 2.f;
   const float kx = (float)W / rx, ky = (float)H / ry;      // pixels per NDC unit (approximate index only)
   // wave-private staging.  __builtin_amdgcn_wave_barrier() is the only ordering needed: it keeps the compiler from
@@ -814,7 +746,8 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
   int* mark = wMark[wave];
   unsigned short* pl = wPl[wave];
   for (int si = blockIdx.x; si < total; si += gridDim.x) {
-    const int s = p.strip_order[si];
+    const int cls_ = r_list_class(s_pre, R_NCLS, si);
+    const int s = p.cls_list[(size_t)cls_ * p.max_strips + (si - s_pre[cls_])];
     const int b = p.strip_body[s];
     const int x0 = p.strip_col0[s], tw = p.strip_cols[s], x1 = x0 + tw - 1;
     const int sy0 = p.strip_row0[s], nrows = p.strip_rows[s], sy1 = sy0 + nrows - 1;
@@ -1057,8 +990,12 @@ __global__ __launch_bounds__(RB) void k_raster_sums(RasterP p) {
   __shared__ float sh[RB / 64];
   const int tid = threadIdx.x;
   const int H = p.H, W = p.W, P = H * W;
-  const int total = p.total[0];
-  for (int s = blockIdx.x; s < total; s += gridDim.x) {
+  __shared__ int s_pre[R_NCLS + 1];
+  r_lists_load(p, s_pre, p.cls_count, R_NCLS, p.max_strips);
+  const int total = s_pre[R_NCLS];
+  for (int si = blockIdx.x; si < total; si += gridDim.x) {
+    const int cls_ = r_list_class(s_pre, R_NCLS, si);
+    const int s = p.cls_list[(size_t)cls_ * p.max_strips + (si - s_pre[cls_])];
     const int b = p.strip_body[s], t = b / p.N, n = b % p.N;
     const int x0 = p.strip_col0[s], tw = p.strip_cols[s];
     const int sy0 = p.strip_row0[s], npx = p.strip_rows[s] * tw;
@@ -1138,27 +1075,57 @@ __global__ void k_raster_body_out(RasterP p) {
   p.sil_corr[b] = 0.f;                        // accumulated by k_raster_grads, consumed and cleared by k_raster_finish
 }
 
-// after k_raster_grads: silhouette loss value with the alpha-dependent part accumulated by the gradient kernel
-// (thread b < B), and the chain of the depth-range leaves (thread t < T; optimizer.py:683-688: min_z = softplus(zmin),
-// max_z = min_z.detach() + 1 + softplus(zmax))
-__global__ void k_raster_finish(RasterP p, int T, int do_sil, const float* zmin_lin, const float* zmax_lin, float* gzmin, float* gzmax) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (do_sil && i < p.B) {
-    p.sil_body[i] = p.sil_apply[i] * (p.sil_S[i] + p.sil_corr[i]) / (p.sil_D[i] + 1.f);        // losses.py:35-38
-    p.sil_corr[i] = 0.f;
-  }
-  if (gzmin && i < T) {
-    const int N = p.N;
+// Last kernel of the rasterised terms, one thread per FRAME (a single workgroup: a few microseconds of work that used to
+// be three launches -- k_raster_body_out between selection and gradients, this kernel, and a reduction for the log):
+//   from_partials != 0 (gradients were requested: k_raster_grads has run): per body, the sums of its tiles in fixed order
+//     -> depth loss, depth-range partials, silhouette loss with the alpha-dependent part k_raster_grads accumulated
+//     (cleared here for the next launch);
+//   from_partials == 0 (values only): k_raster_body_out has done that from k_raster_sums' totals;
+//   then the chain of the depth-range leaves (optimizer.py:683-688: min_z = softplus(zmin), max_z = min_z.detach() + 1 +
+//   softplus(zmax)) and, when asked for, the two loss sums of the log row.
+__global__ __launch_bounds__(256) void k_raster_finish(RasterP p, int T, int from_partials, const float* zmin_lin, const float* zmax_lin,
+                                                       float* gzmin, float* gzmax, float* log_depth, float* log_sil) {
+  __shared__ float sh[256 / 64];
+  const int N = p.N;
+  float ld = 0.f, ls = 0.f;
+  for (int t = threadIdx.x; t < T; t += 256) {
     float g0 = 0.f, g1 = 0.f;
     for (int n = 0; n < N; ++n) {
-      g0 += p.dinv[((size_t)i * N + n) * 2];
-      g1 += p.dinv[((size_t)i * N + n) * 2 + 1];
+      const int b = t * N + n;
+      if (from_partials) {
+        float S[6];
+        r_body_sums(p, b, S);
+        const float cnt = S[2] + 1.f;
+        const float diff = S[0] / cnt - S[1] / cnt;                                                  // losses.py:24-27
+        p.depth_body[b] = diff * diff;
+        const float gB = p.coef_depth * (-2.f) * diff / cnt;
+        g0 += gB * S[3];                          // d/d(1/min_z) through the target disparity
+        g1 += gB * S[4];                          // d/d(1/max_z)
+        p.sil_body[b] = p.sil_apply[b] * (p.sil_S[b] + p.sil_corr[b]) / (p.sil_D[b] + 1.f);        // losses.py:35-38
+        p.sil_corr[b] = 0.f;
+      } else {
+        g0 += p.dinv[(size_t)b * 2];
+        g1 += p.dinv[(size_t)b * 2 + 1];
+        p.sil_corr[b] = 0.f;                      // (gradients AND images in one call: k_raster_grads ran after k_raster_body_out)
+      }
+      ld += p.depth_body[b];
+      ls += p.sil_body[b];
     }
-    const float e0 = expf(zmin_lin[i]), e1 = expf(zmax_lin[i]);
-    const float min_z = logf(1.f + e0);
-    const float max_z = min_z + 1.f + logf(1.f + e1);
-    gzmin[i] += g0 * (-1.f / (min_z * min_z)) * (e0 / (1.f + e0));
-    gzmax[i] += g1 * (-1.f / (max_z * max_z)) * (e1 / (1.f + e1));
+    if (gzmin) {
+      const float e0 = expf(zmin_lin[t]), e1 = expf(zmax_lin[t]);
+      const float min_z = logf(1.f + e0);
+      const float max_z = min_z + 1.f + logf(1.f + e1);
+      gzmin[t] += g0 * (-1.f / (min_z * min_z)) * (e0 / (1.f + e0));
+      gzmax[t] += g1 * (-1.f / (max_z * max_z)) * (e1 / (1.f + e1));
+    }
+  }
+  if (log_depth || log_sil) {
+    ld = r_block_sum(ld, sh);
+    ls = r_block_sum(ls, sh);
+    if (threadIdx.x == 0) {
+      if (log_depth) *log_depth = ld;
+      if (log_sil) *log_sil = ls;
+    }
   }
 }
 
@@ -1374,9 +1341,13 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
   const bool use_tab = TAB;
   int* plist = (int*)(gtab + (use_tab ? p.V * 3 : 0));
   int* s_n = plist + RG_LIST;
-  const int nunits = p.gunit_total[0];
+  __shared__ int s_pre[R_NGCLS + 1];
+  r_lists_load(p, s_pre, p.gcls_count, R_NGCLS, p.max_units);
+  const int nunits = s_pre[R_NGCLS];
   for (int u = blockIdx.x; u < nunits; u += gridDim.x) {
-    const int b = p.gunit_body[u], up0 = p.gunit_p0[u];
+    const int ucls = r_list_class(s_pre, R_NGCLS, u);
+    const unsigned long long ue = p.gcls_list[(size_t)ucls * p.max_units + (u - s_pre[ucls])];
+    const int b = (int)(ue >> 32), up0 = (int)(ue & 0xffffffffu) * RG_UNIT;
     const int t = b / p.N, n = b % p.N;
     const int x0 = p.win[b * 4], ww = p.win[b * 4 + 2], y0 = p.win[b * 4 + 1], wh = p.win[b * 4 + 3];
     const int npx = min(ww * wh, up0 + RG_UNIT);
@@ -1580,10 +1551,6 @@ extern "C" int mh_raster_get_sort_margin(void) { return raster_sort_margin(); }
 
 static size_t r_align(size_t x) { return (x + 255) & ~(size_t)255; }
 static size_t r_max_units(size_t B, int H, int W) { return B + B * (size_t)H * W / RG_UNIT + 1; }
-static size_t r_ws_extra(size_t B, int V, int F, int H) {
-  return r_align(B * V * 3 * 4) + 2 * r_align(B * F * 4) + r_align(B * (size_t)(2 * (H + 1) + 1) * 4) + 2 * r_align(B * 4) + r_align(B * 8) +
-         r_align(B * V * 4) + r_align(B * 8) + r_align(B * 4) + r_align(16);     // rowb, sort_tag, stale, sort_count
-}
 static int r_max_strips(int B, int H, int W) {
   // full-width windows give the most tiles per body
   const int th = W <= R_CAP ? (R_CAP / W > 0 ? R_CAP / W : 1) : R_CAP / R_TILE_W;
@@ -1592,14 +1559,7 @@ static int r_max_strips(int B, int H, int W) {
   return B * (per_body > H ? per_body : H);
 }
 
-extern "C" size_t mh_raster_workspace_bytes(int T, int N, int V, int F, int H, int W) {
-  const size_t B = (size_t)T * N, ms = (size_t)r_max_strips((int)B, H, W);
-  return r_ws_extra(B, V, F, H) + 2 * r_align(r_max_units(B, H, W) * 4) + r_align(4) + r_align(B * 4 * 4) + 2 * r_align(B * 4) + r_align(4) + 6 * r_align(ms * 4) + r_align(ms * 6 * 4) +
-         r_align(B * 2 * 4) + r_align(B * (size_t)H * W * 5 * 8);
-}
-
-
-static void r_carve(RasterP& p, void* ws) {
+static size_t r_carve(RasterP& p, void* ws) {
   const size_t B = (size_t)p.B;
   const int V = p.V, F = p.F, H = p.H, W = p.W;
   p.max_strips = r_max_strips(p.B, H, W);
@@ -1608,13 +1568,11 @@ static void r_carve(RasterP& p, void* ws) {
   p.win = (int*)c; c += r_align(B * 4 * 4);
   p.body_first = (int*)c; c += r_align(B * 4);
   p.body_ns = (int*)c; c += r_align(B * 4);
-  p.total = (int*)c; c += r_align(4);
   p.strip_body = (int*)c; c += r_align(ms * 4);
   p.strip_row0 = (int*)c; c += r_align(ms * 4);
   p.strip_rows = (int*)c; c += r_align(ms * 4);
   p.strip_col0 = (int*)c; c += r_align(ms * 4);
   p.strip_cols = (int*)c; c += r_align(ms * 4);
-  p.strip_order = (int*)c; c += r_align(ms * 4);
   p.partial = (float*)c; c += r_align(ms * 6 * 4);
   p.dinv = (float*)c; c += r_align(B * 2 * 4);
   p.ndc = (float*)c; c += r_align(B * V * 3 * 4);
@@ -1622,27 +1580,71 @@ static void r_carve(RasterP& p, void* ws) {
   p.fsort = (unsigned*)c; c += r_align(B * F * 4);
   p.row_start = (int*)c; c += r_align(B * (size_t)(2 * (H + 1) + 1) * 4);
   p.maxh = (int*)c; c += r_align(B * 4);
-  p.sil_corr = (float*)c; c += r_align(B * 4);
   p.body_koff = (long long*)c; c += r_align(B * 8);
   p.rowb = (float*)c; c += r_align(B * V * 4);
-  p.sort_tag = (unsigned long long*)c; c += r_align(B * 8);
-  p.stale = (int*)c; c += r_align(B * 4);
-  p.sort_count = (unsigned long long*)c; c += r_align(16);
   p.margin = raster_sort_margin();
-  p.gunit_body = (int*)c; c += r_align(r_max_units(B, H, W) * 4);
-  p.gunit_p0 = (int*)c; c += r_align(r_max_units(B, H, W) * 4);
-  p.gunit_total = (int*)c; c += r_align(4);
-  p.gkeys = (unsigned long long*)c;
+  p.max_units = (int)r_max_units(B, H, W);
+  p.cls_list = (int*)c; c += r_align((size_t)R_NCLS * ms * 4);
+  p.gcls_list = (unsigned long long*)c; c += r_align((size_t)R_NGCLS * p.max_units * 8);
+  // control words: everything mh_raster_workspace_init clears, contiguous
+  p.ctl = (unsigned*)c; c += r_align(16);
+  p.cls_count = (int*)c; c += r_align(2 * R_NCLS * 4);
+  p.gcls_count = (int*)c; c += r_align(2 * R_NGCLS * 4);
+  p.px_total = (long long*)c; c += r_align(16);
+  p.sort_count = (unsigned long long*)c; c += r_align(16);
+  p.sort_tag = (unsigned long long*)c; c += r_align(B * 8);
+  p.sil_corr = (float*)c; c += r_align(B * 4);
+  p.ctl_end = c;
+  p.gkeys = (unsigned long long*)c; c += r_align(B * (size_t)H * W * 5 * 8);
+  return (size_t)(c - (char*)ws);
 }
 
-extern "C" int mh_raster_sort_counters(int T, int N, int V, int F, int H, int W, void* ws, unsigned long long* out_host, void* stream) {
-  MH_CHECK(ws && out_host, "null argument");
+extern "C" size_t mh_raster_workspace_bytes(int T, int N, int V, int F, int H, int W) {
+  if (T <= 0 || N <= 0 || V <= 0 || F <= 0 || H <= 0 || W <= 0) return 0;
+  RasterP p;
+  p.B = T * N; p.N = N; p.V = V; p.F = F; p.H = H; p.W = W;
+  return r_carve(p, nullptr);
+}
+
+// A workspace must be initialised ONCE before its first launch (and again if its bytes were overwritten): the control
+// words -- epoch / ticket of the work lists, list counters, face-list tags, the silhouette accumulator -- are cleared;
+// everything else is rebuilt by the launches themselves.  Stream-ordered.
+extern "C" int mh_raster_workspace_init(int T, int N, int V, int F, int H, int W, void* ws, void* stream) {
+  MH_CHECK(ws, "null argument");
   MH_CHECK(T > 0 && N > 0 && V > 0 && F > 0 && H > 0 && W > 0, "empty input");
   RasterP p;
   p.B = T * N; p.N = N; p.V = V; p.F = F; p.H = H; p.W = W;
   r_carve(p, ws);
-  MH_HIP(hipMemcpyAsync(out_host, p.sort_count, 16, hipMemcpyDeviceToHost, (hipStream_t)stream));
-  MH_HIP(hipStreamSynchronize((hipStream_t)stream));
+  MH_HIP(hipMemsetAsync(p.ctl, 0, (size_t)(p.ctl_end - (char*)p.ctl), (hipStream_t)stream));
+  return MH_OK;
+}
+
+// byte offsets inside the workspace of what an inspection tool reads after a launch: [0] win (B x 4 int32),
+// [1] body_koff (B x int64: first window pixel of a body in the key array), [2] the key array (5 x uint64 per window pixel)
+extern "C" int mh_raster_workspace_offsets(int T, int N, int V, int F, int H, int W, size_t* out /*[3]*/) {
+  MH_CHECK(out, "null argument");
+  MH_CHECK(T > 0 && N > 0 && V > 0 && F > 0 && H > 0 && W > 0, "empty input");
+  RasterP p;
+  p.B = T * N; p.N = N; p.V = V; p.F = F; p.H = H; p.W = W;
+  r_carve(p, nullptr);
+  out[0] = (size_t)((char*)p.win - (char*)nullptr);
+  out[1] = (size_t)((char*)p.body_koff - (char*)nullptr);
+  out[2] = (size_t)((char*)p.gkeys - (char*)nullptr);
+  return MH_OK;
+}
+
+extern "C" int mh_raster_sort_counters(int T, int N, int V, int F, int H, int W, void* ws, unsigned long long* out_host, void* stream) {
+  MH_CHECK(ws, "null argument");
+  MH_CHECK(T > 0 && N > 0 && V > 0 && F > 0 && H > 0 && W > 0, "empty input");
+  RasterP p;
+  p.B = T * N; p.N = N; p.V = V; p.F = F; p.H = H; p.W = W;
+  r_carve(p, ws);
+  if (out_host) {
+    MH_HIP(hipMemcpyAsync(out_host, p.sort_count, 16, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    MH_HIP(hipStreamSynchronize((hipStream_t)stream));
+  } else {            // out_host NULL: reset (a workspace holds anything when it is handed over)
+    MH_HIP(hipMemsetAsync(p.sort_count, 0, 16, (hipStream_t)stream));
+  }
   return MH_OK;
 }
 
@@ -1652,7 +1654,7 @@ static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const flo
                              const uint32_t* front, const float* sil_apply, const float* sil_D, const float* sil_S,
                              float coef_depth, float coef_sil, float eps, float* gverts, float* gzmin, float* gzmax,
                              float* depth_body, float* sil_body, void* ws, float* zbuf_out, float* alpha_out,
-                             int phases, void* stream) {
+                             int phases, float* log_depth, float* log_sil, void* stream) {
   MH_CHECK(cam_K_host && verts && faces && bits && ebits && depths && zmin_lin && zmax_lin && pose2d_valid && front &&
                sil_apply && sil_D && sil_S && depth_body && sil_body && ws,
            "null argument");
@@ -1691,9 +1693,7 @@ static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const flo
     MH_LAUNCH_CHECK();
   }
   if (alpha_out) MH_HIP(hipMemsetAsync(alpha_out, 0, (size_t)p.B * H * W * sizeof(float), st));
-  hipLaunchKernelGGL(k_raster_windows, dim3(p.B), dim3(RWT), 0, st, p);
-  MH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_raster_face_sort, dim3(p.B + 1), dim3(RFS), (size_t)2 * (H + 1) * sizeof(int), st, p);
+  hipLaunchKernelGGL(k_raster_prepare, dim3(p.B), dim3(RPREP), (size_t)2 * (H + 1) * sizeof(int), st, p);
   MH_LAUNCH_CHECK();
   // persistent grids over the device-side work list (the strip count is only known on the device)
   const int grid = 256 * 3 * 4;
@@ -1707,8 +1707,10 @@ static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const flo
     MH_LAUNCH_CHECK();
     mh_prof_mark(MH_PROF_RASTER_SUMS, 1, st);
   }
-  hipLaunchKernelGGL(k_raster_body_out, dim3((p.B + 255) / 256), dim3(256), 0, st, p);
-  MH_LAUNCH_CHECK();
+  if (!gverts || zbuf_out || alpha_out) {   // with gradients the per-body values come out of k_raster_finish
+    hipLaunchKernelGGL(k_raster_body_out, dim3((p.B + 255) / 256), dim3(256), 0, st, p);
+    MH_LAUNCH_CHECK();
+  }
   }   // selection phase
   if (!(phases & 2)) return MH_OK;
   if (gverts) {
@@ -1732,10 +1734,11 @@ static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const flo
     MH_LAUNCH_CHECK();
     mh_prof_mark(MH_PROF_RASTER_GRADS, 1, st);
   }
-  if (gverts || (gzmin && gzmax)) {
-    const int n = p.B > T ? p.B : T;
-    hipLaunchKernelGGL(k_raster_finish, dim3((n + 255) / 256), dim3(256), 0, st, p, T, gverts ? 1 : 0, zmin_lin, zmax_lin,
-                       (gzmin && gzmax) ? gzmin : (float*)nullptr, gzmax);
+  if (gverts || (gzmin && gzmax) || log_depth || log_sil) {
+    // values-only launches with images requested went through k_raster_body_out (sums of k_raster_sums): then only the chain
+    const int from_partials = (gverts && !zbuf_out && !alpha_out) ? 1 : 0;
+    hipLaunchKernelGGL(k_raster_finish, dim3(1), dim3(256), 0, st, p, T, from_partials, zmin_lin, zmax_lin,
+                       (gzmin && gzmax) ? gzmin : (float*)nullptr, gzmax, log_depth, log_sil);
     MH_LAUNCH_CHECK();
   }
   return MH_OK;
@@ -1750,7 +1753,7 @@ extern "C" int mh_raster_terms(int T, int N, int V, int F, int H, int W, const f
                                void* stream) {
   return raster_terms_impl(T, N, V, F, H, W, cam_K_host, verts, faces, bits, ebits, depths, zmin_lin, zmax_lin, pose2d_valid, front,
                            sil_apply, sil_D, sil_S, coef_depth, coef_sil, eps, gverts, gzmin, gzmax, depth_body, sil_body, ws, zbuf_out,
-                           alpha_out, 3, stream);
+                           alpha_out, 3, nullptr, nullptr, stream);
 }
 
 extern "C" int mh_raster_terms_phase(int T, int N, int V, int F, int H, int W, const float* cam_K_host, const float* verts,
@@ -1763,5 +1766,18 @@ extern "C" int mh_raster_terms_phase(int T, int N, int V, int F, int H, int W, c
   MH_CHECK(phases >= 1 && phases <= 3, "phases: 1 = selection + values, 2 = gradients, 3 = both");
   return raster_terms_impl(T, N, V, F, H, W, cam_K_host, verts, faces, bits, ebits, depths, zmin_lin, zmax_lin, pose2d_valid, front,
                            sil_apply, sil_D, sil_S, coef_depth, coef_sil, eps, gverts, gzmin, gzmax, depth_body, sil_body, ws, zbuf_out,
-                           alpha_out, phases, stream);
+                           alpha_out, phases, nullptr, nullptr, stream);
+}
+
+extern "C" int mh_raster_terms_phase_log(int T, int N, int V, int F, int H, int W, const float* cam_K_host, const float* verts,
+                                         const int32_t* faces, const uint32_t* bits, const uint32_t* ebits, const float* depths,
+                                         const float* zmin_lin, const float* zmax_lin, const float* pose2d_valid,
+                                         const uint32_t* front, const float* sil_apply, const float* sil_D, const float* sil_S,
+                                         float coef_depth, float coef_sil, float eps, float* gverts, float* gzmin, float* gzmax,
+                                         float* depth_body, float* sil_body, void* ws, float* zbuf_out, float* alpha_out,
+                                         int phases, float* log_depth, float* log_sil, void* stream) {
+  MH_CHECK(phases >= 1 && phases <= 3, "phases: 1 = selection + values, 2 = gradients, 3 = both");
+  return raster_terms_impl(T, N, V, F, H, W, cam_K_host, verts, faces, bits, ebits, depths, zmin_lin, zmax_lin, pose2d_valid, front,
+                           sil_apply, sil_D, sil_S, coef_depth, coef_sil, eps, gverts, gzmin, gzmax, depth_body, sil_body, ws, zbuf_out,
+                           alpha_out, phases, log_depth, log_sil, stream);
 }

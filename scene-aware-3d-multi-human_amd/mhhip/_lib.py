@@ -113,6 +113,9 @@ def lib():
         L.mh_raster_set_deterministic.argtypes = [ctypes.c_int]
         L.mh_raster_set_sort_margin.argtypes = [ctypes.c_int]
         L.mh_raster_sort_counters.argtypes = [ctypes.c_int] * 6 + [vp, ctypes.POINTER(ctypes.c_ulonglong), vp]
+        L.mh_raster_terms_phase_log.argtypes = [ctypes.c_int] * 6 + [c_float_p] + [vp] * 12 + [ctypes.c_float] * 3 + [vp] * 8 + [ctypes.c_int, vp, vp, vp]
+        L.mh_raster_workspace_init.argtypes = [ctypes.c_int] * 6 + [vp, vp]
+        L.mh_raster_workspace_offsets.argtypes = [ctypes.c_int] * 6 + [ctypes.POINTER(ctypes.c_size_t)]
         L.mh_avg_depth_loss.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_float, vp, vp, vp]
         L.mh_avg_depth_loss_backward.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_float, vp, ctypes.c_float, vp, vp, vp]
         L.mh_masked_mse.argtypes = [vp, vp, vp, ctypes.c_size_t, vp, vp]

@@ -18,29 +18,33 @@ class RasterTerms(object):
         self.faces = torch.as_tensor(np.ascontiguousarray(np.asarray(e.m.faces).astype(np.int32))).to(e.dev)
         self.ws = torch.empty(_lib.lib().mh_raster_workspace_bytes(e.T, e.N, e.V, self.faces.shape[0], e.H, e.W), dtype=torch.uint8, device=e.dev)
         self.K = np.ascontiguousarray(e.K.reshape(9))
+        self.dims = (e.T, e.N, e.V, int(self.faces.shape[0]), e.H, e.W)
+        self.init_workspace()
+
+    def init_workspace(self):
+        """mh_raster_workspace_init: once per workspace (again after its bytes were overwritten)"""
+        check(_lib.lib().mh_raster_workspace_init(*self.dims, ptr(self.ws), _lib.stream_ptr(self.dev)))
 
     def __call__(self, e, gverts, log, with_grads=True, zbuf_out=None, alpha_out=None, phases=3):
         """phases: 1 = selection + values (does not touch gverts), 2 = gradients + log entries, 3 = both"""
         L = _lib.lib()
         st = _lib.stream_ptr(e.dev)
         g = e.grads
-        check(L.mh_raster_terms_phase(e.T, e.N, e.V, self.faces.shape[0], e.H, e.W, self.K.ctypes.data_as(_lib.c_float_p),
+        check(L.mh_raster_terms_phase_log(e.T, e.N, e.V, self.faces.shape[0], e.H, e.W, self.K.ctypes.data_as(_lib.c_float_p),
                                       ptr(e.verts), ptr(self.faces), ptr(e.bits), ptr(e.ebits), ptr(e.depths),
                                       ptr(e.leaf('zmin_lin')), ptr(e.leaf('zmax_lin')), ptr(e.p2d_valid), ptr(e.front),
                                       ptr(e.sil_apply), ptr(e.sil_D), ptr(e.sil_S), float(e.c['depth']),
                                       float(e.c['silhouette']), float(e.eps), ptr(gverts) if with_grads else None,
                                       ptr(e.leaf('zmin_lin', g)) if with_grads else None,
                                       ptr(e.leaf('zmax_lin', g)) if with_grads else None, ptr(e.depth_body), ptr(e.sil_body),
-                                      ptr(self.ws), ptr(zbuf_out), ptr(alpha_out), int(phases), st))
-        if phases & 2:
-            check(L.mh_reduce_sum2(ptr(e.depth_body), ptr(e.sil_body), e.B, 1.0, ptr(log[1:2]), ptr(log[2:3]), st))
+                                      ptr(self.ws), ptr(zbuf_out), ptr(alpha_out), int(phases), ptr(log[1:2]), ptr(log[2:3]), st))
 
 
     def sort_counters(self, e):
         """(bodies seen, bodies whose face lists were re-sorted), cumulative over the launches on this workspace"""
         import ctypes
         out = (ctypes.c_ulonglong * 2)()
-        check(_lib.lib().mh_raster_sort_counters(e.T, e.N, e.V, self.faces.shape[0], e.H, e.W, ptr(self.ws), out, _lib.stream_ptr(e.dev)))
+        check(_lib.lib().mh_raster_sort_counters(*self.dims, ptr(self.ws), out, _lib.stream_ptr(e.dev)))
         return int(out[0]), int(out[1])
 
     def selection(self, e):
@@ -48,13 +52,20 @@ class RasterTerms(object):
         every body's screen window; koff (B+1,): first window pixel of every body; keys (window pixels, 5) uint64: per
         pixel, row-major inside the window, slot 0 = nearest face of the blur-1e-4 pass, slots 1-4 = the K=4 list of the
         blur-2e-5 pass, ascending; key = float bits of z << 32 | face, all ones = empty)."""
-        B, H, W = e.B, e.H, e.W
-        win = self.ws[:B * 16].view(torch.int32).view(B, 4).cpu().numpy()
-        gk_bytes = ((B * H * W * 40) + 255) // 256 * 256
+        import ctypes
+        B = e.B
+        off = (ctypes.c_size_t * 3)()
+        check(_lib.lib().mh_raster_workspace_offsets(*self.dims, off))
+        win = self.ws[off[0]:off[0] + B * 16].view(torch.int32).view(B, 4).cpu().numpy()
+        first = self.ws[off[1]:off[1] + B * 8].view(torch.int64).cpu().numpy()
         npix = np.maximum(win[:, 2], 0).astype(np.int64) * np.maximum(win[:, 3], 0)
+        total = int(npix.sum())
+        raw = self.ws[off[2]:off[2] + total * 40].cpu().numpy().view(np.uint64).reshape(-1, 5)
+        # the bodies' key windows lie in the array in the order their workgroups got there: back into body order
         koff = np.concatenate([[0], np.cumsum(npix)])
-        gk = self.ws[self.ws.numel() - gk_bytes:]
-        keys = gk[:int(koff[-1]) * 40].cpu().numpy().view(np.uint64).reshape(-1, 5)
+        keys = np.empty_like(raw)
+        for b in range(B):
+            keys[koff[b]:koff[b + 1]] = raw[first[b]:first[b] + npix[b]]
         return win, koff, keys
 
 
@@ -88,6 +99,7 @@ def render(model, verts, cam_K, image_size):
     zbuf, alpha = torch.empty(B, H, W, device=dev), torch.empty(B, H, W, device=dev)
     K = np.ascontiguousarray(np.asarray(cam_K, np.float32).reshape(9))
     ws = torch.empty(_lib.lib().mh_raster_workspace_bytes(B, 1, V, faces.shape[0], H, W), dtype=torch.uint8, device=dev)
+    check(_lib.lib().mh_raster_workspace_init(B, 1, V, int(faces.shape[0]), H, W, ptr(ws), _lib.stream_ptr(dev)))
     check(_lib.lib().mh_raster_terms(B, 1, V, faces.shape[0], H, W, K.ctypes.data_as(_lib.c_float_p), ptr(verts.contiguous()),
                                      ptr(faces), ptr(bits), ptr(bits), ptr(depths), ptr(tz), ptr(tz), ptr(ones), ptr(zi(B)),
                                      ptr(tz), ptr(ones), ptr(tz), 0.0, 0.0, 1e-3, None, None, None, ptr(zf(B)), ptr(zf(B)),

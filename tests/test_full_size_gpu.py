@@ -15,7 +15,7 @@ import torch
 
 import golden_inputs as gi
 from oracle import raster_oracle as ro
-from test_fit_full_gpu import LEAF_MAP, _oracle_grad, _setup
+from test_fit_full_gpu import LEAF_MAP, _HipSelectionRasteriser, _oracle_grad, _setup
 from test_scene_knn_gpu import _dy_reference, _run
 
 pytestmark = pytest.mark.gpu
@@ -34,29 +34,6 @@ def _compare_grads(e, o, frac=0.01, tight=5e-3, med=1e-3):
         off = float((err > tight * scale).mean())
         assert off < frac, '%s: %.4f of the entries above %g*max (max err %.2e, scale %.2e)' % (name, off, tight, err.max(), scale)
         assert np.median(err) < med * scale, name
-
-
-class _HipSelectionRasteriser(object):
-    """the oracle's differentiable rendering on the faces the HIP selection pass picked (per frame): separates "which
-    faces" (tests/test_raster_gpu.py enumerates the differences and verifies them as near-ties) from "what comes out
-    of them", so that the gradients can be compared on EVERY entry"""
-    wants_frames = True
-
-    def __init__(self, faces, K, image_size, N):
-        self.faces, self.K, self.size, self.N, self.sel = faces, K, image_size, N, None
-
-    def take(self, raster, e, oracle=None):
-        """the selection of the cycle the engine just ran; oracle: also evaluate the oracle's terms AT the engine's vertices
-        (oracle/fit_oracle.py verts_value_override: sliver faces make the rasterised gradients ill-conditioned in the
-        vertices, and the LBS forward has its own parity tests at 1e-5 m)"""
-        from test_raster_gpu import _hip_selection
-        self.sel = _hip_selection(raster.selection(e), e.B, e.H, e.W).reshape(e.T, self.N, e.H, e.W, 5)
-        if oracle is not None:
-            oracle.verts_value_override = e.verts.view(e.T, self.N, -1, 3).cpu().clone()
-
-    def __call__(self, verts, frames):
-        s = self.sel[np.asarray(frames)].reshape(-1, *self.sel.shape[2:])
-        return ro.render(verts, self.faces, self.K, self.size, selection=(s[..., :1], s[..., 1:]))
 
 
 def test_c3_full_size_cycle_matches_oracle(smpl_struct, smpl_regs, oracle_model, tmp_path):
@@ -185,9 +162,9 @@ def test_c5_shape_cycle_restricts_to_the_first_batch(smpl_struct, smpl_regs, ora
 
 def test_selection_does_not_depend_on_what_the_workspace_held(smpl_struct, smpl_regs, oracle_model, tmp_path):
     """The tile schedule (longest first) is estimated beside the face sort from whatever the previous cycle left in the
-    workspace; a fresh workspace holds anything.  ~7000 tiles at C3 (more than the order's register-resident part): the
-    per-body depth sums, which come out of the selection in fixed order, must be bit-identical whether the workspace
-    held zeros, random bits or the previous cycle's tables."""
+    workspace (kept face lists, cost classes); a fresh workspace holds anything beside its cleared control words.  ~7000
+    tiles at C3: the per-body depth sums, which come out of the selection in fixed order, must be bit-identical whether
+    the workspace held zeros, random bits or the previous cycle's tables."""
     T, N, W, H, batch = 200, 4, 240, 135, 50
     opt, dl, o, batches, seq = _setup(smpl_struct, smpl_regs, oracle_model, tmp_path, T, N, W, H, batch, 41, True)
     opt._stage_from_dataloader(dl)
@@ -200,6 +177,8 @@ def test_selection_does_not_depend_on_what_the_workspace_held(smpl_struct, smpl_
             raster.ws.zero_()
         elif fill == 'random':
             raster.ws.copy_(torch.randint(0, 256, raster.ws.shape, dtype=torch.uint8, device=raster.ws.device))
+        if fill != 'previous':
+            raster.init_workspace()        # the contract: control words cleared once per (overwritten) workspace
         e.cycle(0, raster=raster)
         torch.cuda.synchronize()
         outs.append((e.depth_body.clone(), e.sil_body.clone(), e.leaf('poses_T', e.grads).clone()))
@@ -223,6 +202,7 @@ def test_kept_face_lists_give_the_same_selection_as_a_fresh_sort(smpl_struct, sm
     e = opt.engine
     kept, fresh = RasterTerms(e), RasterTerms(e)
     kept.ws.copy_(torch.randint(0, 256, kept.ws.shape, dtype=torch.uint8, device=kept.ws.device))     # a workspace holds anything
+    kept.init_workspace()
     gv, log = torch.zeros_like(e.verts), torch.zeros(16, device=e.dev)
     old = set_sort_margin(1)
     try:

@@ -20,15 +20,14 @@ e = opt.engine
 L = _lib.lib()
 r = RasterTerms(e)
 r.ws.zero_()
+r.init_workspace()
 e.cycle(0, raster=r)               # mask statistics + forward + raster
 torch.cuda.synchronize()
 W, H = bench.IMG
 B = e.B
-gk_bytes = ((B * H * W * 40) + 255) // 256 * 256
-gk = r.ws[r.ws.numel() - gk_bytes:]
-win = r.ws[:B * 16].view(torch.int32).view(B, 4).cpu().numpy()
-npx = int((np.maximum(win[:, 2], 0).astype(np.int64) * np.maximum(win[:, 3], 0)).sum())
-keys = gk[:npx * 40].cpu().numpy()
+win, koff_, keys5 = r.selection(e)
+npx = int(koff_[-1])
+keys = keys5.view(np.uint8).reshape(-1)
 print('window pixels', npx, 'keys sha1', hashlib.sha1(keys.tobytes()).hexdigest(), 'log', [float(x) for x in e.log[0][:3].cpu()])
 gv = torch.zeros_like(e.verts); log = torch.zeros(16, device=e.dev)
 def run():

@@ -9,8 +9,9 @@
 //   k_raster_prepare      one workgroup per body: NDC projection of the vertices + screen window; pixel-row range of every
 //                         face and counting sort by first row (a tile's candidate faces become contiguous ranges) -- only
 //                         when a vertex has moved more than `margin` rows since the body's last sort (temporal coherence);
-//                         the body's tiles of <= R_CAP pixels and gradient work units appended to per-cost-class lists
-//                         (longest first; no serial pass, no host sync)
+//                         the body's tiles of <= R_CAP pixels with their cost classes
+//   k_raster_lists        one workgroup: where each body's keys live, tiles ordered by cost class (longest first),
+//                         work units of the gradient kernel -- device-side lists, no host sync
 //   k_raster_strip        one workgroup per tile; every wave runs barrier-free rounds of 64 faces (3-deep gather
 //                         pipeline, bbox, pair list / even split, depth cull) and inserts 64-bit (z, face) keys into
 //                         the tile's LDS window with ds_min_u64: slot 0 = nearest face of the blur 1e-4 pass (all
@@ -74,14 +75,15 @@ struct RasterP {
   unsigned* fsort;           // [B][F] faces ordered by their first row: hi << 20 | face
   int* row_start;            // [B][2][H+1] (+1): per class (near class first), first entry of fsort with lo >= row
   int* maxh;                 // [B] tallest face (rows) of the body
-  // work lists (see k_raster_prepare): per cost class, append-only, counters double-buffered by the epoch's parity
+  // work lists (put together by the last workgroup of k_raster_prepare)
   int max_units;
-  unsigned* ctl;             // [0] epoch, [1] ticket of the preparation kernel
-  int* cls_count;            // [2][R_NCLS] tiles per cost class
-  int* cls_list;             // [R_NCLS][max_strips] tile slots
-  int* gcls_count;           // [2][R_NGCLS] gradient work units per class
-  unsigned long long* gcls_list;   // [R_NGCLS][max_units] body << 32 | piece
-  long long* px_total;       // [2] window pixels handed out in gkeys
+  unsigned* ctl;             // (reserved control words)
+  int* total;                // [1] number of tiles
+  int* strip_cls;            // [max_strips] cost class of a tile (by slot)
+  int* strip_order;          // [max_strips] tile slots, most expensive class first
+  int* gunit_total;          // [1]
+  unsigned long long* gunit_list;   // [max_units] body << 32 | piece: RG_UNIT window pixels of one body, full pieces first
+  int* stale;                // [B] 1 = the body's face lists were rebuilt this launch
   float* sil_corr;           // [B] sum over the silhouette pixels of alpha^2 - 2 alpha seg (accumulated by k_raster_grads)
   // temporal coherence of the face sort (see k_raster_face_sort): the sorted lists of a body are kept until one of its
   // vertices has moved `margin` pixel rows away from where it was when the lists were built
@@ -107,6 +109,13 @@ __device__ __forceinline__ float r_ndc_to_pix(float ndc, int S1, int S2) {
 }
 __device__ __forceinline__ float r_edge(float px, float py, float ax, float ay, float bx, float by) {
   return (px - ax) * (by - ay) - (py - ay) * (bx - ax);
+}
+// the same without operation fusing: used where the VALUE decides something discrete in two different places (the
+// degenerate-area exclusion of a face is taken by the face sort or by the strip kernel, depending on whether the lists
+// are kept; the compiler contracts a * b - c * d into an fma differently from context to context, and a sliver near the
+// 1e-8 threshold then existed for one and not for the other: 1 pixel of 850 000 differed, tests/test_full_size_gpu.py)
+__device__ __forceinline__ float r_edge_exact(float px, float py, float ax, float ay, float bx, float by) {
+  return __fsub_rn(__fmul_rn(__fsub_rn(px, ax), __fsub_rn(by, ay)), __fmul_rn(__fsub_rn(py, ay), __fsub_rn(bx, ax)));
 }
 // squared distance to segment ab; returns the clamped parameter in *t (deg: degenerate segment)
 __device__ __forceinline__ float r_seg(float px, float py, float ax, float ay, float bx, float by, float* t, bool* deg) {
@@ -356,13 +365,14 @@ __device__ __forceinline__ int r_wave_scan_max(int x) {              // values >
 // lo | hi << 16 with bit 15 = sign of the screen-space area (which side of the face looks at the camera)
 __device__ __forceinline__ unsigned r_face_rows_xyz(const RasterP& p, float ra, float rk, const float (&x)[3], const float (&y)[3],
                                                      const float (&z)[3], float* zmin_out) {
-  const float farea = r_edge(x[0], y[0], x[1], y[1], x[2], y[2]);
+  const float farea = r_edge(x[0], y[0], x[1], y[1], x[2], y[2]);     // its sign only orders the list (near class first)
   unsigned out = 1u;                                     // lo = 1 > hi = 0: skipped
-  // With kept lists (margin > 0) the two exclusions of the rasteriser -- a vertex behind the camera, a degenerate
-  // screen-space area -- are decided by k_raster_strip from the CURRENT coordinates (a sliver seen edge-on crosses the
-  // 1e-8 area threshold under the smallest motion): the list must hold every face that can be on screen within the
-  // margin.  Rebuilding every launch (margin 0) they can be dropped here, as in rounds 1-2.
-  const bool ok = p.margin > 0 || (fminf(z[0], fminf(z[1], z[2])) >= R_KEPS && !(farea <= R_KEPS && farea >= -R_KEPS));
+  // The two exclusions of the rasteriser -- a vertex behind the camera, a degenerate screen-space area -- are NOT applied
+  // here: k_raster_strip decides them from the current coordinates, in ONE place whether the lists are kept or fresh (a
+  // sliver seen edge-on crosses the 1e-8 area threshold under the smallest motion, and two compilations of the same
+  // a * b - c * d differ in the last bit: decided here for fresh lists and there for kept ones, 1-3 of 850 000 window
+  // pixels came out different, tests/test_full_size_gpu.py).  The list holds every face with a valid row range.
+  const bool ok = true;
   if (ok) {
     const float blur_d = sqrtf(BLUR_D);
     const float bymin = fminf(y[0], fminf(y[1], y[2])) - blur_d, bymax = fmaxf(y[0], fmaxf(y[1], y[2])) + blur_d;
@@ -380,43 +390,20 @@ __device__ __forceinline__ unsigned r_face_rows_xyz(const RasterP& p, float ra, 
   return out;
 }
 // ---------------------------------------------------------------------------------------------------------------------
-// Work lists without a serial pass.  Every body owns a fixed range of tile slots (s = b * cap + k), so the per-body sums
-// over a body's tiles keep their fixed order; the ORDER in which tiles (and the work units of the gradient kernel) are
-// processed is a schedule only -- any permutation yields the same keys -- and is kept as one append-only list per cost
-// class (longest-processing-time first: without it the last tiles to start were often among the most expensive and the
-// selection ended ~40 % later than its work divided by the CU count).  The lists are filled with atomics by the per-body
-// workgroups of k_raster_prepare; the consumers map a running index to (class, position) through a 64-entry prefix.
-// The counters are double-buffered by the parity of an epoch word: the workgroup that finishes the preparation LAST
-// (ticket) clears the other parity for the next launch and advances the epoch -- no memset node, no host state, so the
-// sequence replays from a captured graph.  (Rounds 1-2 built dense tables in ONE extra workgroup: prefix sums over the
-// bodies, then a counting sort of ~7000 tiles by cost -- 45 us of serial work that the face sort used to hide and the
-// kept face lists exposed.)
+// Work lists.  Every body owns a fixed range of tile slots (s = b * cap + k), so the per-body sums over a body's tiles
+// keep their fixed order and a body's workgroup can write its tiles without knowing about the others.  The ORDER in
+// which tiles (and the work units of the gradient kernel) are processed is a schedule only -- any permutation yields the
+// same keys: longest-processing-time first by cost class (without it the last tiles to start were often among the most
+// expensive and the selection ended ~40 % later than its work divided by the CU count).  The dense, ordered lists are
+// put together by whichever workgroup of k_raster_prepare finishes LAST (a ticket), with all its threads:
+// prefix sum of the window sizes (where a body's keys live), counting sort of the tiles by the classes their owners
+// computed, the gradient units.  (Rounds 1-2 did this in one extra workgroup that also evaluated the cost classes -- a
+// chain of dependent loads per tile, 45 us of serial work that the face sort used to hide and the kept face lists
+// exposed; a first version of this round appended to per-class lists with atomics from every workgroup: four
+// same-address round trips on every workgroup's tail, 30 us slower than the serial pass it replaced.)
 #define R_NCLS 64            // cost classes of the tiles (0 = most expensive)
 #define R_NGCLS 33           // gradient work units: class 0 = full units, 1..32 = partial units by decreasing size
-struct RLists {
-  int par;                   // parity the consumers of this launch read
-  int total;
-  int pre[R_NCLS + 1];
-};
 __device__ __forceinline__ int r_cap(const RasterP& p) { return p.max_strips / p.B; }
-// (to be called by all threads of a workgroup) tiles of the launch that just prepared: LDS prefix over the classes
-__device__ __forceinline__ void r_lists_load(const RasterP& p, int* sh_pre /*[R_NCLS+1]*/, const int* counts, int ncls, int cap_total) {
-  if ((int)threadIdx.x == 0) {
-    const int par = (int)((p.ctl[0] - 1u) & 1u);
-    int a = 0;
-    for (int c = 0; c < ncls; ++c) {
-      sh_pre[c] = a;
-      a += min(max(counts[par * ncls + c], 0), cap_total);
-    }
-    sh_pre[ncls] = a;
-  }
-  __syncthreads();
-}
-__device__ __forceinline__ int r_list_class(const int* sh_pre, int ncls, int i) {
-  int c = 0;
-  while (c + 1 < ncls && sh_pre[c + 1] <= i) ++c;          // <= 64 LDS reads per tile; a tile is thousands of cycles
-  return c;
-}
 
 // cost class of a tile from the body's face lists: ~7 ns per candidate face and ~76 ns per window pixel (measured, C3)
 __device__ __forceinline__ int r_tile_class(const RasterP& p, const int* rs, int mh, int sy0, int nrows, int ncols) {
@@ -545,6 +532,118 @@ __device__ __forceinline__ void r_face_sort(const RasterP& p, int b, int* hist /
   __syncthreads();             // rs / maxh of this body are read by the tile classes below (same workgroup: L2-coherent stores + barrier)
 }
 
+// k_raster_lists (ONE workgroup of NT threads, its own launch behind k_raster_prepare): dense work lists from the per-body
+// tables.  (Measured on the way, MI355X: doing this in the workgroup of k_raster_prepare that finishes last -- a ticket
+// behind __threadfence() -- cost 14 us for the fence + ticket of 800 workgroups and 26 us for this function reading the
+// other workgroups' tables with device-scope loads: the eight XCDs have their own L2s, so device-scope ordering inside a
+// kernel means write-backs and L2 bypasses; a kernel boundary is cheaper than that.)
+#define R_FCLS 16            // tile classes of a body kept in registers between the histogram and the placement
+#define RLISTS 1024
+template <int NT>
+__device__ __forceinline__ void r_finalize_lists(const RasterP& p) {
+  __shared__ long long f_wave[NT / 64];
+  __shared__ long long f_carry;
+  __shared__ int f_hist[R_NCLS], f_cur[R_NCLS], f_ghist[64], f_gcur[64];
+  __shared__ int f_stale;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cap = r_cap(p);
+  if (tid == 0) { f_carry = 0; f_stale = 0; }
+  if (tid < R_NCLS) { f_hist[tid] = 0; f_ghist[tid] = 0; }
+  __syncthreads();
+  auto unit_class = [&](int rem) { return 1 + (31 - min(31, rem * 32 / RG_UNIT)); };
+  const int nchunk = (p.B + NT - 1) / NT;
+  // per-thread body of a chunk: window size, tile count, the first R_FCLS tile classes (all loads issued together)
+  int ns = 0, cls[R_FCLS];
+  long long v = 0;
+  auto load_body = [&](int b) {
+    int ww = 0, wh = 0, st = 0;
+    ns = 0;
+    if (b < p.B) { ww = p.win[b * 4 + 2]; wh = p.win[b * 4 + 3]; ns = p.body_ns[b]; st = p.stale[b]; }
+#pragma unroll
+    for (int k = 0; k < R_FCLS; ++k) cls[k] = (b < p.B && k < ns) ? p.strip_cls[(size_t)b * cap + k] : 0;
+    v = (ww > 0 && wh > 0) ? (long long)ww * wh : 0ll;
+    return st;
+  };
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int b = ch * NT + tid;
+    const int st = load_body(b);
+    // ---- where a body's keys live: exclusive prefix of the window sizes in body order (wave scan + wave totals) ----------
+    long long incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const long long u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    if (lane == 63) f_wave[wave] = incl;
+    __syncthreads();
+    long long before = f_carry;
+    for (int w = 0; w < wave; ++w) before += f_wave[w];
+    if (b < p.B) p.body_koff[b] = before + incl - v;
+    // ---- class histograms ----------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < R_FCLS; ++k)
+      if (k < ns) atomicAdd(&f_hist[cls[k]], 1);
+    for (int k = R_FCLS; k < ns; ++k) atomicAdd(&f_hist[p.strip_cls[(size_t)b * cap + k]], 1);
+    const long long nfull = v / RG_UNIT;
+    const int rem = (int)(v % RG_UNIT);
+    if (nfull) atomicAdd(&f_ghist[0], (int)min(nfull, (long long)p.max_units));
+    if (rem) atomicAdd(&f_ghist[unit_class(rem)], 1);
+    if (st) atomicAdd(&f_stale, 1);
+    __syncthreads();
+    if (tid == 0) {
+      long long a = f_carry;
+      for (int w = 0; w < NT / 64; ++w) a += f_wave[w];
+      f_carry = a;
+    }
+    __syncthreads();
+  }
+  // ---- class offsets: exclusive scans of the two histograms by the first two waves --------------------------------------
+  if (wave < 2) {
+    int* hist = wave == 0 ? f_hist : f_ghist;
+    int* cur = wave == 0 ? f_cur : f_gcur;
+    const int h = hist[lane];
+    const int incl = mh_wave_scan_add(h);
+    cur[lane] = incl - h;
+    if (lane == 63) {
+      if (wave == 0) {
+        p.total[0] = min(incl, p.max_strips);
+        p.sort_count[0] += (unsigned long long)p.B;
+        p.sort_count[1] += (unsigned long long)f_stale;
+      } else {
+        p.gunit_total[0] = min(incl, p.max_units);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- placement (up to NT bodies: still in registers) ---------------------------------------------------------------------
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int b = ch * NT + tid;
+    if (nchunk > 1) load_body(b);
+    if (b >= p.B) continue;
+#pragma unroll
+    for (int k = 0; k < R_FCLS; ++k)
+      if (k < ns) {
+        const int pos = atomicAdd(&f_cur[cls[k]], 1);
+        if (pos < p.max_strips) p.strip_order[pos] = b * cap + k;
+      }
+    for (int k = R_FCLS; k < ns; ++k) {
+      const int pos = atomicAdd(&f_cur[p.strip_cls[(size_t)b * cap + k]], 1);
+      if (pos < p.max_strips) p.strip_order[pos] = b * cap + k;
+    }
+    const long long nfull = v / RG_UNIT;
+    const int rem = (int)(v % RG_UNIT);
+    if (nfull) {
+      const int n = (int)min(nfull, (long long)p.max_units);
+      const int pos = atomicAdd(&f_gcur[0], n);
+      for (int k = 0; k < n; ++k)
+        if (pos + k < p.max_units) p.gunit_list[pos + k] = ((unsigned long long)(unsigned)b << 32) | (unsigned)k;
+    }
+    if (rem) {
+      const int pos = atomicAdd(&f_gcur[unit_class(rem)], 1);
+      if (pos < p.max_units) p.gunit_list[pos] = ((unsigned long long)(unsigned)b << 32) | (unsigned)nfull;
+    }
+  }
+}
+
 // One workgroup per body: NDC projection of the vertices (kept in HBM, 12 B per vertex) + screen window, how far the
 // vertices have moved since the body's face lists were sorted, the sort itself when they moved too far (temporal
 // coherence: the optimiser moves a body by a small fraction of a pixel per cycle; the lists stay a SUPERSET of every
@@ -552,16 +651,13 @@ __device__ __forceinline__ void r_face_sort(const RasterP& p, int b, int* hist /
 // decides every face from the current coordinates, so the keys are bit-identical to those of a fresh sort), and the
 // body's tiles and gradient work units appended to the cost-class lists.
 #ifndef RPREP
-#define RPREP 1024
+#define RPREP 512
 #endif
 __global__ __launch_bounds__(RPREP) void k_raster_prepare(RasterP p) {
   extern __shared__ int hist[];                     // [2][H + 1] of the sort
   __shared__ float sbb[RPREP / 64][4];
   __shared__ int s_win[4];
-  __shared__ long long s_koff;
   const int b = blockIdx.x, tid = threadIdx.x;
-  const unsigned epoch = p.ctl[0];                  // constant while this kernel runs: advanced by its last workgroup
-  const int par = (int)(epoch & 1u);
   const float* vb = p.verts + (size_t)b * p.V * 3;
   // extremes in NDC; the (monotonically decreasing) NDC -> pixel map is applied once to the four results
   float mnx = 1e30f, mny = 1e30f, mxx = -1e30f, mxy = -1e30f;
@@ -593,8 +689,6 @@ __global__ __launch_bounds__(RPREP) void k_raster_prepare(RasterP p) {
   }
   __syncthreads();
   if (tid == 0) {
-    atomicAdd(&p.sort_count[0], 1ull);
-    if (any_moved) atomicAdd(&p.sort_count[1], 1ull);
     for (int w = 1; w < RPREP / 64; ++w) {
       mnx = fminf(mnx, sbb[w][0]); mny = fminf(mny, sbb[w][1]);
       mxx = fmaxf(mxx, sbb[w][2]); mxy = fmaxf(mxy, sbb[w][3]);
@@ -617,18 +711,15 @@ __global__ __launch_bounds__(RPREP) void k_raster_prepare(RasterP p) {
     p.win[b * 4 + 3] = wh;
     if (ww <= 0 || wh <= 0) ww = wh = 0;
     s_win[0] = x0; s_win[1] = y0; s_win[2] = ww; s_win[3] = wh;
-    // the body's window of selection keys: dense in gkeys, in whatever order the bodies get here (only an address)
-    s_koff = (long long)atomicAdd((unsigned long long*)&p.px_total[par], (unsigned long long)((long long)ww * wh));
-    p.body_koff[b] = s_koff;
   }
   if (p.margin == 0 || any_moved) r_face_sort<RPREP>(p, b, hist);       // (ends with a barrier)
   else __syncthreads();
-  // ---- tiles of the window -> the cost-class lists ------------------------------------------------------------------
+  // ---- tiles of the window: geometry and cost class into the body's own slots -------------------------------------------
   const int x0 = s_win[0], y0 = s_win[1], ww = s_win[2], wh = s_win[3];
   int tw = 1, th = 1, ncol = 0, nrow = 0;
   if (ww > 0) r_tiling(ww, wh, &tw, &th, &ncol, &nrow);
   const int cap = r_cap(p), ns = min(ncol * nrow, cap), first = b * cap;
-  if (tid == 0) { p.body_first[b] = first; p.body_ns[b] = ns; }
+  if (tid == 0) { p.body_first[b] = first; p.body_ns[b] = ns; p.stale[b] = any_moved; }
   const int* rs = p.row_start + (size_t)b * (2 * (p.H + 1) + 1);
   const int mh = p.maxh[b];
   for (int k = tid; k < ns; k += RPREP) {
@@ -637,35 +728,11 @@ __global__ __launch_bounds__(RPREP) void k_raster_prepare(RasterP p) {
     p.strip_body[s] = b;
     p.strip_row0[s] = r0; p.strip_rows[s] = nr;
     p.strip_col0[s] = c0; p.strip_cols[s] = nc;
-    const int c = r_tile_class(p, rs, mh, r0, nr, nc);
-    const int pos = atomicAdd(&p.cls_count[par * R_NCLS + c], 1);
-    if (pos < p.max_strips) p.cls_list[(size_t)c * p.max_strips + pos] = s;
-  }
-  // ---- work units of the gradient kernel: the window in pieces of RG_UNIT pixels; the full pieces first so that the long
-  // units start early, the partial ones by decreasing size behind them (the per-body version finished 2x later than its
-  // work divided by the CU count: the largest bodies happened to start last)
-  const long long npx = (long long)ww * wh;
-  const int nfull = (int)(npx / RG_UNIT), rem = (int)(npx % RG_UNIT);
-  for (int k = tid; k < nfull + (rem ? 1 : 0); k += RPREP) {
-    const int c = k < nfull ? 0 : 1 + (31 - min(31, rem * 32 / RG_UNIT));
-    const int pos = atomicAdd(&p.gcls_count[par * R_NGCLS + c], 1);
-    if (pos < p.max_units) p.gcls_list[(size_t)c * p.max_units + pos] = ((unsigned long long)(unsigned)b << 32) | (unsigned)k;
-  }
-  // ---- ticket: the last workgroup clears the other parity for the next launch and advances the epoch ------------------
-  __syncthreads();
-  if (tid == 0) {
-    __threadfence();
-    const unsigned t = atomicAdd(&p.ctl[1], 1u);
-    if (t == (unsigned)p.B - 1u) {
-      for (int c = 0; c < R_NCLS; ++c) p.cls_count[(par ^ 1) * R_NCLS + c] = 0;
-      for (int c = 0; c < R_NGCLS; ++c) p.gcls_count[(par ^ 1) * R_NGCLS + c] = 0;
-      p.px_total[par ^ 1] = 0;
-      p.ctl[1] = 0u;
-      __threadfence();
-      p.ctl[0] = epoch + 1u;
-    }
+    p.strip_cls[s] = r_tile_class(p, rs, mh, r0, nr, nc);
   }
 }
+
+__global__ __launch_bounds__(RLISTS) void k_raster_lists(RasterP p) { r_finalize_lists<RLISTS>(p); }
 
 // depth-term sums of one tile straight from its LDS key window (optimizer.py:432-442): only the nearest key of a pixel is
 // needed -- no face gathers -- so this rides in the epilogue of k_raster_strip; the silhouette sum needs alpha and is taken
@@ -731,9 +798,7 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = p.H, W = p.W;
   const float blur_d = sqrtf(BLUR_D);
-  __shared__ int s_pre[R_NCLS + 1];
-  r_lists_load(p, s_pre, p.cls_count, R_NCLS, p.max_strips);
-  const int total = s_pre[R_NCLS];
+  const int total = p.total[0];
   const float rx = W > H ? 2.f * (float)W / (float)H : 2.f, ry = H > W ? 2.f * (float)H / (float)W : 2.f;
   const float kx = (float)W / rx, ky = (float)H / ry;      // pixels per NDC unit (approximate index only)
   // wave-private staging.  __builtin_amdgcn_wave_barrier() is the only ordering needed: it keeps the compiler from
@@ -746,8 +811,7 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
   int* mark = wMark[wave];
   unsigned short* pl = wPl[wave];
   for (int si = blockIdx.x; si < total; si += gridDim.x) {
-    const int cls_ = r_list_class(s_pre, R_NCLS, si);
-    const int s = p.cls_list[(size_t)cls_ * p.max_strips + (si - s_pre[cls_])];
+    const int s = p.strip_order[si];
     const int b = p.strip_body[s];
     const int x0 = p.strip_col0[s], tw = p.strip_cols[s], x1 = x0 + tw - 1;
     const int sy0 = p.strip_row0[s], nrows = p.strip_rows[s], sy1 = sy0 + nrows - 1;
@@ -814,11 +878,10 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
           }
           cnt = max(0, xb - xa + 1) * max(0, yb - ya + 1);
           const float farea = r_edge(ca[6], ca[7], ca[0], ca[1], ca[3], ca[4]);
-          if (p.margin > 0) {
-            // the rasteriser's exclusions, from the current coordinates (with kept lists the sort does not apply them):
-            // a vertex behind the camera, a degenerate screen-space area (the edge function is antisymmetric:
-            // edge(v2; v0, v1) = edge(v0; v1, v2) up to the rounding of the products, same test as r_face_rows_xyz)
-            const float fa = r_edge(ca[0], ca[1], ca[3], ca[4], ca[6], ca[7]);
+          {
+            // the rasteriser's exclusions (RasterizeMeshesNaive: zmin < kEpsilon, |face area| <= kEpsilon with
+            // area = edge(v0; v1, v2)), from the current coordinates, unfused like the CPU reference computes them
+            const float fa = r_edge_exact(ca[0], ca[1], ca[3], ca[4], ca[6], ca[7]);
             if (!(fminf(ca[2], fminf(ca[5], ca[8])) >= R_KEPS) || (fa <= R_KEPS && fa >= -R_KEPS)) cnt = 0;
           }
           if (cnt > 0) {
@@ -990,12 +1053,9 @@ __global__ __launch_bounds__(RB) void k_raster_sums(RasterP p) {
   __shared__ float sh[RB / 64];
   const int tid = threadIdx.x;
   const int H = p.H, W = p.W, P = H * W;
-  __shared__ int s_pre[R_NCLS + 1];
-  r_lists_load(p, s_pre, p.cls_count, R_NCLS, p.max_strips);
-  const int total = s_pre[R_NCLS];
+  const int total = p.total[0];
   for (int si = blockIdx.x; si < total; si += gridDim.x) {
-    const int cls_ = r_list_class(s_pre, R_NCLS, si);
-    const int s = p.cls_list[(size_t)cls_ * p.max_strips + (si - s_pre[cls_])];
+    const int s = p.strip_order[si];
     const int b = p.strip_body[s], t = b / p.N, n = b % p.N;
     const int x0 = p.strip_col0[s], tw = p.strip_cols[s];
     const int sy0 = p.strip_row0[s], npx = p.strip_rows[s] * tw;
@@ -1083,15 +1143,18 @@ __global__ void k_raster_body_out(RasterP p) {
 //   from_partials == 0 (values only): k_raster_body_out has done that from k_raster_sums' totals;
 //   then the chain of the depth-range leaves (optimizer.py:683-688: min_z = softplus(zmin), max_z = min_z.detach() + 1 +
 //   softplus(zmax)) and, when asked for, the two loss sums of the log row.
-__global__ __launch_bounds__(256) void k_raster_finish(RasterP p, int T, int from_partials, const float* zmin_lin, const float* zmax_lin,
-                                                       float* gzmin, float* gzmax, float* log_depth, float* log_sil) {
-  __shared__ float sh[256 / 64];
-  const int N = p.N;
+#define RFIN 1024
+__global__ __launch_bounds__(RFIN) void k_raster_finish(RasterP p, int T, int from_partials, const float* zmin_lin, const float* zmax_lin,
+                                                        float* gzmin, float* gzmax, float* log_depth, float* log_sil) {
+  __shared__ float sh[RFIN / 64];
+  __shared__ float s_g0[RFIN], s_g1[RFIN];
+  const int N = p.N, tid = threadIdx.x;
+  const int fpc = max(1, RFIN / N);              // frames per pass: thread = body, then thread = frame
   float ld = 0.f, ls = 0.f;
-  for (int t = threadIdx.x; t < T; t += 256) {
+  for (int t0 = 0; t0 < T; t0 += fpc) {
+    const int b = t0 * N + tid;
     float g0 = 0.f, g1 = 0.f;
-    for (int n = 0; n < N; ++n) {
-      const int b = t * N + n;
+    if (tid < fpc * N && b < p.B) {
       if (from_partials) {
         float S[6];
         r_body_sums(p, b, S);
@@ -1099,30 +1162,36 @@ __global__ __launch_bounds__(256) void k_raster_finish(RasterP p, int T, int fro
         const float diff = S[0] / cnt - S[1] / cnt;                                                  // losses.py:24-27
         p.depth_body[b] = diff * diff;
         const float gB = p.coef_depth * (-2.f) * diff / cnt;
-        g0 += gB * S[3];                          // d/d(1/min_z) through the target disparity
-        g1 += gB * S[4];                          // d/d(1/max_z)
+        g0 = gB * S[3];                           // d/d(1/min_z) through the target disparity
+        g1 = gB * S[4];                           // d/d(1/max_z)
         p.sil_body[b] = p.sil_apply[b] * (p.sil_S[b] + p.sil_corr[b]) / (p.sil_D[b] + 1.f);        // losses.py:35-38
         p.sil_corr[b] = 0.f;
       } else {
-        g0 += p.dinv[(size_t)b * 2];
-        g1 += p.dinv[(size_t)b * 2 + 1];
+        g0 = p.dinv[(size_t)b * 2];
+        g1 = p.dinv[(size_t)b * 2 + 1];
         p.sil_corr[b] = 0.f;                      // (gradients AND images in one call: k_raster_grads ran after k_raster_body_out)
       }
       ld += p.depth_body[b];
       ls += p.sil_body[b];
     }
-    if (gzmin) {
+    s_g0[tid] = g0; s_g1[tid] = g1;
+    __syncthreads();
+    const int t = t0 + tid;
+    if (gzmin && tid < fpc && t < T) {
+      float a0 = 0.f, a1 = 0.f;
+      for (int n = 0; n < N; ++n) { a0 += s_g0[tid * N + n]; a1 += s_g1[tid * N + n]; }
       const float e0 = expf(zmin_lin[t]), e1 = expf(zmax_lin[t]);
       const float min_z = logf(1.f + e0);
       const float max_z = min_z + 1.f + logf(1.f + e1);
-      gzmin[t] += g0 * (-1.f / (min_z * min_z)) * (e0 / (1.f + e0));
-      gzmax[t] += g1 * (-1.f / (max_z * max_z)) * (e1 / (1.f + e1));
+      gzmin[t] += a0 * (-1.f / (min_z * min_z)) * (e0 / (1.f + e0));
+      gzmax[t] += a1 * (-1.f / (max_z * max_z)) * (e1 / (1.f + e1));
     }
+    __syncthreads();
   }
   if (log_depth || log_sil) {
     ld = r_block_sum(ld, sh);
     ls = r_block_sum(ls, sh);
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
       if (log_depth) *log_depth = ld;
       if (log_sil) *log_sil = ls;
     }
@@ -1341,12 +1410,9 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
   const bool use_tab = TAB;
   int* plist = (int*)(gtab + (use_tab ? p.V * 3 : 0));
   int* s_n = plist + RG_LIST;
-  __shared__ int s_pre[R_NGCLS + 1];
-  r_lists_load(p, s_pre, p.gcls_count, R_NGCLS, p.max_units);
-  const int nunits = s_pre[R_NGCLS];
+  const int nunits = p.gunit_total[0];
   for (int u = blockIdx.x; u < nunits; u += gridDim.x) {
-    const int ucls = r_list_class(s_pre, R_NGCLS, u);
-    const unsigned long long ue = p.gcls_list[(size_t)ucls * p.max_units + (u - s_pre[ucls])];
+    const unsigned long long ue = p.gunit_list[u];
     const int b = (int)(ue >> 32), up0 = (int)(ue & 0xffffffffu) * RG_UNIT;
     const int t = b / p.N, n = b % p.N;
     const int x0 = p.win[b * 4], ww = p.win[b * 4 + 2], y0 = p.win[b * 4 + 1], wh = p.win[b * 4 + 3];
@@ -1584,13 +1650,14 @@ static size_t r_carve(RasterP& p, void* ws) {
   p.rowb = (float*)c; c += r_align(B * V * 4);
   p.margin = raster_sort_margin();
   p.max_units = (int)r_max_units(B, H, W);
-  p.cls_list = (int*)c; c += r_align((size_t)R_NCLS * ms * 4);
-  p.gcls_list = (unsigned long long*)c; c += r_align((size_t)R_NGCLS * p.max_units * 8);
+  p.strip_cls = (int*)c; c += r_align(ms * 4);
+  p.strip_order = (int*)c; c += r_align(ms * 4);
+  p.gunit_list = (unsigned long long*)c; c += r_align((size_t)p.max_units * 8);
+  p.stale = (int*)c; c += r_align(B * 4);
+  p.total = (int*)c; c += r_align(4);
+  p.gunit_total = (int*)c; c += r_align(4);
   // control words: everything mh_raster_workspace_init clears, contiguous
   p.ctl = (unsigned*)c; c += r_align(16);
-  p.cls_count = (int*)c; c += r_align(2 * R_NCLS * 4);
-  p.gcls_count = (int*)c; c += r_align(2 * R_NGCLS * 4);
-  p.px_total = (long long*)c; c += r_align(16);
   p.sort_count = (unsigned long long*)c; c += r_align(16);
   p.sort_tag = (unsigned long long*)c; c += r_align(B * 8);
   p.sil_corr = (float*)c; c += r_align(B * 4);
@@ -1607,7 +1674,7 @@ extern "C" size_t mh_raster_workspace_bytes(int T, int N, int V, int F, int H, i
 }
 
 // A workspace must be initialised ONCE before its first launch (and again if its bytes were overwritten): the control
-// words -- epoch / ticket of the work lists, list counters, face-list tags, the silhouette accumulator -- are cleared;
+// words -- the ticket of the preparation kernel, the re-sort counters, face-list tags, the silhouette accumulator -- are cleared;
 // everything else is rebuilt by the launches themselves.  Stream-ordered.
 extern "C" int mh_raster_workspace_init(int T, int N, int V, int F, int H, int W, void* ws, void* stream) {
   MH_CHECK(ws, "null argument");
@@ -1630,6 +1697,20 @@ extern "C" int mh_raster_workspace_offsets(int T, int N, int V, int F, int H, in
   out[0] = (size_t)((char*)p.win - (char*)nullptr);
   out[1] = (size_t)((char*)p.body_koff - (char*)nullptr);
   out[2] = (size_t)((char*)p.gkeys - (char*)nullptr);
+  return MH_OK;
+}
+
+// (developer aid, not in the public header) more offsets: ndc, frows, fsort, row_start, maxh, rowb
+extern "C" int mh_raster_debug_offsets(int T, int N, int V, int F, int H, int W, size_t* out /*[6]*/) {
+  RasterP p;
+  p.B = T * N; p.N = N; p.V = V; p.F = F; p.H = H; p.W = W;
+  r_carve(p, nullptr);
+  out[0] = (size_t)((char*)p.ndc - (char*)nullptr);
+  out[1] = (size_t)((char*)p.frows - (char*)nullptr);
+  out[2] = (size_t)((char*)p.fsort - (char*)nullptr);
+  out[3] = (size_t)((char*)p.row_start - (char*)nullptr);
+  out[4] = (size_t)((char*)p.maxh - (char*)nullptr);
+  out[5] = (size_t)((char*)p.rowb - (char*)nullptr);
   return MH_OK;
 }
 
@@ -1695,6 +1776,8 @@ static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const flo
   if (alpha_out) MH_HIP(hipMemsetAsync(alpha_out, 0, (size_t)p.B * H * W * sizeof(float), st));
   hipLaunchKernelGGL(k_raster_prepare, dim3(p.B), dim3(RPREP), (size_t)2 * (H + 1) * sizeof(int), st, p);
   MH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_raster_lists, dim3(1), dim3(RLISTS), 0, st, p);
+  MH_LAUNCH_CHECK();
   // persistent grids over the device-side work list (the strip count is only known on the device)
   const int grid = 256 * 3 * 4;
   mh_prof_mark(MH_PROF_RASTER_STRIP, 0, st);
@@ -1737,7 +1820,7 @@ static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const flo
   if (gverts || (gzmin && gzmax) || log_depth || log_sil) {
     // values-only launches with images requested went through k_raster_body_out (sums of k_raster_sums): then only the chain
     const int from_partials = (gverts && !zbuf_out && !alpha_out) ? 1 : 0;
-    hipLaunchKernelGGL(k_raster_finish, dim3(1), dim3(256), 0, st, p, T, from_partials, zmin_lin, zmax_lin,
+    hipLaunchKernelGGL(k_raster_finish, dim3(1), dim3(RFIN), 0, st, p, T, from_partials, zmin_lin, zmax_lin,
                        (gzmin && gzmax) ? gzmin : (float*)nullptr, gzmax, log_depth, log_sil);
     MH_LAUNCH_CHECK();
   }

@@ -319,6 +319,7 @@ __global__ __launch_bounds__(256, 2) void k_skin_fwd(SkinFwdP p) {
 
 struct SkinFwd16P {
   int B, G, V, VP, nw;
+  int tpb;                 // vertex tiles per workgroup (<= FWD16_WAVES * FWD16_TPW): chosen by the host for an even load
   float unscale;           // 2^-(feature shift + basis shift)
   const uint16_t* F16;
   const float* A;
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, 2 * FWD16_WAVES / 4) void k_skin_
   const int li = lane & 31, lh = lane >> 5;
   const int g = blockIdx.y;
   const int ntiles = p.VP / 32;
-  if ((int)blockIdx.x * FWD16_WAVES * FWD16_TPW >= ntiles) return;
+  if ((int)blockIdx.x * p.tpb >= ntiles) return;
   {
     const f32x4* srcF = (const f32x4*)(p.F16 + (size_t)g * (MH_FS / 16) * 2 * 64 * 8);
     for (int i = threadIdx.x; i < FWD16_SF_BYTES / 16; i += FWD16_WAVES * 64) ((f32x4*)sF)[i] = srcF[i];
@@ -378,8 +379,10 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, 2 * FWD16_WAVES / 4) void k_skin_
     }
   }
   __syncthreads();
+  // tile k of the workgroup goes to wave k % WAVES: with tpb = 11 three waves take two tiles, five take one
   for (int rep_ = 0; rep_ < FWD16_TPW; ++rep_) {
-  const int tile = (blockIdx.x * FWD16_WAVES + wave) * FWD16_TPW + rep_;
+  if (wave + rep_ * FWD16_WAVES >= p.tpb) return;
+  const int tile = blockIdx.x * p.tpb + wave + rep_ * FWD16_WAVES;
   if (tile >= ntiles) return;
   const int v = tile * 32 + li;
   // this lane's vertex constants: issued before the matrix phase, consumed after it
@@ -584,7 +587,16 @@ static int lbs_forward_impl(const mh_model* m, int B, int NB, const float* betas
     if (mh_first_on_device(attr16[ki]))
       MH_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     mh_prof_mark(MH_PROF_SKIN_FWD, 0, st);
-    hipLaunchKernelGGL(kern, dim3(((m->VP / 32 + FWD16_WAVES * FWD16_TPW - 1) / (FWD16_WAVES * FWD16_TPW) + 7) / 8 * 8, G), dim3(FWD16_WAVES * 64), lds, st, sp);
+    // Two workgroups fit on a CU (66 KB of LDS each): aim at 2 x 256 of them, all resident at once and every CU with the same
+    // number of vertex tiles.  (Rounds 1-2 gave every workgroup 16 tiles: 350 workgroups at C3, so 94 CUs carried two of
+    // them and 162 one -- the kernel took as long as the CUs with 32 tiles; with 11 tiles per workgroup every CU has ~22.)
+    const int ntiles = m->VP / 32;
+    int bpg = std::max(1, (2 * 256) / G);
+    int tpb = std::min(FWD16_WAVES * FWD16_TPW, (ntiles + bpg - 1) / bpg);
+    if (const char* e = getenv("MHHIP_FWD_TPB")) tpb = std::max(1, std::min(FWD16_WAVES * FWD16_TPW, atoi(e)));
+    sp.tpb = tpb;
+    bpg = (ntiles + tpb - 1) / tpb;
+    hipLaunchKernelGGL(kern, dim3(bpg, G), dim3(FWD16_WAVES * 64), lds, st, sp);
     MH_LAUNCH_CHECK();
     mh_prof_mark(MH_PROF_SKIN_FWD, 1, st);
     return MH_OK;

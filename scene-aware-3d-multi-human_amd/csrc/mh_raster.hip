@@ -73,7 +73,7 @@ struct RasterP {
   float* ndc;                // [B][V][3] projected vertices (NDC x, y, view z)
   unsigned* frows;           // [B][F] conservative pixel-row range of every face: lo | hi << 16 (lo > hi: skip)
   unsigned* fsort;           // [B][F] faces ordered by their first row: hi << 20 | face
-  int* row_start;            // [B][2][H+1] (+1): per class (near class first), first entry of fsort with lo >= row
+  int* row_start;            // [B][3][H+1] (+1): per list (near short, far short, tall), first entry of fsort with lo >= row
   int* maxh;                 // [B] tallest face (rows) of the body
   // work lists (put together by the last workgroup of k_raster_prepare)
   int max_units;
@@ -401,6 +401,7 @@ __device__ __forceinline__ unsigned r_face_rows_xyz(const RasterP& p, float ra, 
 // chain of dependent loads per tile, 45 us of serial work that the face sort used to hide and the kept face lists
 // exposed; a first version of this round appended to per-class lists with atomics from every workgroup: four
 // same-address round trips on every workgroup's tail, 30 us slower than the serial pass it replaced.)
+#define R_SHORT 2            // faces of up to R_SHORT + 1 rows go to the two short lists, taller ones to the third
 #define R_NCLS 64            // cost classes of the tiles (0 = most expensive)
 #define R_NGCLS 33           // gradient work units: class 0 = full units, 1..32 = partial units by decreasing size
 __device__ __forceinline__ int r_cap(const RasterP& p) { return p.max_strips / p.B; }
@@ -411,8 +412,8 @@ __device__ __forceinline__ int r_tile_class(const RasterP& p, const int* rs, int
   const long long cmax = (long long)p.F + 11ll * R_CAP + 1;
   const int sy1 = sy0 + nrows - 1;
   mh = min(max(mh, 0), H);
-  const int ra = max(0, sy0 - mh - p.margin), rb = min(sy1 + 1 + p.margin, H);
-  const long long n = (long long)(rs[rb] - rs[ra]) + (long long)(rs[H + 1 + rb] - rs[H + 1 + ra]);
+  const int ra = max(0, sy0 - R_SHORT - p.margin), rt = max(0, sy0 - mh - p.margin), rb = min(sy1 + 1 + p.margin, H);
+  const long long n = (long long)(rs[rb] - rs[ra]) + (long long)(rs[H + 1 + rb] - rs[H + 1 + ra]) + (long long)(rs[2 * (H + 1) + rb] - rs[2 * (H + 1) + rt]);
   const long long cost = min(max(n, 0ll), (long long)p.F) + 11ll * nrows * ncols;
   return R_NCLS - 1 - (int)min((long long)(R_NCLS - 1), max(0ll, cost * R_NCLS / cmax));
 }
@@ -424,7 +425,7 @@ __device__ __forceinline__ int r_tile_class(const RasterP& p, const int* rs, int
 // closed mesh: the ones looking at it) come first in fsort, so that a tile rasterises them first and the depth cull of
 // k_raster_strip then removes most of the far-side candidates.  row_start: [2][H+1] (+ total), class-major in that order.
 template <int NT>
-__device__ __forceinline__ void r_face_sort(const RasterP& p, int b, int* hist /*LDS [2][H+1]*/) {
+__device__ __forceinline__ void r_face_sort(const RasterP& p, int b, int* hist /*LDS [3][H+1]*/) {
   __shared__ int s_maxh, s_flip;
   __shared__ float s_z[2];
   __shared__ int s_n[2];
@@ -432,8 +433,8 @@ __device__ __forceinline__ void r_face_sort(const RasterP& p, int b, int* hist /
   const float* nb = p.ndc + (size_t)b * p.V * 3;
   unsigned* fr = p.frows + (size_t)b * p.F;
   unsigned* fs = p.fsort + (size_t)b * p.F;
-  int* rs = p.row_start + (size_t)b * (2 * HB + 1);
-  for (int i = tid; i < 2 * HB; i += NT) hist[i] = 0;
+  int* rs = p.row_start + (size_t)b * (3 * HB + 1);
+  for (int i = tid; i < 3 * HB; i += NT) hist[i] = 0;
   if (tid == 0) { s_maxh = 0; s_z[0] = s_z[1] = 0.f; s_n[0] = s_n[1] = 0; }
   __syncthreads();
   int mh = 0, n0 = 0, n1 = 0;
@@ -446,12 +447,16 @@ __device__ __forceinline__ void r_face_sort(const RasterP& p, int b, int* hist /
   } else if (tid == 0) {
     p.sort_tag[b] = 0ull;                  // lists without the margin's slack: never to be kept by a later launch
   }
+  // third list: the few TALL faces (more than R_SHORT rows: 5 % of them at C3, slivers and close-ups).  A tile must start
+  // reading a list `tallest face of the list` rows above its first row; one list for all faces made every tile wade through
+  // the faces of the nine rows above it (the mean tallest face) to find the handful that reach down -- 1.44x the entries
+  // that really overlap a tile, 1.13x with the tall ones in a list of their own
   auto tally = [&](unsigned r, float zm, bool live) {
-    const int lo = (int)(r & 0x7fffu), hi = (int)(r >> 16), cls = (int)((r >> 15) & 1u);
+    const int lo = (int)(r & 0x7fffu), hi = (int)(r >> 16), sg = (int)((r >> 15) & 1u);
     if (live && lo <= hi) {
-      atomicAdd(&hist[cls * HB + lo], 1);
+      atomicAdd(&hist[(hi - lo > R_SHORT ? 2 : sg) * HB + lo], 1);
       mh = max(mh, hi - lo);
-      if (cls) { z1 += zm; ++n1; } else { z0 += zm; ++n0; }
+      if (sg) { z1 += zm; ++n1; } else { z0 += zm; ++n0; }
     }
   };
   // The gathers of RFS_U faces are in flight together: the sort is bound by the chain index load -> vertex gather ->
@@ -503,24 +508,24 @@ __device__ __forceinline__ void r_face_sort(const RasterP& p, int b, int* hist /
   const int flip = s_flip;
   if (tid < 64) {                                   // exclusive scan of the (class order, row) histogram by one wave
     int carry = 0;
-    for (int base = 0; base < 2 * HB; base += 64) {
-      const int i = base + tid;                     // position in the output order
-      const int o = i / HB, rrow = i - o * HB;
-      const int bin = ((o ^ flip) & 1) * HB + rrow;
-      const int v = i < 2 * HB ? hist[bin] : 0;
+    for (int base = 0; base < 3 * HB; base += 64) {
+      const int i = base + tid;                     // position in the output order: near short, far short, tall
+      const int o = min(i / HB, 2), rrow = i - o * HB;
+      const int bin = (o < 2 ? ((o ^ flip) & 1) : 2) * HB + rrow;
+      const int v = i < 3 * HB ? hist[bin] : 0;
       const int incl = r_wave_scan_add(v);
-      if (i < 2 * HB) {
+      if (i < 3 * HB) {
         hist[bin] = carry + incl - v;
         rs[i] = carry + incl - v;
       }
       carry += __builtin_amdgcn_readlane(incl, 63);
     }
-    if (tid == 0) { p.maxh[b] = s_maxh; rs[2 * HB] = carry; }
+    if (tid == 0) { p.maxh[b] = s_maxh; rs[3 * HB] = carry; }
   }
   __syncthreads();
   auto place = [&](unsigned r, int f, bool live) {
-    const int lo = (int)(r & 0x7fffu), hi = (int)(r >> 16), cls = (int)((r >> 15) & 1u);
-    if (live && lo <= hi) fs[atomicAdd(&hist[cls * HB + lo], 1)] = ((unsigned)hi << 20) | (unsigned)f;
+    const int lo = (int)(r & 0x7fffu), hi = (int)(r >> 16), sg = (int)((r >> 15) & 1u);
+    if (live && lo <= hi) fs[atomicAdd(&hist[(hi - lo > R_SHORT ? 2 : sg) * HB + lo], 1)] = ((unsigned)hi << 20) | (unsigned)f;
   };
   for (int f0 = tid; f0 < p.F; f0 += RFS_V * NT) {        // the row words of RFS_V faces are fetched together
     unsigned r[RFS_V];
@@ -654,7 +659,7 @@ __device__ __forceinline__ void r_finalize_lists(const RasterP& p) {
 #define RPREP 512
 #endif
 __global__ __launch_bounds__(RPREP) void k_raster_prepare(RasterP p) {
-  extern __shared__ int hist[];                     // [2][H + 1] of the sort
+  extern __shared__ int hist[];                     // [3][H + 1] of the sort
   __shared__ float sbb[RPREP / 64][4];
   __shared__ int s_win[4];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -720,7 +725,7 @@ __global__ __launch_bounds__(RPREP) void k_raster_prepare(RasterP p) {
   if (ww > 0) r_tiling(ww, wh, &tw, &th, &ncol, &nrow);
   const int cap = r_cap(p), ns = min(ncol * nrow, cap), first = b * cap;
   if (tid == 0) { p.body_first[b] = first; p.body_ns[b] = ns; p.stale[b] = any_moved; }
-  const int* rs = p.row_start + (size_t)b * (2 * (p.H + 1) + 1);
+  const int* rs = p.row_start + (size_t)b * (3 * (p.H + 1) + 1);
   const int mh = p.maxh[b];
   for (int k = tid; k < ns; k += RPREP) {
     const int tr = k / ncol, tc = k - tr * ncol, s = first + k;
@@ -818,17 +823,19 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
     const int npx = nrows * tw;
     const float* nb = p.ndc + (size_t)b * p.V * 3;
     const unsigned* fs = p.fsort + (size_t)b * p.F;
-    const int* rs = p.row_start + (size_t)b * (2 * (H + 1) + 1);
+    const int* rs = p.row_start + (size_t)b * (3 * (H + 1) + 1);
     __syncthreads();
     for (int i = tid; i < npx * 5; i += RB) keys[i] = RS_EMPTY;
     for (int i = tid; i < tw; i += RB) sXf[i] = r_pix_to_ndc(W - 1 - (x0 + i), W, H);
     for (int i = tid; i < nrows; i += RB) sYf[i] = r_pix_to_ndc(H - 1 - (sy0 + i), H, W);
     // candidate faces: the near class of the rows first, then the far class (two contiguous ranges of fsort)
-    // kept lists: a face's first row may have moved by up to `margin` rows either way since the sort
-    const int ra_ = max(0, sy0 - p.maxh[b] - p.margin), rb_ = min(sy1 + 1 + p.margin, H);
+    // three contiguous ranges of fsort: near short faces, far short faces, tall faces.  Kept lists: a face's first row may
+    // have moved by up to `margin` rows either way since the sort
+    const int ra_ = max(0, sy0 - R_SHORT - p.margin), rt_ = max(0, sy0 - min(max(p.maxh[b], 0), H) - p.margin), rb_ = min(sy1 + 1 + p.margin, H);
     const int a0 = rs[ra_], na = rs[rb_] - a0, b0 = rs[H + 1 + ra_], nbk = rs[H + 1 + rb_] - b0;
-    const int i1 = na + nbk;
-    auto fs_at = [&](int j) { return fs[j < na ? a0 + j : b0 + (j - na)]; };
+    const int c0 = rs[2 * (H + 1) + rt_], nc = rs[2 * (H + 1) + rb_] - c0;
+    const int nab = na + nbk, i1 = nab + nc;
+    auto fs_at = [&](int j) { return fs[j < na ? a0 + j : (j < nab ? b0 + (j - na) : c0 + (j - nab))]; };
     __syncthreads();
     if (i1 > 0) {
       const int last = i1 - 1, stride = RW * 64;
@@ -1644,7 +1651,7 @@ static size_t r_carve(RasterP& p, void* ws) {
   p.ndc = (float*)c; c += r_align(B * V * 3 * 4);
   p.frows = (unsigned*)c; c += r_align(B * F * 4);
   p.fsort = (unsigned*)c; c += r_align(B * F * 4);
-  p.row_start = (int*)c; c += r_align(B * (size_t)(2 * (H + 1) + 1) * 4);
+  p.row_start = (int*)c; c += r_align(B * (size_t)(3 * (H + 1) + 1) * 4);
   p.maxh = (int*)c; c += r_align(B * 4);
   p.body_koff = (long long*)c; c += r_align(B * 8);
   p.rowb = (float*)c; c += r_align(B * V * 4);
@@ -1774,7 +1781,7 @@ static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const flo
     MH_LAUNCH_CHECK();
   }
   if (alpha_out) MH_HIP(hipMemsetAsync(alpha_out, 0, (size_t)p.B * H * W * sizeof(float), st));
-  hipLaunchKernelGGL(k_raster_prepare, dim3(p.B), dim3(RPREP), (size_t)2 * (H + 1) * sizeof(int), st, p);
+  hipLaunchKernelGGL(k_raster_prepare, dim3(p.B), dim3(RPREP), (size_t)3 * (H + 1) * sizeof(int), st, p);
   MH_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_raster_lists, dim3(1), dim3(RLISTS), 0, st, p);
   MH_LAUNCH_CHECK();

@@ -53,7 +53,7 @@ for c in range(40):
                 maxh = arr(r, 4, B_ * 4, torch.int32)[body]
                 rowb = arr(r, 5, B_ * V_ * 4, torch.float32).reshape(B_, V_)[body]
                 fs = arr(r, 2, B_ * F_ * 4, torch.int32).reshape(B_, F_)[body].view(np.uint32)
-                rs = arr(r, 3, B_ * (2 * (H + 1) + 1) * 4, torch.int32).reshape(B_, -1)[body]
+                rs = arr(r, 3, B_ * (3 * (H + 1) + 1) * 4, torch.int32).reshape(B_, -1)[body]
                 for f in (fk ^ ff):
                     v = faces[f]
                     y = ndc[v, 1]; rows_now = (H - 0.5 - 0.5 * H) - y * (H / 2.0)

@@ -101,7 +101,11 @@ int mh_lbs_forward(const mh_model* m, int B, int NB, const float* betas /*(NB,10
                    void* ws, void* stream);
 
 /* lbs(..., pose2rot=False) (smpl.py:490-491, 553-558): the 24 joint rotations are given as matrices
- * rotmats (B,24,3,3) instead of axis-angle vectors; forward only.                                             */
+ * rotmats (B,24,3,3) instead of axis-angle vectors.  mh_lbs_forward_ex: either input form, and v_posed kept for
+ * mh_lbs_backward_ex.                                                                                         */
+int mh_lbs_forward_ex(const mh_model* m, int B, int NB, const float* betas, const float* poses /*or NULL*/,
+                      const float* rotmats /*or NULL*/, const float* xscale, const float* transl, float* verts,
+                      float* vposed /*or NULL*/, float* posed_joints /*or NULL*/, void* ws, void* stream);
 int mh_lbs_forward_rotmats(const mh_model* m, int B, int NB, const float* betas, const float* rotmats /*(B,24,3,3)*/,
                            const float* xscale, const float* transl, float* verts, float* posed_joints /*or NULL*/,
                            void* ws, void* stream);
@@ -134,6 +138,18 @@ int mh_lbs_backward(const mh_model* m, int B, int NB, const float* betas, const 
                     const float* xscale, const float* transl, const float* vposed,
                     const float* gverts, const float* gjoints, float* gposes, float* gtransl,
                     float* gbetas, float* gxscale, void* ws, void* ws2, void* stream);
+/* The same with the inputs / outputs smpl.py's autograd also covers: exactly one of `poses` (axis-angle, gposes) and
+ * `rotmats` ((B,24,3,3) as given to mh_lbs_forward_rotmats -- lbs(pose2rot=False), smpl.py:541-558 -- with grotmats
+ * (B,24,9) +=); gposed (B,24,3) or NULL: dL/d(posed joints) = joints_smpl24 of SMPL.forward (smpl.py:362, 735). */
+int mh_lbs_backward_ex(const mh_model* m, int B, int NB, const float* betas, const float* poses, const float* rotmats,
+                       const float* vposed, const float* gverts, const float* gjoints, const float* gposed,
+                       float* gposes, float* grotmats, float* gtransl, float* gbetas, float* gxscale,
+                       void* ws, void* ws2, void* stream);
+/* adjoint of mh_joints_regress for any of the four regressors (smpl.py:367-386 under autograd; optimizer.py:41, 75, 695-696
+ * with another smpl_sparse_joints_key): gverts (B,V,3) += reg^T gjoints; gcorr (B,3) += (1 - row sums) gjoints (NULL
+ * when the joints were regressed without a translation correction).  Deterministic (no atomics). */
+int mh_joints_regress_backward(const mh_model* m, int which, int B, const float* gjoints /*(B,J,3)*/, int root_relative_to,
+                               float* gverts, float* gcorr, void* stream);
 
 /* ---- a11/a12: pinhole projection of the 17 key-points + masked 2D residual ------------------
  * (transforms.py:74-95, optimizer.py:364-368, 404-405, 414-420).

@@ -196,7 +196,7 @@ class SequenceOracle(object):
         vis = torch.tensor((pose2d[..., 2:] > joints_thr).astype(np.float32))
         gt = torch.tensor(pose2d[..., :2].astype(np.float32))
         with torch.no_grad():
-            j17 = lbs_oracle.smpl_forward(self.model, be, th)['joints_alphapose'].view(T, N, 17, 3)
+            j17 = lbs_oracle.smpl_forward(self.model, be, th)[getattr(self, 'joints_key', 'joints_alphapose')].view(T, N, 17, 3)
         m = torch.zeros_like(pT)
         v = torch.zeros_like(pT)
         lr = 0.5
@@ -267,7 +267,7 @@ class SequenceOracle(object):
         be = self.betas.expand(b, N, 10).reshape(-1, 10)
         out = lbs_oracle.smpl_forward(self.model, be, th)
         verts = out['verts'].view(b, N, -1, 3)
-        j17 = out['joints_alphapose'].view(b, N, 17, 3)
+        j17 = out[getattr(self, 'joints_key', 'joints_alphapose')].view(b, N, 17, 3)     # smpl_sparse_joints_key, optimizer.py:75, 695-696
         pT = self.poses_T[idx]
         verts_abs = scale * verts + pT
         ov = getattr(self, 'verts_value_override', None)

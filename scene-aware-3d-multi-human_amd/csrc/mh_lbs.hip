@@ -552,6 +552,13 @@ extern "C" int mh_lbs_forward_rotmats(const mh_model* m, int B, int NB, const fl
   return lbs_forward_impl(m, B, NB, betas, nullptr, rotmats, xscale, transl, verts, nullptr, posed_joints, ws, stream);
 }
 
+extern "C" int mh_lbs_forward_ex(const mh_model* m, int B, int NB, const float* betas, const float* poses, const float* rotmats,
+                                 const float* xscale, const float* transl, float* verts, float* vposed, float* posed_joints,
+                                 void* ws, void* stream) {
+  MH_CHECK((poses != nullptr) != (rotmats != nullptr), "exactly one of poses (axis-angle) and rotmats");
+  return lbs_forward_impl(m, B, NB, betas, poses, rotmats, xscale, transl, verts, vposed, posed_joints, ws, stream);
+}
+
 static int lbs_forward_impl(const mh_model* m, int B, int NB, const float* betas, const float* poses, const float* rotmats,
                             const float* xscale, const float* transl, float* verts, float* vposed, float* posed_joints,
                             void* ws, void* stream) {
@@ -637,13 +644,17 @@ __global__ __launch_bounds__(64) void k_joints_regress(int B, int V, int J, cons
       a1 = mh_wave_sum(a1);
       a2 = mh_wave_sum(a2);
       if (corr) {
-        const float c = 1.f - rowsum[j];
+        // the vertices carry the translation `corr` with weight rowsum (regressor rows need not sum to one): plain joints
+        // get the missing (1 - rowsum) t; root-relative joints are cleared of it (and get one t back below), so that
+        // the result is s (J_j - J_root) + t -- what the reference forms as scale * joints + poses_T (optimizer.py:701-703)
+        const float c = root >= 0 ? -rowsum[j] : 1.f - rowsum[j];
         a0 = fmaf(c, corr[(size_t)b * 3], a0);
         a1 = fmaf(c, corr[(size_t)b * 3 + 1], a1);
         a2 = fmaf(c, corr[(size_t)b * 3 + 2], a2);
       }
       if (pass == 0) {
         rx = a0; ry = a1; rz = a2;
+        if (corr) { rx -= corr[(size_t)b * 3]; ry -= corr[(size_t)b * 3 + 1]; rz -= corr[(size_t)b * 3 + 2]; }
         break;
       }
       if (lane == 0) {
@@ -666,6 +677,57 @@ extern "C" int mh_joints_regress(const mh_model* m, int which, int B, const floa
   MH_CHECK(B > 0, "B must be positive");
   hipLaunchKernelGGL(k_joints_regress, dim3(B), dim3(64), 0, (hipStream_t)stream, B, m->V, r.J, r.ptr, r.vidx, r.w,
                      r.rowsum, verts, corr, root_relative_to, joints);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+// adjoint of mh_joints_regress for ANY of the four regressors: gverts[b, v] += sum_j reg[j, v] g[b, j] (and the share of
+// the translation correction).  One wave per body walks the joints one after the other -- inside a joint's row the
+// vertices are distinct, so plain read-modify-writes in a fixed order, no atomics: deterministic.  (The fused 2D term
+// of the optimiser has this built into k_skinbwd16 for the AlphaPose regressor; this is the path of the other
+// smpl_sparse_joints_key values and of the overlay's autograd for joints_h36m17 / joints_mupots / j3d.)
+__global__ __launch_bounds__(64) void k_joints_regress_bwd(int B, int V, int J, const int* ptr, const int* vidx, const float* w,
+                                                           const float* rowsum, const float* gjoints, int root, float* gverts,
+                                                           float* gcorr) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float* gv = gverts + (size_t)b * V * 3;
+  const float* gj = gjoints + (size_t)b * J * 3;
+  // joints relative to a root joint: J_j - J_root, so the root's row receives minus the sum of all adjoints
+  float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+  if (root >= 0)
+    for (int j = 0; j < J; ++j) { r0 += gj[j * 3]; r1 += gj[j * 3 + 1]; r2 += gj[j * 3 + 2]; }
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+  for (int j = 0; j < J; ++j) {
+    float g0 = gj[j * 3], g1 = gj[j * 3 + 1], g2 = gj[j * 3 + 2];
+    if (j == root) { g0 -= r0; g1 -= r1; g2 -= r2; }
+    for (int e = ptr[j] + lane; e < ptr[j + 1]; e += 64) {
+      const float ww = w[e];
+      float* q = gv + (size_t)vidx[e] * 3;
+      q[0] = fmaf(ww, g0, q[0]);
+      q[1] = fmaf(ww, g1, q[1]);
+      q[2] = fmaf(ww, g2, q[2]);
+    }
+    // d joint / d corr: (1 - rowsum_j) for plain joints; the root-relative form s (J_j - J_root) + t has exactly 1
+    const float c = root >= 0 ? 1.f : 1.f - rowsum[j];
+    c0 = fmaf(c, gj[j * 3], c0); c1 = fmaf(c, gj[j * 3 + 1], c1); c2 = fmaf(c, gj[j * 3 + 2], c2);
+    __threadfence_block();                         // the next joint's row may touch the same vertices
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (gcorr && lane == 0) {
+    gcorr[(size_t)b * 3] += c0; gcorr[(size_t)b * 3 + 1] += c1; gcorr[(size_t)b * 3 + 2] += c2;
+  }
+}
+
+extern "C" int mh_joints_regress_backward(const mh_model* m, int which, int B, const float* gjoints, int root_relative_to,
+                                          float* gverts, float* gcorr, void* stream) {
+  MH_CHECK(m && gjoints && gverts, "null argument");
+  MH_CHECK(which >= 0 && which < 4, "unknown joint set");
+  const mh_regressor& r = m->reg[which];
+  MH_CHECK(r.J > 0, "this joint regressor was not given to mh_model_create");
+  MH_CHECK(root_relative_to < r.J, "root joint out of range");
+  MH_CHECK(B > 0, "B must be positive");
+  hipLaunchKernelGGL(k_joints_regress_bwd, dim3(B), dim3(64), 0, (hipStream_t)stream, B, m->V, r.J, r.ptr, r.vidx, r.w, r.rowsum,
+                     gjoints, root_relative_to, gverts, gcorr);
   MH_LAUNCH_CHECK();
   return MH_OK;
 }
@@ -1213,6 +1275,9 @@ struct PoseBwdP {
   const float* poses;
   const float* gjoints;     // null ok
   const float* kp_rowsum;   // [17] (null when no key-point regressor)
+  const float* rotmats;     // [B][24][9]: the forward ran on given rotation matrices (lbs(pose2rot=False)); null: axis-angle
+  const float* gposed;      // [B][24][3] dL/d(posed joints = translation of the global joint transforms), null ok
+  float* grotmats;          // [B][24][9] += (with rotmats)
   const float* scale;
   const float* Jt;
   const float* JS;
@@ -1288,7 +1353,10 @@ __global__ __launch_bounds__(256) void k_pose_bwd(PoseBwdP p) {
   float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, J[3] = {0, 0, 0}, th[3] = {0, 0, 0};
   if (valid && act) {
     mh_joint_rest(p.Jt, p.JS, beta, j, J);
-    if (j < 22) {
+    if (p.rotmats) {
+#pragma unroll
+      for (int e = 0; e < 9; ++e) R[e] = p.rotmats[((size_t)b * MH_NJ + j) * 9 + e];
+    } else if (j < 22) {
       th[0] = p.poses[(size_t)b * 72 + 3 * j];
       th[1] = p.poses[(size_t)b * 72 + 3 * j + 1];
       th[2] = p.poses[(size_t)b * 72 + 3 * j + 2];
@@ -1348,7 +1416,8 @@ __global__ __launch_bounds__(256) void k_pose_bwd(PoseBwdP p) {
         sgG[bl][j][r * 4 + c] = gA[r * 4 + c] - gt * J[c];
         gJ[c] -= Gm[r * 4 + c] * gt;
       }
-      sgG[bl][j][r * 4 + 3] = gt;
+      // the posed joint IS the translation of G (smpl.py:735: joints_smpl24), so its adjoint joins here
+      sgG[bl][j][r * 4 + 3] = gt + ((p.gposed && valid) ? p.gposed[((size_t)b * MH_NJ + j) * 3 + r] : 0.f);
     }
     sgJ[bl][j][0] = gJ[0]; sgJ[bl][j][1] = gJ[1]; sgJ[bl][j][2] = gJ[2];
   }
@@ -1398,8 +1467,13 @@ __global__ __launch_bounds__(256) void k_pose_bwd(PoseBwdP p) {
 #pragma unroll
     for (int e = 0; e < 9; ++e) gR[e] += sGF[bl][10 + (j - 1) * 9 + e];
   }
-  // 6. adjoint of rodrigues (joints 0..21)
-  if (valid && act && j < 22) {
+  // 6. given rotation matrices: their adjoint is the result (all 24 joints); else the adjoint of rodrigues (joints 0..21)
+  if (p.rotmats) {
+    if (valid && act && p.grotmats) {
+#pragma unroll
+      for (int e = 0; e < 9; ++e) p.grotmats[((size_t)b * MH_NJ + j) * 9 + e] += gR[e];
+    }
+  } else if (valid && act && j < 22) {
     const float e = 1e-8f;
     const float a0 = th[0] + e, a1 = th[1] + e, a2 = th[2] + e;
     const float ang = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
@@ -1510,12 +1584,36 @@ extern "C" size_t mh_lbs_backward_workspace_bytes(int B) {
          align256(GB * MH_NUM_BETAS * 4) + align256(GB * 4);
 }
 
+static int lbs_backward_impl(const mh_model* m, int B, int NB, const float* betas, const float* poses, const float* rotmats,
+                             const float* vposed, const float* gverts, const float* gjoints, const float* gposed,
+                             float* gposes, float* grotmats, float* gtransl, float* gbetas, float* gxscale,
+                             void* ws, void* ws2, void* stream);
+
 extern "C" int mh_lbs_backward(const mh_model* m, int B, int NB, const float* betas, const float* poses,
                                const float* xscale, const float* transl, const float* vposed, const float* gverts,
                                const float* gjoints, float* gposes, float* gtransl, float* gbetas, float* gxscale,
                                void* ws, void* ws2, void* stream) {
   (void)xscale; (void)transl;
-  MH_CHECK(m && betas && poses && vposed && gposes && ws && ws2, "null argument");
+  MH_CHECK(poses && gposes, "null argument");
+  return lbs_backward_impl(m, B, NB, betas, poses, nullptr, vposed, gverts, gjoints, nullptr, gposes, nullptr, gtransl, gbetas,
+                           gxscale, ws, ws2, stream);
+}
+
+extern "C" int mh_lbs_backward_ex(const mh_model* m, int B, int NB, const float* betas, const float* poses, const float* rotmats,
+                                  const float* vposed, const float* gverts, const float* gjoints, const float* gposed,
+                                  float* gposes, float* grotmats, float* gtransl, float* gbetas, float* gxscale,
+                                  void* ws, void* ws2, void* stream) {
+  MH_CHECK((poses != nullptr) != (rotmats != nullptr), "exactly one of poses (axis-angle) and rotmats");
+  MH_CHECK(poses ? gposes != nullptr : grotmats != nullptr, "null gradient output");
+  return lbs_backward_impl(m, B, NB, betas, poses, rotmats, vposed, gverts, gjoints, gposed, gposes, grotmats, gtransl, gbetas,
+                           gxscale, ws, ws2, stream);
+}
+
+static int lbs_backward_impl(const mh_model* m, int B, int NB, const float* betas, const float* poses, const float* rotmats,
+                             const float* vposed, const float* gverts, const float* gjoints, const float* gposed,
+                             float* gposes, float* grotmats, float* gtransl, float* gbetas, float* gxscale,
+                             void* ws, void* ws2, void* stream) {
+  MH_CHECK(m && betas && vposed && ws && ws2, "null argument");
   MH_CHECK(gverts || gjoints, "need gverts and/or gjoints");
   MH_CHECK(B > 0 && NB > 0, "B and NB must be positive");
   MH_CHECK(!gjoints || m->reg[MH_REG_ALPHAPOSE].J == MH_NKP, "gjoints needs the key-point regressor");
@@ -1566,6 +1664,7 @@ extern "C" int mh_lbs_backward(const mh_model* m, int B, int NB, const float* be
   PoseBwdP pp;
   pp.B = B; pp.NB = NB; pp.G = G; pp.CH = CH;
   pp.betas = betas; pp.poses = poses; pp.gjoints = gjoints;
+  pp.rotmats = rotmats; pp.gposed = gposed; pp.grotmats = grotmats;
   pp.kp_rowsum = m->reg[MH_REG_ALPHAPOSE].rowsum;
   pp.scale = fw.scale; pp.Jt = m->Jt; pp.JS = m->JS;
   pp.pF = bw.pF; pp.pA = bw.pA; pp.pS = bw.pS;

@@ -58,8 +58,11 @@ def lib():
         L.mh_model_faces.argtypes = [vp]
         L.mh_lbs_forward.argtypes = [vp, ctypes.c_int, ctypes.c_int] + [vp] * 9
         L.mh_lbs_forward_rotmats.argtypes = [vp, ctypes.c_int, ctypes.c_int] + [vp] * 8
+        L.mh_lbs_forward_ex.argtypes = [vp, ctypes.c_int, ctypes.c_int] + [vp] * 10
         L.mh_joints_regress.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int, vp, vp]
         L.mh_lbs_backward.argtypes = [vp, ctypes.c_int, ctypes.c_int] + [vp] * 14
+        L.mh_lbs_backward_ex.argtypes = [vp, ctypes.c_int, ctypes.c_int] + [vp] * 15
+        L.mh_joints_regress_backward.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp]
         L.mh_project_joints_loss.argtypes = [ctypes.c_int, vp, c_float_p, c_float_p, vp, ctypes.c_float, ctypes.c_int,
                                              ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp]
         L.mh_project_joints_loss_w.argtypes = [ctypes.c_int, vp, c_float_p, c_float_p, c_float_p, vp, ctypes.c_float,

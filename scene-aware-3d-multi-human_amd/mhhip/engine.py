@@ -128,17 +128,19 @@ class BodyModel(object):
                                         ptr(verts), ptr(vposed), ptr(posed), ptr(ws), _lib.stream_ptr(self.device)))
         return verts, vposed, posed, ws
 
-    def lbs_forward_rotmats(self, betas, rotmats, xscale=None, transl=None, want_posed=True):
-        """``lbs(pose2rot=False)``: rotmats (B,24,3,3); forward only."""
+    def lbs_forward_rotmats(self, betas, rotmats, xscale=None, transl=None, want_posed=True, want_vposed=False):
+        """``lbs(pose2rot=False)``: rotmats (B,24,3,3).  want_vposed: also (v_posed, workspace) for ``lbs_backward_ex``
+        -> (verts, vposed, posed, ws); else (verts, posed)."""
         B, NB = rotmats.shape[0], betas.shape[0]
         f = lambda t: None if t is None else t.contiguous().float()
         betas, rotmats, xscale, transl = f(betas), f(rotmats), f(xscale), f(transl)
         verts = torch.empty(B, self.V, 3, dtype=torch.float32, device=self.device)
+        vposed = torch.empty_like(verts) if want_vposed else None
         posed = torch.empty(B, 24, 3, dtype=torch.float32, device=self.device) if want_posed else None
         ws = self.workspace(B)
-        check(_lib.lib().mh_lbs_forward_rotmats(self.handle, B, NB, ptr(betas), ptr(rotmats), ptr(xscale), ptr(transl),
-                                                ptr(verts), ptr(posed), ptr(ws), _lib.stream_ptr(self.device)))
-        return verts, posed
+        check(_lib.lib().mh_lbs_forward_ex(self.handle, B, NB, ptr(betas), None, ptr(rotmats), ptr(xscale), ptr(transl),
+                                           ptr(verts), ptr(vposed), ptr(posed), ptr(ws), _lib.stream_ptr(self.device)))
+        return (verts, vposed, posed, ws) if want_vposed else (verts, posed)
 
     def joints_regress(self, which, verts, corr=None, root=-1):
         B = verts.shape[0]
@@ -160,6 +162,35 @@ class BodyModel(object):
                                          ptr(vposed), ptr(gverts), ptr(gjoints), ptr(gposes), ptr(gtransl),
                                          ptr(gbetas), ptr(gxscale), ptr(ws), ptr(ws2), _lib.stream_ptr(self.device)))
         return gposes, gtransl, gbetas, gxscale
+
+
+def _bm_lbs_backward_ex(self, betas, vposed, gverts, ws, poses=None, rotmats=None, gjoints=None, gposed=None, ws2=None):
+    """mh_lbs_backward_ex: backward of the forward on axis-angle ``poses`` (B,72) or on ``rotmats`` (B,24,3,3), with the
+    adjoints of the vertices, the 17 AlphaPose key-points and / or the 24 posed joints.  Returns (gposes | grotmats, gbetas)."""
+    B, NB = gverts.shape[0], betas.shape[0]
+    z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=self.device)
+    gposes = z(B, 72) if poses is not None else None
+    grot = z(B, 24, 3, 3) if rotmats is not None else None
+    gbetas = z(NB, 10)
+    ws2 = ws2 if ws2 is not None else self.backward_workspace(B)
+    check(_lib.lib().mh_lbs_backward_ex(self.handle, B, NB, ptr(betas), ptr(poses), ptr(rotmats), ptr(vposed), ptr(gverts),
+                                        ptr(gjoints), ptr(gposed), ptr(gposes), ptr(grot), None, ptr(gbetas), None,
+                                        ptr(ws), ptr(ws2), _lib.stream_ptr(self.device)))
+    return (gposes if poses is not None else grot), gbetas
+
+
+def _bm_joints_regress_backward(self, which, gjoints, root=-1, gverts=None, gcorr=None):
+    """gverts (B,V,3) += reg^T gjoints (allocated as zeros when not given); gcorr (B,3) += (1 - row sums) gjoints"""
+    B = gjoints.shape[0]
+    if gverts is None:
+        gverts = torch.zeros(B, self.V, 3, dtype=torch.float32, device=self.device)
+    check(_lib.lib().mh_joints_regress_backward(self.handle, which, B, ptr(gjoints.contiguous()), int(root), ptr(gverts), ptr(gcorr),
+                                                _lib.stream_ptr(self.device)))
+    return gverts
+
+
+BodyModel.lbs_backward_ex = _bm_lbs_backward_ex
+BodyModel.joints_regress_backward = _bm_joints_regress_backward
 
 
 def project_joints_loss(joints, K, Kd, pose2d, thr, mode, img_w, img_h, coef=1.0, want_uv=True):

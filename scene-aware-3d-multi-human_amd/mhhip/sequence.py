@@ -51,8 +51,14 @@ def _dev(a, device, dtype=torch.float32):
 @_lib.on_own_device
 class SequenceEngine(object):
     def __init__(self, model, image_size, num_frames, num_people, cam_K, cam_dist_coef=None, coefs=None,
-                 joint_confidence_thr=0.5, eps=1e-3, batch_size=10, max_cycles=1024, joint_weights=None):
+                 joint_confidence_thr=0.5, eps=1e-3, batch_size=10, max_cycles=1024, joint_weights=None, joints_reg=None):
         self.m = model
+        # the 17 key-points of the 2D term: (regressor, root joint or -1) -- reference smpl_sparse_joints_key
+        # (optimizer.py:41, 75, 695-696).  The AlphaPose regressor's adjoint is fused into the LBS backward; any other
+        # regressor goes through mh_joints_regress_backward into the vertex-gradient buffer.
+        self.joints_reg = (engine.REG_ALPHAPOSE, -1) if joints_reg is None else (int(joints_reg[0]), int(joints_reg[1]))
+        assert engine.NUM_REG_JOINTS[self.joints_reg[0]] == 17, 'the 2D term compares with 17 detected key-points'
+        self.kp_fused = self.joints_reg[0] == engine.REG_ALPHAPOSE
         # per-key-point weights of the 2D term (reference optimizer.py:75-130, 259), mean 1; None = uniform
         self.joint_w = None if joint_weights is None else np.ascontiguousarray(np.asarray(joint_weights, np.float32).reshape(17))
         self.dev = model.device
@@ -410,8 +416,8 @@ class SequenceEngine(object):
             self._regress(_lib.stream_ptr(self.dev))
 
     def _regress(self, st):
-        check(_lib.lib().mh_joints_regress(self.m.handle, engine.REG_ALPHAPOSE, self.B, ptr(self.verts),
-                                           ptr(self.leaf('poses_T')), -1, ptr(self.kp), st))
+        check(_lib.lib().mh_joints_regress(self.m.handle, self.joints_reg[0], self.B, ptr(self.verts),
+                                           ptr(self.leaf('poses_T')), self.joints_reg[1], ptr(self.kp), st))
 
     def _side_stream(self):
         if not hasattr(self, '_side'):
@@ -477,7 +483,7 @@ class SequenceEngine(object):
         scene = self.scene_pts is not None
         filt = self.verts_filt is not None and self.pT_filt is not None
         images = use_images and self.has_images
-        need_gv = scene or filt or (images and raster is not None)
+        need_gv = scene or filt or (images and raster is not None) or not self.kp_fused
         log = self.tmp_log
         gv = None
         if need_gv:
@@ -510,6 +516,11 @@ class SequenceEngine(object):
                     self._toc(ev)
                 else:
                     gv.zero_()
+            if not self.kp_fused:
+                # key-points from another regressor: their adjoint goes into the (just initialised) vertex gradients and
+                # the translation gradient here; the LBS backward then runs without key-point adjoints
+                check(L.mh_joints_regress_backward(self.m.handle, self.joints_reg[0], B, ptr(self.gj), self.joints_reg[1], ptr(gv),
+                                                   ptr(self.leaf('poses_T', self.grads)), s2))
             if not hasattr(self, '_ev_gv'):
                 self._ev_gv = torch.cuda.Event()
             self._ev_gv.record(side)
@@ -580,7 +591,7 @@ class SequenceEngine(object):
             self._toc(ev)
         ev = self._tic('lbs_backward')
         check(L.mh_lbs_backward(self.m.handle, B, N, ptr(self.leaf('betas')), ptr(self.leaf('poses_smpl')),
-                                ptr(self.leaf('xscale')), ptr(pT), ptr(self.vposed), ptr(gv), ptr(self.gj), ptr(gposes),
+                                ptr(self.leaf('xscale')), ptr(pT), ptr(self.vposed), ptr(gv), ptr(self.gj) if self.kp_fused else None, ptr(gposes),
                                 ptr(gpT), ptr(gbetas), ptr(gxs), ptr(self.ws), ptr(self.ws2), st))
         self._toc(ev)
         if row is not None:

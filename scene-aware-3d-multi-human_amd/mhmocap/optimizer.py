@@ -51,7 +51,6 @@ class SMPLOptimizerBase(object):
         self.device = torch.device(device)
         if self.device.type != 'cuda' and engine_factory is None:
             raise RuntimeError('the MI355X build of mhmocap.optimizer needs a HIP device, got %s' % device)
-        assert smpl_sparse_joints_key == 'joints_alphapose', 'only the 17 AlphaPose key-points are accelerated'
         self.smpl_model_parameters_path = os.path.abspath(smpl_model_parameters_path)
         p = lambda f: os.path.join(smpl_model_parameters_path, f)
         self.SMPLPY = SMPL(smpl_model_parameters_path, J_reg_extra9_path=p(smpl_J_reg_extra_path),
@@ -59,6 +58,13 @@ class SMPLOptimizerBase(object):
                            data_struct=smpl_data_struct).to(self.device)
         self.faces_smpl = torch.tensor(np.asarray(self.SMPLPY.faces)[np.newaxis, :].astype(np.int32), device=self.device)
         self.smpl_sparse_joints_key = smpl_sparse_joints_key
+        # the joint set the 2D term compares with the 17 detected key-points (reference :41, 75, 695-696): any 17-joint
+        # regressor the body model holds; joints_h36m17 is root-relative to joint 14 like SMPL.forward makes it (smpl.py:371-372)
+        regs = {'joints_alphapose': (engine.REG_ALPHAPOSE, -1), 'joints_h36m17': (engine.REG_H36M17, 14),
+                'joints_mupots': (engine.REG_MUPOTS, -1)}
+        if smpl_sparse_joints_key not in regs:
+            raise ValueError('smpl_sparse_joints_key must name a 17-joint set (%s), got %r' % (', '.join(regs), smpl_sparse_joints_key))
+        self._joints_reg = regs[smpl_sparse_joints_key]
         w17 = np.ones(17, np.float32) if pose17j_weights is None else np.asarray(pose17j_weights, np.float32)
         assert w17.shape == (17,), 'pose17j_weights must hold one weight per key-point'
         w17 = (len(w17) * w17 / np.sum(w17)).astype(np.float32)            # normalised to mean 1 (reference :128-130)
@@ -254,6 +260,8 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
                   num_people=self.num_people, cam_K=self.cam_K, cam_dist_coef=self.cam_dist_coef, coefs=self.coefs,
                   joint_confidence_thr=self.joint_confidence_thr, eps=self.eps, batch_size=int(batch_size),
                   joint_weights=self._joint_w)
+        if self._joints_reg[0] != engine.REG_ALPHAPOSE:
+            kw['joints_reg'] = self._joints_reg
         if self._engine_factory is not None:
             self.engine = self._engine_factory(**kw)
         else:
@@ -299,7 +307,7 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
         st = _lib.stream_ptr(dev)
         f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
         verts, _, _, _ = m.lbs_forward(f32(betas_smpl).view(B, 10), f32(poses_smpl).view(B, 72), want_vposed=False)
-        local = m.joints_regress(engine.REG_ALPHAPOSE, verts)                 # (B,17,3), constant during warm-up
+        local = m.joints_regress(self._joints_reg[0], verts, root=self._joints_reg[1])   # (B,17,3), constant during warm-up
         del verts
         pT = f32(np.tile(np.array([[0, 0, 1]], np.float32), (B, 1)))          # :729
         p2d, xs = f32(pose2d).view(B, 17, 3), f32(xscale)

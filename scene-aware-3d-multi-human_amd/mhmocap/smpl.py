@@ -7,9 +7,11 @@ hand-written HIP kernels behind ``include/mhmocap_hip.h`` (``mh_lbs_forward`` /
 ``mh_lbs_backward`` / ``mh_joints_regress``).  There is no CPU path: constructing the model
 without a HIP device raises.
 
-Differentiability: ``verts`` and ``joints_alphapose`` carry gradients to ``betas`` / ``poses``
-through the hand-written backward (this is what the optimiser consumes, optimizer.py:75,695-696);
-the other joint sets are returned without a graph.
+Differentiability: every entry of the output dict carries its graph to ``betas`` / ``poses`` like the
+reference's (smpl.py:362-397) -- ``verts``, ``joints_alphapose`` and ``joints_smpl24`` through the
+hand-written LBS backward (``mh_lbs_backward_ex``), the other joint sets through the regressors'
+adjoint (``mh_joints_regress_backward``); ``lbs(pose2rot=False)`` is differentiable in the rotation
+matrices.
 """
 import os
 import os.path as osp
@@ -39,28 +41,47 @@ class Struct(object):
 
 
 class _LbsFn(torch.autograd.Function):
-    """verts, joints_alphapose = f(betas, poses) with the hand-written HIP backward."""
+    """verts, joints_alphapose, joints_smpl24 = f(betas, pose) with the hand-written HIP backward; ``pose`` is (B,72)
+    axis-angle or, with ``rot``, (B,24,3,3) rotation matrices (``lbs(pose2rot=False)``, smpl.py:541-558).  All three
+    outputs are differentiable, like the reference's autograd graph (smpl.py:362-397)."""
 
     @staticmethod
-    def forward(ctx, betas, poses, model, want_kp):
-        verts, vposed, posed, ws = model.lbs_forward(betas, poses, want_posed=True)
-        kp = model.joints_regress(engine.REG_ALPHAPOSE, verts) if want_kp else verts.new_zeros(poses.shape[0], 17, 3)
-        ctx.model, ctx.ws, ctx.want_kp = model, ws, want_kp
-        ctx.save_for_backward(betas, poses, vposed)
-        ctx.mark_non_differentiable(posed)
+    def forward(ctx, betas, pose, model, want_kp, rot):
+        if rot:
+            verts, vposed, posed, ws = model.lbs_forward_rotmats(betas, pose, want_posed=True, want_vposed=True)
+        else:
+            verts, vposed, posed, ws = model.lbs_forward(betas, pose, want_posed=True)
+        kp = model.joints_regress(engine.REG_ALPHAPOSE, verts) if want_kp else verts.new_zeros(pose.shape[0], 17, 3)
+        ctx.model, ctx.ws, ctx.want_kp, ctx.rot = model, ws, want_kp, rot
+        ctx.save_for_backward(betas, pose, vposed)
         return verts, kp, posed
 
     @staticmethod
-    def backward(ctx, gverts, gkp, _gposed):
-        betas, poses, vposed = ctx.saved_tensors
-        gv = gverts.contiguous().float() if gverts is not None else None
-        gk = gkp.contiguous().float() if (gkp is not None and ctx.want_kp) else None
-        if gv is None and gk is None:
-            return None, None, None, None
+    def backward(ctx, gverts, gkp, gposed):
+        betas, pose, vposed = ctx.saved_tensors
+        f = lambda g: None if g is None else g.contiguous().float()
+        gv, gk, gp = f(gverts), f(gkp) if ctx.want_kp else None, f(gposed)
+        if gv is None and gk is None and gp is None:
+            return None, None, None, None, None
         if gv is None:
-            gv = torch.zeros(poses.shape[0], ctx.model.V, 3, device=poses.device)
-        gposes, _, gbetas, _ = ctx.model.lbs_backward(betas, poses, None, None, vposed, gv, gk, ctx.ws)
-        return gbetas, gposes, None, None
+            gv = torch.zeros(pose.shape[0], ctx.model.V, 3, device=pose.device)
+        kw = dict(rotmats=pose) if ctx.rot else dict(poses=pose)
+        gpose, gbetas = ctx.model.lbs_backward_ex(betas, vposed, gv, ctx.ws, gjoints=gk, gposed=gp, **kw)
+        return gbetas, gpose.view_as(pose), None, None, None
+
+
+class _RegressFn(torch.autograd.Function):
+    """joints = regressor . verts (optionally relative to a root joint) with its adjoint in HIP: the other joint sets
+    of SMPL.forward (joints_h36m17 / joints_mupots / the extra nine of j3d) keep their graph (smpl.py:367-386)"""
+
+    @staticmethod
+    def forward(ctx, verts, model, which, root):
+        ctx.model, ctx.which, ctx.root = model, which, root
+        return model.joints_regress(which, verts.contiguous(), root=root)
+
+    @staticmethod
+    def backward(ctx, gj):
+        return ctx.model.joints_regress_backward(ctx.which, gj.contiguous().float(), root=ctx.root), None, None, None
 
 
 class SMPL(nn.Module):
@@ -144,18 +165,17 @@ class SMPL(nn.Module):
         if betas.shape[0] != poses.shape[0]:
             betas = betas.expand(poses.shape[0], -1).contiguous()
         want_kp = m.has_reg[engine.REG_ALPHAPOSE]
-        verts, kp, j24 = _LbsFn.apply(betas, poses, m, want_kp)
-        vd = verts.detach()
-        j3d = torch.cat([j24, vd[:, self._extra_idx]], dim=1)       # smpl.py:362-365
+        verts, kp, j24 = _LbsFn.apply(betas, poses, m, want_kp, False)
+        j3d = torch.cat([j24, verts[:, self._extra_idx]], dim=1)    # smpl.py:362-365 (the 21 picked vertices: an index, not arithmetic)
         out = {'verts': verts, 'j3d': j3d, 'joints_smpl24': j24}
         if m.has_reg[engine.REG_H36M17]:
-            out['joints_h36m17'] = m.joints_regress(engine.REG_H36M17, vd, root=14)   # smpl.py:367-373
+            out['joints_h36m17'] = _RegressFn.apply(verts, m, engine.REG_H36M17, 14)   # smpl.py:367-373
         if want_kp:
             out['joints_alphapose'] = kp
         if m.has_reg[engine.REG_MUPOTS]:
-            out['joints_mupots'] = m.joints_regress(engine.REG_MUPOTS, vd)
+            out['joints_mupots'] = _RegressFn.apply(verts, m, engine.REG_MUPOTS, -1)
         if m.has_reg[engine.REG_EXTRA9]:
-            out['j3d'] = torch.cat([j3d, m.joints_regress(engine.REG_EXTRA9, vd)], dim=1)   # smpl.py:383-386
+            out['j3d'] = torch.cat([j3d, _RegressFn.apply(verts, m, engine.REG_EXTRA9, -1)], dim=1)   # smpl.py:383-386
         if transl is not None:
             t = transl.to(m.device).unsqueeze(1)
             out = {k: v + t for k, v in out.items()}                # smpl.py:396-397
@@ -174,7 +194,7 @@ _LBS_CACHE = {}
 def lbs(betas, pose, v_template, shapedirs, posedirs, J_regressor, parents, lbs_weights, pose2rot=True,
         dtype=torch.float32):
     """Call-compatible with reference smpl.py:490-576: builds (and caches) a device model from the given tensors
-    and runs the HIP forward.  ``pose2rot=False`` (pose = (B,24,3,3) rotation matrices, :553-558) is forward only."""
+    and runs the HIP forward (+ backward under autograd).  ``pose2rot=False``: pose = (B,24,3,3) rotation matrices, :553-558."""
     key = (v_template.data_ptr(), posedirs.data_ptr(), lbs_weights.data_ptr())
     if key not in _LBS_CACHE:
         V = v_template.shape[0]
@@ -193,8 +213,9 @@ def lbs(betas, pose, v_template, shapedirs, posedirs, J_regressor, parents, lbs_
     if b.shape[0] != p.shape[0]:
         b = b.expand(p.shape[0], -1)
     if not pose2rot:
-        return m.lbs_forward_rotmats(b.contiguous(), p.reshape(p.shape[0], 24, 3, 3))
-    verts, _, posed = _LbsFn.apply(b.contiguous(), p.contiguous(), m, False)
+        verts, _, posed = _LbsFn.apply(b.contiguous(), p.reshape(p.shape[0], 24, 3, 3).contiguous(), m, False, True)
+        return verts, posed
+    verts, _, posed = _LbsFn.apply(b.contiguous(), p.contiguous(), m, False, False)
     return verts, posed
 
 

@@ -353,3 +353,129 @@ def test_staging_reads_a_plain_dataset_directly_and_a_custom_loader_through_its_
         np.testing.assert_array_equal(other[1], got[0][1])
         np.testing.assert_array_equal(other[2], got[0][2])
         assert other[3] == got[0][3] == 5
+
+
+# ---- round 3: the rest of the overlay's API surface ---------------------------------------------------
+@pytest.mark.parametrize('key', ['joints_h36m17', 'joints_mupots'])
+def test_other_sparse_joint_sets_inside_fit(smpl_struct, smpl_regs, oracle_model, tmp_path, key):
+    """``smpl_sparse_joints_key`` other than the shipped 'joints_alphapose' (reference optimizer.py:41, 75, 695-696): warm-up,
+    gradients of a cycle and three cycles of ``fit`` against the oracle on the same joint set.  joints_h36m17 is
+    root-relative to joint 14 (smpl.py:371-372), the reference adds poses_T to it like to any other set."""
+    import mhmocap.optimizer as mo
+    from mhhip import engine
+    fin = gi.fit_inputs()
+    if key == 'joints_mupots':         # the reference's base class loads three regressors (no MuPoTs one): hand it over like SMPL() takes it
+        np.save(str(tmp_path / 'mupots.npy'), smpl_regs['mupots'])
+    opt = _new_opt(smpl_struct, smpl_regs, tmp_path, fin, smpl_sparse_joints_key=key)
+    if key == 'joints_mupots':
+        from mhmocap.smpl import SMPL
+        p = lambda f: str(tmp_path / f)
+        opt.SMPLPY = SMPL(str(tmp_path), J_reg_extra9_path=p('J_regressor_extra.npy'), J_reg_h36m17_path=p('J_regressor_h36m.npy'),
+                          J_reg_alphapose_path=p('SMPL_AlphaPose_Regressor_RMSprop_6.npy'), J_reg_mupots_path=p('mupots.npy'),
+                          data_struct=smpl_struct).to(opt.device)
+    log0 = opt.init_optimized_variables(fin['pose2d'], fin['poses_smpl'], fin['betas_smpl'], fin['valid_smpl'], num_iter=5)
+    o = fo.SequenceOracle(oracle_model, (fin['W'], fin['H']), fin['T'], fin['cam_K'], coefs=gi.COEFS,
+                          rasteriser=lambda v: (-torch.ones(v.shape[0], fin['H'], fin['W']) + 0.0 * v.sum(),
+                                                torch.zeros(v.shape[0], fin['H'], fin['W']) + 0.0 * v.sum()))
+    o.joints_key = key
+    o.xscale = torch.zeros(1, fin['N'], 1, 1)
+    ol = o.init_optimized_variables(fin['pose2d'], fin['poses_smpl'], fin['betas_smpl'], fin['valid_smpl'], num_iter=5)
+    np.testing.assert_allclose([l['loss_2d'] for l in log0], ol, rtol=1e-4)
+    e = opt.engine
+    e.leaf('poses_T').copy_(torch.tensor(o.poses_T.detach().numpy()).view(fin['T'], fin['N'], 3))
+    e.leaf('zmax_lin').copy_(torch.tensor(o.zmax_lin.detach().numpy()).view(-1))
+    opt.scene_depth = fin['scene_depth']
+    opt.update_scene_pointcloud(fin['scene_depth'], fin['scene_mask'])
+    o.update_scene_pointcloud(fin['scene_depth'], fin['scene_mask'])
+    dl = torch.utils.data.DataLoader(_DS(fin), batch_size=5, shuffle=False)
+    opt._stage_from_dataloader(dl)
+    assert e.joints_reg == {'joints_h36m17': (engine.REG_H36M17, 14), 'joints_mupots': (engine.REG_MUPOTS, -1)}[key] and not e.kp_fused
+    e.cycle(0)
+    want = o.cycle_grads(_batches(fin))
+    np.testing.assert_allclose(e.read_log(1)[0]['loss_pose24j'], want['loss_pose24j'], rtol=1e-4)
+    for name, ename in LEAF_MAP:
+        w = _oracle_grad(o, name)
+        g = e.leaf(ename, e.grads).cpu().numpy().reshape(w.shape)
+        np.testing.assert_allclose(g, w, atol=3e-4 * max(np.abs(w).max(), 1e-8), rtol=0, err_msg=name)
+    log = opt.fit(dl, num_iter=3)
+    wl = o.fit(_batches(fin), 3)
+    np.testing.assert_allclose([l['loss_pose24j'] for l in log], [l['loss_pose24j'] for l in wl], rtol=2e-3)
+    ov, wv = opt.get_optimized_variables(), o.optimized_variables()
+    for k in ['poses_T', 'poses_smpl', 'betas_smpl']:
+        np.testing.assert_allclose(ov[k], wv[k], atol=2e-4, err_msg=k)
+
+
+def test_smpl_call_dict_and_gradients_of_every_entry(golden, smpl_struct, smpl_regs, oracle_model, tmp_path):
+    """The whole output dict of ``SMPL.__call__`` against the reference's fixtures (incl. j3d's 21 picked vertices and 9 extra
+    joints), and the gradient of EVERY entry w.r.t. betas / poses against float64 autograd of the oracle -- the reference's
+    dict is differentiable throughout (smpl.py:362-397); until round 2 only verts / joints_alphapose were here."""
+    from mhmocap.smpl import SMPL
+    paths = {}
+    for k, fn in [('extra9', 'e9.npy'), ('h36m', 'h36m.npy'), ('alphapose', 'ap.npy'), ('mupots', 'mu.npy')]:
+        paths[k] = str(tmp_path / fn)
+        np.save(paths[k], smpl_regs[k])
+    model = SMPL(None, J_reg_extra9_path=paths['extra9'], J_reg_h36m17_path=paths['h36m'], J_reg_alphapose_path=paths['alphapose'],
+                 J_reg_mupots_path=paths['mupots'], data_struct=smpl_struct).to('cuda:0')
+    betas, poses = gi.lbs_inputs()
+    tb = torch.tensor(betas, device='cuda:0', requires_grad=True)
+    tp = torch.tensor(poses, device='cuda:0', requires_grad=True)
+    out = model(betas=tb, poses=tp)
+    assert set(out) == {'verts', 'j3d', 'joints_smpl24', 'joints_h36m17', 'joints_alphapose', 'joints_mupots'}
+    for k, v in out.items():
+        a = v.detach().cpu().numpy()
+        want = golden['smpl_' + k]
+        np.testing.assert_allclose(a[:, ::53] if k == 'verts' else a, want, atol=1e-5, err_msg=k)
+    assert out['j3d'].shape == (len(poses), 54, 3)
+    import oracle.lbs_oracle as lo64
+    om = lo.BodyModel(smpl_struct, smpl_regs, dtype=torch.float64)
+    rng = np.random.RandomState(8)
+    for k in ['joints_smpl24', 'joints_h36m17', 'joints_mupots', 'j3d', 'joints_alphapose', 'verts']:
+        wgt = rng.normal(0, 1, out[k].shape)
+        tb.grad = tp.grad = None
+        out = model(betas=tb, poses=tp)
+        (out[k] * torch.tensor(wgt, device='cuda:0', dtype=torch.float32)).sum().backward()
+        db = torch.tensor(betas, dtype=torch.float64, requires_grad=True)
+        dp = torch.tensor(poses, dtype=torch.float64, requires_grad=True)
+        ref = lo.smpl_forward(om, db, dp)
+        (ref[k] * torch.tensor(wgt)).sum().backward()
+        for got, w, nm in ((tb.grad, db.grad, 'betas'), (tp.grad, dp.grad, 'poses')):
+            w = w.numpy()
+            np.testing.assert_allclose(got.cpu().numpy(), w, atol=2e-4 * max(np.abs(w).max(), 1e-12), rtol=0, err_msg='%s wrt %s' % (k, nm))
+
+
+def test_lbs_rotation_matrices_backward(smpl_struct, oracle_model):
+    """``lbs(pose2rot=False)`` under autograd (smpl.py:541-558): gradients w.r.t. the (B,24,3,3) matrices and betas against
+    float64 autograd of the same chain (all 24 given rotations are used, hands included)"""
+    import mhmocap.smpl as hsmpl
+    m = lo.BodyModel(smpl_struct, {}, dtype=torch.float64)
+    dev = torch.device('cuda:0')
+    rng = np.random.RandomState(21)
+    B = 5
+    betas = rng.normal(0, 0.6, (B, 10)).astype(np.float32)
+    rv = rng.normal(0, 0.4, (B * 24, 3))
+    R = lo.rodrigues(torch.tensor(rv)).view(B, 24, 3, 3).numpy() + rng.normal(0, 0.01, (B, 24, 3, 3))     # generic matrices: no constraint assumed
+    f32 = lambda a: torch.tensor(np.asarray(a, np.float32), device=dev)
+    m32 = oracle_model
+    args = (m32.v_template.to(dev), m32.shapedirs.to(dev), m32.posedirs.to(dev), m32.J_regressor.to(dev),
+            torch.tensor(m32.parents).to(dev), m32.weights.to(dev))
+    tb = f32(betas).requires_grad_(True)
+    tr = f32(R).requires_grad_(True)
+    verts, joints = hsmpl.lbs(tb, tr, *args, pose2rot=False)
+    wv, wj = rng.normal(0, 1, tuple(verts.shape)), rng.normal(0, 1, tuple(joints.shape))
+    ((verts * f32(wv)).sum() + (joints * f32(wj)).sum()).backward()
+    # float64 chain
+    db = torch.tensor(betas, dtype=torch.float64, requires_grad=True)
+    dr = torch.tensor(R, dtype=torch.float64, requires_grad=True)
+    v_shaped = m.v_template[None] + torch.einsum('bl,vcl->bvc', db, m.shapedirs)
+    J = torch.einsum('jv,bvc->bjc', m.J_regressor, v_shaped)
+    feat = (dr[:, 1:] - torch.eye(3, dtype=torch.float64)).reshape(B, 207)
+    v_posed = v_shaped + torch.matmul(feat, m.posedirs).view(B, -1, 3)
+    posed, A = lo.rigid_chain(dr, J, m.parents)
+    T = torch.matmul(m.weights[None].expand(B, -1, -1), A.view(B, 24, 16)).view(B, -1, 4, 4)
+    vh = torch.cat([v_posed, torch.ones(B, v_posed.shape[1], 1, dtype=torch.float64)], dim=2)
+    vref = torch.matmul(T, vh.unsqueeze(-1))[:, :, :3, 0]
+    np.testing.assert_allclose(verts.detach().cpu().numpy(), vref.detach().numpy(), atol=1e-5)
+    ((vref * torch.tensor(wv)).sum() + (posed * torch.tensor(wj)).sum()).backward()
+    for got, w, nm in ((tb.grad, db.grad, 'betas'), (tr.grad, dr.grad, 'rotmats')):
+        w = w.numpy()
+        np.testing.assert_allclose(got.cpu().numpy(), w, atol=2e-4 * np.abs(w).max(), rtol=0, err_msg=nm)

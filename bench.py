@@ -69,6 +69,27 @@ def load_pmc_traffic():
         return json.load(f)
 
 
+def file_sha(rel):
+    import hashlib
+    with open(os.path.join(ROOT, rel), 'rb') as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def profile_stamp():
+    """profiles/stamp.json (written by tools/make_profiles.py): git hash and sha256 of every kernel source the committed
+    counter passes were taken on.  Counter-derived numbers are only printed for sources that still have that hash."""
+    path = os.path.join(ROOT, 'profiles', 'stamp.json')
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return json.load(f)
+
+
+def counters_fresh(stamp, src):
+    rel = 'scene-aware-3d-multi-human_amd/csrc/' + src
+    return bool(stamp) and stamp.get('sha256', {}).get(src) == file_sha(rel)
+
+
 def load_pmc_valu(kernel):
     """Vector instructions per launch of `kernel` from the committed SQ counter pass (profiles/README.md)"""
     import glob
@@ -290,6 +311,8 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    pc = raster.pair_counters(e)          # counted by k_raster_strip while the profile switch was on
+    sort_seen, sort_rebuilt = raster.sort_counters(e)
     kern = e.timing_summary()
     e.enable_timing(False)
     kernel_us = {k: 1e3 * float(np.mean(v)) for k, v in prof.items() if v}
@@ -305,28 +328,38 @@ def main():
         V, F = int(e.V), int(raster.faces.shape[0])
         dom = max(kernel_us, key=kernel_us.get) if kernel_us else None
         traffic = load_pmc_traffic()
-        # dominant kernel: k_raster_strip, an integer / LDS-atomic z-buffer selection.  What binds it is vector-instruction
-        # issue (one wave64 VALU instruction per 4 cycles per SIMD), so THAT is the roofline reported; its HBM side
-        # (algorithmic bytes per launch, DESIGN.md section 4: every body's projected vertices 12 B x V and row-sorted
-        # face list 4 B x F in, the 40-byte key record of every window pixel out, the face table once) is kept beside it
+        pairs = None
+        if pc[0] > 0 and 'k_raster_strip' in kernel_us:
+            t_s = kernel_us['k_raster_strip'] * 1e-6
+            pairs = {'candidate_pairs_per_launch': round(pc[1] / pc[0]), 'pairs_evaluated_per_launch': round(pc[2] / pc[0]),
+                     'candidate_pairs_per_s': round(pc[1] / pc[0] / t_s, 1), 'pairs_evaluated_per_s': round(pc[2] / pc[0] / t_s, 1),
+                     'what': '(face, pixel-centre) pairs inside the blurred bounding boxes / pairs that survive the depth cull and '
+                             'are evaluated (barycentrics, distances, K-nearest insertion)'}
+        # roofline of the dominant kernel (k_raster_strip) as the contract defines it: ALGORITHMIC bytes per launch (DESIGN.md
+        # section 4: every body's projected vertices 12 B x V and row-sorted face list 4 B x F in, the 40-byte key record of
+        # every window pixel out, the face table once) / the launch duration measured in THIS run (HIP events on the launch
+        # stream) / 8 TB/s.  The kernel is a face-parallel z-buffer selection in LDS, bound by vector-instruction issue:
+        # that utilisation is kept beside it ("valu": SQ_INSTS_VALU of the committed counter pass / this launch time
+        # against one wave64 VALU instruction per 4 cycles per SIMD), and the pair-test rates SURVEY 8(d)(iv) asks for in
+        # "pairs" (counted live by the kernel while the instrumented region runs).  Counter-derived entries are null when the
+        # kernel source no longer has the hash the committed passes were taken on (profiles/stamp.json).
+        stamp = profile_stamp()
         roof = None
         if 'k_raster_strip' in kernel_us:
             us = kernel_us['k_raster_strip']
             algo = bodies * (12.0 * V + 4.0 * F) + 40.0 * window_px + 12.0 * F
             gbs = algo / (us * 1e-6) / 1e9
-            hbm = {'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
-                   'algorithmic_bytes': algo, 'window_pixels': window_px}
-            roof = {'kernel': 'k_raster_strip', 'bound': 'hbm', 'achieved': hbm['achieved'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                    'frac': hbm['frac'], 'traffic': traffic.get('k_raster_strip'), 'launch_us': round(us, 1), 'hbm': hbm,
-                    'dominant_by_events': dom}
-            nv = load_pmc_valu('k_raster_strip')
+            fresh = counters_fresh(stamp, 'mh_raster.hip')
+            roof = {'kernel': 'k_raster_strip', 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                    'frac': round(gbs / PEAK_HBM_GBS, 4), 'traffic': traffic.get('k_raster_strip') if fresh else None,
+                    'launch_us': round(us, 1), 'algorithmic_bytes': algo, 'window_pixels': window_px, 'dominant_by_events': dom,
+                    'counters_taken_on': stamp.get('git') if fresh else None, 'valu': None, 'pairs': pairs}
+            nv = load_pmc_valu('k_raster_strip') if fresh else None
             if nv and not args.strong and frames_here == 200 and N_PEOPLE == 4:
                 gi = nv / (us * 1e-6) / 1e9
-                roof.update({'bound': 'valu', 'achieved': round(gi, 1), 'peak': PEAK_VALU_GIPS, 'unit': 'G wave-instr/s',
-                             'frac': round(gi / PEAK_VALU_GIPS, 3), 'wave_instructions_per_launch': nv,
-                             'note': 'bound = vector-instruction issue (SQ_INSTS_VALU of the committed rocprofv3 pass / this '
-                                     'launch time, against 1024 SIMDs x 2.4 GHz / 4 cycles); the contract\'s HBM view is in '
-                                     '"hbm": traffic ~ algorithmic bytes, 5 % of 8 TB/s'})
+                roof['valu'] = {'what': 'vector-instruction issue utilisation (not a roofline fraction of useful work)',
+                                'achieved': round(gi, 1), 'peak': PEAK_VALU_GIPS, 'unit': 'G wave-instr/s',
+                                'utilisation': round(gi / PEAK_VALU_GIPS, 3), 'wave_instructions_per_launch': nv}
         # SURVEY 8(d) unit of the LBS + projection pair: 167 028 B per human.frame.iteration + the 19.35 MB of constants
         # once per launch pair, over forward + backward of the skinning kernels (HIP events around them)
         lbs = None
@@ -341,7 +374,8 @@ def main():
                    'mfma_16bit': {'issued_tflops': round(fl16 / t_pair / 1e12, 1), 'peak': 2500.0, 'frac': round(fl16 / t_pair / 2.5e15, 4)},
                    'tolerance': 'vertices within 2.4e-7 m and gradients within 6e-6 (relative to the largest entry) of the '
                                 'exact-fp32 MFMA kernels of round 1 (tools/time_lbs.py); fixtures: 1e-5 m / 2e-4',
-                   'traffic': {k: traffic.get(k) for k in ('k_skin_fwd16', 'k_skinbwd16') if traffic.get(k)}}
+                   'traffic': ({k: traffic.get(k) for k in ('k_skin_fwd16', 'k_skinbwd16') if traffic.get(k)}
+                               if counters_fresh(stamp, 'mh_lbs.hip') else None)}
         unit_frames = T_TOTAL if args.strong else T_LOCAL
         out = {
             'metric': 'optimizer iterations/sec (N humans x T frames)',
@@ -364,6 +398,9 @@ def main():
             'filter_updates_in_timed_region': sum(1 for c in range(args.warmup, args.warmup + args.steps)
                                                   if c >= upd_at and (c - upd_at) % 25 == 0),
             'organic_scene': organic, 'roofline': roof, 'roofline_lbs_projection': lbs,
+            'face_lists_rebuilt': {'bodies_seen': sort_seen, 'bodies_resorted': sort_rebuilt,
+                                   'what': 'rasteriser preparation since the start of the run: a body\'s face lists are re-sorted only when '
+                                           'one of its vertices has moved a pixel row since its last sort'},
             'kernel_us': {k: round(v, 1) for k, v in kernel_us.items()},
             'kernel_group_ms': {k: round(v, 4) for k, v in kern.items()},
             'loss_first_cycle': {k: float(v) for k, v in log[0].items()},

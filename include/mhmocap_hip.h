@@ -265,6 +265,8 @@ int mh_prior_terms(int T, int N, int nbatches, const float* poses, const float* 
 int mh_reduce_sum(const float* x, size_t n, float scale, float* out, void* stream);
 /* two arrays of the same length in one launch (the depth / silhouette log entries of a cycle); each sum in the order
  * of mh_reduce_sum */
+/* n <= 8 independent sums in one launch: xs / lens / outs are HOST arrays of device pointers and lengths */
+int mh_reduce_sum_multi(int n, const float* const* xs, const size_t* lens, float* const* outs, void* stream);
 int mh_reduce_sum2(const float* x0, const float* x1, size_t n, float scale, float* out0, float* out1,
                    void* stream);
 
@@ -399,6 +401,9 @@ int mh_raster_terms_phase_log(int T, int N, int V, int F, int H, int W, const fl
  * window pixels), key array (5 x uint64 per window pixel)} for inspection tools. */
 int mh_raster_workspace_init(int T, int N, int V, int F, int H, int W, void* ws, void* stream);
 int mh_raster_workspace_offsets(int T, int N, int V, int F, int H, int W, size_t* out /*[3]*/);
+/* work of the selection kernel, counted while mh_profile_enable(1): {launches, candidate (face, pixel-centre) pairs,
+ * pairs evaluated after the depth cull}, cumulative (achieved pair tests per second); synchronises */
+int mh_raster_pair_counters(int T, int N, int V, int F, int H, int W, void* ws, unsigned long long* out_host /*[3]*/, void* stream);
 int mh_raster_set_sort_margin(int rows);
 int mh_raster_get_sort_margin(void);
 int mh_raster_sort_counters(int T, int N, int V, int F, int H, int W, void* ws, unsigned long long* out_host /*[2]*/, void* stream);

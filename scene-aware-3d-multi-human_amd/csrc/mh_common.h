@@ -28,6 +28,7 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 void mh_set_error(const char* fmt, ...);
 // event brackets around the named kernels (no-ops unless mh_profile_enable(1)); edge 0 = before, 1 = after
 void mh_prof_mark(int which, int edge, hipStream_t st);
+bool mh_prof_on();
 
 #define MH_HIP(call)                                                                   \
   do {                                                                                 \

@@ -281,6 +281,42 @@ __global__ __launch_bounds__(256) void k_reduce_sum(const float* x, size_t n, fl
   if (threadIdx.x == 0) out[0] = scale * s[0];
 }
 
+// several small sums in ONE launch (one workgroup each, fixed summation order): the log entries of a cycle were five
+// single-workgroup launches of their own
+struct MultiSumP {
+  int n;
+  const float* x[8];
+  unsigned long long len[8];
+  float* out[8];
+};
+__global__ __launch_bounds__(256) void k_reduce_sum_multi(MultiSumP p) {
+  __shared__ float s[256];
+  const int k = blockIdx.x;
+  float a = 0.f;
+  for (size_t i = threadIdx.x; i < (size_t)p.len[k]; i += 256) a += p.x[k][i];
+  s[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) p.out[k][0] = s[0];
+}
+
+extern "C" int mh_reduce_sum_multi(int n, const float* const* xs, const size_t* lens, float* const* outs, void* stream) {
+  MH_CHECK(xs && lens && outs, "null argument");
+  MH_CHECK(n >= 1 && n <= 8, "1..8 sums per launch");
+  MultiSumP p;
+  p.n = n;
+  for (int k = 0; k < n; ++k) {
+    MH_CHECK(xs[k] && outs[k], "null argument");
+    p.x[k] = xs[k]; p.len[k] = lens[k]; p.out[k] = outs[k];
+  }
+  hipLaunchKernelGGL(k_reduce_sum_multi, dim3(n), dim3(256), 0, (hipStream_t)stream, p);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
 extern "C" int mh_reduce_sum(const float* x, size_t n, float scale, float* out, void* stream) {
   MH_CHECK(x && out, "null argument");
   hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, (hipStream_t)stream, x, n, scale, out, (const float*)nullptr, (float*)nullptr);

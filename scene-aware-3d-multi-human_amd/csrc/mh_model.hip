@@ -36,6 +36,7 @@ extern "C" int mh_profile_enable(int on) {
   return MH_OK;
 }
 
+bool mh_prof_on() { return g_prof_on; }
 void mh_prof_mark(int which, int edge, hipStream_t st) {
   if (!g_prof_on || which < 0 || which >= MH_PROF_COUNT) return;
   (void)hipEventRecord(g_prof_ev[which][edge], st);

@@ -92,6 +92,8 @@ struct RasterP {
   unsigned long long* sort_tag;   // [B] validity tag of the body's lists (a fresh workspace holds anything)
   char* ctl_end;             // (host) end of the control words
   unsigned long long* sort_count;  // [2] launches x bodies seen, bodies rebuilt (cumulative)
+  unsigned long long* pairs;       // [3] launches, candidate (face, pixel-centre) pairs, pairs evaluated after the depth cull
+                                   // (cumulative); NULL unless mh_profile_enable(1): SURVEY 8(d)(iv) asks for the rate
 };
 #define RS_TAG(b, m) (0x5bd1e995c0ffee00ull ^ ((unsigned long long)(b) * 0x9E3779B97F4A7C15ull) ^ (unsigned long long)(m))
 
@@ -815,6 +817,7 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
   int* fid = wFid[wave];
   int* mark = wMark[wave];
   unsigned short* pl = wPl[wave];
+  unsigned long long n_cand = 0ull, n_eval = 0ull;        // wave-uniform
   for (int si = blockIdx.x; si < total; si += gridDim.x) {
     const int s = p.strip_order[si];
     const int b = p.strip_body[s];
@@ -949,6 +952,7 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
           const int nk = __popc(keepm);
           const int kincl = r_wave_scan_add(nk);
           const int nkeep = __builtin_amdgcn_readlane(kincl, 63);
+          n_cand += (unsigned)npairs; n_eval += (unsigned)nkeep;
           {
             int pos = kincl - nk;
             for (unsigned m = keepm; m; m &= m - 1u) pl[pos++] = (unsigned short)(lane | ((__ffs((int)m) - 1) << 6));
@@ -971,6 +975,7 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
           __builtin_amdgcn_wave_barrier();
         } else if (npairs > 0) {
           // ---- larger faces: the pairs are split evenly over the lanes, every lane walks a contiguous run ----------
+          n_cand += (unsigned)npairs; n_eval += (unsigned)npairs;
           pre[lane] = excl;
           if (lane == 63) pre[64] = npairs;
           mark[lane] = -1;
@@ -1033,6 +1038,11 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
       gk[((size_t)(sy0 - wy0 + r) * ww + (x0 - wx0 + cc)) * 5 + c] = keys[i];
     }
     r_tile_depth_sums(p, s, b, keys, tw, x0, sy0, npx, s_sums);
+  }
+  if (p.pairs && lane == 0) {
+    atomicAdd(&p.pairs[1], n_cand);
+    atomicAdd(&p.pairs[2], n_eval);
+    if (blockIdx.x == 0 && wave == 0) atomicAdd(&p.pairs[0], 1ull);
   }
 }
 
@@ -1666,6 +1676,7 @@ static size_t r_carve(RasterP& p, void* ws) {
   // control words: everything mh_raster_workspace_init clears, contiguous
   p.ctl = (unsigned*)c; c += r_align(16);
   p.sort_count = (unsigned long long*)c; c += r_align(16);
+  p.pairs = (unsigned long long*)c; c += r_align(32);
   p.sort_tag = (unsigned long long*)c; c += r_align(B * 8);
   p.sil_corr = (float*)c; c += r_align(B * 4);
   p.ctl_end = c;
@@ -1718,6 +1729,18 @@ extern "C" int mh_raster_debug_offsets(int T, int N, int V, int F, int H, int W,
   out[3] = (size_t)((char*)p.row_start - (char*)nullptr);
   out[4] = (size_t)((char*)p.maxh - (char*)nullptr);
   out[5] = (size_t)((char*)p.rowb - (char*)nullptr);
+  return MH_OK;
+}
+
+// {launches, candidate pairs, evaluated pairs} of k_raster_strip, counted while mh_profile_enable(1) (synchronises)
+extern "C" int mh_raster_pair_counters(int T, int N, int V, int F, int H, int W, void* ws, unsigned long long* out_host, void* stream) {
+  MH_CHECK(ws && out_host, "null argument");
+  MH_CHECK(T > 0 && N > 0 && V > 0 && F > 0 && H > 0 && W > 0, "empty input");
+  RasterP p;
+  p.B = T * N; p.N = N; p.V = V; p.F = F; p.H = H; p.W = W;
+  r_carve(p, ws);
+  MH_HIP(hipMemcpyAsync(out_host, p.pairs, 24, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  MH_HIP(hipStreamSynchronize((hipStream_t)stream));
   return MH_OK;
 }
 
@@ -1774,6 +1797,7 @@ static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const flo
   p.gverts = gverts; p.depth_body = depth_body; p.sil_body = sil_body;
   p.zbuf_out = zbuf_out; p.alpha_out = alpha_out;
   r_carve(p, ws);
+  if (!mh_prof_on()) p.pairs = nullptr;
   hipStream_t st = (hipStream_t)stream;
   if (phases & 1) {
   if (zbuf_out) {   // -1 = empty, like fragments.zbuf

@@ -89,6 +89,7 @@ def lib():
         L.mh_sil_mask_stats.argtypes = [u32p] + [ctypes.c_int] * 4 + [vp] * 8
         L.mh_prior_terms.argtypes = [ctypes.c_int] * 3 + [vp] * 6 + [ctypes.c_float] * 2 + [vp] * 6
         L.mh_reduce_sum.argtypes = [vp, ctypes.c_size_t, ctypes.c_float, vp, vp]
+        L.mh_reduce_sum_multi.argtypes = [ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(vp), vp]
         L.mh_reduce_sum2.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_float, vp, vp, vp]
         L.mh_lowest_vertex.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp]
         L.mh_contact_knn.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp]
@@ -115,6 +116,7 @@ def lib():
         L.mh_raster_terms_phase.argtypes = [ctypes.c_int] * 6 + [c_float_p] + [vp] * 12 + [ctypes.c_float] * 3 + [vp] * 8 + [ctypes.c_int, vp]
         L.mh_raster_set_deterministic.argtypes = [ctypes.c_int]
         L.mh_raster_set_sort_margin.argtypes = [ctypes.c_int]
+        L.mh_raster_pair_counters.argtypes = [ctypes.c_int] * 6 + [vp, ctypes.POINTER(ctypes.c_ulonglong), vp]
         L.mh_raster_sort_counters.argtypes = [ctypes.c_int] * 6 + [vp, ctypes.POINTER(ctypes.c_ulonglong), vp]
         L.mh_raster_terms_phase_log.argtypes = [ctypes.c_int] * 6 + [c_float_p] + [vp] * 12 + [ctypes.c_float] * 3 + [vp] * 8 + [ctypes.c_int, vp, vp, vp]
         L.mh_raster_workspace_init.argtypes = [ctypes.c_int] * 6 + [vp, vp]
@@ -128,6 +130,15 @@ def lib():
         L.mh_unproject_points.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
         _lib = L
     return _lib
+
+
+def reduce_sum_multi(items, stream):
+    """items: [(x tensor, out tensor of one float)] -> every out = sum(x), one launch"""
+    n = len(items)
+    xs = (vp * n)(*[t.data_ptr() for t, _ in items])
+    ls = (ctypes.c_size_t * n)(*[t.numel() for t, _ in items])
+    os_ = (vp * n)(*[o.data_ptr() for _, o in items])
+    check(lib().mh_reduce_sum_multi(n, xs, ls, os_, stream))
 
 
 def check(rc):

@@ -47,6 +47,13 @@ class RasterTerms(object):
         check(_lib.lib().mh_raster_sort_counters(*self.dims, ptr(self.ws), out, _lib.stream_ptr(e.dev)))
         return int(out[0]), int(out[1])
 
+    def pair_counters(self, e):
+        """(launches, candidate pairs, evaluated pairs) of the selection kernel, counted while mh_profile_enable(1)"""
+        import ctypes
+        out = (ctypes.c_ulonglong * 3)()
+        check(_lib.lib().mh_raster_pair_counters(*self.dims, ptr(self.ws), out, _lib.stream_ptr(e.dev)))
+        return int(out[0]), int(out[1]), int(out[2])
+
     def selection(self, e):
         """Inspection aid: what the last selection pass left in the workspace -- (win (B,4) int32: x0, y0, width, height of
         every body's screen window; koff (B+1,): first window pixel of every body; keys (window pixels, 5) uint64: per

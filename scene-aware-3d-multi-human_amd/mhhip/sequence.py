@@ -456,8 +456,7 @@ class SequenceEngine(object):
                                ptr(self.leaf('betas', g)), ptr(self.leaf('xscale', g)), ptr(self.prior_body), ptr(log[9:12]), s2))
         check(L.mh_velocity_term(T, N, ptr(pT), ptr(h.get('pT_prev')), ptr(h.get('pT_next')), float(c['reg_velocity']),
                                  ptr(self.leaf('poses_T', g)), ptr(log[7:8]), s2))
-        check(L.mh_reduce_sum(ptr(self.prior_body), self.B, 1.0, ptr(log[3:4]), s2))
-        self.forward(regress=False)
+        self.forward(regress=False)      # (the per-body pose-prior values are summed with the other log entries, _finish_a)
         main.wait_stream(side)
 
     def cycle_finish(self, row, use_images=True, raster=None, scene_ready=False):
@@ -504,7 +503,6 @@ class SequenceEngine(object):
         jwp = None if self.joint_w is None else self.joint_w.ctypes.data_as(_lib.c_float_p)
         check(L.mh_project_joints_loss_w(B, ptr(self.kp), Kp, Kdp, jwp, ptr(self.pose2d), self.thr, 0, float(self.W),
                                          float(self.H), float(c['proj2d']), ptr(self.uv), ptr(self.gj), ptr(self.loss2d), s2))
-        check(L.mh_reduce_sum(ptr(self.loss2d), B, 1.0, ptr(log[0:1]), s2))
         with torch.cuda.stream(side):
             if need_gv:
                 if filt:
@@ -525,9 +523,12 @@ class SequenceEngine(object):
                 self._ev_gv = torch.cuda.Event()
             self._ev_gv.record(side)
         self._scene_done = False
+        sums = [(self.loss2d, log[0:1]), (self.prior_body, log[3:4])]
         if scene and (self._scene_dev is None or scene_ready):     # static scene, or its event already waited for
-            self._scene_terms(s2)
+            self._scene_terms(s2, reduce=False)
+            sums += [(self.batch_contact, log[5:6]), (self.batch_foot, log[6:7])]
             self._scene_done = True
+        _lib.reduce_sum_multi(sums, s2)                            # the small log sums of the side branch: one launch
         # ---- main branch: rasterised depth / silhouette terms ----------------------------------------------------------
         joined = False
         if images:
@@ -549,7 +550,7 @@ class SequenceEngine(object):
         if not joined:
             main.wait_stream(side)
 
-    def _scene_terms(self, st):
+    def _scene_terms(self, st, reduce=True):
         """contact + in-batch foot sliding (optimizer.py:485-518) on stream st; gradients by atomics / disjoint writes"""
         L = _lib.lib()
         c = self.c
@@ -567,8 +568,8 @@ class SequenceEngine(object):
             check(L.mh_contact_foot_terms(T, N, self.V, self.batch, ptr(self.verts), ptr(self.low_idx), ptr(self.low_xyz),
                                           ptr(self.dy), float(c['reg_contact']), float(c['reg_foot_sliding']), ptr(gpT),
                                           ptr(gv), ptr(self.batch_contact), ptr(self.batch_foot), st))
-        check(L.mh_reduce_sum(ptr(self.batch_contact), self.nbatches, 1.0, ptr(log[5:6]), st))
-        check(L.mh_reduce_sum(ptr(self.batch_foot), self.nbatches, 1.0, ptr(log[6:7]), st))
+        if reduce:
+            _lib.reduce_sum_multi([(self.batch_contact, log[5:6]), (self.batch_foot, log[6:7])], st)
 
     def _finish_b(self, row, use_images=True, raster=None):
         """scene terms when they could not run in the side branch (eager launches with the cloud rebuilt on the device

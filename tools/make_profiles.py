@@ -33,3 +33,13 @@ for k in sorted(set(fetch) | set(write)):
                               '(MI355X_MICROARCH.md, HBM)'}
 json.dump(traffic, open(os.path.join(out, 'pmc_traffic.json'), 'w'), indent=1, sort_keys=True)
 print(json.dumps({k: v for k, v in traffic.items() if k in ('k_raster_strip', 'k_skin_fwd16', 'k_skinbwd16', 'k_raster_grads')}, indent=1))
+
+# stamp: what these passes were taken on (bench.py prints counter-derived numbers only for sources that still match)
+import hashlib, subprocess
+csrc = os.path.join(ROOT, 'scene-aware-3d-multi-human_amd', 'csrc')
+sha = {f: hashlib.sha256(open(os.path.join(csrc, f), 'rb').read()).hexdigest() for f in sorted(os.listdir(csrc))}
+try:
+    git = subprocess.run(['git', '-C', ROOT, 'rev-parse', 'HEAD'], capture_output=True, text=True).stdout.strip() or None
+except Exception:
+    git = None
+json.dump({'round': tag, 'git': git or os.environ.get('GRAFT_GIT_HEAD'), 'sha256': sha}, open(os.path.join(out, 'stamp.json'), 'w'), indent=1, sort_keys=True)

@@ -92,8 +92,8 @@ struct RasterP {
   unsigned long long* sort_tag;   // [B] validity tag of the body's lists (a fresh workspace holds anything)
   char* ctl_end;             // (host) end of the control words
   unsigned long long* sort_count;  // [2] launches x bodies seen, bodies rebuilt (cumulative)
-  unsigned long long* pairs;       // [3] launches, candidate (face, pixel-centre) pairs, pairs evaluated after the depth cull
-                                   // (cumulative); NULL unless mh_profile_enable(1): SURVEY 8(d)(iv) asks for the rate
+  unsigned long long* pairs;       // [2 + 2 x R_STRIP_GRID]: launches, -, then per workgroup: candidate (face, pixel-centre) pairs,
+                                   // pairs evaluated after the depth cull (cumulative); NULL unless mh_profile_enable(1)
 };
 #define RS_TAG(b, m) (0x5bd1e995c0ffee00ull ^ ((unsigned long long)(b) * 0x9E3779B97F4A7C15ull) ^ (unsigned long long)(m))
 
@@ -405,6 +405,7 @@ __device__ __forceinline__ unsigned r_face_rows_xyz(const RasterP& p, float ra, 
 // same-address round trips on every workgroup's tail, 30 us slower than the serial pass it replaced.)
 #define R_SHORT 2            // faces of up to R_SHORT + 1 rows go to the two short lists, taller ones to the third
 #define R_NCLS 64            // cost classes of the tiles (0 = most expensive)
+#define R_STRIP_GRID (256 * 3 * 4)   // persistent grid of the selection kernel
 #define R_NGCLS 33           // gradient work units: class 0 = full units, 1..32 = partial units by decreasing size
 __device__ __forceinline__ int r_cap(const RasterP& p) { return p.max_strips / p.B; }
 
@@ -1039,10 +1040,19 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
     }
     r_tile_depth_sums(p, s, b, keys, tw, x0, sy0, npx, s_sums);
   }
-  if (p.pairs && lane == 0) {
-    atomicAdd(&p.pairs[1], n_cand);
-    atomicAdd(&p.pairs[2], n_eval);
-    if (blockIdx.x == 0 && wave == 0) atomicAdd(&p.pairs[0], 1ull);
+  if (p.pairs) {
+    // per-workgroup slots, plain adds (49 000 same-address atomics at the end of the kernel doubled its duration)
+    __shared__ unsigned long long s_cnt[RW][2];
+    __syncthreads();
+    if (lane == 0) { s_cnt[wave][0] = n_cand; s_cnt[wave][1] = n_eval; }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long a = 0ull, b2 = 0ull;
+      for (int w = 0; w < RW; ++w) { a += s_cnt[w][0]; b2 += s_cnt[w][1]; }
+      unsigned long long* slot = p.pairs + 2 + 2 * (size_t)blockIdx.x;
+      slot[0] += a; slot[1] += b2;
+      if (blockIdx.x == 0) p.pairs[0] += 1ull;
+    }
   }
 }
 
@@ -1676,7 +1686,7 @@ static size_t r_carve(RasterP& p, void* ws) {
   // control words: everything mh_raster_workspace_init clears, contiguous
   p.ctl = (unsigned*)c; c += r_align(16);
   p.sort_count = (unsigned long long*)c; c += r_align(16);
-  p.pairs = (unsigned long long*)c; c += r_align(32);
+  p.pairs = (unsigned long long*)c; c += r_align((2 + 2 * (size_t)R_STRIP_GRID) * 8);
   p.sort_tag = (unsigned long long*)c; c += r_align(B * 8);
   p.sil_corr = (float*)c; c += r_align(B * 4);
   p.ctl_end = c;
@@ -1739,8 +1749,11 @@ extern "C" int mh_raster_pair_counters(int T, int N, int V, int F, int H, int W,
   RasterP p;
   p.B = T * N; p.N = N; p.V = V; p.F = F; p.H = H; p.W = W;
   r_carve(p, ws);
-  MH_HIP(hipMemcpyAsync(out_host, p.pairs, 24, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  static unsigned long long host[2 + 2 * R_STRIP_GRID];
+  MH_HIP(hipMemcpyAsync(host, p.pairs, sizeof(host), hipMemcpyDeviceToHost, (hipStream_t)stream));
   MH_HIP(hipStreamSynchronize((hipStream_t)stream));
+  out_host[0] = host[0]; out_host[1] = 0ull; out_host[2] = 0ull;
+  for (int i = 0; i < R_STRIP_GRID; ++i) { out_host[1] += host[2 + 2 * i]; out_host[2] += host[3 + 2 * i]; }
   return MH_OK;
 }
 
@@ -1810,7 +1823,7 @@ static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const flo
   hipLaunchKernelGGL(k_raster_lists, dim3(1), dim3(RLISTS), 0, st, p);
   MH_LAUNCH_CHECK();
   // persistent grids over the device-side work list (the strip count is only known on the device)
-  const int grid = 256 * 3 * 4;
+  const int grid = R_STRIP_GRID;
   mh_prof_mark(MH_PROF_RASTER_STRIP, 0, st);
   hipLaunchKernelGGL(k_raster_strip, dim3(grid), dim3(RB), 0, st, p);
   MH_LAUNCH_CHECK();

@@ -37,7 +37,7 @@ print(json.dumps({k: v for k, v in traffic.items() if k in ('k_raster_strip', 'k
 # stamp: what these passes were taken on (bench.py prints counter-derived numbers only for sources that still match)
 import hashlib, subprocess
 csrc = os.path.join(ROOT, 'scene-aware-3d-multi-human_amd', 'csrc')
-sha = {f: hashlib.sha256(open(os.path.join(csrc, f), 'rb').read()).hexdigest() for f in sorted(os.listdir(csrc))}
+sha = {f: hashlib.sha256(open(os.path.join(csrc, f), 'rb').read()).hexdigest() for f in sorted(os.listdir(csrc)) if os.path.isfile(os.path.join(csrc, f))}
 try:
     git = subprocess.run(['git', '-C', ROOT, 'rev-parse', 'HEAD'], capture_output=True, text=True).stdout.strip() or None
 except Exception:

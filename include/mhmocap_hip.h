@@ -71,7 +71,8 @@ int mh_version(void);
 
 /* Measurement aid (bench.py, DESIGN.md "measurement"): when enabled, the library brackets the launches of its
  * dominant kernels with HIP events on the caller's stream; mh_profile_read synchronises on the pair of the most recent
- * launch and returns its duration.  Off by default; not meant to be on during stream capture. */
+ * launch and returns its duration.  Off by default; not meant to be on during stream capture.  on = 2 additionally
+ * switches on the work counters inside the kernels (mh_raster_pair_counters); their stores cost the kernel a few percent. */
 enum mh_profile_kernel {
   MH_PROF_RASTER_STRIP = 0, MH_PROF_RASTER_GRADS = 1, MH_PROF_SKIN_FWD = 2, MH_PROF_SKIN_BWD = 3,
   MH_PROF_CONTACT_KNN = 4, MH_PROF_RASTER_SUMS = 5, MH_PROF_COUNT = 6
@@ -396,12 +397,12 @@ int mh_raster_terms_phase_log(int T, int N, int V, int F, int H, int W, const fl
  * first use); 0 = sort every launch.  mh_raster_sort_counters: {bodies seen, bodies re-sorted}, cumulative over the
  * launches on this workspace (synchronises the stream); out_host NULL resets them (stream-ordered). */
 /* A workspace must be initialised ONCE before its first launch (stream-ordered; again if its bytes were overwritten):
- * clears the control words (work-list epoch and counters, face-list tags, silhouette accumulator).
+ * clears the control words (re-sort and pair counters, face-list tags, silhouette accumulator).
  * mh_raster_workspace_offsets: byte offsets of {window table (B x 4 int32), first key of every body (B x int64, in
  * window pixels), key array (5 x uint64 per window pixel)} for inspection tools. */
 int mh_raster_workspace_init(int T, int N, int V, int F, int H, int W, void* ws, void* stream);
 int mh_raster_workspace_offsets(int T, int N, int V, int F, int H, int W, size_t* out /*[3]*/);
-/* work of the selection kernel, counted while mh_profile_enable(1): {launches, candidate (face, pixel-centre) pairs,
+/* work of the selection kernel, counted while mh_profile_enable(2) (level 2 = event brackets + in-kernel work counters): {launches, candidate (face, pixel-centre) pairs,
  * pairs evaluated after the depth cull}, cumulative (achieved pair tests per second); synchronises */
 int mh_raster_pair_counters(int T, int N, int V, int F, int H, int W, void* ws, unsigned long long* out_host /*[3]*/, void* stream);
 int mh_raster_set_sort_margin(int rows);

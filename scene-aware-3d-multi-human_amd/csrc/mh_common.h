@@ -29,6 +29,7 @@ void mh_set_error(const char* fmt, ...);
 // event brackets around the named kernels (no-ops unless mh_profile_enable(1)); edge 0 = before, 1 = after
 void mh_prof_mark(int which, int edge, hipStream_t st);
 bool mh_prof_on();
+int mh_prof_level();     // 1: event brackets; 2: + work counters inside the kernels (their stores perturb the timings)
 
 #define MH_HIP(call)                                                                   \
   do {                                                                                 \

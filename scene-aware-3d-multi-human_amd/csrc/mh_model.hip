@@ -21,6 +21,7 @@ extern "C" int mh_version(void) { return 1; }
 
 // ---- measurement aid --------------------------------------------------------------------------------------
 static bool g_prof_on = false;
+static int g_prof_level = 0;
 static hipEvent_t g_prof_ev[MH_PROF_COUNT][2];
 static bool g_prof_have[MH_PROF_COUNT];
 static bool g_prof_init = false;
@@ -33,10 +34,12 @@ extern "C" int mh_profile_enable(int on) {
   }
   for (int i = 0; i < MH_PROF_COUNT; ++i) g_prof_have[i] = false;
   g_prof_on = on != 0;
+  g_prof_level = on;
   return MH_OK;
 }
 
 bool mh_prof_on() { return g_prof_on; }
+int mh_prof_level() { return g_prof_level; }
 void mh_prof_mark(int which, int edge, hipStream_t st) {
   if (!g_prof_on || which < 0 || which >= MH_PROF_COUNT) return;
   (void)hipEventRecord(g_prof_ev[which][edge], st);

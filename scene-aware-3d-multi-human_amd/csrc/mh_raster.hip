@@ -1810,7 +1810,7 @@ static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const flo
   p.gverts = gverts; p.depth_body = depth_body; p.sil_body = sil_body;
   p.zbuf_out = zbuf_out; p.alpha_out = alpha_out;
   r_carve(p, ws);
-  if (!mh_prof_on()) p.pairs = nullptr;
+  if (mh_prof_level() < 2) p.pairs = nullptr;
   hipStream_t st = (hipStream_t)stream;
   if (phases & 1) {
   if (zbuf_out) {   // -1 = empty, like fragments.zbuf

@@ -31,7 +31,12 @@
 #define BLUR_D 1e-4f         // optimizer.py:213
 #define BLUR_S 2e-5f         // optimizer.py:223
 #define SIGMA_S 1e-4f        // BlendParams.sigma default used by SoftSilhouetteShader
+#ifndef RB
 #define RB 512               // threads per strip workgroup
+#endif
+#ifndef RMINW
+#define RMINW 4
+#endif
 #define R_CAP 640            // window pixels per tile (5 x u64 each = 25.6 KB of LDS; 2 workgroups per CU)
 #define RT 13                // floats staged per face: 9 NDC coordinates, 1/area, 1/|edge|^2 x 3
 
@@ -661,6 +666,9 @@ __device__ __forceinline__ void r_finalize_lists(const RasterP& p) {
 #ifndef RPREP
 #define RPREP 512
 #endif
+#ifndef RPV
+#define RPV 7                // vertices per thread whose loads are in flight together (6890 = 2 x 7 x 512 - 278)
+#endif
 __global__ __launch_bounds__(RPREP) void k_raster_prepare(RasterP p) {
   extern __shared__ int hist[];                     // [3][H + 1] of the sort
   __shared__ float sbb[RPREP / 64][4];
@@ -675,15 +683,34 @@ __global__ __launch_bounds__(RPREP) void k_raster_prepare(RasterP p) {
   const bool tagged = p.margin > 0 && p.sort_tag[b] == RS_TAG(b, p.margin);
   bool moved = !tagged;
   const float thr = (float)p.margin - 0.02f;
-  for (int v = tid; v < p.V; v += RPREP) {
-    const float X = vb[(size_t)v * 3], Y = vb[(size_t)v * 3 + 1], Z = vb[(size_t)v * 3 + 2];
-    const float xn = p.s * (-X) / Z + p.w1, yn = p.s * (-Y) / Z + p.h1;
-    float* o = p.ndc + ((size_t)b * p.V + v) * 3;
-    o[0] = xn; o[1] = yn; o[2] = Z;
-    if (tagged) moved = moved || !(fabsf(fmaf(-yn, rk, ra) - rowb[v]) < thr);      // NaN-safe: anything odd rebuilds
-    if (Z > R_KEPS) {
-      mnx = fminf(mnx, xn); mxx = fmaxf(mxx, xn);
-      mny = fminf(mny, yn); mxy = fmaxf(mxy, yn);
+  // RPV vertices per thread and trip with all their loads in flight together: one load -> wait -> divide -> store per
+  // iteration was a chain of 2 x 14 memory latencies per thread (the loop bound is a kernel argument, the compiler does
+  // not batch the loads by itself)
+  float* nbo = p.ndc + (size_t)b * p.V * 3;
+  for (int v0 = tid; v0 < p.V; v0 += RPV * RPREP) {
+    float X[RPV], Y[RPV], Z[RPV], rb[RPV];
+#pragma unroll
+    for (int u = 0; u < RPV; ++u) {
+      const unsigned o = __umul24((unsigned)min(v0 + u * RPREP, p.V - 1), 3u);
+      X[u] = vb[o]; Y[u] = vb[o + 1u]; Z[u] = vb[o + 2u];
+    }
+    if (tagged) {
+#pragma unroll
+      for (int u = 0; u < RPV; ++u) rb[u] = rowb[min(v0 + u * RPREP, p.V - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < RPV; ++u) {
+      const int v = v0 + u * RPREP;
+      if (v < p.V) {
+        const float xn = p.s * (-X[u]) / Z[u] + p.w1, yn = p.s * (-Y[u]) / Z[u] + p.h1;
+        float* o = nbo + __umul24((unsigned)v, 3u);
+        o[0] = xn; o[1] = yn; o[2] = Z[u];
+        if (tagged) moved = moved || !(fabsf(fmaf(-yn, rk, ra) - rb[u]) < thr);      // NaN-safe: anything odd rebuilds
+        if (Z[u] > R_KEPS) {
+          mnx = fminf(mnx, xn); mxx = fmaxf(mxx, xn);
+          mny = fminf(mny, yn); mxy = fmaxf(mxy, yn);
+        }
+      }
     }
   }
 #pragma unroll
@@ -792,7 +819,7 @@ __device__ __forceinline__ void r_tile_depth_sums(const RasterP& p, int s, int b
 // split evenly over the 64 lanes (every lane walks a contiguous run of pairs, the staged face stays in registers
 // while the run stays inside one face).  The run start -> face lookup is a scatter + prefix-max instead of a
 // search.  Only the key window is shared by the waves (LDS atomics).
-__global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 waves/SIMD: two workgroups per CU
+__global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       // 4 waves/SIMD: two workgroups per CU
   __shared__ unsigned long long keys[R_CAP * 5];
   __shared__ float wT[RW][64 * RT];         // staged faces of the wave's current round
   __shared__ int wPre[RW][65];              // exclusive prefix of the candidate counts
@@ -854,7 +881,8 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
       for (int k = 0; k < 3; ++k) vb_[k] = p.faces[3 * (int)(e_b & 0xfffffu) + k];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        ca[3 * k] = nb[(size_t)va[k] * 3]; ca[3 * k + 1] = nb[(size_t)va[k] * 3 + 1]; ca[3 * k + 2] = nb[(size_t)va[k] * 3 + 2];
+        const unsigned o = __umul24((unsigned)va[k], 3u);        // 32-bit offsets: SGPR base + VGPR offset loads
+        ca[3 * k] = nb[o]; ca[3 * k + 1] = nb[o + 1u]; ca[3 * k + 2] = nb[o + 2u];
       }
       for (; idx - lane < i1; idx += stride) {
         // ---- issue the next rounds' gathers before working on this one ------------------------------------
@@ -865,7 +893,8 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
         for (int k = 0; k < 3; ++k) vn[k] = p.faces[3 * (int)(e_c & 0xfffffu) + k];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          cn[3 * k] = nb[(size_t)vb_[k] * 3]; cn[3 * k + 1] = nb[(size_t)vb_[k] * 3 + 1]; cn[3 * k + 2] = nb[(size_t)vb_[k] * 3 + 2];
+          const unsigned o = __umul24((unsigned)vb_[k], 3u);
+          cn[3 * k] = nb[o]; cn[3 * k + 1] = nb[o + 1u]; cn[3 * k + 2] = nb[o + 2u];
         }
         // ---- this round: bbox against the tile, candidate count, staging -----------------------------------
         int cnt = 0;
@@ -887,7 +916,7 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
             ya += sYf[ya - sy0] > bymax ? 1 : 0;
             yb -= sYf[yb - sy0] < bymin ? 1 : 0;
           }
-          cnt = max(0, xb - xa + 1) * max(0, yb - ya + 1);
+          cnt = (int)__umul24((unsigned)max(0, xb - xa + 1), (unsigned)max(0, yb - ya + 1));
           const float farea = r_edge(ca[6], ca[7], ca[0], ca[1], ca[3], ca[4]);
           {
             // the rasteriser's exclusions (RasterizeMeshesNaive: zmin < kEpsilon, |face area| <= kEpsilon with
@@ -907,9 +936,11 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
             T[11] = l02 <= R_KEPS ? 0.f : __builtin_amdgcn_rcpf(l02);
             T[12] = l12 <= R_KEPS ? 0.f : __builtin_amdgcn_rcpf(l12);
             desc[lane] = (xa - x0) | ((ya - sy0) << 10) | ((xb - xa + 1) << 20);
-            f_pix = (ya - sy0) * tw + (xa - x0);
+            f_pix = (int)__umul24((unsigned)(ya - sy0), (unsigned)tw) + (xa - x0);
             f_nx = xb - xa + 1;
-            fid[lane] = (int)(e_a & 0xfffffu);
+            // face id | M << 20 with M = floor(1024 / nx) + 1: for a box of up to 16 pixels (nx <= 16, k < 16)
+            // (k * M) >> 10 == k / nx exactly (k * (M * nx - 1024) <= 15 * 16 < 1024); wider boxes never use M
+            fid[lane] = (int)((e_a & 0xfffffu) | ((unsigned)((int)(1024.f * __builtin_amdgcn_rcpf((float)f_nx)) + 1) << 20));
             {
               // nearest vertex depth MINUS 16 ulps: the interpolated depth (normalised weights through v_rcp_f32) can fall a
               // few ulps short of the nearest vertex, and on such a tie the depth cull below dropped a candidate or not
@@ -933,22 +964,36 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
           // per pair: 324 vector instructions per round against ~220 now, the kernel is bound by their issue.)
           unsigned keepm = 0u;
           if (cnt > 0) {
-            int kx = 0, pix = f_pix;
+            // byte offset of the pixel's key block; the walk over the box is branch-free and multiply-free, reads past the
+            // box (the last trip) land on other LDS words and are masked out below
+            unsigned a = __umul24((unsigned)f_pix, 40u);
+            const unsigned wrap = __umul24((unsigned)(tw - f_nx), 40u);
+            const char* kb = (const char*)keys;
+            int kx = 0;
             for (int k0 = 0; k0 < cnt; k0 += 4) {          // four pixels per trip: their eight key words are in flight together
-              unsigned q1[4], q9[4];
+              unsigned ad[4], q1[4], q9[4];
 #pragma unroll
               for (int u = 0; u < 4; ++u) {
-                const unsigned* qh = (const unsigned*)(keys + (size_t)(k0 + u < cnt ? pix : f_pix) * 5);
+                ad[u] = a;
+                ++kx;
+                const bool w = kx == f_nx;
+                a += 40u + (w ? wrap : 0u);
+                kx = w ? 0 : kx;
+              }
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const unsigned* qh = (const unsigned*)(kb + ad[u]);
                 q1[u] = qh[1]; q9[u] = qh[9];
-                ++pix;
-                if (++kx == f_nx) { kx = 0; pix += tw - f_nx; }
               }
+              unsigned mx[4];
 #pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                const bool keep = k0 + u < cnt && !(f_zb > q1[u] && f_zb > q9[u]);
-                keepm |= (keep ? 1u : 0u) << (k0 + u);
-              }
+              for (int u = 0; u < 4; ++u) mx[u] = max(q1[u], q9[u]);       // behind BOTH keys <=> behind the farther one
+              unsigned bits = 0u;
+#pragma unroll
+              for (int u = 0; u < 4; ++u) bits |= (f_zb <= mx[u] ? 1u : 0u) << u;
+              keepm |= bits << k0;
             }
+            keepm &= (1u << cnt) - 1u;                       // cnt <= 16 here
           }
           const int nk = __popc(keepm);
           const int kincl = r_wave_scan_add(nk);
@@ -960,18 +1005,18 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
           }
           __builtin_amdgcn_wave_barrier();
           for (int i = lane; i < nkeep; i += 64) {
-            const int e = (int)pl[i], lo = e & 63, k = e >> 6;
-            const int d = desc[lo];
-            const int nx = d >> 20;
-            const int ky_ = (int)(((float)k + 0.5f) * __builtin_amdgcn_rcpf((float)nx)), kx_ = k - ky_ * nx;
-            const int xi = (d & 1023) + kx_, yi = ((d >> 10) & 1023) + ky_;
+            const unsigned e = pl[i], lo = e & 63u, k = e >> 6;
+            const unsigned d = (unsigned)desc[lo], fw = (unsigned)fid[lo];
+            const unsigned nx = d >> 20;
+            const unsigned ky_ = __umul24(k, fw >> 20) >> 10, kx_ = k - __umul24(ky_, nx);
+            const unsigned xi = (d & 1023u) + kx_, yi = ((d >> 10) & 1023u) + ky_;
             float T[RT];
 #pragma unroll
             for (int q = 0; q < RT; ++q) T[q] = T_[lo * RT + q];
             float pz, dd;
             bool inside;
             r_eval_fast(T, sXf[xi], sYf[yi], &pz, &inside, &dd);
-            r_insert(keys + (size_t)(yi * tw + xi) * 5, pz, inside, dd, fid[lo]);
+            r_insert((unsigned long long*)((char*)keys + __umul24(__umul24(yi, (unsigned)tw) + xi, 40u)), pz, inside, dd, (int)(fw & 0xfffffu));
           }
           __builtin_amdgcn_wave_barrier();
         } else if (npairs > 0) {
@@ -994,7 +1039,7 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
             float T[RT];
 #pragma unroll
             for (int q = 0; q < RT; ++q) T[q] = T_[lo * RT + q];
-            int d = desc[lo], f = fid[lo];
+            int d = desc[lo], f = fid[lo] & 0xfffff;
             int nx = d >> 20, xa = d & 1023, ya = (d >> 10) & 1023;
             const int k = j0 - pre[lo];
             int ky_ = k / nx, kx_ = k - ky_ * nx;
@@ -1004,7 +1049,7 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
               float pz, dd;
               bool inside;
               r_eval_fast(T, sXf[xi], sYf[yi], &pz, &inside, &dd);
-              r_insert(keys + (size_t)(yi * tw + xi) * 5, pz, inside, dd, f);
+              r_insert((unsigned long long*)((char*)keys + __umul24(__umul24((unsigned)yi, (unsigned)tw) + (unsigned)xi, 40u)), pz, inside, dd, f);
               if (++j >= j1) break;
               if (++kx_ == nx) { kx_ = 0; ++ky_; }
               if (j >= nextp) {                          // the run moves on to the next face with candidates
@@ -1012,7 +1057,7 @@ __global__ __launch_bounds__(RB, 4) void k_raster_strip(RasterP p) {       // 4 
                 while (pre[lo + 1] <= j) ++lo;
 #pragma unroll
                 for (int q = 0; q < RT; ++q) T[q] = T_[lo * RT + q];
-                d = desc[lo]; f = fid[lo];
+                d = desc[lo]; f = fid[lo] & 0xfffff;
                 nx = d >> 20; xa = d & 1023; ya = (d >> 10) & 1023;
                 kx_ = 0; ky_ = 0;
                 nextp = pre[lo + 1];

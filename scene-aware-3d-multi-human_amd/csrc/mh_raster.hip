@@ -811,7 +811,12 @@ __device__ __forceinline__ void r_tile_depth_sums(const RasterP& p, int s, int b
 }
 
 #define RW (RB / 64)         // waves per tile workgroup
+#ifndef RPL
 #define RPL 512              // pair descriptors per wave and round (sub-pixel face path)
+#endif
+#ifndef R_SUBMAX
+#define R_SUBMAX 16          // most candidate pixels of a face on the sub-pixel path (<= 32: one mask word, k * M >> 10 exact)
+#endif
 
 // One workgroup per tile.  Every wave runs its own rounds of 64 candidate faces with no workgroup barrier in
 // between: gather (software-pipelined three rounds deep: sort entry -> vertex ids -> projected vertices), blurred
@@ -954,7 +959,7 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
         const int incl = r_wave_scan_add(cnt);
         const int npairs = __builtin_amdgcn_readlane(incl, 63);
         const int excl = incl - cnt;
-        if (npairs > 0 && npairs <= RPL && __ballot(cnt > 16) == 0ull) {
+        if (npairs > 0 && npairs <= RPL && __ballot(cnt > R_SUBMAX) == 0ull) {
           // ---- sub-pixel faces (a few candidates each).  Depth cull first, per face lane: the clipped-barycentric depth
           // of a face is never below its nearest vertex, so a pair whose face lies entirely behind both the pixel's current
           // nearest key and its current 4th silhouette key cannot change the window (the keys only ever decrease).  A lane
@@ -993,7 +998,7 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
               for (int u = 0; u < 4; ++u) bits |= (f_zb <= mx[u] ? 1u : 0u) << u;
               keepm |= bits << k0;
             }
-            keepm &= (1u << cnt) - 1u;                       // cnt <= 16 here
+            keepm &= cnt >= 32 ? ~0u : (1u << cnt) - 1u;
           }
           const int nk = __popc(keepm);
           const int kincl = r_wave_scan_add(nk);

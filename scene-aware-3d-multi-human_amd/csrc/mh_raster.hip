@@ -1834,6 +1834,7 @@ static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const flo
            "null argument");
   MH_CHECK(T > 0 && N > 0 && N <= 32 && V > 0 && F > 0 && H > 0 && W > 0, "empty input");
   MH_CHECK(H <= 4095 && W <= 65535 && F < (1 << 20), "sorted face entries hold 12-bit rows and 20-bit face ids");
+  MH_CHECK(V < (1 << 22), "vertex offsets of the gathers are 24-bit products (3 * vertex index)");
   RasterP p;
   p.B = T * N; p.N = N; p.V = V; p.F = F; p.H = H; p.W = W;
   // transforms.py:222-255 with image_size = (W, H)

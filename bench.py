@@ -354,9 +354,16 @@ def main():
             gbs = algo / (us * 1e-6) / 1e9
             fresh = counters_fresh(stamp, 'mh_raster.hip')
             roof = {'kernel': 'k_raster_strip', 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                    'frac': round(gbs / PEAK_HBM_GBS, 4), 'traffic': traffic.get('k_raster_strip') if fresh else None,
+                    'frac': round(gbs / PEAK_HBM_GBS, 4), 'traffic': None, 'traffic_detail': None,
                     'launch_us': round(us, 1), 'algorithmic_bytes': algo, 'window_pixels': window_px, 'dominant_by_events': dom,
                     'counters_taken_on': stamp.get('git') if fresh else None, 'valu': None, 'pairs': pairs}
+            td = traffic.get('k_raster_strip') if fresh else None
+            if td and not args.strong and frames_here == 200 and N_PEOPLE == 4:
+                # HBM bytes per launch from the committed FETCH_SIZE / WRITE_SIZE passes (separate --pmc runs, KiB x 1024).  The
+                # guide's gfx950 correction (x2) applies to wide 16 B/lane streaming reads only; this kernel reads 12-byte
+                # gathers and 4-byte list entries, which are uncalibrated widths: the raw sum is printed
+                roof['traffic'] = float(td['fetch_bytes'] + td['write_bytes'])
+                roof['traffic_detail'] = td
             nv = load_pmc_valu('k_raster_strip') if fresh else None
             if nv and not args.strong and frames_here == 200 and N_PEOPLE == 4:
                 gi = nv / (us * 1e-6) / 1e9

@@ -227,8 +227,10 @@ def _face_eval64(ndc, faces, b, f, xf, yf):
 
 def _selection_differences(r):
     """Pixels where the HIP selection and the oracle's brute-force selection (same vertices) pick different faces, each
-    checked to be a NEAR-TIE in float64: the face that differs either reaches the pixel centre to within 1e-4 of the blur
-    radius (in / out of the band) or its depth is within 1e-5 of the depth at the cut of the K-nearest list."""
+    checked to be a NEAR-TIE in float64: the HIP list is a valid K-nearest list (depths within 1e-5 of the cut count as equal)
+    of the faces in the blur band for some resolution of the faces that reach the pixel centre to within 1e-4 of the blur
+    radius.  (A tie face that drops out of the band is replaced by the next-nearest face, which is itself no tie:
+    tools/fuzz_raster.py found two such pixels in 180 random scenes.)"""
     T, N, H, W = r['shape']
     B = T * N
     faces = r['faces']
@@ -242,6 +244,7 @@ def _selection_differences(r):
     ndiff, not_ties = 0, []
     d0 = got[..., 0] != want[..., 0]
     d4 = (np.sort(got[..., 1:], -1) != np.sort(want[..., 1:], -1)).any(-1)    # alpha is a product: the K=4 list is a set
+    import itertools
     for b, y, x in zip(*np.nonzero(d0 | d4)):
         ndiff += 1
         xf, yf = float(xs[x]), float(ys[y])
@@ -249,14 +252,26 @@ def _selection_differences(r):
             A, Bset = set(got[b, y, x, lo:hi]) - {-1}, set(want[b, y, x, lo:hi]) - {-1}
             if A == Bset:
                 continue
-            ev = {f: _face_eval64(ndc, faces, b, f, xf, yf) for f in A | Bset}
-            zcut = max(ev[f][0] for f in A | Bset)                  # depth of the farthest face either side kept
-            for f in A ^ Bset:
-                pz, inside, d2 = ev[f]
-                band_tie = (not inside) and abs(d2 - blur) <= 1e-4 * blur
-                depth_tie = any(abs(pz - ev[g][0]) <= 1e-5 * max(abs(pz), 1e-6) for g in (A | Bset) if g != f) or abs(pz - zcut) <= 1e-5 * zcut
-                if not (band_tie or depth_tie):
-                    not_ties.append((int(b), int(y), int(x), int(f), pz, inside, d2))
+            K = hi - lo
+            U = A | Bset
+            ev = {f: _face_eval64(ndc, faces, b, f, xf, yf) for f in U}
+            # faces whose band membership is a tie in float64; every other face of U is in the band (it was selected by one side)
+            ties = [f for f in U if (not ev[f][1]) and abs(ev[f][2] - blur) <= 1e-4 * blur]
+            sure = [f for f in U if f not in ties]
+            ok = False
+            # the HIP list must be a K-nearest list (depth ties at the cut allowed) of the faces in the band for SOME resolution
+            # of the band ties -- a tie face that drops out is replaced by the next face, which is then no tie itself
+            for r_ in range(len(ties) + 1):
+                for S in itertools.combinations(ties, r_):
+                    members = set(sure) | set(S)
+                    if not A <= members or len(A) != min(K, len(members)):
+                        continue
+                    zmax = max(ev[f][0] for f in A)
+                    if all(ev[f][0] >= zmax - 1e-5 * abs(zmax) for f in members - A):
+                        ok = True
+            if not ok:
+                for f in A ^ Bset:
+                    not_ties.append((int(b), int(y), int(x), int(f)) + ev[f])
     return ndiff, live, not_ties
 
 

@@ -102,7 +102,14 @@ struct RasterP {
 };
 #define RS_TAG(b, m) (0x5bd1e995c0ffee00ull ^ ((unsigned long long)(b) * 0x9E3779B97F4A7C15ull) ^ (unsigned long long)(m))
 
+// NDC coordinate of a pixel centre (PixToNonSquareNdc of the CPU rasteriser): every operation rounded on its own.  The
+// compiler's contraction of range * i + offset into one fma moves a centre by up to 1.3e-7 -- nothing for the selection
+// (one more near-tie convention), but 2.6e-5 of a 0.3-pixel face, and the barycentric Jacobian of such a face turns that
+// into 5e-4 of the largest entry of dL/dverts: the last systematic difference to the float64 oracle that
+// tools/fuzz_raster_grads.py / tools/grad_debug.py found (round 3).
+// (#pragma clang fp contract(off) is what keeps the operations apart: hip's __fmul_rn / __fadd_rn are plain operators.)
 __device__ __forceinline__ float r_pix_to_ndc(int i, int S1, int S2) {
+#pragma clang fp contract(off)
   float range = 2.0f;
   if (S1 > S2) range = ((float)S1 * range) / (float)S2;
   const float offset = range / 2.0f;
@@ -122,7 +129,9 @@ __device__ __forceinline__ float r_edge(float px, float py, float ax, float ay, 
 // are kept; the compiler contracts a * b - c * d into an fma differently from context to context, and a sliver near the
 // 1e-8 threshold then existed for one and not for the other: 1 pixel of 850 000 differed, tests/test_full_size_gpu.py)
 __device__ __forceinline__ float r_edge_exact(float px, float py, float ax, float ay, float bx, float by) {
-  return __fsub_rn(__fmul_rn(__fsub_rn(px, ax), __fsub_rn(by, ay)), __fmul_rn(__fsub_rn(py, ay), __fsub_rn(bx, ax)));
+#pragma clang fp contract(off)
+  const float a = (px - ax) * (by - ay), b = (py - ay) * (bx - ax);
+  return a - b;
 }
 // squared distance to segment ab; returns the clamped parameter in *t (deg: degenerate segment)
 __device__ __forceinline__ float r_seg(float px, float py, float ax, float ay, float bx, float by, float* t, bool* deg) {
@@ -1336,12 +1345,27 @@ __device__ __forceinline__ void rg_pixel(const RasterP& p, const RgBody& bd, con
         gwc[k] = gpz * tr.z[k];          // d/d(normalised clipped weight)
         dotn += gwc[k] * nw[k];
       }
+      // d pz / d c_k = (z_k - sum_j n_j z_j) / cs.  With sum_j n_j = 1 this is sum_j (z_k - z_j) n_j / cs: the depths of a
+      // face's vertices agree to ~1e-3, so subtracting them FIRST (exact in fp32) keeps the digits that
+      // gwc[k] - sum_j gwc[j] n_j loses to cancellation (2e-7 / 1e-3 = 2e-4 relative, then times 1/area of a sliver:
+      // up to 5e-3 of the largest entry of the whole gradient on 16 entries of one random scene, where the float32
+      // autograd of the oracle is itself 1e-3 off its float64 self; tools/fuzz_raster_grads.py, tools/grad_debug.py)
       float gw[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        const float gc = (gwc[k] - (craw > 1e-5f ? dotn : 0.f)) * ics;
+        float gc;
+        if (craw > 1e-5f) {
+          float acc = 0.f;
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+            if (j != k) acc += (tr.z[k] - tr.z[j]) * nw[j];
+          gc = gpz * acc * ics;
+        } else {
+          gc = gwc[k] * ics;               // the clamp of the weight sum is active: no normalisation term
+        }
         gw[k] = w[k] > 0.f ? gc : 0.f;
       }
+      (void)dotn;
       // w_i = e_i / area
       const float ge[3] = {gw[0] * ia, gw[1] * ia, gw[2] * ia};
       const float garea = -(gw[0] * w[0] + gw[1] * w[1] + gw[2] * w[2]) * ia;

@@ -25,7 +25,7 @@ def _scene(T, N, W, H, seed, zlo, zhi):
     return sp, pT.astype(np.float32), rng
 
 
-def _run_case(smpl_struct, smpl_regs, T, N, W, H, seed, zlo=3.0, zhi=6.0, fov=60.0, hip_selection=False):
+def _run_case(smpl_struct, smpl_regs, T, N, W, H, seed, zlo=3.0, zhi=6.0, fov=60.0, hip_selection=False, oracle_dtype=torch.float32, coefs=None):
     from mhhip import engine
     from mhhip.sequence import SequenceEngine
     from mhhip.raster import RasterTerms
@@ -35,7 +35,7 @@ def _run_case(smpl_struct, smpl_regs, T, N, W, H, seed, zlo=3.0, zhi=6.0, fov=60
     omodel = lo.BodyModel(smpl_struct, smpl_regs)
     faces = np.asarray(smpl_struct.f).astype(np.int64)
     betas = sp['betas_gt']
-    coefs = dict(depth=0.05, silhouette=0.1)
+    coefs = dict(coefs or dict(depth=0.05, silhouette=0.1))
     e = SequenceEngine(model, (W, H), T, N, K, None, coefs, batch_size=2)
     zmin = rng.uniform(0.5, 1.5, T).astype(np.float32)
     zmax = rng.uniform(4.0, 9.0, T).astype(np.float32)
@@ -69,35 +69,36 @@ def _run_case(smpl_struct, smpl_regs, T, N, W, H, seed, zlo=3.0, zhi=6.0, fov=60
     sel = rt.selection(e)
 
     # ---- oracle -----------------------------------------------------------------------------------
-    verts = e.verts.cpu().clone().requires_grad_(True)
-    tzmin = torch.tensor(zmin, requires_grad=True)
-    tzmax = torch.tensor(zmax, requires_grad=True)
+    dt = oracle_dtype                                  # float64: what the float32 oracle itself is worth on an entry
+    verts = e.verts.cpu().clone().to(dt).requires_grad_(True)
+    tzmin = torch.tensor(zmin, dtype=dt, requires_grad=True)
+    tzmax = torch.tensor(zmax, dtype=dt, requires_grad=True)
     got_sel = _hip_selection(sel, T * N, H, W)
     zbuf, alpha = ro.render(verts, faces, K, (W, H), selection=(got_sel[..., :1], got_sel[..., 1:]) if hip_selection else None)
     zbuf, alpha = zbuf.view(T, N, H, W), alpha.view(T, N, H, W)
-    tseg = torch.tensor(seg)
-    conf = (torch.tensor(pose2d[..., 2:3]) >= 0.5).float()
-    p2d_valid = (conf.sum(dim=(2, 3)) >= 2).float()
-    mask_valid = (tseg.sum(dim=(2, 3)) >= 0.005 * H * W).float()
+    tseg = torch.tensor(seg, dtype=dt)
+    conf = (torch.tensor(pose2d[..., 2:3]) >= 0.5).to(dt)
+    p2d_valid = (conf.sum(dim=(2, 3)) >= 2).to(dt)
+    mask_valid = (tseg.sum(dim=(2, 3)) >= 0.005 * H * W).to(dt)
     min_z = fo.softplus(tzmin).view(T, 1, 1)
     max_z = min_z.detach() + 1.0 + fo.softplus(tzmax).view(T, 1, 1)
-    tgt = torch.tensor(depths) * (1.0 / min_z - 1.0 / max_z) + 1.0 / max_z
-    m = (zbuf > 0).float() * fo.erode3x3(fo.erode3x3(tseg)) * p2d_valid[..., None, None]
+    tgt = torch.tensor(depths, dtype=dt) * (1.0 / min_z - 1.0 / max_z) + 1.0 / max_z
+    m = (zbuf > 0).to(dt) * fo.erode3x3(fo.erode3x3(tseg)) * p2d_valid[..., None, None]
     pred = 1.0 / torch.clamp(zbuf + 0.2, min=1e-3)
     lp = m * torch.log(torch.clamp(pred, min=1e-3))
     lt = m * torch.log(torch.clamp(tgt.unsqueeze(1), min=1e-3))
     cnt = m.sum(dim=(2, 3)) + 1
     depth_tn = (lp.sum(dim=(2, 3)) / cnt - lt.sum(dim=(2, 3)) / cnt) ** 2
     order = torch.argsort(torch.tensor(pT)[..., 2], dim=1)
-    sil_tn = torch.zeros(T, N)
+    sil_tn = torch.zeros(T, N, dtype=dt)
     sil_list = []
     for t in range(T):
-        acc = torch.zeros(H, W)
+        acc = torch.zeros(H, W, dtype=dt)
         for r in range(N):
             n = int(order[t, r])
             if float(mask_valid[t, r] * p2d_valid[t, r]) > 0:
                 sil_list.append((t, n, fo.masked_mse_loss(alpha[t, n], tseg[t, n], 1 - acc)))
-            acc = ((acc + tseg[t, n]) > 0).float()
+            acc = ((acc + tseg[t, n]) > 0).to(dt)
     total = coefs['depth'] * depth_tn.sum() + coefs['silhouette'] * sum(x[2] for x in sil_list)
     total.backward()
     want_sil = np.zeros((T, N), np.float32)

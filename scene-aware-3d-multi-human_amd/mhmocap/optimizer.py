@@ -337,6 +337,11 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
         T, N = self.num_frames, self.num_people
         H, W = self.img_h, self.img_w
         bs = getattr(dataloader, 'batch_size', None)
+        if getattr(dataloader, 'drop_last', False) and len(getattr(dataloader, 'dataset', ())) % int(bs or 1) != 0:
+            # the reference would never show the dropped tail frames to the data terms; staging reads every frame once and
+            # the cycle covers all of them -- refuse rather than optimise something else silently
+            raise ValueError('dataloader drops its last, incomplete batch (drop_last=True with %d frames in batches of %s): '
+                             'not supported by the staged optimisation loop' % (len(dataloader.dataset), bs))
         if self._is_shuffled(dataloader) and self._world()[0] > 1:
             import warnings
             warnings.warn('dataloader has shuffle=True (configs/predict_mupots.yml:14) in a FRAME-SHARDED run: a random batch '

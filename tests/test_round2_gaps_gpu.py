@@ -355,6 +355,21 @@ def test_staging_reads_a_plain_dataset_directly_and_a_custom_loader_through_its_
         assert other[3] == got[0][3] == 5
 
 
+def test_a_loader_that_drops_its_tail_is_refused(smpl_struct, smpl_regs, tmp_path):
+    """drop_last=True with an incomplete last batch: the reference never shows those frames to the data terms; the staged loop
+    would optimise all of them -- it refuses instead of computing something else (a complete last batch is fine)"""
+    fin = gi.fit_inputs()
+    opt = _new_opt(smpl_struct, smpl_regs, tmp_path, fin)
+    opt.init_optimized_variables(fin['pose2d'], fin['poses_smpl'], fin['betas_smpl'], fin['valid_smpl'], num_iter=0)
+    T = fin['T']
+    bad = next(b for b in (7, 3, 4, 6, 9) if T % b)
+    with pytest.raises(ValueError, match='drop_last'):
+        opt._stage_from_dataloader(torch.utils.data.DataLoader(_DS(fin), batch_size=bad, shuffle=False, drop_last=True))
+    good = next(b for b in (5, 2, 4, 3, 1) if T % b == 0)
+    opt._stage_from_dataloader(torch.utils.data.DataLoader(_DS(fin), batch_size=good, shuffle=False, drop_last=True))
+    assert opt.engine.batch == good
+
+
 # ---- round 3: the rest of the overlay's API surface (VERDICT r02 item 8) ---------------------------------------------------
 @pytest.mark.parametrize('key', ['joints_h36m17', 'joints_mupots'])
 def test_other_sparse_joint_sets_inside_fit(smpl_struct, smpl_regs, oracle_model, tmp_path, key):

@@ -505,7 +505,9 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
             e.set_batch_table(None)
         self.batch_tables = tables
         check_every = 25 if os.environ.get('MHHIP_CHECK_REPLICAS') == '1' else 0
-        lr = 0.01                                                             # a new RMSprop + ExponentialLR per fit (:355-356)
+        lr = 0.01                                                             # a new RMSprop + ExponentialLR per fit (:355-356):
+        e.sq.zero_()                                                          # ... its running squares and momentum buffers
+        e.buf.zero_()                                                         # start at zero in EVERY call
         cycles = range(num_iter)
         if verbose and tqdm is not None and rank == 0:
             cycles = tqdm(cycles)

@@ -182,6 +182,26 @@ def test_second_fit_on_the_same_optimizer_replays_valid_graphs(smpl_struct, smpl
             np.testing.assert_allclose(l1[c][k], l0[c][k], rtol=2e-3, atol=1e-6, err_msg='%s cycle %d' % (k, c))
 
 
+def test_every_fit_starts_a_new_rmsprop(smpl_struct, smpl_regs, oracle_model, tmp_path):
+    """The reference builds a new torch.optim.RMSprop (and ExponentialLR) inside every ``fit`` (optimizer.py:355-356), so the
+    first step of a SECOND fit is again lr * g / (sqrt((1 - alpha) g^2) + eps) = 0.01 * sign(g) / sqrt(0.5) for every entry
+    with a gradient -- with the moments of the first fit kept it would be anything else.  (Found while listing where the
+    staged loop could diverge silently from the reference; round 3.)"""
+    T, N, W, H, batch = 4, 2, 96, 54, 2
+    opt, dl, o, batches, seq = _setup(smpl_struct, smpl_regs, oracle_model, tmp_path, T, N, W, H, batch, 37, False)
+    opt.fit(dl, num_iter=4)
+    e = opt.engine
+    before = e.params.clone()
+    opt.fit(dl, num_iter=1)
+    torch.cuda.synchronize()
+    step = (e.params - before).abs().cpu().numpy()
+    g = e.grads.cpu().numpy()
+    big = np.abs(g) > 1e-4 * np.abs(g).max()                      # entries whose sign is not rounding noise
+    assert big.sum() > 100
+    np.testing.assert_allclose(step[big], 0.01 / np.sqrt(0.5), rtol=2e-3)
+    assert (step[g == 0] == 0).all()
+
+
 def test_eight_cycles_step_by_step(smpl_struct, smpl_regs, oracle_model, tmp_path):
     """Eight cycles of the whole loop, compared cycle by cycle instead of only at the end: a free-running comparison of two
     fp32 implementations of this optimiser diverges by construction (RMSprop's first steps are lr * sign(g) / sqrt(1 - alpha):

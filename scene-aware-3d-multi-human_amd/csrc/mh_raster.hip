@@ -395,8 +395,15 @@ __device__ __forceinline__ unsigned r_face_rows_xyz(const RasterP& p, float ra, 
     // rows whose pixel centre lies inside the blurred bbox (centres at the integers of the row coordinate), 1e-3 px
     // absorbs the rounding.  A tight range matters: the tallest face of a body sets how far above a tile its
     // candidate range starts
-    const float lo = ceilf(fmaf(-bymax, rk, ra) - 1e-3f), hi = floorf(fmaf(-bymin, rk, ra) + 1e-3f);
+    const float lo = ceilf(fmaf(-bymax, rk, ra) - 1e-3f);
+    float hi = floorf(fmaf(-bymin, rk, ra) + 1e-3f);
     const float mg = (float)p.margin;
+    // A blurred range that contains NO pixel-centre row (hi = lo - 1: images under 100 rows, where the blur band is
+    // narrower than a pixel) is skipped by a fresh sort -- but a KEPT list must hold the face: after moving a fraction of
+    // a row it may cover row lo - 1 or row lo.  It is listed at row lo with one row; the tiles' margins then find it
+    // wherever it can have gone.  (Found at 96x54 by a test that fits twice: hundreds of window pixels of every kept
+    // launch had lost such faces; at the bench's 240x135 the band alone spans 1.35 rows and the case cannot occur.)
+    if (mg > 0.f && hi == lo - 1.f) hi = lo;
     if (hi >= lo && hi >= -mg && lo <= (float)(p.H - 1) + mg) {          // (false for NaN rows)
       const unsigned ulo = (unsigned)fminf(fmaxf(lo, 0.f), (float)(p.H - 1)), uhi = (unsigned)fminf(fmaxf(hi, 0.f), (float)(p.H - 1));
       out = ulo | (uhi << 16) | (farea > 0.f ? 0x8000u : 0u);

@@ -186,6 +186,12 @@ class SequenceEngine(object):
         T, N, H, W = self.T, self.N, self.H, self.W
         L = _lib.lib()
         st = _lib.stream_ptr(self.dev)
+        # staging again (another dataloader handed to a later fit): captured cycles bake the addresses of the tensors
+        # allocated below, and the device scene update holds transposed copies of the old depths / background masks
+        if getattr(self, '_graphs', None):
+            torch.cuda.current_stream(self.dev).synchronize()
+            self._graphs = {}
+        self._scene_dev = None
         self.pose2d = _dev(pose2d, self.dev).view(self.B, 17, 3)
         self.poses_ref = _dev(poses_ref, self.dev).view(self.B, 72)
         self.valid = _dev(valid, self.dev).view(self.B)

@@ -434,6 +434,11 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
         self._backmasks = None if 'backmasks' not in store else np.array(loc('backmasks'))
         keep.clear()
         self._staged = True
+        try:
+            import weakref
+            self._staged_from = weakref.ref(dataloader)
+        except TypeError:
+            self._staged_from = None
 
     @staticmethod
     def _is_shuffled(dataloader):
@@ -485,7 +490,10 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
     # -- reference optimizer.py:324-602 ---------------------------------------------------------------
     def fit(self, dataloader, num_iter=250, min_cutoff1=0.01, min_cutoff2=0.001, beta1=0.02, beta2=0.5,
             update_filters_every=25, verbose=False):
-        if not self._staged:
+        # the inputs are read once; a DIFFERENT dataloader object means different inputs (the reference reads whatever it is
+        # handed in every cycle), so it is staged afresh -- the same object is trusted to deliver the same frames
+        other = self._staged and getattr(self, '_staged_from', None) is not None and self._staged_from() is not dataloader
+        if not self._staged or other:
             self._stage_from_dataloader(dataloader)
         e, sh = self.engine, self.sh
         world, rank = self._world()

@@ -202,6 +202,41 @@ def test_every_fit_starts_a_new_rmsprop(smpl_struct, smpl_regs, oracle_model, tm
     assert (step[g == 0] == 0).all()
 
 
+def test_fit_with_another_dataloader_reads_the_new_inputs(smpl_struct, smpl_regs, oracle_model, tmp_path):
+    """The reference reads whatever dataloader it is handed, every cycle.  The staged loop reads its inputs once -- so a
+    DIFFERENT dataloader object in a later ``fit`` must be staged afresh (new device tensors, captured cycles and the device
+    scene state dropped), and the result must be that of an optimiser that had those inputs from the start."""
+    from mhhip import synthetic_seq
+    T, N, W, H, batch = 6, 2, 96, 54, 3
+    opt, dl_a, o, batches, seq = _setup(smpl_struct, smpl_regs, oracle_model, tmp_path, T, N, W, H, batch, 43, True)
+    opt.fit(dl_a, num_iter=3)
+    seq_b = dict(seq)
+    seq_b['depths'] = (1.0 - seq['depths']).astype(np.float32)
+    seq_b['pose2d'] = seq['pose2d'].copy()
+    seq_b['pose2d'][..., :2] += 3.0
+    dl_b = torch.utils.data.DataLoader(synthetic_seq.SequenceDataset(seq_b), batch_size=batch, shuffle=False)
+    leaves = opt.engine.params.clone()
+    log1 = opt.fit(dl_b, num_iter=2)
+    np.testing.assert_array_equal(opt.engine.depths.cpu().numpy().reshape(T, H, W), seq_b['depths'])
+    np.testing.assert_array_equal(opt.engine.pose2d.cpu().numpy().reshape(T, N, 17, 3), seq_b['pose2d'])
+    # the same leaves on an optimiser that only ever saw the second loader
+    sub = tmp_path / 'b'
+    sub.mkdir()
+    opt2, _, _, _, _ = _setup(smpl_struct, smpl_regs, oracle_model, sub, T, N, W, H, batch, 43, True)
+    opt2._stage_from_dataloader(dl_b)
+    opt2.engine.params.copy_(leaves)
+    log2 = opt2.fit(dl_b, num_iter=2)
+    for c in range(2):
+        for k in ['loss_pose24j', 'loss_depth', 'loss_silhouette', 'reg_contact']:
+            np.testing.assert_allclose(log1[c][k], log2[c][k], rtol=1e-4, atol=1e-7, err_msg='%s cycle %d' % (k, c))
+    p1, p2 = opt.engine.params.cpu().numpy(), opt2.engine.params.cpu().numpy()
+    assert float((np.abs(p1 - p2) > 1e-4).mean()) < 0.01          # float atomics + sign-like first steps on noise-level entries
+    # and the same loader object again is NOT staged again
+    d_ptr = opt.engine.depths.data_ptr()
+    opt.fit(dl_b, num_iter=1)
+    assert opt.engine.depths.data_ptr() == d_ptr
+
+
 def test_eight_cycles_step_by_step(smpl_struct, smpl_regs, oracle_model, tmp_path):
     """Eight cycles of the whole loop, compared cycle by cycle instead of only at the end: a free-running comparison of two
     fp32 implementations of this optimiser diverges by construction (RMSprop's first steps are lr * sign(g) / sqrt(1 - alpha):

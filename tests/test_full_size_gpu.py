@@ -189,14 +189,16 @@ def test_selection_does_not_depend_on_what_the_workspace_held(smpl_struct, smpl_
         assert float((g - outs[0][2]).abs().max()) <= 2e-3 * scale        # float atomics in the gradient scatter
 
 
-def test_kept_face_lists_give_the_same_selection_as_a_fresh_sort(smpl_struct, smpl_regs, oracle_model, tmp_path):
+@pytest.mark.parametrize('T,N,W,H,batch', [(100, 4, 240, 135, 10), (12, 3, 96, 54, 3), (10, 2, 48, 80, 5), (8, 2, 64, 36, 4)])
+def test_kept_face_lists_give_the_same_selection_as_a_fresh_sort(smpl_struct, smpl_regs, oracle_model, tmp_path, T, N, W, H, batch):
     """Temporal coherence of the rasteriser's preparation (mh_raster_set_sort_margin, default 1 row): over 40 optimisation
     cycles at the C3 shape -- RMSprop's first, largest steps included -- the selection keys (40 B per window pixel: z and
     face of the nearest face and of the K=4 list) of the launch that KEEPS its face lists must equal, bit for bit, those
     of a launch that sorts afresh on a second workspace; the lists must actually be kept (most bodies, most cycles) and
     must be rebuilt when a body moves by more than the margin."""
     from mhhip.raster import RasterTerms, set_sort_margin
-    T, N, W, H, batch = 100, 4, 240, 135, 10
+    # (images under 100 rows: the blur band is narrower than a pixel there, and a face whose band holds no pixel-centre row
+    # at sort time can hold one a cycle later -- the kept lists of round 3's first version had lost those faces)
     opt, dl, o, batches, seq = _setup(smpl_struct, smpl_regs, oracle_model, tmp_path, T, N, W, H, batch, 47, True)
     opt._stage_from_dataloader(dl)
     e = opt.engine
@@ -226,4 +228,4 @@ def test_kept_face_lists_give_the_same_selection_as_a_fresh_sort(smpl_struct, sm
         set_sort_margin(old)
     assert seen == 40 * e.B
     print('face lists rebuilt for %d of %d (body, cycle) pairs' % (rebuilt, seen))
-    assert e.B <= rebuilt < 0.6 * seen                            # everything once, the jump, the early large steps -- not every cycle
+    assert e.B <= rebuilt < (0.6 if H >= 100 else 0.9) * seen     # everything once, the jump, the early large steps -- not every cycle

@@ -61,3 +61,49 @@ def test_random_scenes_gradients_against_the_float64_oracle(smpl_struct, smpl_re
         for k in ('gzmin', 'gzmax'):
             np.testing.assert_allclose(r[k], r['want_' + k], atol=2e-4 * max(np.abs(r['want_' + k]).max(), 1e-12), err_msg=where)
     assert nonzero >= 4
+
+
+@pytest.mark.parametrize('seed', [707])
+def test_kept_face_lists_under_random_motion(smpl_struct, smpl_regs, oracle_model, tmp_path, seed):
+    """Kept face lists against a fresh sort under random motion: image sizes from 32x24 to 240x135 (landscape, portrait), 1-4
+    humans, per-launch random perturbations of translations and poses from a hundredth of a pixel to several pixels, a jump,
+    sort margins 1-3 -- every 40-byte selection key of every launch identical (tools/fuzz_kept.py: 204 such cases clean
+    after the fix for images under 100 rows)."""
+    import torch
+    from mhhip.raster import RasterTerms, set_sort_margin
+    import test_fit_full_gpu as tf
+    rng = np.random.RandomState(seed)
+    for case in range(8):
+        W, H = [(32, 24), (48, 80), (64, 36), (96, 54), (80, 80), (160, 90), (240, 135), (54, 96)][rng.randint(8)]
+        T, N = int(rng.randint(2, 8)), int(rng.randint(1, 5))
+        margin = int(rng.choice([1, 1, 2, 3]))
+        amp = float(rng.choice([1e-4, 1e-3, 5e-3, 2e-2]))
+        sub = tmp_path / ('k%d' % case)
+        sub.mkdir()
+        opt, dl, o, batches, seq = tf._setup(smpl_struct, smpl_regs, oracle_model, sub, T, N, W, H, max(1, T // 2), int(rng.randint(1 << 30)), False)
+        opt._stage_from_dataloader(dl)
+        e = opt.engine
+        kept, fresh = RasterTerms(e), RasterTerms(e)
+        gv, log = torch.zeros_like(e.verts), torch.zeros(16, device=e.dev)
+        old = set_sort_margin(margin)
+        try:
+            for c in range(12):
+                e.leaf('poses_T').add_(torch.tensor(rng.normal(0, amp, (T, N, 3)).astype(np.float32), device=e.dev))
+                e.leaf('poses_smpl').add_(torch.tensor(rng.normal(0, amp, (T, N, 72)).astype(np.float32), device=e.dev))
+                if c == 7:
+                    e.leaf('poses_T')[::2, :, :2] += 0.05
+                e.cycle(c, raster=kept)
+                torch.cuda.synchronize()
+                _, _, k1 = kept.selection(e)
+                set_sort_margin(0)
+                fresh(e, gv, log, phases=1)
+                torch.cuda.synchronize()
+                set_sort_margin(margin)
+                _, _, k0 = fresh.selection(e)
+                assert k1.shape == k0.shape and (k1 == k0).all(), \
+                    'case %d (%dx%d, T %d, N %d, margin %d, step %.0e m) launch %d: %d window pixels differ' % (
+                        case, W, H, T, N, margin, amp, c, int((k1 != k0).any(axis=1).sum()) if k1.shape == k0.shape else -1)
+            seen, rebuilt = kept.sort_counters(e)
+            assert rebuilt < seen                          # lists were actually kept
+        finally:
+            set_sort_margin(old)

@@ -17,8 +17,11 @@ rng = np.random.RandomState(int(os.environ.get('SEED', '5')))
 worst = {}
 set_deterministic(True)
 for c in range(int(os.environ.get('CASES', '10'))):
-    W, H = [(96, 54), (64, 96), (80, 80), (120, 68)][rng.randint(4)]
-    T, N = int(rng.randint(3, 14)), int(rng.randint(1, 4))
+    sizes = [(96, 54), (64, 96), (80, 80), (120, 68)] + ([(32, 24), (40, 72), (200, 40)] if os.environ.get('EDGE') == '1' else [])
+    W, H = sizes[rng.randint(len(sizes))]
+    T, N = int(rng.randint(1 if os.environ.get('EDGE') == '1' else 3, 14)), int(rng.randint(1, 7 if os.environ.get('EDGE') == '1' else 4))
+    if os.environ.get('NSET'):
+        N = int(rng.choice([int(x) for x in os.environ['NSET'].split(',')])); T = min(T, 3)
     batch = int(rng.choice([2, 3, 5, 7]))
     scene = bool(rng.randint(2))
     seed = int(rng.randint(1 << 30))

@@ -14,6 +14,7 @@ import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+from netutil import free_port
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 T, N, W, H, BATCH, CYCLES = 12, 2, 48, 32, 3, 33
@@ -94,7 +95,7 @@ def _worker(rank, world, port, out):
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize('world,bounds', [(2, [(0, 6), (6, 12)]), (3, [(0, 6), (6, 9), (9, 12)])])
 def test_fit_on_several_ranks_matches_one(tmp_path, world, bounds):
-    port = 31500 + os.getpid() % 2000 + 7 * world
+    port = free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     one = os.path.join(str(tmp_path), 'one')
     os.makedirs(one)

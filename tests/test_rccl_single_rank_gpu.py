@@ -8,6 +8,8 @@ import sys
 
 import pytest
 
+from netutil import free_port
+
 pytestmark = pytest.mark.gpu
 
 SCRIPT = r'''
@@ -31,7 +33,8 @@ dist.destroy_process_group()
 
 
 def test_rccl_initialises_and_runs_the_drivers_collectives():
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29571', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+    port = free_port()                                # (another job on the box may hold a fixed one)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
                HSA_ENABLE_IPC_MODE_LEGACY='0')
     r = subprocess.run([sys.executable, '-c', SCRIPT], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and 'RCCL_OK nccl' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -9,6 +9,7 @@ import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+from netutil import free_port
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -75,7 +76,7 @@ def _worker(rank, world, port, out):
 
 @pytest.mark.timeout(600)
 def test_two_ranks_match_single_process(tmp_path):
-    port = 29500 + os.getpid() % 2000
+    port = free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     # single process reference
     model, sp, K, pose2d = _inputs()

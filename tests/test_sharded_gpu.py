@@ -10,6 +10,7 @@ import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+from netutil import free_port
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -96,7 +97,7 @@ def _worker(rank, world, port, out):
 
 @pytest.mark.timeout(900)
 def test_two_ranks_on_the_device_match_one(tmp_path):
-    port = 29500 + os.getpid() % 2000
+    port = free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     _paths()
     from mhhip import sharded
@@ -190,7 +191,7 @@ def test_fit_of_the_drop_in_on_two_ranks(tmp_path):
     """``SMPLDepthSequenceOptimizer.fit`` under an initialised process group: frames sharded, leaves broadcast, halos,
     one all-reduce per cycle, filters handed over at cycle 31, scene aggregated pixel-sharded from cycle 30 on, whole
     sequence gathered by ``get_optimized_variables`` -- against the same call in one process."""
-    port = 30500 + os.getpid() % 2000
+    port = free_port()
     mp.spawn(_fit_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     one = os.path.join(str(tmp_path), 'one')
     os.makedirs(one)

@@ -17,6 +17,7 @@ import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+from netutil import free_port
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 T, N, W, H, BATCH, CYCLES = 22, 2, 48, 32, 2, 4
@@ -121,14 +122,14 @@ def _check(tmp_path, world, want_bounds):
 
 @pytest.mark.timeout(900)
 def test_three_ranks_uneven_shards(tmp_path):
-    port = 26500 + os.getpid() % 2000
+    port = free_port()
     mp.spawn(_worker, args=(3, port, str(tmp_path), 0), nprocs=3, join=True)
     _check(tmp_path, 3, [(0, 8), (8, 16), (16, 22)])
 
 
 @pytest.mark.timeout(1200)
 def test_eight_ranks(tmp_path):
-    port = 24500 + os.getpid() % 2000
+    port = free_port()
     mp.spawn(_worker, args=(8, port, str(tmp_path), 0), nprocs=8, join=True)
     _check(tmp_path, 8, [(0, 4), (4, 8), (8, 12), (12, 14), (14, 16), (16, 18), (18, 20), (20, 22)])
 
@@ -137,6 +138,6 @@ def test_eight_ranks(tmp_path):
 def test_subgroup_not_starting_at_global_rank_zero(tmp_path):
     """4 processes, the sequence sharded over the group of global ranks 1..3: halos and filter state must reach the
     group neighbours (P2POp / send / recv address GLOBAL ranks)"""
-    port = 22500 + os.getpid() % 2000
+    port = free_port()
     mp.spawn(_worker, args=(4, port, str(tmp_path), 1), nprocs=4, join=True)
     _check(tmp_path, 3, [(0, 8), (8, 16), (16, 22)])

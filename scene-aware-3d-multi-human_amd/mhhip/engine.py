@@ -98,6 +98,44 @@ class BodyModel(object):
             check(_lib.lib().mh_model_create(ctypes.byref(handle), ctypes.byref(h)))
         self.handle = handle
         del keep
+        self._self_check()
+
+    _CHECKED = set()
+
+    def _self_check(self):
+        """First use of the split 16-bit LBS forward on a device: 40 back-to-back launches must be bit-identical among
+        themselves and within 2e-5 m of the exact-fp32 kernels.  A toolchain that packs the fp32 epilogue arithmetic beside
+        the MFMAs (the hazard mhhip/build.py describes: wrong values on some lanes, more often under back-to-back launches)
+        is caught here -- the process then stays on the exact kernels and says so -- instead of in somebody's results.
+        ~2 ms once per device; MHHIP_LBS_SELFCHECK=0 skips it."""
+        import os
+        import warnings
+        L = _lib.lib()
+        key = str(self.device)
+        if os.environ.get('MHHIP_LBS_SELFCHECK', '1') == '0' or key in BodyModel._CHECKED or L.mh_lbs_get_mode() == 0:
+            return
+        BodyModel._CHECKED.add(key)
+        g = torch.Generator().manual_seed(7)
+        B = 96
+        betas = (0.7 * torch.randn(B, 10, generator=g)).to(self.device)
+        poses = (0.3 * torch.randn(B, 72, generator=g)).to(self.device)
+        ws = self.workspace(B)
+        first, stable = None, True
+        for _ in range(40):
+            v = self.lbs_forward(betas, poses, ws=ws, want_vposed=False)[0]
+            if first is None:
+                first = v
+            else:
+                stable = stable and bool(torch.equal(v, first))
+        check(L.mh_lbs_set_mode(0))
+        exact = self.lbs_forward(betas, poses, ws=ws, want_vposed=False)[0]
+        err = float((first - exact).abs().max())
+        if stable and err <= 2e-5:
+            check(L.mh_lbs_set_mode(1))
+        else:
+            warnings.warn('split 16-bit LBS kernels failed their first-use check on %s (bit-stable over 40 launches: %s, max '
+                          'deviation from the exact fp32 kernels %.2e m): staying on the exact fp32 kernels for this process '
+                          '(3-4x slower LBS).  See mhhip/build.py for the compiler hazard this guards against.' % (key, stable, err))
 
     def __del__(self):
         try:

@@ -267,3 +267,38 @@ def test_split16_kernels_are_bit_stable_under_back_to_back_launches(hip_model):
         assert int(nbad) == 0, '%d gradient values differ between launches of the split-bf16 backward' % int(nbad)
     finally:
         L.mh_lbs_set_mode(mode0)
+
+
+def test_first_use_self_check_falls_back_to_the_exact_kernels(smpl_struct, smpl_regs, monkeypatch):
+    """a build whose split 16-bit forward is not bit-stable (the packed-fp32 compiler hazard of mhhip/build.py)
+    must not reach anybody's results.  The first model on a device launches the forward 40 times back to back; here one of
+    those launches is made to return a corrupted lane -- the process must warn and stay on the exact fp32 kernels."""
+    from mhhip import engine, _lib
+    L = _lib.lib()
+    assert L.mh_lbs_get_mode() == 1
+    real = engine.BodyModel.lbs_forward
+    calls = [0]
+
+    def flaky(self, *a, **k):
+        out = real(self, *a, **k)
+        calls[0] += 1
+        if calls[0] == 17:
+            out[0][3, 100, 1] += 1e-3
+        return out
+
+    monkeypatch.setattr(engine.BodyModel, 'lbs_forward', flaky)
+    monkeypatch.setattr(engine.BodyModel, '_CHECKED', set())
+    try:
+        with pytest.warns(UserWarning, match='first-use check'):
+            engine.BodyModel(smpl_struct, smpl_regs)
+        assert L.mh_lbs_get_mode() == 0
+    finally:
+        _lib.check(L.mh_lbs_set_mode(1))
+    # and a healthy build passes it silently
+    monkeypatch.setattr(engine.BodyModel, 'lbs_forward', real)
+    monkeypatch.setattr(engine.BodyModel, '_CHECKED', set())
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        engine.BodyModel(smpl_struct, smpl_regs)
+    assert L.mh_lbs_get_mode() == 1

@@ -220,10 +220,14 @@ class SequenceOracle(object):
 
     # -- optimizer.py:262-321 ---------------------------------------------------------------
     def init_optimized_variables(self, pose2d, poses_smpl, betas_smpl, valid_smpl, num_iter=100,
-                                 poses_T=None):
+                                 poses_T=None, scale_factor=None):
         T, N = pose2d.shape[:2]
         self.N = N
-        self.xscale = torch.zeros(1, N, 1, 1, requires_grad=True)
+        if scale_factor is not None:      # optimizer.py:277-280: a given person scale is a constant (1.1 ** x = scale), not a leaf
+            x = (np.log(np.asarray(scale_factor)) / np.log(1.1)).astype(np.float32)      # in the caller's dtype, as :280 does
+            self.xscale = torch.tensor(x).view(1, N, 1, 1)
+        else:
+            self.xscale = torch.zeros(1, N, 1, 1, requires_grad=True)
         log = []
         if poses_T is None:
             poses_T, log = self.init_global_poses(pose2d, poses_smpl, betas_smpl, num_iter)

@@ -1,0 +1,120 @@
+"""Golden fixture for the constructor / initialisation OPTIONS of the optimiser that the shipped configuration does not use
+(and that the other fixtures therefore do not pin): another sparse joint set (``smpl_sparse_joints_key='joints_h36m17'``,
+optimizer.py:41, 75, 695-696), lens distortion (``cam_dist_coef``, :170, 412-415), non-uniform key-point weights
+(``pose17j_weights``, :108-130), a given, un-optimised person scale (``init_optimized_variables(scale_factor=...)``, :277-283),
+another confidence threshold and clamp (``joint_confidence_thr``, ``eps``), intrinsics from the field of view (``cam_K=None``,
+:186-193).
+
+Runs the REFERENCE's own ``init_optimized_variables(num_iter=5)`` and ``fit`` (PyTorch3D / cv2 stubbed as in make_golden.py,
+scene injected) for every variant and records: the translations after the warm-up and its loss log, the per-leaf gradients
+after cycle 1, the leaves after 1 and 3 cycles.  Only in the build container (``/root/reference``); writes numbers only.
+
+    python tests/golden/make_golden_options.py
+"""
+import importlib
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), 'scene-aware-3d-multi-human_amd'))
+import golden_inputs as gi  # noqa: E402
+import make_golden as mg  # noqa: E402
+from mhhip import synthetic  # noqa: E402
+
+
+
+def main():
+    assert os.path.isdir(mg.REF), 'reference not present: fixtures can only be regenerated in the build container'
+    sys.argv = ['x']
+    mg._install_stubs()
+    mg._ref_package()
+    smpl = importlib.import_module('refmh.smpl')
+    optim = importlib.import_module('refmh.optimizer')
+    torch.set_num_threads(8)
+    struct = synthetic.make_smpl_struct(1)
+    regs = synthetic.make_extra_regressors(1, struct)
+    tmp = tempfile.mkdtemp()
+    paths = {}
+    for k, fn in [('extra9', 'J_regressor_extra.npy'), ('h36m', 'J_regressor_h36m.npy'),
+                  ('alphapose', 'SMPL_AlphaPose_Regressor_RMSprop_6.npy')]:
+        paths[k] = os.path.join(tmp, fn)
+        np.save(paths[k], regs[k])
+    optim.SMPL = lambda path, **kw: smpl.SMPL(None, data_struct=smpl.Struct(**struct.__dict__), **kw)
+    fin = gi.fit_inputs()
+    coef_kw = dict(proj2d_loss_coef=gi.COEFS['proj2d'], depth_loss_coef=gi.COEFS['depth'],
+                   silhouette_loss_coef=gi.COEFS['silhouette'], reg_velocity_coef=gi.COEFS['reg_velocity'],
+                   reg_verts_filter_coef=gi.COEFS['reg_verts_filter'], reg_poses_coef=gi.COEFS['reg_poses'],
+                   reg_scales_coef=gi.COEFS['reg_scales'], reg_contact_coef=gi.COEFS['reg_contact'],
+                   reg_foot_sliding_coef=gi.COEFS['reg_foot_sliding'])
+    served = []
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return fin['T']
+
+        def __getitem__(self, i):
+            served.append(int(i))                 # the order the loader asked for the frames in (num_workers = 0)
+            return dict(images=fin['images'][i], depths=fin['depths'][i], seg_mask=fin['seg_mask'][i],
+                        backmasks=fin['backmasks'][i], pose2d=fin['pose2d'][i], poses_smpl=fin['poses_smpl'][i],
+                        betas_smpl=fin['betas_smpl'][i], valid_smpl=fin['valid_smpl'][i], idxs=i)
+
+    W17 = np.array([1, 2, 2, 0.5, 0.5, 1, 1, 3, 3, 1, 1, 2, 2, 1, 1, 0.25, 4], np.float32)
+    KD = np.array([-0.12, 0.05, 1e-3, -2e-3, 0.01], np.float32)
+    VARIANTS = {
+        'h36m': (dict(smpl_sparse_joints_key='joints_h36m17'), {}),
+        'dist': (dict(cam_dist_coef=KD), {}),
+        'w17': (dict(pose17j_weights=W17), {}),
+        'scale': ({}, dict(scale_factor=np.array([1.05, 0.93], np.float32))),
+        'thr': (dict(joint_confidence_thr=0.7, eps=5e-3), {}),
+        'fov': (dict(cam_K=None, fov=50.0), {}),
+    }
+
+    def run(tag, k):
+        ckw, ikw = VARIANTS[tag]
+        kw = dict(image_size=(fin['W'], fin['H']), num_frames=fin['T'], cam_K=fin['cam_K'], device='cpu',
+                  smpl_model_parameters_path=tmp, **coef_kw)
+        kw.update(ckw)
+        opt = optim.SMPLDepthSequenceOptimizer(**kw)
+        ilog = opt.init_optimized_variables(fin['pose2d'], fin['poses_smpl'], fin['betas_smpl'], fin['valid_smpl'], num_iter=5, **ikw)
+        names = ['poses_T', 'poses_smpl', 'betas_smpl', 'zmin_lin', 'zmax_lin', 'xscale_factor']
+        init = {n: getattr(opt, n).detach().numpy().copy() for n in names}
+        opt.scene_depth = fin['scene_depth']
+        opt.update_scene_pointcloud(fin['scene_depth'], fin['scene_mask'])
+        dl = torch.utils.data.DataLoader(DS(), batch_size=5, shuffle=False)
+        try:
+            opt.fit(dl, num_iter=k)
+        except UnboundLocalError:
+            pass                                       # optimizer.py:595 quirk for num_iter <= 30
+        leaves = {n: getattr(opt, n).detach().numpy().copy() for n in names}
+        grads = {n: (getattr(opt, n).grad.numpy().copy() if getattr(opt, n).grad is not None else None) for n in names}
+        return init, np.array([float(v['loss_2d']) for v in ilog], np.float32), leaves, grads, np.asarray(opt.cam_K, np.float32)
+
+    out = {'opt_w17': W17, 'opt_kd': KD}
+    for tag in VARIANTS:
+        init, ilog, leaves, grads, camK = run(tag, 1)
+        out['opt_%s_cam_K' % tag] = camK
+        out['opt_%s_init_log' % tag] = ilog
+        for n, v in init.items():
+            out['opt_%s_init_%s' % (tag, n)] = v
+        for n, v in grads.items():
+            if v is not None:
+                out['opt_%s_k1_grad_%s' % (tag, n)] = v
+        for n, v in leaves.items():
+            out['opt_%s_k1_%s' % (tag, n)] = v
+        _, _, leaves, _, _ = run(tag, 3)
+        for n, v in leaves.items():
+            out['opt_%s_k3_%s' % (tag, n)] = v
+        print(tag, 'ok', 'grad leaves:', [n for n, v in grads.items() if v is not None])
+    path = os.path.join(HERE, 'reference_options_cpu.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, os.path.getsize(path) // 1024, 'KiB,', len(out), 'arrays')
+
+
+if __name__ == '__main__':
+    main()

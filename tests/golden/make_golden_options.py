@@ -3,7 +3,7 @@
 optimizer.py:41, 75, 695-696), lens distortion (``cam_dist_coef``, :170, 412-415), non-uniform key-point weights
 (``pose17j_weights``, :108-130), a given, un-optimised person scale (``init_optimized_variables(scale_factor=...)``, :277-283),
 another confidence threshold and clamp (``joint_confidence_thr``, ``eps``), intrinsics from the field of view (``cam_K=None``,
-:186-193).
+:186-193), coefficients at zero (the switch ``(reg_scales_coef > 0)`` of :539).
 
 Runs the REFERENCE's own ``init_optimized_variables(num_iter=5)`` and ``fit`` (PyTorch3D / cv2 stubbed as in make_golden.py,
 scene injected) for every variant and records: the translations after the warm-up and its loss log, the per-leaf gradients
@@ -73,6 +73,8 @@ def main():
         'scale': ({}, dict(scale_factor=np.array([1.05, 0.93], np.float32))),
         'thr': (dict(joint_confidence_thr=0.7, eps=5e-3), {}),
         'fov': (dict(cam_K=None, fov=50.0), {}),
+        # coefficients at zero: the un-weighted scale term is switched by (reg_scales_coef > 0), optimizer.py:539
+        'zero': (dict(reg_scales_coef=0.0, reg_contact_coef=0.0, reg_foot_sliding_coef=0.0), {}),
     }
 
     def run(tag, k):

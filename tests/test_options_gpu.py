@@ -14,7 +14,7 @@ from test_round2_gaps_gpu import _new_opt
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VARIANTS = ['h36m', 'dist', 'w17', 'scale', 'thr', 'fov']
+VARIANTS = ['h36m', 'dist', 'w17', 'scale', 'thr', 'fov', 'zero']
 
 
 @pytest.fixture(scope='module')
@@ -25,7 +25,8 @@ def optfx():
 def _build(tag, fx, smpl_struct, smpl_regs, tmp_path, fin):
     kw = {'h36m': dict(smpl_sparse_joints_key='joints_h36m17'), 'dist': dict(cam_dist_coef=fx['opt_kd']),
           'w17': dict(pose17j_weights=fx['opt_w17']), 'scale': {}, 'thr': dict(joint_confidence_thr=0.7, eps=5e-3),
-          'fov': dict(cam_K=None, fov=50.0)}[tag]
+          'fov': dict(cam_K=None, fov=50.0),
+          'zero': dict(reg_scales_coef=0.0, reg_contact_coef=0.0, reg_foot_sliding_coef=0.0)}[tag]
     ikw = dict(scale_factor=np.array([1.05, 0.93], np.float32)) if tag == 'scale' else {}
     return _new_opt(smpl_struct, smpl_regs, tmp_path, fin, **kw), ikw
 

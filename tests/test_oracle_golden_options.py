@@ -13,7 +13,7 @@ from oracle import fit_oracle as fo
 from test_oracle_golden import LEAVES, _batches, _oracle_leaves, close
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VARIANTS = ['h36m', 'dist', 'w17', 'scale', 'thr', 'fov']
+VARIANTS = ['h36m', 'dist', 'w17', 'scale', 'thr', 'fov', 'zero']
 
 
 @pytest.fixture(scope='module')
@@ -30,6 +30,8 @@ def oracle_for(tag, fx, oracle_model, fin):
         kw['cam_dist_coef'] = fx['opt_kd']
     if tag == 'thr':
         kw.update(joint_confidence_thr=0.7, eps=5e-3)
+    if tag == 'zero':
+        kw['coefs'] = dict(gi.COEFS, reg_scales=0.0, reg_contact=0.0, reg_foot_sliding=0.0)
     o = fo.SequenceOracle(oracle_model, (fin['W'], fin['H']), fin['T'], fx['opt_%s_cam_K' % tag], **kw)
     if tag == 'h36m':
         o.joints_key = 'joints_h36m17'

@@ -472,8 +472,10 @@ def fit_block(struct, regs, tmp, device, K, seq):
     ov = opt.get_optimized_variables()
     return {'wall_s': round(t_stage + t_fit, 4), 'staging_s': round(t_stage, 4), 'cycles_s': round(t_fit, 4),
             'cycles_per_s_incl_everything': round(250.0 / (t_stage + t_fit), 1), 'init_optimized_variables_s': round(t_init, 4),
-            'init_note': 'init_optimized_variables(num_iter=100) of a fresh optimiser: building the body model constants (host-side '
-                         'operand tables + upload, ~45 ms) + one LBS forward + 100 Adam iterations on the (T,N,3) problem (~4 ms)',
+            'init_note': 'init_optimized_variables(num_iter=100) of a fresh optimiser in a process that has built this body model '
+                         'before (what predict_mupots.py does per sequence): content hash of the model arrays (~3-8 ms; the '
+                         'device tables are shared per process since round 3 -- building them is ~45 ms, once) + one LBS '
+                         'forward + 100 Adam iterations on the (T,N,3) problem (~4 ms)',
             'what': 'opt.fit(dataloader, num_iter=250) as predict.py:343 calls it on C3: staging, graph captures, 250 cycles, '
                     '9 one-euro filter updates, 220 device scene updates, scene image; log read back',
             'final_loss_pose24j': float(log[-1]['loss_pose24j']), 'scene_points': int(opt.scene_pcd.shape[2]),

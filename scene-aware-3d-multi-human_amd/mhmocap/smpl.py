@@ -133,7 +133,7 @@ class SMPL(nn.Module):
             dev = self._device or torch.device('cuda:0')
             if dev.type != 'cuda':
                 raise RuntimeError('mhmocap.smpl.SMPL (MI355X build) needs a HIP device; got %s' % dev)
-            self._model = engine.BodyModel(self._struct, self._regs, device=dev)
+            self._model = engine.BodyModel.shared(self._struct, self._regs, device=dev)
             self._device = dev
         return self._model
 

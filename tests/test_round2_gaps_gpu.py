@@ -494,3 +494,31 @@ def test_lbs_rotation_matrices_backward(smpl_struct, oracle_model):
     for got, w, nm in ((tb.grad, db.grad, 'betas'), (tr.grad, dr.grad, 'rotmats')):
         w = w.numpy()
         np.testing.assert_allclose(got.cpu().numpy(), w, atol=2e-4 * np.abs(w).max(), rtol=0, err_msg=nm)
+
+
+def test_body_model_constants_are_shared_per_content_and_device(smpl_struct, smpl_regs, tmp_path):
+    """predict_mupots.py builds a new optimiser (and SMPL) for every sequence of the test set: the ~45 ms of host work that
+    turn the model arrays into device tables are paid once per (contents, device) and process"""
+    import copy
+    import time
+    from mhmocap.smpl import SMPL
+    _save_regs(tmp_path, smpl_regs)
+    kw = dict(J_reg_extra9_path=str(tmp_path / 'J_regressor_extra.npy'), J_reg_h36m17_path=str(tmp_path / 'J_regressor_h36m.npy'),
+              J_reg_alphapose_path=str(tmp_path / 'SMPL_AlphaPose_Regressor_RMSprop_6.npy'))
+    a = SMPL(None, data_struct=smpl_struct, device='cuda:0', **kw)
+    ma = a.body_model
+    t0 = time.perf_counter()
+    b = SMPL(None, data_struct=copy.deepcopy(smpl_struct), device='cuda:0', **kw)          # equal contents, other objects
+    mb = b.body_model
+    dt = time.perf_counter() - t0
+    assert mb is ma and dt < 0.03, dt
+    c = SMPL(None, data_struct=smpl_struct, device='cuda:0', J_reg_extra9_path=kw['J_reg_extra9_path'])   # other regressors
+    assert c.body_model is not ma
+    other = copy.deepcopy(smpl_struct)
+    other.v_template = np.asarray(other.v_template).copy()
+    other.v_template[5, 1] += 1e-3
+    d = SMPL(None, data_struct=other, device='cuda:0', **kw)
+    assert d.body_model is not ma
+    betas, poses = torch.zeros(2, 10), torch.zeros(2, 72)
+    va, vd = a(betas=betas, poses=poses)['verts'], d(betas=betas, poses=poses)['verts']
+    assert abs(float((vd - va)[0, 5, 1]) - 1e-3) < 1e-6

@@ -30,7 +30,7 @@ def _host_staged_dist():
     return hostdist.host_staged()
 
 
-def _build(f0, f1):
+def _build(f0, f1, T=T):
     _paths()
     from mhhip import synthetic, synthetic_seq, engine
     from mhhip.sequence import SequenceEngine
@@ -51,7 +51,7 @@ def _build(f0, f1):
     return e
 
 
-def _backmasks():
+def _backmasks(T=T):
     _paths()
     from mhhip import synthetic, synthetic_seq, engine
     struct = synthetic.make_smpl_struct(1)
@@ -72,20 +72,20 @@ def _run(sh, e):
     return sh.read_log(CYCLES)
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, T=T):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     _paths()
     from mhhip import sharded
     sharded.dist = _host_staged_dist()
     f0, f1 = sharded.shard_bounds(T, world, BATCH)[rank]
-    e = _build(f0, f1)
+    e = _build(f0, f1, T)
     sh = sharded.ShardedSequence(e, f0, T)
     log = _run(sh, e)
     # pixel-sharded scene aggregation: every rank ends with the scene of the WHOLE sequence
     import numpy as np_
     from mhhip import synthetic as syn_, synthetic_seq as sseq_
-    sh.scene_setup(_backmasks()[f0:f1])
+    sh.scene_setup(_backmasks(T)[f0:f1])
     sh.scene_update()
     sh.scene_swap()
     depth, mask, pts = e.scene_device_result()
@@ -96,40 +96,43 @@ def _worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(900)
-def test_two_ranks_on_the_device_match_one(tmp_path):
+@pytest.mark.parametrize('world,T', [(2, 8), (3, 10)])
+def test_ranks_on_the_device_match_one(tmp_path, world, T):
+    """(3 ranks over 10 frames in batches of 2: blocks of 4, 4, 2 -- a middle rank with both halos and an uneven tail, on the
+    real engine with captured graphs)"""
     port = free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), T), nprocs=world, join=True)
     _paths()
     from mhhip import sharded
-    e = _build(0, T)
+    e = _build(0, T, T)
     sh = sharded.ShardedSequence(e, 0, T)
     log = _run(sh, e)
-    r = [torch.load(os.path.join(str(tmp_path), 'rank%d.pt' % k), weights_only=False) for k in range(2)]
-    assert (r[0]['f0'], r[0]['f1'], r[1]['f0'], r[1]['f1']) == (0, 4, 4, 8)
+    r = [torch.load(os.path.join(str(tmp_path), 'rank%d.pt' % k), weights_only=False) for k in range(world)]
+    assert [(q['f0'], q['f1']) for q in r] == ([(0, 4), (4, 8)] if world == 2 else [(0, 4), (4, 8), (8, 10)])
     for name in ['poses_T', 'poses_smpl', 'zmin_lin', 'zmax_lin']:
         full = e.leaf(name).cpu().numpy()
-        for k in range(2):
-            ek = _build(r[k]['f0'], r[k]['f1'])
+        for k in range(world):
+            ek = _build(r[k]['f0'], r[k]['f1'], T)
             got = ek.leaf(name, r[k]['params'].to(ek.dev)).cpu().numpy()
             want = full[r[k]['f0']:r[k]['f1']]
             # float atomics in the raster gradients: tight but not bit-exact
             np.testing.assert_allclose(got, want, atol=3e-4 * max(1.0, np.abs(want).max()), err_msg=name)
     for name in ['betas', 'xscale']:
-        for k in range(2):
-            ek = _build(r[k]['f0'], r[k]['f1'])
+        for k in range(world):
+            ek = _build(r[k]['f0'], r[k]['f1'], T)
             np.testing.assert_allclose(ek.leaf(name, r[k]['params'].to(ek.dev)).cpu().numpy(), e.leaf(name).cpu().numpy(), atol=3e-4,
                                        err_msg=name)
     for c in range(CYCLES):
         for key in log[c]:
-            np.testing.assert_allclose(r[0]['log'][c][key], log[c][key], rtol=2e-3, atol=1e-6, err_msg='%s cycle %d' % (key, c))
-            np.testing.assert_allclose(r[1]['log'][c][key], log[c][key], rtol=2e-3, atol=1e-6)
+            for q in r:
+                np.testing.assert_allclose(q['log'][c][key], log[c][key], rtol=2e-3, atol=1e-6, err_msg='%s cycle %d' % (key, c))
     assert log[2]['reg_filter_verts'] > 0 and log[0]['loss_depth'] > 0
     # scene of the whole sequence from the single process (same leaves up to the atomics noise of the run above)
-    sh.scene_setup(_backmasks())
+    sh.scene_setup(_backmasks(T))
     sh.scene_update()
     sh.scene_swap()
     depth, mask, pts = e.scene_device_result()
-    for k in range(2):
+    for k in range(world):
         np.testing.assert_array_equal(r[k]['scene_mask'], mask)
         bad = np.abs(r[k]['scene_depth'] - depth) > 2e-3 * np.maximum(1.0, np.abs(depth))
         assert bad.mean() < 0.01, '%.4f of the pixels differ (%d)' % (float(bad.mean()), int(bad.sum()))

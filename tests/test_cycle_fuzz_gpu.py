@@ -2,8 +2,11 @@
 random small sequences against the CPU oracle: frame counts that are no batch multiples (ragged last batch, batch larger than
 the sequence), 1-3 humans, landscape / portrait / square images, with and without a scene cloud.  EVERY entry of every leaf
 gradient and every log entry (deterministic scatter; the oracle renders the faces the kernel selected at the vertices the
-kernel produced, as in tests/test_full_size_gpu.py).  tools/fuzz_cycle.py runs the same loop for any number of sequences:
-52 of them had 6.2e-5 as the worst entry of the five large leaves and 7e-7 on the log."""
+kernel produced, as in tests/test_full_size_gpu.py -- and renders them in float64: on faces of a fraction of a pixel the
+float32 autograd of the oracle's renderer is itself off by up to 3e-3 of a leaf's largest entry, one sequence in 70 showed
+it, and in float64 the same sequence agrees to 4e-6).  tools/fuzz_cycle.py runs the same loop for any number of sequences:
+110 of them (F64=1; single frames, up to six humans, 32x24 to 200x40 among them) had 5.7e-5 as the worst entry of the five
+large leaves, 1.6e-4 on the scale leaf and 1.3e-6 on the log."""
 import numpy as np
 import pytest
 
@@ -31,7 +34,8 @@ def test_random_sequences_cycle_filters_cycle(smpl_struct, smpl_regs, oracle_mod
             opt._stage_from_dataloader(dl)
             e = opt.engine
             raster = RasterTerms(e)
-            hsel = tf._HipSelectionRasteriser(np.asarray(smpl_struct.f).astype(np.int64), synthetic.default_cam_K((W, H), 60.0), (W, H), N)
+            hsel = tf._HipSelectionRasteriser(np.asarray(smpl_struct.f).astype(np.int64), synthetic.default_cam_K((W, H), 60.0), (W, H), N,
+                                               wide=True)
             o.rasteriser = hsel
             where = 'sequence %d (%dx%d, T %d, N %d, batch %d, scene %s)' % (c, W, H, T, N, batch, scene)
             for cyc in range(2):
@@ -48,7 +52,7 @@ def test_random_sequences_cycle_filters_cycle(smpl_struct, smpl_regs, oracle_mod
                     w = tf._oracle_grad(o, name)
                     g = e.leaf(ename, e.grads).cpu().numpy().reshape(w.shape)
                     # xscale: N entries, each the sum of everything a person's vertices receive -- it can cancel to ~0
-                    tol = 2e-3 if name == 'xscale' else 2e-4
+                    tol = 1e-3 if name == 'xscale' else 1e-4
                     np.testing.assert_allclose(g, w, atol=tol * max(np.abs(w).max(), 1e-8), rtol=0,
                                                err_msg='%s cycle %d leaf %s' % (where, cyc, name))
     finally:

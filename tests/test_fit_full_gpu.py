@@ -64,8 +64,10 @@ class _HipSelectionRasteriser(object):
     of them", so that the gradients can be compared on EVERY entry"""
     wants_frames = True
 
-    def __init__(self, faces, K, image_size, N):
-        self.faces, self.K, self.size, self.N, self.sel = faces, K, image_size, N, None
+    def __init__(self, faces, K, image_size, N, wide=False):
+        """wide: render (and differentiate) in float64 -- on faces of a fraction of a pixel the float32 autograd of the
+        oracle's renderer is itself up to ~1e-3 off (tools/fuzz_cycle.py F64=1, tools/grad_debug.py)"""
+        self.faces, self.K, self.size, self.N, self.sel, self.wide = faces, K, image_size, N, None, wide
 
     def take(self, raster, e, oracle=None):
         """the selection of the cycle the engine just ran; oracle: also evaluate the oracle's terms AT the engine's vertices
@@ -78,6 +80,9 @@ class _HipSelectionRasteriser(object):
 
     def __call__(self, verts, frames):
         s = self.sel[np.asarray(frames)].reshape(-1, *self.sel.shape[2:])
+        if self.wide:
+            z, a = ro.render(verts.double(), self.faces, self.K, self.size, selection=(s[..., :1], s[..., 1:]))
+            return z.to(verts.dtype), a.to(verts.dtype)
         return ro.render(verts, self.faces, self.K, self.size, selection=(s[..., :1], s[..., 1:]))
 
 

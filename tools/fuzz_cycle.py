@@ -1,7 +1,8 @@
 """developer tool: one full optimisation cycle (nine terms; then the one-euro filters and a second cycle with the
 filtered-vertex term) of the drop-in against the CPU oracle on random small sequences -- frame counts that are not batch
 multiples, 1-3 humans, portrait / landscape / square images, with and without a scene cloud.  Prints the worst entry of
-every leaf gradient (relative to the leaf's largest) and of the loss log."""
+every leaf gradient (relative to the leaf's largest) and of the loss log.  ONLY=<case> runs one case of the sequence;
+F64=1 lets the oracle render in float64 (on faces of a fraction of a pixel its float32 autograd is itself ~1e-3 off)."""
 import os, sys, tempfile, pathlib
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,12 +26,15 @@ for c in range(int(os.environ.get('CASES', '10'))):
     batch = int(rng.choice([2, 3, 5, 7]))
     scene = bool(rng.randint(2))
     seed = int(rng.randint(1 << 30))
+    if os.environ.get('ONLY') and c != int(os.environ['ONLY']):
+        continue
     tmp = pathlib.Path(tempfile.mkdtemp())
     opt, dl, o, batches, seq = tf._setup(struct, regs, omodel, tmp, T, N, W, H, batch, seed, scene)
     opt._stage_from_dataloader(dl)
     e = opt.engine
     raster = RasterTerms(e)
-    hsel = tf._HipSelectionRasteriser(np.asarray(struct.f).astype(np.int64), synthetic.default_cam_K((W, H), 60.0), (W, H), N)
+    hsel = tf._HipSelectionRasteriser(np.asarray(struct.f).astype(np.int64), synthetic.default_cam_K((W, H), 60.0), (W, H), N,
+                                       wide=os.environ.get('F64') == '1')
     o.rasteriser = hsel
     line = 'case %2d %3dx%-3d T%-2d N%d batch %d scene %d:' % (c, W, H, T, N, batch, scene)
     for cyc in range(2):

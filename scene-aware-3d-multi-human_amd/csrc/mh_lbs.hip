@@ -1279,6 +1279,7 @@ struct PoseBwdP {
   const float* gposed;      // [B][24][3] dL/d(posed joints = translation of the global joint transforms), null ok
   float* grotmats;          // [B][24][9] += (with rotmats)
   const float* scale;
+  const float* A;        // [G*32][24][12] joint transforms of the forward (k_pose_fwd), rest pose removed
   const float* Jt;
   const float* JS;
   const float* pF;
@@ -1293,78 +1294,98 @@ struct PoseBwdP {
 };
 
 __global__ __launch_bounds__(256) void k_pose_bwd(PoseBwdP p) {
-  __shared__ float sGA[8][12 * MH_NJ];   // summed dL/dA  [e][j]
-  __shared__ float sGF[8][MH_FS];        // summed dL/dfeat
-  __shared__ float sG[8][MH_NJ][12];
-  __shared__ float sgG[8][MH_NJ][12];
-  __shared__ float sJ[8][MH_NJ][3];
-  __shared__ float sgJ[8][MH_NJ][3];
-  __shared__ float sS[8][4];
-  const int bl = threadIdx.x >> 5, j = threadIdx.x & 31;
-  const int b = blockIdx.x * 8 + bl;
-  const bool valid = b < p.B, act = j < MH_NJ;
+  __shared__ float sGA[1][12 * MH_NJ];   // summed dL/dA  [e][j]
+  __shared__ float sGF[1][MH_FS];        // summed dL/dfeat
+  __shared__ float sG[1][MH_NJ][12];
+  __shared__ float sgG[1][MH_NJ][12];
+  __shared__ float sJ[1][MH_NJ][3];
+  __shared__ float sgJ[1][MH_NJ][3];
+  __shared__ float sS[1][4];
   const size_t GB = (size_t)p.G * 32;
-  // 1. sum the chunk partials (fixed order)
-  // chunk-outer, element-inner: the 16 loads of a chunk are independent (the element-outer form waited for one
-  // L2 round trip per addend: 160 of them in a row); the per-element summation order (chunks ascending) is unchanged
+  // 1. sum the chunk partials.  The sums used to be the kernel's longest phase (five dependent trips of 64 loads per thread
+  // in 100 workgroups): half-wave g of the body's workgroup now takes the chunks g, g + 8, g + 16 ... (one trip), and the
+  // eight partial sums are added in fixed order -- ((chunks = 0 mod 8) + (= 1 mod 8)) + ... -- from LDS.  Only half-wave 0
+  // goes on from there (a barrier only waits for the waves that are still alive).
+  __shared__ float sP[8][12 * MH_NJ + MH_FS + 4];
+  const int g = threadIdx.x >> 5, j = threadIdx.x & 31, bl = 0;
+  const int b = blockIdx.x;
+  const bool valid = b < p.B, act = j < MH_NJ;
+  // the state of the forward, asked for before the chunk partials so that its round trip hides behind theirs: rest joints,
+  // rotations, and the rotation part of the global transforms as k_pose_fwd left it in A = [G.R | G.t - G.R.J] (the chain
+  // itself is not walked again; nothing below needs G.t other than in that difference)
+  float beta[MH_NUM_BETAS];
+  float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, J[3] = {0, 0, 0}, th[3] = {0, 0, 0};
+  float Gm[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  if (g == 0) {
+#pragma unroll
+    for (int l = 0; l < MH_NUM_BETAS; ++l) beta[l] = valid ? p.betas[(size_t)(b % p.NB) * MH_NUM_BETAS + l] : 0.f;
+    if (valid && act) {
+#pragma unroll
+      for (int e = 0; e < 12; ++e) Gm[e] = p.A[((size_t)b * MH_NJ + j) * 12 + e];
+      mh_joint_rest(p.Jt, p.JS, beta, j, J);
+      if (p.rotmats) {
+#pragma unroll
+        for (int e = 0; e < 9; ++e) R[e] = p.rotmats[((size_t)b * MH_NJ + j) * 9 + e];
+      } else if (j < 22) {
+        th[0] = p.poses[(size_t)b * 72 + 3 * j];
+        th[1] = p.poses[(size_t)b * 72 + 3 * j + 1];
+        th[2] = p.poses[(size_t)b * 72 + 3 * j + 2];
+        mh_rodrigues(th, R);
+      }
+    }
+  }
   {
-    float aA[9], aF[7];
+    float aA[9], aF[7], aS = 0.f;
 #pragma unroll
     for (int i = 0; i < 9; ++i) aA[i] = 0.f;
 #pragma unroll
     for (int i = 0; i < 7; ++i) aF[i] = 0.f;
-    // four chunks (64 loads) in flight per round trip; a missing chunk re-reads the last one and adds zero
-    for (int c0 = 0; c0 < p.CH; c0 += 4) {
-      float tA[4][9], tF[4][7];
+    // up to four chunks (64 loads) in flight per round trip; a missing chunk re-reads the last one and adds zero
+    for (int c0 = g; c0 < p.CH; c0 += 32) {
+      float tA[4][9], tF[4][7], tS[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int c = min(c0 + u, p.CH - 1);
+        const int c = min(c0 + 8 * u, p.CH - 1);
         const float* qa = p.pA + ((size_t)c * GB + b) * 288 + j;
         const float* qf = p.pF + ((size_t)c * GB + b) * MH_FS + j;
 #pragma unroll
         for (int i = 0; i < 9; ++i) tA[u][i] = qa[32 * i];
 #pragma unroll
         for (int i = 0; i < 7; ++i) tF[u][i] = qf[32 * i];
+        tS[u] = p.pS[((size_t)c * GB + b) * 4 + (j & 3)];
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const float m = c0 + u < p.CH ? 1.f : 0.f;
+        const float m = c0 + 8 * u < p.CH ? 1.f : 0.f;
 #pragma unroll
         for (int i = 0; i < 9; ++i) aA[i] = fmaf(m, tA[u][i], aA[i]);
 #pragma unroll
         for (int i = 0; i < 7; ++i) aF[i] = fmaf(m, tF[u][i], aF[i]);
+        aS = fmaf(m, tS[u], aS);
       }
     }
 #pragma unroll
-    for (int i = 0; i < 9; ++i) sGA[bl][j + 32 * i] = aA[i];
+    for (int i = 0; i < 9; ++i) sP[g][j + 32 * i] = aA[i];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) sGF[bl][j + 32 * i] = aF[i];
+    for (int i = 0; i < 7; ++i) sP[g][288 + j + 32 * i] = aF[i];
+    if (j < 4) sP[g][288 + MH_FS + j] = aS;
   }
-  if (j < 4) {
-    float a = 0;
-    for (int c = 0; c < p.CH; ++c) a += p.pS[((size_t)c * GB + b) * 4 + j];
-    if (j == 3 && p.scale_from_joint_sums) a = 0.f;
-    sS[bl][j] = a;
-  }
-  // 2. recompute the forward chain
-  float beta[MH_NUM_BETAS];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 12 * MH_NJ + MH_FS + 4; e += 256) {
+    float a = sP[0][e];
 #pragma unroll
-  for (int l = 0; l < MH_NUM_BETAS; ++l) beta[l] = valid ? p.betas[(size_t)(b % p.NB) * MH_NUM_BETAS + l] : 0.f;
-  float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, J[3] = {0, 0, 0}, th[3] = {0, 0, 0};
-  if (valid && act) {
-    mh_joint_rest(p.Jt, p.JS, beta, j, J);
-    if (p.rotmats) {
-#pragma unroll
-      for (int e = 0; e < 9; ++e) R[e] = p.rotmats[((size_t)b * MH_NJ + j) * 9 + e];
-    } else if (j < 22) {
-      th[0] = p.poses[(size_t)b * 72 + 3 * j];
-      th[1] = p.poses[(size_t)b * 72 + 3 * j + 1];
-      th[2] = p.poses[(size_t)b * 72 + 3 * j + 2];
-      mh_rodrigues(th, R);
-    }
+    for (int k = 1; k < 8; ++k) a += sP[k][e];
+    if (e < 288) sGA[0][e] = a;
+    else if (e < 288 + MH_FS) sGF[0][e - 288] = a;
+    else sS[0][e - 288 - MH_FS] = (e - 288 - MH_FS == 3 && p.scale_from_joint_sums) ? 0.f : a;
   }
+  __syncthreads();
+  if (g != 0) return;
+  // 2. parents' transforms and rest joints where the chain's adjoint finds them
   if (act) {
     sJ[bl][j][0] = J[0]; sJ[bl][j][1] = J[1]; sJ[bl][j][2] = J[2];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) sG[bl][j][e] = Gm[e];
   }
   __syncthreads();
   const int par = act ? p.tree.parent[j] : -1;
@@ -1372,25 +1393,6 @@ __global__ __launch_bounds__(256) void k_pose_bwd(PoseBwdP p) {
   float rel[3] = {J[0], J[1], J[2]};
   if (act && j > 0) {
     rel[0] -= sJ[bl][par][0]; rel[1] -= sJ[bl][par][1]; rel[2] -= sJ[bl][par][2];
-  }
-  float Gm[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-  for (int l = 0; l <= p.tree.maxlevel; ++l) {
-    if (act && lev == l) {
-      if (l == 0) {
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          Gm[r * 4 + 0] = R[r * 3]; Gm[r * 4 + 1] = R[r * 3 + 1]; Gm[r * 4 + 2] = R[r * 3 + 2]; Gm[r * 4 + 3] = J[r];
-        }
-      } else {
-        float Gp[12];
-#pragma unroll
-        for (int e = 0; e < 12; ++e) Gp[e] = sG[bl][par][e];
-        mh_compose(Gp, R, rel, Gm);
-      }
-#pragma unroll
-      for (int e = 0; e < 12; ++e) sG[bl][j][e] = Gm[e];
-    }
-    __syncthreads();
   }
   // 3. adjoint of A = [G.R | G.t - G.R.J]
   float gA[12];
@@ -1401,10 +1403,8 @@ __global__ __launch_bounds__(256) void k_pose_bwd(PoseBwdP p) {
       // verts = s.x + t with x = sum_j w_j A_j [q;1]  =>  sum_v g.x = (1/s) sum_j <A_j, dL/dA_j>  (dL/dA_j carries the s)
       float d = 0.f;
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const float gj = fmaf(Gm[r * 4 + 2], J[2], fmaf(Gm[r * 4 + 1], J[1], Gm[r * 4 + 0] * J[0]));
-        d += gA[r * 4] * Gm[r * 4] + gA[r * 4 + 1] * Gm[r * 4 + 1] + gA[r * 4 + 2] * Gm[r * 4 + 2] + gA[r * 4 + 3] * (Gm[r * 4 + 3] - gj);
-      }
+      for (int r = 0; r < 3; ++r)
+        d += gA[r * 4] * Gm[r * 4] + gA[r * 4 + 1] * Gm[r * 4 + 1] + gA[r * 4 + 2] * Gm[r * 4 + 2] + gA[r * 4 + 3] * Gm[r * 4 + 3];
       atomicAdd(&sS[bl][3], d / fmaxf(p.scale[valid ? b : 0], 1e-30f));
     }
     float gJ[3] = {0, 0, 0};
@@ -1503,14 +1503,19 @@ __global__ __launch_bounds__(256) void k_pose_bwd(PoseBwdP p) {
     o[2] += gd2 / ang + gat * a2 / ang;
   }
   // 7. shape: direct rows of the basis + the joint-location path
-  if (b < p.G * 32 && j < MH_NUM_BETAS) {
-    float a = 0;
-    if (valid) {
-      a = sGF[bl][j];
-      for (int q = 0; q < MH_NJ * 3; ++q) a = fmaf(p.JS[q * MH_NUM_BETAS + j], sgJ[bl][q / 3][q % 3], a);
+  // (the 72 products of a coefficient in three runs of 24 on lanes j, j + 10, j + 20, added in that order)
+  {
+    float a = 0.f;
+    if (valid && j < 3 * MH_NUM_BETAS) {
+      const int l = j % MH_NUM_BETAS, q0 = (j / MH_NUM_BETAS) * (MH_NJ * 3 / 3);
+#pragma unroll 8
+      for (int q = q0; q < q0 + MH_NJ * 3 / 3; ++q) a = fmaf(p.JS[q * MH_NUM_BETAS + l], sgJ[bl][q / 3][q % 3], a);
     }
-    p.gbeta_b[(size_t)b * MH_NUM_BETAS + j] = a;
+    sP[0][j] = a;
   }
+  __syncthreads();
+  if (b < p.G * 32 && j < MH_NUM_BETAS)
+    p.gbeta_b[(size_t)b * MH_NUM_BETAS + j] = valid ? ((sGF[bl][j] + sP[0][j]) + sP[0][j + MH_NUM_BETAS]) + sP[0][j + 2 * MH_NUM_BETAS] : 0.f;
   // 8. translation and scale
   if (b < p.G * 32 && j == 31) p.gxs_b[b] = valid ? sS[bl][3] * p.scale[b] * 0.0953101798043249f /* ln 1.1 */ : 0.f;
   if (valid && j >= 24 && j < 27 && p.gtransl) {
@@ -1666,12 +1671,12 @@ static int lbs_backward_impl(const mh_model* m, int B, int NB, const float* beta
   pp.betas = betas; pp.poses = poses; pp.gjoints = gjoints;
   pp.rotmats = rotmats; pp.gposed = gposed; pp.grotmats = grotmats;
   pp.kp_rowsum = m->reg[MH_REG_ALPHAPOSE].rowsum;
-  pp.scale = fw.scale; pp.Jt = m->Jt; pp.JS = m->JS;
+  pp.scale = fw.scale; pp.A = fw.A; pp.Jt = m->Jt; pp.JS = m->JS;
   pp.pF = bw.pF; pp.pA = bw.pA; pp.pS = bw.pS;
   pp.gposes = gposes; pp.gtransl = gtransl; pp.gbeta_b = bw.gbeta_b; pp.gxs_b = bw.gxs_b;
   pp.scale_from_joint_sums = split16 ? 1 : 0;
   pp.tree = m->tree;
-  hipLaunchKernelGGL(k_pose_bwd, dim3(G * 4), dim3(256), 0, st, pp);
+  hipLaunchKernelGGL(k_pose_bwd, dim3(G * 32), dim3(256), 0, st, pp);
   MH_LAUNCH_CHECK();
   if (gbetas || gxscale) {
     hipLaunchKernelGGL(k_person_reduce, dim3(NB, 11), dim3(256), 0, st, B, NB, bw.gbeta_b, bw.gxs_b, gbetas, gxscale);

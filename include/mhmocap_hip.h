@@ -186,6 +186,12 @@ int mh_warmup_project_w(int B, int NB, const float* local_joints, const float* x
 /* ---- a20: optimiser updates (optimizer.py:355-356, 586-587, 738-739, 764-765) --------------- */
 int mh_rmsprop_step(float* params, const float* grads, float* square_avg, float* momentum_buf,
                     size_t n, float lr, float alpha, float momentum, float eps, void* stream);
+/* mh_rmsprop_step, and in the same launch nlog floats copied from log_src to log_dst: the captured
+ * cycle writes its loss sums to a staging row at a fixed address, the row of the log they belong
+ * to changes every cycle (optimizer.py:588-590 appends a dict per cycle); nlog = 0: no copy.    */
+int mh_rmsprop_step_log(float* params, const float* grads, float* square_avg, float* momentum_buf,
+                        size_t n, float lr, float alpha, float momentum, float eps,
+                        const float* log_src, float* log_dst, int nlog, void* stream);
 /* the same update with the learning rate resident on the device (lr_dev[0]); afterwards
  * lr_dev[0] *= gamma (ExponentialLR).  No host scalar changes between calls, so the whole cycle can
  * be captured in a hipGraph and replayed.                                                      */

@@ -167,6 +167,35 @@ __global__ void k_rmsprop(float* p, const float* g, float* sq, float* buf, size_
   }
 }
 
+// the same update and, riding along in its first workgroup, the cycle's log entries copied from the staging row the captured
+// graph wrote them to into their row of the log (one small launch less behind every graph replay)
+__global__ void k_rmsprop_log(float* p, const float* g, float* sq, float* buf, size_t n, float lr, float alpha,
+                              float mom, float eps, const float* log_src, float* log_dst, int nlog) {
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < nlog; i += blockDim.x) log_dst[i] = log_src[i];
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float s = alpha * sq[i] + (1.f - alpha) * gi * gi;
+    sq[i] = s;
+    const float b = mom * buf[i] + gi / (sqrtf(s) + eps);
+    buf[i] = b;
+    p[i] = p[i] - lr * b;
+  }
+}
+
+extern "C" int mh_rmsprop_step_log(float* params, const float* grads, float* square_avg, float* momentum_buf, size_t n,
+                                   float lr, float alpha, float momentum, float eps, const float* log_src, float* log_dst,
+                                   int nlog, void* stream) {
+  MH_CHECK(params && grads && square_avg && momentum_buf, "null argument");
+  MH_CHECK(nlog == 0 || (log_src && log_dst && nlog > 0), "log_src / log_dst / nlog");
+  if (n == 0 && nlog == 0) return MH_OK;
+  const int blocks = n == 0 ? 1 : (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(k_rmsprop_log, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, square_avg,
+                     momentum_buf, n, lr, alpha, momentum, eps, log_src, log_dst, nlog);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
 extern "C" int mh_rmsprop_step(float* params, const float* grads, float* square_avg, float* momentum_buf, size_t n,
                                float lr, float alpha, float momentum, float eps, void* stream) {
   MH_CHECK(params && grads && square_avg && momentum_buf, "null argument");

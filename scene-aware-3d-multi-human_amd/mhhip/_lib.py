@@ -71,6 +71,7 @@ def lib():
                                           ctypes.c_float, ctypes.c_float, vp, vp, vp]
         L.mh_lbs_set_mode.argtypes = [ctypes.c_int]
         L.mh_rmsprop_step.argtypes = [vp, vp, vp, vp, ctypes.c_size_t] + [ctypes.c_float] * 4 + [vp]
+        L.mh_rmsprop_step_log.argtypes = [vp, vp, vp, vp, ctypes.c_size_t] + [ctypes.c_float] * 4 + [vp, vp, ctypes.c_int, vp]
         L.mh_rmsprop_step_dev.argtypes = [vp, vp, vp, vp, ctypes.c_size_t, vp] + [ctypes.c_float] * 4 + [vp]
         L.mh_adam_step.argtypes = [vp, vp, vp, vp, ctypes.c_size_t, ctypes.c_int] + [ctypes.c_float] * 4 + [vp]
         L.mh_one_euro_scan.argtypes = [vp, vp, ctypes.c_int, ctypes.c_size_t] + [ctypes.c_float] * 3 + [vp]

@@ -295,6 +295,12 @@ def rmsprop_step(params, grads, sq, buf, lr, alpha=0.5, momentum=0.9, eps=1e-8):
                                      eps, _lib.stream_ptr(params.device)))
 
 
+def rmsprop_step_log(params, grads, sq, buf, lr, log_src, log_dst, alpha=0.5, momentum=0.9, eps=1e-8):
+    """mh_rmsprop_step_log: the update and, in the same launch, the cycle's log entries from their staging row into log_dst"""
+    check(_lib.lib().mh_rmsprop_step_log(ptr(params), ptr(grads), ptr(sq), ptr(buf), params.numel(), lr, alpha, momentum,
+                                         eps, ptr(log_src), ptr(log_dst), log_src.numel(), _lib.stream_ptr(params.device)))
+
+
 def adam_step(params, grads, m, v, step, lr, b1=0.5, b2=0.5, eps=1e-6):
     check(_lib.lib().mh_adam_step(ptr(params), ptr(grads), ptr(m), ptr(v), params.numel(), int(step), lr, b1, b2, eps,
                                   _lib.stream_ptr(params.device)))

@@ -99,6 +99,7 @@ class SequenceEngine(object):
         self.filt_loss = z(1)
         self.log = z(max_cycles, 16)
         self.tmp_log = self._grads_log[n:]
+        self._log_pending = None         # row of self.log the staging row still has to go to (cycle_graphed -> step)
         self.scene_pts = None
         self.scene_grid = None
         self.scene_M = 0                 # capacity the grid workspace was sized for
@@ -443,6 +444,7 @@ class SequenceEngine(object):
         T, N = self.T, self.N
         g = self.grads
         log = self.tmp_log
+        self._flush_log()                # (never inside a capture: cycle_graphed has flushed before it replays)
         self._grads_log.zero_()
         # the terms that only read the leaves (silhouette mask statistics, priors, velocity) run on the second stream
         # beside the MFMA-bound forward; their scalars land directly in the log row
@@ -606,7 +608,19 @@ class SequenceEngine(object):
 
     def step(self, lr, alpha=0.5, momentum=0.9, eps=1e-8):
         self._wait_scene_snapshot()
-        engine.rmsprop_step(self.params, self.grads, self.sq, self.buf, float(lr), alpha, momentum, eps)
+        if self._log_pending is not None:
+            # the log entries of the graph that was just replayed travel to their row in the update's launch
+            row, self._log_pending = self._log_pending, None
+            engine.rmsprop_step_log(self.params, self.grads, self.sq, self.buf, float(lr), self.tmp_log, self.log[row],
+                                    alpha, momentum, eps)
+        else:
+            engine.rmsprop_step(self.params, self.grads, self.sq, self.buf, float(lr), alpha, momentum, eps)
+
+    def _flush_log(self):
+        """the staging row of the last replayed cycle into its row of the log, when no ``step`` has taken it along"""
+        if self._log_pending is not None:
+            row, self._log_pending = self._log_pending, None
+            self.log[row].copy_(self.tmp_log)
 
     # -- hipGraph replay of a cycle -------------------------------------------------------------------
     # A cycle is ~45 launches of 5-600 us kernels; replaying it as a captured graph removes the host
@@ -655,6 +669,7 @@ class SequenceEngine(object):
         ``cycle_begin`` / ``cycle_finish`` separately around its exchanges).  scene_update: also launch this cycle's
         device-side scene update (``scene_device_update``), after the first replay has been enqueued."""
         key = self._graph_key(raster)
+        self._flush_log()
         if scene_update:
             self.scene_device_mark()
         if self._scene_dev is not None:
@@ -677,11 +692,12 @@ class SequenceEngine(object):
             self.replay(('full',) + key, body)
             if scene_update:
                 self.scene_device_launch()
-        self.log[row].copy_(self.tmp_log)
+        self._log_pending = row            # copied by the next step() (same launch) or by whoever reads the log first
 
     def step_dev(self, alpha=0.5, momentum=0.9, eps=1e-8, gamma=0.99, lr0=0.01):
         if not hasattr(self, 'lr_dev'):
             self.lr_dev = torch.full((1,), lr0, dtype=torch.float32, device=self.dev)
+        self._flush_log()
         self._wait_scene_snapshot()
         check(_lib.lib().mh_rmsprop_step_dev(ptr(self.params), ptr(self.grads), ptr(self.sq), ptr(self.buf),
                                              self.params.numel(), ptr(self.lr_dev), gamma, alpha, momentum, eps,
@@ -711,6 +727,7 @@ class SequenceEngine(object):
 
     # -- logs back on the host (one D2H per fit) ---------------------------------------------------
     def read_log(self, rows, nbatches_total=None):
+        self._flush_log()
         raw = self.log[:rows].cpu().numpy().astype(np.float64)
         nb = float(nbatches_total or self.nbatches)
         out = []

@@ -272,6 +272,7 @@ class ShardedSequence(object):
     # -- logs: raw sums are all-reduced once, at the end ----------------------------------------------
     def read_log(self, rows):
         e = self.e
+        e._flush_log()
         raw = e.log[:rows].clone()
         if self.world > 1:
             dist.all_reduce(raw, op=dist.ReduceOp.SUM, group=self.group)

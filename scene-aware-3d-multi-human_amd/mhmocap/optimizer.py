@@ -500,6 +500,7 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
         if not self.optim_scale_factor:
             print('WARNING!!! Not optimizing scale_factor!')
         if num_iter > e.log.shape[0]:
+            e._flush_log()
             e.log = torch.zeros(num_iter, 16, device=self.device)
         raster = None
         if self.use_rasteriser and e.has_images:

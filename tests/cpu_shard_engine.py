@@ -290,6 +290,9 @@ class CpuShardEngine(object):
         y, out = one_euro_shard_np(x.detach().numpy(), min_cutoff, beta, first_frame, st)
         return torch.tensor(y), (torch.tensor(out[0]), torch.tensor(out[1]))
 
+    def _flush_log(self):
+        """(the device engine parks a replayed cycle's log row until its update's launch; rows are written at once here)"""
+
     def read_log(self, rows, nbatches_total=None):
         raw = self.log[:rows].numpy().astype(np.float64)
         nb = float(nbatches_total or self.nbatches)

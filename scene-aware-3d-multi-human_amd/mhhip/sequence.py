@@ -436,9 +436,11 @@ class SequenceEngine(object):
         self.cycle_begin()
         self.cycle_finish(row, use_images, raster)
 
-    def cycle_begin(self):
+    def cycle_begin(self, join=True):
         """zero the gradient buffer and run the LBS forward of all local frames (the frame-sharded
-        driver exchanges boundary vertices between this and ``cycle_finish``)."""
+        driver exchanges boundary vertices between this and ``cycle_finish``).  join=False: the leaf-only terms of the side
+        branch are NOT waited for here -- the caller's next join covers them (``cycle_graphed``: the one in front of the
+        rasteriser's gradient half; its selection half reads nothing they write)."""
         L = _lib.lib()
         c = self.c
         T, N = self.T, self.N
@@ -454,6 +456,10 @@ class SequenceEngine(object):
         s2 = side.cuda_stream
         pT = self.leaf('poses_T')
         h = self.halo or {}
+        # the chain's kernels are captured BEFORE the side branch's: a replayed graph keeps the branch whose nodes come first
+        # on the queue it was launched on and moves the other one to a second queue, and every hop between queues costs
+        # 10-14 us of idle time (rocprofv3 trace: the forward used to start 19 us into the cycle, now 9)
+        self.forward(regress=False)      # (the per-body pose-prior values are summed with the other log entries, _finish_a)
         if self.has_images:
             check(L.mh_sil_mask_stats(ptr(self.bits), T, N, self.H, self.W, ptr(pT), ptr(self.p2d_valid),
                                       ptr(self.mask_valid), ptr(self.front), ptr(self.sil_apply), ptr(self.sil_D),
@@ -464,8 +470,8 @@ class SequenceEngine(object):
                                ptr(self.leaf('betas', g)), ptr(self.leaf('xscale', g)), ptr(self.prior_body), ptr(log[9:12]), s2))
         check(L.mh_velocity_term(T, N, ptr(pT), ptr(h.get('pT_prev')), ptr(h.get('pT_next')), float(c['reg_velocity']),
                                  ptr(self.leaf('poses_T', g)), ptr(log[7:8]), s2))
-        self.forward(regress=False)      # (the per-body pose-prior values are summed with the other log entries, _finish_a)
-        main.wait_stream(side)
+        if join:
+            main.wait_stream(side)
 
     def cycle_finish(self, row, use_images=True, raster=None, scene_ready=False):
         self._finish_a(use_images, raster, scene_ready=scene_ready)
@@ -507,42 +513,52 @@ class SequenceEngine(object):
         side = self._side_stream()
         side.wait_stream(main)
         s2 = side.cuda_stream
-        self._regress(s2)
-        jwp = None if self.joint_w is None else self.joint_w.ctypes.data_as(_lib.c_float_p)
-        check(L.mh_project_joints_loss_w(B, ptr(self.kp), Kp, Kdp, jwp, ptr(self.pose2d), self.thr, 0, float(self.W),
-                                         float(self.H), float(c['proj2d']), ptr(self.uv), ptr(self.gj), ptr(self.loss2d), s2))
-        with torch.cuda.stream(side):
-            if need_gv:
-                if filt:
-                    E = N * self.V * 3
-                    ev = self._tic('filtered_verts')
-                    check(L.mh_filtered_verts_term_init(T, E, ptr(self.verts), ptr(self.verts_filt), ptr(h.get('v_prev')),
-                                                        ptr(h.get('vf_prev')), ptr(h.get('v_next')), ptr(h.get('vf_next')),
-                                                        float(c['reg_verts_filter']), ptr(gv), ptr(log[8:9]), ptr(self.fv_ws), s2))
-                    self._toc(ev)
-                else:
-                    gv.zero_()
-            if not self.kp_fused:
-                # key-points from another regressor: their adjoint goes into the (just initialised) vertex gradients and
-                # the translation gradient here; the LBS backward then runs without key-point adjoints
-                check(L.mh_joints_regress_backward(self.m.handle, self.joints_reg[0], B, ptr(self.gj), self.joints_reg[1], ptr(gv),
-                                                   ptr(self.leaf('poses_T', self.grads)), s2))
-            if not hasattr(self, '_ev_gv'):
-                self._ev_gv = torch.cuda.Event()
-            self._ev_gv.record(side)
-        self._scene_done = False
-        sums = [(self.loss2d, log[0:1]), (self.prior_body, log[3:4])]
-        if scene and (self._scene_dev is None or scene_ready):     # static scene, or its event already waited for
-            self._scene_terms(s2, reduce=False)
-            sums += [(self.batch_contact, log[5:6]), (self.batch_foot, log[6:7])]
-            self._scene_done = True
-        _lib.reduce_sum_multi(sums, s2)                            # the small log sums of the side branch: one launch
+
+        def side_branch():
+            self._regress(s2)
+            jwp = None if self.joint_w is None else self.joint_w.ctypes.data_as(_lib.c_float_p)
+            check(L.mh_project_joints_loss_w(B, ptr(self.kp), Kp, Kdp, jwp, ptr(self.pose2d), self.thr, 0, float(self.W),
+                                             float(self.H), float(c['proj2d']), ptr(self.uv), ptr(self.gj), ptr(self.loss2d), s2))
+            with torch.cuda.stream(side):
+                if need_gv:
+                    if filt:
+                        E = N * self.V * 3
+                        ev = self._tic('filtered_verts')
+                        check(L.mh_filtered_verts_term_init(T, E, ptr(self.verts), ptr(self.verts_filt), ptr(h.get('v_prev')),
+                                                            ptr(h.get('vf_prev')), ptr(h.get('v_next')), ptr(h.get('vf_next')),
+                                                            float(c['reg_verts_filter']), ptr(gv), ptr(log[8:9]), ptr(self.fv_ws), s2))
+                        self._toc(ev)
+                    else:
+                        gv.zero_()
+                if not self.kp_fused:
+                    # key-points from another regressor: their adjoint goes into the (just initialised) vertex gradients and
+                    # the translation gradient here; the LBS backward then runs without key-point adjoints
+                    check(L.mh_joints_regress_backward(self.m.handle, self.joints_reg[0], B, ptr(self.gj), self.joints_reg[1], ptr(gv),
+                                                       ptr(self.leaf('poses_T', self.grads)), s2))
+                if not hasattr(self, '_ev_gv'):
+                    self._ev_gv = torch.cuda.Event()
+                self._ev_gv.record(side)
+            self._scene_done = False
+            sums = [(self.loss2d, log[0:1]), (self.prior_body, log[3:4])]
+            if scene and (self._scene_dev is None or scene_ready):     # static scene, or its event already waited for
+                self._scene_terms(s2, reduce=False)
+                sums += [(self.batch_contact, log[5:6]), (self.batch_foot, log[6:7])]
+                self._scene_done = True
+            _lib.reduce_sum_multi(sums, s2)                            # the small log sums of the side branch: one launch
         # ---- main branch: rasterised depth / silhouette terms ----------------------------------------------------------
         joined = False
+        # capture order: the chain's kernels BEFORE the side branch's -- the replayed graph keeps the branch whose nodes
+        # come first on the queue it was launched on and puts the other one on a second queue; a hop between queues costs
+        # the chain 10-14 us of idle time each way (rocprofv3 trace), the side branch has the slack for it
+        main_first = images and raster is not None
+        if not main_first:
+            side_branch()
         if images:
             if raster is not None:
                 ev = self._tic('raster_terms')
                 raster(self, gv, log, phases=1)
+                if main_first:
+                    side_branch()
                 # the whole side branch ends long before the selection does: ONE join here instead of a wait for the
                 # buffer initialisation here and a second join in front of the backward (every cross-stream edge of
                 # the replayed graph costs several us of idle time on the chain, even when its event has long been
@@ -680,14 +696,18 @@ class SequenceEngine(object):
             # static scene.  (Until late in round 2 the cycle was split in two graphs at the contact chain: a graph
             # boundary of ~30 us and the chain on the critical path.)
             def body_org():
-                self.cycle_begin()
+                nj = raster is not None and self.has_images and self.halo is None
+                self.cycle_begin(join=not nj)
                 self.cycle_finish(None, raster=raster, scene_ready=True)
             self.replay(('full+scene',) + key, body_org)
             if scene_update:
                 self.scene_device_launch()
         else:
             def body():
-                self.cycle_begin()
+                # nothing of the rasteriser's selection half reads what the leaf-only terms of the side branch write: with
+                # gradients asked for, the one join in front of the gradient half covers them
+                nj = raster is not None and self.has_images and self.halo is None
+                self.cycle_begin(join=not nj)
                 self.cycle_finish(None, raster=raster)
             self.replay(('full',) + key, body)
             if scene_update:

@@ -283,11 +283,41 @@ __global__ void k_one_euro(const float* x, float* y, int T, size_t E, float min_
       y[e] = xp;
       first = 1;
     }
-    for (int k = first; k < T; ++k) {
+    // the frames of a channel are a dependent chain of ~15 operations each; the loads are not: eight frames' values are
+    // asked for before the chain walks them (the chain alone is ~12 us of the kernel at T = 200)
+    int k = first;
+    for (; k + 8 <= T; k += 8) {
+      float xv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xv[u] = x[(size_t)(k + u) * E + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+#pragma clang fp contract(off)
+        const int i = i0 + k + u;
+        ti = ti + (float)((double)i / (double)frame_rate);
+        const float xi = xv[u];
+        const float te = ti - tp;
+        float r = two_pi * te;
+        const float ad = r / (r + 1.f);
+        const float dx = (xi - xp) / te;
+        const float dxh = ad * dx + (1.f - ad) * dxp;
+        const float cutoff = min_cutoff + beta * fabsf(dxh);
+        r = (two_pi * cutoff) * te;
+        const float a = r / (r + 1.f);
+        const float xh = a * xi + (1.f - a) * xp;
+        y[(size_t)(k + u) * E + e] = xh;
+        xp = xh;
+        dxp = dxh;
+        tp = ti;
+      }
+    }
+    for (; k < T; ++k) {
+#pragma clang fp contract(off)
       const int i = i0 + k;                                   // global frame index
       ti = __fadd_rn(ti, (float)((double)i / (double)frame_rate));     // optimizer.py:671 (float32 running sum)
       const float xi = x[(size_t)k * E + e];
-      // numpy evaluates every product/sum separately in float32: no FMA contraction here
+      // numpy evaluates every product/sum separately in float32: no FMA contraction (hip's __fmul_rn / __fadd_rn are plain
+      // operators and do not prevent it -- the pragma does)
       const float te = __fsub_rn(ti, tp);
       float r = __fmul_rn(two_pi, te);                        // d_cutoff = 1
       const float ad = __fdiv_rn(r, __fadd_rn(r, 1.f));

@@ -306,9 +306,14 @@ def adam_step(params, grads, m, v, step, lr, b1=0.5, b2=0.5, eps=1e-6):
                                   _lib.stream_ptr(params.device)))
 
 
-def one_euro_scan(x, min_cutoff, beta, frame_rate=25.0):
+def one_euro_scan(x, min_cutoff, beta, frame_rate=25.0, out=None):
+    """out: a contiguous float32 tensor of x's size to write the filtered sequence into (returned, viewed like x)"""
     x = x.contiguous()
-    y = torch.empty_like(x)
+    if out is None:
+        y = torch.empty_like(x)
+    else:
+        assert out.is_contiguous() and out.dtype == x.dtype and out.numel() == x.numel() and out.device == x.device
+        y = out.view(x.shape)
     T = x.shape[0]
     check(_lib.lib().mh_one_euro_scan(ptr(x), ptr(y), T, x.numel() // T, float(min_cutoff), float(beta),
                                       float(frame_rate), _lib.stream_ptr(x.device)))

@@ -738,8 +738,17 @@ class SequenceEngine(object):
             self.verts_filt.copy_(verts_filt)
 
     def update_filters(self, c1=0.01, b1=0.02, c2=0.001, b2=0.5):
-        pf = engine.one_euro_scan(self.leaf('poses_T'), c1, b1)
-        self.forward()
+        """optimizer.py:383-392: the translations and the vertices of the current leaves through the one-euro filters.  From
+        the second call on the scans write straight into the buffers the captured cycle graphs read (the first call creates
+        them): no second pass over the 66 MB of vertices; the forward runs without the key-point regression."""
+        pT = self.leaf('poses_T')
+        if self.pT_filt is not None and self.verts_filt is not None and self.pT_filt.numel() == pT.numel():
+            engine.one_euro_scan(pT, c1, b1, out=self.pT_filt)
+            self.forward(regress=False)
+            engine.one_euro_scan(self.verts.view(self.T, -1), c2, b2, out=self.verts_filt)
+            return
+        pf = engine.one_euro_scan(pT, c1, b1)
+        self.forward(regress=False)
         self.set_filters(pf, engine.one_euro_scan(self.verts.view(self.T, -1), c2, b2))
 
     def one_euro_shard(self, x, min_cutoff, beta, first_frame, state_in=None):

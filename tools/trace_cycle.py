@@ -18,3 +18,11 @@ for r in rows[a + 1:b + 1]:
     st, en = int(r['Start_Timestamp']), int(r['End_Timestamp'])
     print('%8.1f %7.1f %6.1f  q%s  %s' % ((st - t0) / 1e3, (en - st) / 1e3, (st - prev_end) / 1e3, r.get('Queue_Id', '?'), r['Kernel_Name'][:48]))
     prev_end = max(prev_end, en)
+# the graph boundary: from the end of the update to the first kernel of the next cycle, and the period over the next cycles
+if b + 1 < len(rows):
+    nxt = int(rows[b + 1]['Start_Timestamp'])
+    print('update ends at %.1f us; first kernel of the next cycle starts %.1f us later (%s)' % (
+        (int(rows[b]['End_Timestamp']) - t0) / 1e3, (nxt - int(rows[b]['End_Timestamp'])) / 1e3, rows[b + 1]['Kernel_Name'][:40]))
+ends = [int(rows[i]['End_Timestamp']) for i in idx[which:which + 11]]
+if len(ends) > 1:
+    print('period over the next %d cycles: %.1f us' % (len(ends) - 1, (ends[-1] - ends[0]) / 1e3 / (len(ends) - 1)))

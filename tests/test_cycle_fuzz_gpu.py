@@ -2,11 +2,11 @@
 random small sequences against the CPU oracle: frame counts that are no batch multiples (ragged last batch, batch larger than
 the sequence), 1-3 humans, landscape / portrait / square images, with and without a scene cloud.  EVERY entry of every leaf
 gradient and every log entry (deterministic scatter; the oracle renders the faces the kernel selected at the vertices the
-kernel produced, as in tests/test_full_size_gpu.py -- and renders them in float64: on faces of a fraction of a pixel the
-float32 autograd of the oracle's renderer is itself off by up to 3e-3 of a leaf's largest entry, one sequence in 70 showed
-it, and in float64 the same sequence agrees to 4e-6).  tools/fuzz_cycle.py runs the same loop for any number of sequences:
-110 of them (F64=1; single frames, up to six humans, 32x24 to 200x40 among them) had 5.7e-5 as the worst entry of the five
-large leaves, 1.6e-4 on the scale leaf and 1.3e-6 on the log."""
+kernel produced, as in tests/test_full_size_gpu.py -- with its renderer in float32 AND in float64; an entry has to agree
+with one of them (test_fit_full_gpu._oracle_grads_both says why neither is the truth for every entry).  tools/fuzz_cycle.py
+runs the same loop for any number of sequences: 180 of them (single frames, up to six humans, 32x24 to 200x40 among them)
+had 5.7e-5 as the worst entry of the five large leaves, 1.6e-4 on the scale leaf and 1.3e-6 on the log; three sequences
+needed float32 (float64 up to 6.7e-4 off), one needed float64 (float32 2.8e-3 off)."""
 import numpy as np
 import pytest
 
@@ -34,8 +34,7 @@ def test_random_sequences_cycle_filters_cycle(smpl_struct, smpl_regs, oracle_mod
             opt._stage_from_dataloader(dl)
             e = opt.engine
             raster = RasterTerms(e)
-            hsel = tf._HipSelectionRasteriser(np.asarray(smpl_struct.f).astype(np.int64), synthetic.default_cam_K((W, H), 60.0), (W, H), N,
-                                               wide=True)
+            hsel = tf._HipSelectionRasteriser(np.asarray(smpl_struct.f).astype(np.int64), synthetic.default_cam_K((W, H), 60.0), (W, H), N)
             o.rasteriser = hsel
             where = 'sequence %d (%dx%d, T %d, N %d, batch %d, scene %s)' % (c, W, H, T, N, batch, scene)
             for cyc in range(2):
@@ -45,15 +44,16 @@ def test_random_sequences_cycle_filters_cycle(smpl_struct, smpl_regs, oracle_mod
                 e.cycle(cyc, raster=raster)
                 hsel.take(raster, e, oracle=o)
                 log = e.read_log(cyc + 1)[cyc]
-                want = o.cycle_grads(batches)
+                want, both = tf._oracle_grads_both(o, hsel, batches)
                 for k in LOG_KEYS + (['reg_filter_verts'] if cyc else []):
                     np.testing.assert_allclose(log[k], want[k], rtol=2e-5, atol=1e-7, err_msg='%s cycle %d %s' % (where, cyc, k))
                 for name, ename in tf.LEAF_MAP:
-                    w = tf._oracle_grad(o, name)
-                    g = e.leaf(ename, e.grads).cpu().numpy().reshape(w.shape)
+                    w32, w64 = both[name]
+                    g = e.leaf(ename, e.grads).cpu().numpy().reshape(w32.shape)
                     # xscale: N entries, each the sum of everything a person's vertices receive -- it can cancel to ~0
                     tol = 1e-3 if name == 'xscale' else 1e-4
-                    np.testing.assert_allclose(g, w, atol=tol * max(np.abs(w).max(), 1e-8), rtol=0,
-                                               err_msg='%s cycle %d leaf %s' % (where, cyc, name))
+                    err = np.minimum(np.abs(g - w32), np.abs(g - w64))          # right = agrees with either precision
+                    assert err.max() <= tol * max(np.abs(w64).max(), 1e-8), '%s cycle %d leaf %s: %.2e of the largest entry' % (
+                        where, cyc, name, err.max() / max(np.abs(w64).max(), 1e-8))
     finally:
         set_deterministic(old)

@@ -86,6 +86,23 @@ class _HipSelectionRasteriser(object):
         return ro.render(verts, self.faces, self.K, self.size, selection=(s[..., :1], s[..., 1:]))
 
 
+def _oracle_grads_both(o, hsel, batches):
+    """the oracle's cycle with its renderer in float32 and in float64: (log, {leaf: (float32 grads, float64 grads)}).
+    Neither precision is the truth for every entry: on a face of a fraction of a pixel the float32 AUTOGRAD of the renderer
+    is up to 3e-3 off (float64 then agrees with the kernel to 1e-6), while a pixel centre within rounding of a face's edge
+    is clipped / kept by the float32 rasteriser the reference runs -- and by the kernel -- but not in float64 (then float32
+    agrees to 1e-5 and float64 is 7e-4 off).  tools/fuzz_cycle.py has found both kinds; an entry is right when it
+    agrees with either."""
+    out, log = {}, None
+    for wide in (False, True):
+        hsel.wide = wide
+        lg = o.cycle_grads(batches)
+        log = log or lg
+        for name, _ in LEAF_MAP:
+            out.setdefault(name, []).append(_oracle_grad(o, name).copy())
+    return log, {k: tuple(v) for k, v in out.items()}
+
+
 def _oracle_grad(o, name):
     p = dict(zip(['poses_T', 'poses_smpl', 'betas', 'zmin_lin', 'zmax_lin', 'xscale'], o.leaves()))[name]
     return p.grad.numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)

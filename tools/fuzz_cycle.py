@@ -2,7 +2,10 @@
 filtered-vertex term) of the drop-in against the CPU oracle on random small sequences -- frame counts that are not batch
 multiples, 1-3 humans, portrait / landscape / square images, with and without a scene cloud.  Prints the worst entry of
 every leaf gradient (relative to the leaf's largest) and of the loss log.  ONLY=<case> runs one case of the sequence;
-F64=1 lets the oracle render in float64 (on faces of a fraction of a pixel its float32 autograd is itself ~1e-3 off)."""
+F64=1 lets the oracle render in float64 (on faces of a fraction of a pixel its float32 autograd is itself ~1e-3 off);
+F64=both evaluates it at both precisions and counts an entry as right when it agrees with either (a pixel centre within
+rounding of a face's edge is decided by float32 arithmetic in the reference and in the kernel, differently in float64).
+COEF_OFF=depth,silhouette takes terms out on both sides."""
 import os, sys, tempfile, pathlib
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,6 +17,9 @@ import test_fit_full_gpu as tf
 import test_full_size_gpu as tfs
 struct = synthetic.make_smpl_struct(1); regs = synthetic.make_extra_regressors(1, struct)
 omodel = lo.BodyModel(struct, regs)
+import golden_inputs as _gi
+for _k in [k for k in os.environ.get('COEF_OFF', '').split(',') if k]:      # COEF_OFF=depth,silhouette: terms taken out on both sides
+    _gi.COEFS[_k] = 0.0
 rng = np.random.RandomState(int(os.environ.get('SEED', '5')))
 worst = {}
 set_deterministic(True)
@@ -43,15 +49,19 @@ for c in range(int(os.environ.get('CASES', '10'))):
         e.cycle(cyc, raster=raster)
         hsel.take(raster, e, oracle=o)
         log = e.read_log(cyc + 1)[cyc]
-        want = o.cycle_grads(batches)
+        if os.environ.get('F64') == 'both':
+            want, both = tf._oracle_grads_both(o, hsel, batches)
+        else:
+            want, both = o.cycle_grads(batches), None
         lw = 0.0
         for k in tfs.LOG_KEYS + (['reg_filter_verts'] if cyc else []):
             lw = max(lw, abs(log[k] - want[k]) / max(abs(want[k]), 1e-6))
         gw = 0.0
         for name, ename in tf.LEAF_MAP:
-            w = tf._oracle_grad(o, name)
+            w = tf._oracle_grad(o, name) if both is None else both[name][1]
             g = e.leaf(ename, e.grads).cpu().numpy().reshape(w.shape)
-            r = float(np.abs(g - w).max() / max(np.abs(w).max(), 1e-8))
+            err = np.abs(g - w) if both is None else np.minimum(np.abs(g - both[name][0]), np.abs(g - both[name][1]))
+            r = float(err.max() / max(np.abs(w).max(), 1e-8))
             worst[name] = max(worst.get(name, 0.0), r)
             if r > 1e-4:
                 i = int(np.argmax(np.abs(g - w)))

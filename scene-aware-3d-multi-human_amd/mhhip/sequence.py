@@ -433,7 +433,10 @@ class SequenceEngine(object):
 
     # -- one optimisation cycle (optimizer.py:375-575), gradients accumulated into self.grads -----
     def cycle(self, row, use_images=True, raster=None):
-        self.cycle_begin()
+        # the same launch order as the captured form (cycle_graphed): the sums of a cycle are then added in the same order
+        # either way, and eager and replayed fits stay bit-identical (deterministic mode) until something else differs
+        nj = raster is not None and use_images and self.has_images and self.halo is None
+        self.cycle_begin(join=not nj)
         self.cycle_finish(row, use_images, raster)
 
     def cycle_begin(self, join=True):
@@ -460,16 +463,25 @@ class SequenceEngine(object):
         # on the queue it was launched on and moves the other one to a second queue, and every hop between queues costs
         # 10-14 us of idle time (rocprofv3 trace: the forward used to start 19 us into the cycle, now 9)
         self.forward(regress=False)      # (the per-body pose-prior values are summed with the other log entries, _finish_a)
-        if self.has_images:
-            check(L.mh_sil_mask_stats(ptr(self.bits), T, N, self.H, self.W, ptr(pT), ptr(self.p2d_valid),
-                                      ptr(self.mask_valid), ptr(self.front), ptr(self.sil_apply), ptr(self.sil_D),
-                                      ptr(self.sil_S), s2))
-        check(L.mh_prior_terms(T, N, self.nbatches, ptr(self.leaf('poses_smpl')), ptr(self.poses_ref), ptr(self.valid),
-                               ptr(self.leaf('betas')), ptr(self.betas_ref), ptr(self.leaf('xscale')),
-                               float(c['reg_poses']), float(c['reg_scales']), ptr(self.leaf('poses_smpl', g)),
-                               ptr(self.leaf('betas', g)), ptr(self.leaf('xscale', g)), ptr(self.prior_body), ptr(log[9:12]), s2))
-        check(L.mh_velocity_term(T, N, ptr(pT), ptr(h.get('pT_prev')), ptr(h.get('pT_next')), float(c['reg_velocity']),
-                                 ptr(self.leaf('poses_T', g)), ptr(log[7:8]), s2))
+        def leaf_terms():
+            if self.has_images:
+                check(L.mh_sil_mask_stats(ptr(self.bits), T, N, self.H, self.W, ptr(pT), ptr(self.p2d_valid),
+                                          ptr(self.mask_valid), ptr(self.front), ptr(self.sil_apply), ptr(self.sil_D),
+                                          ptr(self.sil_S), s2))
+            check(L.mh_prior_terms(T, N, self.nbatches, ptr(self.leaf('poses_smpl')), ptr(self.poses_ref), ptr(self.valid),
+                                   ptr(self.leaf('betas')), ptr(self.betas_ref), ptr(self.leaf('xscale')),
+                                   float(c['reg_poses']), float(c['reg_scales']), ptr(self.leaf('poses_smpl', g)),
+                                   ptr(self.leaf('betas', g)), ptr(self.leaf('xscale', g)), ptr(self.prior_body), ptr(log[9:12]), s2))
+            check(L.mh_velocity_term(T, N, ptr(pT), ptr(h.get('pT_prev')), ptr(h.get('pT_next')), float(c['reg_velocity']),
+                                     ptr(self.leaf('poses_T', g)), ptr(log[7:8]), s2))
+
+        # without a join here nothing needs these terms before the side branch ends: they are launched at its END then
+        # (_finish_a), so that the vertex-dependent kernels start right behind the forward instead of 50 us later
+        self._leaf_terms_later = None
+        if not join:
+            self._leaf_terms_later = leaf_terms
+        else:
+            leaf_terms()
         if join:
             main.wait_stream(side)
 
@@ -514,11 +526,20 @@ class SequenceEngine(object):
         side.wait_stream(main)
         s2 = side.cuda_stream
 
-        def side_branch():
+        def regress_project():
             self._regress(s2)
             jwp = None if self.joint_w is None else self.joint_w.ctypes.data_as(_lib.c_float_p)
             check(L.mh_project_joints_loss_w(B, ptr(self.kp), Kp, Kdp, jwp, ptr(self.pose2d), self.thr, 0, float(self.W),
                                              float(self.H), float(c['proj2d']), ptr(self.uv), ptr(self.gj), ptr(self.loss2d), s2))
+
+        def side_branch():
+            # order (same-box A/B with the chain on the launch queue): the vertex-gradient initialisation first -- 200 MB beside
+            # the rasteriser's preparation, which is bound by latency -- then the key-point terms, the contact chain and, when
+            # the caller left them to this branch, the leaf-only terms: everything behind the initialisation lands under
+            # the selection kernel.  (With the side branch on the launch queue, round 2, the regression had to come first.)
+            fv_first = self.kp_fused
+            if not fv_first:
+                regress_project()
             with torch.cuda.stream(side):
                 if need_gv:
                     if filt:
@@ -538,12 +559,18 @@ class SequenceEngine(object):
                 if not hasattr(self, '_ev_gv'):
                     self._ev_gv = torch.cuda.Event()
                 self._ev_gv.record(side)
+            if fv_first:
+                regress_project()
             self._scene_done = False
+            later = getattr(self, '_leaf_terms_later', None)
+            self._leaf_terms_later = None
             sums = [(self.loss2d, log[0:1]), (self.prior_body, log[3:4])]
             if scene and (self._scene_dev is None or scene_ready):     # static scene, or its event already waited for
                 self._scene_terms(s2, reduce=False)
                 sums += [(self.batch_contact, log[5:6]), (self.batch_foot, log[6:7])]
                 self._scene_done = True
+            if later is not None:
+                later()
             _lib.reduce_sum_multi(sums, s2)                            # the small log sums of the side branch: one launch
         # ---- main branch: rasterised depth / silhouette terms ----------------------------------------------------------
         joined = False

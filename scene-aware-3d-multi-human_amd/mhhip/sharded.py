@@ -98,8 +98,7 @@ class ShardedSequence(object):
             else:
                 if scene_update:
                     e.scene_device_update()
-                e.cycle_begin()
-                e.cycle_finish(row, raster=raster)
+                e.cycle(row, raster=raster)
             return
         halo = {}
         pp, pn = self._gather_boundaries(e.leaf('poses_T'))

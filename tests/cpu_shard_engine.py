@@ -150,6 +150,10 @@ class CpuShardEngine(object):
         with torch.no_grad():
             self.verts = self._verts(self.params)[0].reshape(self.B, -1, 3).clone()
 
+    def cycle(self, row, use_images=True, raster=None):
+        self.cycle_begin()
+        self.cycle_finish(row, use_images, raster)
+
     def cycle_begin(self):
         self.grads.zero_()
         self.forward()

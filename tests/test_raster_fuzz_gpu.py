@@ -30,13 +30,16 @@ def test_random_scenes_differ_from_the_brute_force_selection_only_in_near_ties(s
 
 
 @pytest.mark.parametrize('seed', [303, 404])
-def test_random_scenes_gradients_against_the_float64_oracle(smpl_struct, smpl_regs, seed):
-    """dL/dverts, the depth-range gradients and the loss values of both rasterised terms against the oracle evaluated in
-    FLOAT64 on the HIP selection.  float64 because on faces of a fraction of a pixel the float32 autograd of the oracle is
-    itself up to 1e-3 (of the largest entry) away from its float64 self, more than the kernel is: measured over 120 random
-    scenes (tools/fuzz_raster_grads.py) the kernel's worst entry is 4.5e-4 away, at most 3 entries per scene exceed 2e-4,
-    117 scenes stay below 1.5e-4.  (Before round 3's two fixes -- depth differences taken before the normalisation
-    Jacobian, pixel centres without fused multiply-add -- the same scenes had up to 6e-3 on 16 entries.)"""
+def test_random_scenes_gradients_against_the_oracle_at_both_precisions(smpl_struct, smpl_regs, seed):
+    """dL/dverts, the depth-range gradients and the loss values of both rasterised terms against the oracle evaluated on the
+    HIP selection in FLOAT64 and in float32; an entry of dL/dverts is right when it agrees with either.  Neither precision is
+    the truth everywhere: on faces of a fraction of a pixel the float32 autograd of the oracle is up to 1e-3 (of the largest
+    entry) away from its float64 self where the kernel is not; and where a pixel centre lies within rounding of a face's edge
+    the float32 rasteriser -- the reference's, the oracle's, the kernel's -- decides one way and float64 the other (one face
+    in 100 scenes: kernel and float32 oracle agree to seven digits, float64 is 1.8e-3 away; tools/grad_debug.py).  Measured
+    over 300 random scenes (tools/fuzz_raster_grads.py ORACLE=both): worst entry 7.9e-5; against float64 alone 1.8e-3 with
+    up to 9 entries of a scene above 2e-4.  (Before round 3's two fixes -- depth differences taken before the normalisation
+    Jacobian, pixel centres without fused multiply-add -- the same kind of scene had up to 6e-3 on 16 entries.)"""
     import torch
     rng = np.random.RandomState(seed)
     nonzero = 0
@@ -46,16 +49,18 @@ def test_random_scenes_gradients_against_the_float64_oracle(smpl_struct, smpl_re
         zlo = float(rng.choice([1.1, 1.6, 2.5, 4.0]))
         zhi = zlo + float(rng.choice([0.3, 1.0, 3.0]))
         fov = float(rng.choice([40.0, 60.0, 90.0]))
-        r = tr._run_case(smpl_struct, smpl_regs, T, N, W, H, int(rng.randint(1 << 30)), zlo=zlo, zhi=zhi, fov=fov,
+        scene_seed = int(rng.randint(1 << 30))
+        r = tr._run_case(smpl_struct, smpl_regs, T, N, W, H, scene_seed, zlo=zlo, zhi=zhi, fov=fov,
                          hip_selection=True, oracle_dtype=torch.float64)
         g, w = r['gv'].astype(np.float64), r['want_gv']
         scale = np.abs(w).max()
         if scale == 0:
             continue
         nonzero += 1
-        err = np.abs(g - w) / scale
+        r32 = tr._run_case(smpl_struct, smpl_regs, T, N, W, H, scene_seed, zlo=zlo, zhi=zhi, fov=fov, hip_selection=True)
+        err = np.minimum(np.abs(g - w), np.abs(g - r32['want_gv'].astype(np.float64))) / scale
         where = 'scene %d (%dx%d, T %d, N %d, z %.1f-%.1f, fov %.0f)' % (c, W, H, T, N, zlo, zhi, fov)
-        assert err.max() <= 1e-3 and int((err > 2e-4).sum()) <= 4, '%s: max %.2e, %d entries > 2e-4' % (where, err.max(), int((err > 2e-4).sum()))
+        assert err.max() <= 2e-4, '%s: max %.2e, %d entries > 1e-4' % (where, err.max(), int((err > 1e-4).sum()))
         np.testing.assert_allclose(r['depth'], r['want_depth'], rtol=2e-4, atol=1e-7, err_msg=where)
         np.testing.assert_allclose(r['sil'], r['want_sil'], rtol=2e-4, atol=1e-7, err_msg=where)
         for k in ('gzmin', 'gzmax'):

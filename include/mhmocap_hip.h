@@ -111,6 +111,36 @@ int mh_lbs_forward_rotmats(const mh_model* m, int B, int NB, const float* betas,
                            const float* xscale, const float* transl, float* verts, float* posed_joints /*or NULL*/,
                            void* ws, void* stream);
 
+/* ---- the "LBS + projection" form of the forward (round 4): what the rasteriser needs of the vertices is produced in the
+ * skinning epilogue, where they are in registers -- NDC projection (transforms.py:222-255 with PyTorch3D's R = diag(-1,-1,1);
+ * the same three roundings per coordinate as the stand-alone projection pass of mh_raster_terms), the body's screen
+ * bounding box, whether a vertex has left the pixel-row band its face lists were sorted for, and the lowest vertex
+ * (arg max of y, first index on ties: optimizer.py:487-489).  mh_raster_forward_targets fills the struct for a raster
+ * workspace; mh_raster_terms_projected then skips its own pass over the vertices.
+ * Box and lowest vertex are found WITHOUT cross-lane reductions: a vertex only reports (one atomic min / max) when it
+ * lies beyond the previous launch's extreme minus `slack`; an extreme nobody reported is left at its reset value and the
+ * consumer falls back to a scan of that body (mh_raster_terms_projected / mh_lowest_resolve), so any content of the
+ * previous-launch arrays gives exact results -- it only decides how many vertices report.                     */
+typedef struct mh_fwd_proj {
+  float s, w1, h1;             /* x_ndc = s * (-x) / z + w1, y_ndc = s * (-y) / z + h1                      */
+  float ra, rk, thr;           /* pixel row = fma(-y_ndc, rk, ra); a vertex has moved when |row - rowb| >= thr */
+  float slack_ndc, slack_y;    /* report when beyond (previous extreme -/+ slack): NDC units / metres        */
+  float* ndc;                  /* (B,V,3) out: x_ndc, y_ndc, z                                              */
+  const float* rowb;           /* (B,V)   in : pixel row of every vertex at the body's last face sort        */
+  int32_t* bbox;               /* (B,4)   out: order-preserving int of min x, min y, max x, max y (z > 1e-8 only);
+                                                untouched entries stay at INT_MAX / INT_MIN                  */
+  int32_t* bbox_prev;          /* (B,4)   the previous launch's bbox (copied, then bbox reset, by the launch itself) */
+  unsigned long long* lowkey;  /* (B)     out: order-preserving bits of y << 32 | ~vertex, 0 = nobody reported */
+  unsigned long long* lowkey_prev; /* (B) */
+  int32_t* moved;              /* (B)     out: 1 = some vertex left its band                                 */
+} mh_fwd_proj;
+int mh_lbs_forward_proj(const mh_model* m, int B, int NB, const float* betas, const float* poses,
+                        const float* xscale, const float* transl, float* verts, float* vposed /*or NULL*/,
+                        const mh_fwd_proj* proj, void* ws, void* stream);
+/* low_idx / low_xyz of mh_lowest_vertex from the keys of mh_lbs_forward_proj (a body nobody reported for is scanned) */
+int mh_lowest_resolve(const float* verts /*(B,V,3)*/, int B, int V, unsigned long long* lowkey /*(B): a missing key is written back*/,
+                      int32_t* low_idx /*(B)*/, float* low_xyz /*(B,3)*/, void* stream);
+
 /* Arithmetic of the two dense contractions of the LBS pair (pose/shape blend and its adjoint):
  * split16 = 1 (default): operands carried as two 16-bit terms, three products on the 16-bit matrix pipe with fp32
  * accumulation -- fp16 terms in the forward (vertices within ~1e-7 m of the fp32 result), bf16 terms in the backward
@@ -391,6 +421,20 @@ int mh_raster_terms_phase_log(int T, int N, int V, int F, int H, int W, const fl
                           float coef_depth, float coef_sil, float eps, float* gverts, float* gzmin,
                           float* gzmax, float* depth_body, float* sil_body, void* ws,
                           float* zbuf_out, float* alpha_out, int phases, float* log_depth, float* log_sil, void* stream);
+/* the same after mh_lbs_forward_proj wrote into this workspace (mh_raster_forward_targets): projected != 0 -> the
+ * preparation kernel reads the bounding boxes / motion flags the forward left instead of passing over `verts` (which
+ * may then be NULL); a body whose box is incomplete is scanned from the projected vertices.  Same results, bit for bit. */
+int mh_raster_forward_targets(int T, int N, int V, int F, int H, int W, const float* cam_K_host, void* ws,
+                              mh_fwd_proj* out);
+int mh_raster_terms_projected(int T, int N, int V, int F, int H, int W, const float* cam_K_host,
+                          const float* verts, const int32_t* faces, const uint32_t* bits,
+                          const uint32_t* ebits, const float* depths, const float* zmin_lin,
+                          const float* zmax_lin, const float* pose2d_valid, const uint32_t* front,
+                          const float* sil_apply, const float* sil_D, const float* sil_S,
+                          float coef_depth, float coef_sil, float eps, float* gverts, float* gzmin,
+                          float* gzmax, float* depth_body, float* sil_body, void* ws,
+                          float* zbuf_out, float* alpha_out, int phases, float* log_depth, float* log_sil,
+                          int projected, void* stream);
 /* Deterministic gradient scatter (default off; MHHIP_DETERMINISTIC=1 in the environment switches it on at first use).
  * The production kernel sums the per-pixel vertex gradients of the rasterised terms with fp32 atomics (LDS table,
  * then global): the summation order, hence the last bits, vary from run to run.  on != 0: one workgroup per body,

@@ -35,6 +35,12 @@ struct PoseFwdP {
   float* scale;   // [G*32]
   float* posed;   // [B][24][3] or null
   mh_tree tree;
+  // mh_lbs_forward_proj: the per-body report slots of the skinning epilogue (null otherwise)
+  int* bbox;
+  int* bbox_prev;
+  unsigned long long* lowkey;
+  unsigned long long* lowkey_prev;
+  int* moved;
 };
 
 __device__ __forceinline__ void mh_joint_rest(const float* Jt, const float* JS, const float* beta, int j, float J[3]) {
@@ -168,6 +174,22 @@ __global__ __launch_bounds__(256) void k_pose_fwd(PoseFwdP p) {
       }
       if (j >= 24 && j < 31) put(217 + (j - 24), 0.f);
     }
+  }
+  // report slots of the skinning epilogue (mh_fwd_proj): what the last launch left becomes the filter of this one -- only
+  // COMPLETE entries, so that a launch nobody consumed (no fallback scan wrote the missing extreme back) does not wipe
+  // the filter -- then the slots are reset
+  if (p.bbox && valid && j == 31) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int unset = k < 2 ? 0x7fffffff : (int)0x80000000;
+      const int c = p.bbox[(size_t)b * 4 + k];
+      if (c != unset) p.bbox_prev[(size_t)b * 4 + k] = c;
+      p.bbox[(size_t)b * 4 + k] = unset;
+    }
+    const unsigned long long lk = p.lowkey[b];
+    if (lk) p.lowkey_prev[b] = lk;
+    p.lowkey[b] = 0ull;
+    p.moved[b] = 0;
   }
 }
 
@@ -331,6 +353,7 @@ struct SkinFwd16P {
   const float* skw;
   float* verts;
   float* vposed;
+  mh_fwd_proj P;           // PROJ instantiations only
 };
 
 #ifndef FWD16_STAGES
@@ -344,7 +367,13 @@ struct SkinFwd16P {
 #endif
 #define FWD16_SF_BYTES ((MH_FS / 16) * 2 * 64 * 16)       // 28672: feature terms
 #define FWD16_SA_BYTES (32 * MH_NJ * 12 * 4)              // 36864: bone transforms
-#define FWD16_LDS_BYTES (FWD16_SF_BYTES + FWD16_SA_BYTES + 32 * 16)   // + (scale, translation) per body
+#define FWD16_LDS_BYTES (FWD16_SF_BYTES + FWD16_SA_BYTES + 3 * 32 * 16)   // + (scale, translation), report thresholds per body
+
+// order-preserving integer images of a float: signed (box extremes) and unsigned (high word of the lowest-vertex key)
+__device__ __forceinline__ int mh_ord(float x) { const int i = __float_as_int(x); return i ^ ((i >> 31) & 0x7fffffff); }
+__device__ __forceinline__ float mh_unord(int o) { return __int_as_float(o ^ ((o >> 31) & 0x7fffffff)); }
+__device__ __forceinline__ unsigned mh_ordu(float x) { const unsigned u = __float_as_uint(x); return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u); }
+__device__ __forceinline__ float mh_unordu(unsigned o) { return __uint_as_float(o ^ ((o >> 31) ? 0x80000000u : 0xffffffffu)); }
 
 typedef float f32x3 __attribute__((ext_vector_type(3)));
 
@@ -352,12 +381,19 @@ typedef float f32x3 __attribute__((ext_vector_type(3)));
 // The epilogue is written for instruction count: per accumulator row 13 LDS reads whose row part is an immediate
 // offset (per-lane bases are set up once), 63 fp32 FMAs and two 12-byte stores addressed by a wave-uniform row base
 // plus one 32-bit lane offset.
-template <bool FULL, bool NW4>
+// PROJ (mh_lbs_forward_proj, the "LBS + projection" kernel): the epilogue also projects the vertex to NDC (third row store),
+// tests it against the pixel row its body's face lists were sorted for, and reports it when it lies beyond the previous
+// launch's box / lowest-vertex extremes minus a slack -- plain compares against per-body thresholds in LDS, atomics only
+// from the few vertices near an extreme, no cross-lane reduction (include/mhmocap_hip.h, mh_fwd_proj).
+template <bool FULL, bool NW4, bool PROJ>
 __global__ __launch_bounds__(FWD16_WAVES * 64, 2 * FWD16_WAVES / 4) void k_skin_fwd16(SkinFwd16P p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
   f16x8* sF = (f16x8*)smem16;                                           // [14][2][64]
   float* sA = (float*)(smem16 + FWD16_SF_BYTES);                        // [32][24][12]
   f32x4* sS = (f32x4*)(smem16 + FWD16_SF_BYTES + FWD16_SA_BYTES);       // [32] (scale, tx, ty, tz)
+  f32x4* sTH = sS + 32;                                                 // [32] report thresholds: min x, min y, max x, max y (NDC)
+  f32x4* sLY = sTH + 32;                                                // [32] [0] = report threshold of the lowest vertex (camera y)
+                                                                        // (three arrays of one stride: one per-lane base serves all)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int li = lane & 31, lh = lane >> 5;
   const int g = blockIdx.y;
@@ -376,6 +412,20 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, 2 * FWD16_WAVES / 4) void k_skin_
         if (p.transl) { q[1] = p.transl[(size_t)b * 3]; q[2] = p.transl[(size_t)b * 3 + 1]; q[3] = p.transl[(size_t)b * 3 + 2]; }
       }
       sS[threadIdx.x] = q;
+      if (PROJ) {
+        // nothing reports for a padding body; an unset / garbage previous extreme gives a NaN or arbitrary threshold:
+        // whatever then reports is still exact per slot (a slot is either the true extreme or stays unset)
+        f32x4 th = {-3e38f, -3e38f, 3e38f, 3e38f};
+        float ly = 3e38f;
+        if (b < p.B) {
+          const int4 pb = *(const int4*)(p.P.bbox_prev + (size_t)b * 4);
+          th[0] = mh_unord(pb.x) + p.P.slack_ndc; th[1] = mh_unord(pb.y) + p.P.slack_ndc;
+          th[2] = mh_unord(pb.z) - p.P.slack_ndc; th[3] = mh_unord(pb.w) - p.P.slack_ndc;
+          ly = mh_unordu((unsigned)(p.P.lowkey_prev[b] >> 32)) - p.P.slack_y;
+        }
+        sTH[threadIdx.x] = th;
+        sLY[threadIdx.x] = (f32x4){ly, 0.f, 0.f, 0.f};
+      }
     }
   }
   __syncthreads();
@@ -446,8 +496,21 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, 2 * FWD16_WAVES / 4) void k_skin_
   const unsigned char* sB = (const unsigned char*)sS + (4 * lh) * 16;
   const unsigned lane_off = (unsigned)(4 * lh * p.V + v) * 12u;          // bytes inside a group's row block (< 2^32)
   const size_t row_bytes = (size_t)p.V * 12;
+  const unsigned row_b32 = (unsigned)p.V * 12u;   // every address below: wave-uniform group base + ONE 32-bit lane offset (saddr form)
   unsigned char* const vg = (unsigned char*)p.verts + (size_t)g * 32 * row_bytes;
   unsigned char* const qg = p.vposed ? (unsigned char*)p.vposed + (size_t)g * 32 * row_bytes : nullptr;
+  unsigned char* const ng = PROJ ? (unsigned char*)p.P.ndc + (size_t)g * 32 * row_bytes : nullptr;
+  const unsigned char* const rbg = PROJ ? (const unsigned char*)p.P.rowb + (size_t)g * 32 * p.V * 4 : nullptr;
+  // the sixteen rows' pixel rows at the last face sort: requested HERE, ahead of the row stores -- a load issued between
+  // the stores would be waited for with vmcnt(0), i.e. together with every store in flight (one memory round trip per row)
+  float rbv[16];
+  if (PROJ) {
+    const unsigned lane_off4 = (unsigned)(4 * lh * p.V + v) * 4u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      rbv[r] = *(const float*)(rbg + (size_t)(unsigned)(lane_off4 + (unsigned)((r & 3) + 8 * (r >> 2)) * ((unsigned)p.V * 4u)));
+    __builtin_amdgcn_sched_barrier(0);
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     constexpr int dummy = 0; (void)dummy;
@@ -482,10 +545,38 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, 2 * FWD16_WAVES / 4) void k_skin_
     const float x2 = fmaf(T[10], vp2, fmaf(T[9], vp1, T[8] * vp0)) + T[11];
     const f32x3 o = {fmaf(st[0], x0, st[1]), fmaf(st[0], x1, st[2]), fmaf(st[0], x2, st[3])};
     if (FULL || g * 32 + row0 + 4 * lh < p.B) {
-      *(f32x3*)(vg + (size_t)row0 * row_bytes + lane_off) = o;
+      const unsigned off_r = lane_off + (unsigned)row0 * row_b32;
+      *(f32x3*)(vg + (size_t)off_r) = o;
       if (qg) {
         const f32x3 q = {vp0, vp1, vp2};
-        *(f32x3*)(qg + (size_t)row0 * row_bytes + lane_off) = q;
+        *(f32x3*)(qg + (size_t)off_r) = q;
+      }
+      if (PROJ) {
+        // the same three roundings per coordinate as k_raster_prepare's own projection (multiply, IEEE divide, add)
+        const float Zc = o[2];
+        const float xn = p.P.s * (-o[0]) / Zc + p.P.w1, yn = p.P.s * (-o[1]) / Zc + p.P.h1;
+        const f32x3 nd = {xn, yn, Zc};
+        *(f32x3*)(ng + (size_t)off_r) = nd;
+        const bool mv = !(fabsf(fmaf(-yn, p.P.rk, p.P.ra) - rbv[r]) < p.P.thr);    // NaN-safe: anything odd rebuilds
+        const f32x4 th = *(const f32x4*)(sB + 512 + row0 * 16);
+        const float ly = *(const float*)(sB + 1024 + row0 * 16);
+        const bool zok = Zc > 1e-8f;
+        const bool c0 = zok && xn < th[0], c1 = zok && yn < th[1], c2 = zok && xn > th[2], c3 = zok && yn > th[3];
+        const bool c4 = o[1] > ly;
+        // ONE wave-uniform branch per row (a scalar test of the combined lane mask): nothing below it is on the path of a row
+        // in which no vertex reports -- most rows
+        if (__builtin_amdgcn_ballot_w64(c0 || c1 || c2 || c3 || c4 || mv) != 0ull) {
+          // (the asm keeps the sixteen rows' slot addresses from being computed ahead of the matrix phase and spilled)
+          int b = g * 32 + row0 + 4 * lh;
+          asm volatile("" : "+v"(b));
+          int* bb = p.P.bbox + (size_t)b * 4;
+          if (c0) atomicMin(bb, mh_ord(xn));
+          if (c1) atomicMin(bb + 1, mh_ord(yn));
+          if (c2) atomicMax(bb + 2, mh_ord(xn));
+          if (c3) atomicMax(bb + 3, mh_ord(yn));
+          if (c4) atomicMax(p.P.lowkey + b, ((unsigned long long)mh_ordu(o[1] + 0.0f) << 32) | (unsigned)~(unsigned)v);
+          if (mv) p.P.moved[b] = 1;
+        }
       }
     }
   }
@@ -536,7 +627,17 @@ extern "C" size_t mh_lbs_workspace_bytes(int B) {
 
 static int lbs_forward_impl(const mh_model* m, int B, int NB, const float* betas, const float* poses, const float* rotmats,
                             const float* xscale, const float* transl, float* verts, float* vposed, float* posed_joints,
-                            void* ws, void* stream);
+                            void* ws, void* stream, const mh_fwd_proj* proj = nullptr);
+
+extern "C" int mh_lbs_forward_proj(const mh_model* m, int B, int NB, const float* betas, const float* poses,
+                                   const float* xscale, const float* transl, float* verts, float* vposed,
+                                   const mh_fwd_proj* proj, void* ws, void* stream) {
+  MH_CHECK(poses && proj, "null argument");
+  MH_CHECK(proj->ndc && proj->rowb && proj->bbox && proj->bbox_prev && proj->lowkey && proj->lowkey_prev && proj->moved,
+           "mh_fwd_proj: null target (fill it with mh_raster_forward_targets)");
+  MH_CHECK(lbs_mode() != 0, "mh_lbs_forward_proj: the fused epilogue exists for the split-16-bit kernels only (mh_lbs_set_mode(1))");
+  return lbs_forward_impl(m, B, NB, betas, poses, nullptr, xscale, transl, verts, vposed, nullptr, ws, stream, proj);
+}
 
 extern "C" int mh_lbs_forward(const mh_model* m, int B, int NB, const float* betas, const float* poses,
                               const float* xscale, const float* transl, float* verts, float* vposed,
@@ -561,7 +662,7 @@ extern "C" int mh_lbs_forward_ex(const mh_model* m, int B, int NB, const float* 
 
 static int lbs_forward_impl(const mh_model* m, int B, int NB, const float* betas, const float* poses, const float* rotmats,
                             const float* xscale, const float* transl, float* verts, float* vposed, float* posed_joints,
-                            void* ws, void* stream) {
+                            void* ws, void* stream, const mh_fwd_proj* proj) {
   MH_CHECK(m && betas && verts && ws, "null argument");
   MH_CHECK(B > 0 && NB > 0, "B and NB must be positive");
   hipStream_t st = (hipStream_t)stream;
@@ -575,6 +676,9 @@ static int lbs_forward_impl(const mh_model* m, int B, int NB, const float* betas
   pp.tree = m->tree;
   const bool split16 = lbs_mode() != 0;
   pp.F16 = split16 ? w.F16 : nullptr;
+  pp.bbox = proj ? proj->bbox : nullptr; pp.bbox_prev = proj ? proj->bbox_prev : nullptr;
+  pp.lowkey = proj ? proj->lowkey : nullptr; pp.lowkey_prev = proj ? proj->lowkey_prev : nullptr;
+  pp.moved = proj ? proj->moved : nullptr;
   hipLaunchKernelGGL(k_pose_fwd, dim3(G * 4), dim3(256), 0, st, pp);
   MH_LAUNCH_CHECK();
   if (split16) {
@@ -587,10 +691,13 @@ static int lbs_forward_impl(const mh_model* m, int B, int NB, const float* betas
     MH_CHECK((size_t)32 * m->V * 12 < ((size_t)1 << 32), "model too large for 32-bit lane offsets");
     const size_t lds = FWD16_LDS_BYTES;
     const bool full = (B % 32) == 0, nw4 = m->nw <= 4;
-    auto kern = full ? (nw4 ? k_skin_fwd16<true, true> : k_skin_fwd16<true, false>)
-                     : (nw4 ? k_skin_fwd16<false, true> : k_skin_fwd16<false, false>);
-    static unsigned char attr16[4][MH_MAX_DEVICES];
-    const int ki = (full ? 2 : 0) + (nw4 ? 1 : 0);
+    auto kern = proj ? (full ? (nw4 ? k_skin_fwd16<true, true, true> : k_skin_fwd16<true, false, true>)
+                             : (nw4 ? k_skin_fwd16<false, true, true> : k_skin_fwd16<false, false, true>))
+                     : (full ? (nw4 ? k_skin_fwd16<true, true, false> : k_skin_fwd16<true, false, false>)
+                             : (nw4 ? k_skin_fwd16<false, true, false> : k_skin_fwd16<false, false, false>));
+    static unsigned char attr16[8][MH_MAX_DEVICES];
+    const int ki = (proj ? 4 : 0) + (full ? 2 : 0) + (nw4 ? 1 : 0);
+    sp.P = proj ? *proj : mh_fwd_proj{};
     if (mh_first_on_device(attr16[ki]))
       MH_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     mh_prof_mark(MH_PROF_SKIN_FWD, 0, st);

@@ -99,7 +99,18 @@ struct RasterP {
   unsigned long long* sort_count;  // [2] launches x bodies seen, bodies rebuilt (cumulative)
   unsigned long long* pairs;       // [2 + 2 x R_STRIP_GRID]: launches, -, then per workgroup: candidate (face, pixel-centre) pairs,
                                    // pairs evaluated after the depth cull (cumulative); NULL unless mh_profile_enable(1)
+  // what mh_lbs_forward_proj leaves here (include/mhmocap_hip.h, mh_fwd_proj): with projected != 0 the preparation reads
+  // these instead of passing over the vertices
+  int projected;
+  int* fbbox;                // [B][4] order-preserving ints of the NDC extremes (min x, min y, max x, max y); INT_MAX / INT_MIN = unset
+  int* fbbox_prev;           // [B][4]
+  unsigned long long* flowkey;       // [B]
+  unsigned long long* flowkey_prev;  // [B]
+  int* fmoved;               // [B]
 };
+// order-preserving int of a float (and back): a < b <=> r_ord(a) < r_ord(b)
+__device__ __forceinline__ int r_ord(float x) { const int i = __float_as_int(x); return i ^ ((i >> 31) & 0x7fffffff); }
+__device__ __forceinline__ float r_unord(int o) { return __int_as_float(o ^ ((o >> 31) & 0x7fffffff)); }
 #define RS_TAG(b, m) (0x5bd1e995c0ffee00ull ^ ((unsigned long long)(b) * 0x9E3779B97F4A7C15ull) ^ (unsigned long long)(m))
 
 // NDC coordinate of a pixel centre (PixToNonSquareNdc of the CPU rasteriser): every operation rounded on its own.  The
@@ -690,7 +701,6 @@ __global__ __launch_bounds__(RPREP) void k_raster_prepare(RasterP p) {
   __shared__ float sbb[RPREP / 64][4];
   __shared__ int s_win[4];
   const int b = blockIdx.x, tid = threadIdx.x;
-  const float* vb = p.verts + (size_t)b * p.V * 3;
   // extremes in NDC; the (monotonically decreasing) NDC -> pixel map is applied once to the four results
   float mnx = 1e30f, mny = 1e30f, mxx = -1e30f, mxy = -1e30f;
   float ra, rk;
@@ -699,10 +709,23 @@ __global__ __launch_bounds__(RPREP) void k_raster_prepare(RasterP p) {
   const bool tagged = p.margin > 0 && p.sort_tag[b] == RS_TAG(b, p.margin);
   bool moved = !tagged;
   const float thr = (float)p.margin - 0.02f;
+  float* nbo = p.ndc + (size_t)b * p.V * 3;
+  // projected: mh_lbs_forward_proj has written the NDC vertices, the motion flag and -- unless nobody reported one of the
+  // four extremes -- the box: nothing to read per vertex.  An incomplete box is scanned from the projected vertices and
+  // written back, so that the next forward has a complete previous box to filter with.
+  bool scan = true, have_box = false;
+  int4 fb = {0, 0, 0, 0};
+  if (p.projected) {
+    fb = *(const int4*)(p.fbbox + (size_t)b * 4);
+    have_box = fb.x != 0x7fffffff && fb.y != 0x7fffffff && fb.z != (int)0x80000000 && fb.w != (int)0x80000000;
+    scan = !have_box;
+    moved = moved || p.fmoved[b] != 0;
+  }
+  if (scan) {
+  const float* vb = (p.projected ? p.ndc : p.verts) + (size_t)b * p.V * 3;
   // RPV vertices per thread and trip with all their loads in flight together: one load -> wait -> divide -> store per
   // iteration was a chain of 2 x 14 memory latencies per thread (the loop bound is a kernel argument, the compiler does
   // not batch the loads by itself)
-  float* nbo = p.ndc + (size_t)b * p.V * 3;
   for (int v0 = tid; v0 < p.V; v0 += RPV * RPREP) {
     float X[RPV], Y[RPV], Z[RPV], rb[RPV];
 #pragma unroll
@@ -710,7 +733,7 @@ __global__ __launch_bounds__(RPREP) void k_raster_prepare(RasterP p) {
       const unsigned o = __umul24((unsigned)min(v0 + u * RPREP, p.V - 1), 3u);
       X[u] = vb[o]; Y[u] = vb[o + 1u]; Z[u] = vb[o + 2u];
     }
-    if (tagged) {
+    if (tagged && !p.projected) {
 #pragma unroll
       for (int u = 0; u < RPV; ++u) rb[u] = rowb[min(v0 + u * RPREP, p.V - 1)];
     }
@@ -718,10 +741,13 @@ __global__ __launch_bounds__(RPREP) void k_raster_prepare(RasterP p) {
     for (int u = 0; u < RPV; ++u) {
       const int v = v0 + u * RPREP;
       if (v < p.V) {
-        const float xn = p.s * (-X[u]) / Z[u] + p.w1, yn = p.s * (-Y[u]) / Z[u] + p.h1;
-        float* o = nbo + __umul24((unsigned)v, 3u);
-        o[0] = xn; o[1] = yn; o[2] = Z[u];
-        if (tagged) moved = moved || !(fabsf(fmaf(-yn, rk, ra) - rb[u]) < thr);      // NaN-safe: anything odd rebuilds
+        float xn = X[u], yn = Y[u];
+        if (!p.projected) {
+          xn = p.s * (-X[u]) / Z[u] + p.w1; yn = p.s * (-Y[u]) / Z[u] + p.h1;
+          float* o = nbo + __umul24((unsigned)v, 3u);
+          o[0] = xn; o[1] = yn; o[2] = Z[u];
+          if (tagged) moved = moved || !(fabsf(fmaf(-yn, rk, ra) - rb[u]) < thr);      // NaN-safe: anything odd rebuilds
+        }
         if (Z[u] > R_KEPS) {
           mnx = fminf(mnx, xn); mxx = fmaxf(mxx, xn);
           mny = fminf(mny, yn); mxy = fmaxf(mxy, yn);
@@ -734,15 +760,24 @@ __global__ __launch_bounds__(RPREP) void k_raster_prepare(RasterP p) {
     mnx = fminf(mnx, __shfl_xor(mnx, o, 64)); mny = fminf(mny, __shfl_xor(mny, o, 64));
     mxx = fmaxf(mxx, __shfl_xor(mxx, o, 64)); mxy = fmaxf(mxy, __shfl_xor(mxy, o, 64));
   }
+  }   // scan
   const int any_moved = __syncthreads_or(moved ? 1 : 0);
-  if ((tid & 63) == 0) {
+  if (scan && (tid & 63) == 0) {
     sbb[tid >> 6][0] = mnx; sbb[tid >> 6][1] = mny; sbb[tid >> 6][2] = mxx; sbb[tid >> 6][3] = mxy;
   }
   __syncthreads();
   if (tid == 0) {
-    for (int w = 1; w < RPREP / 64; ++w) {
-      mnx = fminf(mnx, sbb[w][0]); mny = fminf(mny, sbb[w][1]);
-      mxx = fmaxf(mxx, sbb[w][2]); mxy = fmaxf(mxy, sbb[w][3]);
+    if (scan) {
+      for (int w = 1; w < RPREP / 64; ++w) {
+        mnx = fminf(mnx, sbb[w][0]); mny = fminf(mny, sbb[w][1]);
+        mxx = fmaxf(mxx, sbb[w][2]); mxy = fmaxf(mxy, sbb[w][3]);
+      }
+      if (p.projected && mnx <= mxx) {
+        int* o = p.fbbox + (size_t)b * 4;
+        o[0] = r_ord(mnx); o[1] = r_ord(mny); o[2] = r_ord(mxx); o[3] = r_ord(mxy);
+      }
+    } else {
+      mnx = r_unord(fb.x); mny = r_unord(fb.y); mxx = r_unord(fb.z); mxy = r_unord(fb.w);
     }
     if (mnx <= mxx) {       // at least one vertex in front of the camera
       const float px0 = r_ndc_to_pix(mxx, p.W, p.H), px1 = r_ndc_to_pix(mnx, p.W, p.H);
@@ -1771,6 +1806,12 @@ static size_t r_carve(RasterP& p, void* ws) {
   p.sort_tag = (unsigned long long*)c; c += r_align(B * 8);
   p.sil_corr = (float*)c; c += r_align(B * 4);
   p.ctl_end = c;
+  p.fbbox = (int*)c; c += r_align(B * 4 * 4);
+  p.fbbox_prev = (int*)c; c += r_align(B * 4 * 4);
+  p.flowkey = (unsigned long long*)c; c += r_align(B * 8);
+  p.flowkey_prev = (unsigned long long*)c; c += r_align(B * 8);
+  p.fmoved = (int*)c; c += r_align(B * 4);
+  p.projected = 0;
   p.gkeys = (unsigned long long*)c; c += r_align(B * (size_t)H * W * 5 * 8);
   return (size_t)(c - (char*)ws);
 }
@@ -1853,22 +1894,9 @@ extern "C" int mh_raster_sort_counters(int T, int N, int V, int F, int H, int W,
   return MH_OK;
 }
 
-static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const float* cam_K_host, const float* verts,
-                             const int32_t* faces, const uint32_t* bits, const uint32_t* ebits, const float* depths,
-                             const float* zmin_lin, const float* zmax_lin, const float* pose2d_valid,
-                             const uint32_t* front, const float* sil_apply, const float* sil_D, const float* sil_S,
-                             float coef_depth, float coef_sil, float eps, float* gverts, float* gzmin, float* gzmax,
-                             float* depth_body, float* sil_body, void* ws, float* zbuf_out, float* alpha_out,
-                             int phases, float* log_depth, float* log_sil, void* stream) {
-  MH_CHECK(cam_K_host && verts && faces && bits && ebits && depths && zmin_lin && zmax_lin && pose2d_valid && front &&
-               sil_apply && sil_D && sil_S && depth_body && sil_body && ws,
-           "null argument");
-  MH_CHECK(T > 0 && N > 0 && N <= 32 && V > 0 && F > 0 && H > 0 && W > 0, "empty input");
-  MH_CHECK(H <= 4095 && W <= 65535 && F < (1 << 20), "sorted face entries hold 12-bit rows and 20-bit face ids");
-  MH_CHECK(V < (1 << 22), "vertex offsets of the gathers are 24-bit products (3 * vertex index)");
-  RasterP p;
-  p.B = T * N; p.N = N; p.V = V; p.F = F; p.H = H; p.W = W;
-  // transforms.py:222-255 with image_size = (W, H)
+// NDC calibration of transforms.py:222-255 with image_size = (W, H) and PyTorch3D's R = diag(-1,-1,1)
+static void r_calibration(RasterP& p, const float* cam_K_host) {
+  const int W = p.W, H = p.H;
   const float fx = cam_K_host[0], fy = cam_K_host[4], cx = cam_K_host[2], cy = cam_K_host[5];
   if (W > H) {
     p.s = 2.f * fy / H;
@@ -1885,6 +1913,24 @@ static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const flo
     p.w1 = (W - 2.f * cx) / W;
     p.h1 = (H - 2.f * cy) / H;
   }
+}
+
+static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const float* cam_K_host, const float* verts,
+                             const int32_t* faces, const uint32_t* bits, const uint32_t* ebits, const float* depths,
+                             const float* zmin_lin, const float* zmax_lin, const float* pose2d_valid,
+                             const uint32_t* front, const float* sil_apply, const float* sil_D, const float* sil_S,
+                             float coef_depth, float coef_sil, float eps, float* gverts, float* gzmin, float* gzmax,
+                             float* depth_body, float* sil_body, void* ws, float* zbuf_out, float* alpha_out,
+                             int phases, float* log_depth, float* log_sil, void* stream, int projected = 0) {
+  MH_CHECK(cam_K_host && (verts || projected) && faces && bits && ebits && depths && zmin_lin && zmax_lin && pose2d_valid && front &&
+               sil_apply && sil_D && sil_S && depth_body && sil_body && ws,
+           "null argument");
+  MH_CHECK(T > 0 && N > 0 && N <= 32 && V > 0 && F > 0 && H > 0 && W > 0, "empty input");
+  MH_CHECK(H <= 4095 && W <= 65535 && F < (1 << 20), "sorted face entries hold 12-bit rows and 20-bit face ids");
+  MH_CHECK(V < (1 << 22), "vertex offsets of the gathers are 24-bit products (3 * vertex index)");
+  RasterP p;
+  p.B = T * N; p.N = N; p.V = V; p.F = F; p.H = H; p.W = W;
+  r_calibration(p, cam_K_host);
   p.verts = verts; p.faces = faces; p.bits = bits; p.ebits = ebits; p.depths = depths;
   p.zmin_lin = zmin_lin; p.zmax_lin = zmax_lin; p.p2d_valid = pose2d_valid; p.front = front;
   p.sil_apply = sil_apply; p.sil_D = sil_D; p.sil_S = sil_S;
@@ -1892,6 +1938,7 @@ static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const flo
   p.gverts = gverts; p.depth_body = depth_body; p.sil_body = sil_body;
   p.zbuf_out = zbuf_out; p.alpha_out = alpha_out;
   r_carve(p, ws);
+  p.projected = projected ? 1 : 0;
   if (mh_prof_level() < 2) p.pairs = nullptr;
   hipStream_t st = (hipStream_t)stream;
   if (phases & 1) {
@@ -1989,4 +2036,44 @@ extern "C" int mh_raster_terms_phase_log(int T, int N, int V, int F, int H, int 
   return raster_terms_impl(T, N, V, F, H, W, cam_K_host, verts, faces, bits, ebits, depths, zmin_lin, zmax_lin, pose2d_valid, front,
                            sil_apply, sil_D, sil_S, coef_depth, coef_sil, eps, gverts, gzmin, gzmax, depth_body, sil_body, ws, zbuf_out,
                            alpha_out, phases, log_depth, log_sil, stream);
+}
+
+extern "C" int mh_raster_terms_projected(int T, int N, int V, int F, int H, int W, const float* cam_K_host, const float* verts,
+                                         const int32_t* faces, const uint32_t* bits, const uint32_t* ebits, const float* depths,
+                                         const float* zmin_lin, const float* zmax_lin, const float* pose2d_valid,
+                                         const uint32_t* front, const float* sil_apply, const float* sil_D, const float* sil_S,
+                                         float coef_depth, float coef_sil, float eps, float* gverts, float* gzmin, float* gzmax,
+                                         float* depth_body, float* sil_body, void* ws, float* zbuf_out, float* alpha_out,
+                                         int phases, float* log_depth, float* log_sil, int projected, void* stream) {
+  MH_CHECK(phases >= 1 && phases <= 3, "phases: 1 = selection + values, 2 = gradients, 3 = both");
+  return raster_terms_impl(T, N, V, F, H, W, cam_K_host, verts, faces, bits, ebits, depths, zmin_lin, zmax_lin, pose2d_valid, front,
+                           sil_apply, sil_D, sil_S, coef_depth, coef_sil, eps, gverts, gzmin, gzmax, depth_body, sil_body, ws, zbuf_out,
+                           alpha_out, phases, log_depth, log_sil, stream, projected);
+}
+
+// where mh_lbs_forward_proj writes for this workspace, and the constants of the projection / motion test (the host-side
+// twins of r_row_affine and of the threshold in k_raster_prepare: one definition each)
+extern "C" int mh_raster_forward_targets(int T, int N, int V, int F, int H, int W, const float* cam_K_host, void* ws,
+                                         mh_fwd_proj* out) {
+  MH_CHECK(cam_K_host && ws && out, "null argument");
+  MH_CHECK(T > 0 && N > 0 && V > 0 && F > 0 && H > 0 && W > 0, "empty input");
+  RasterP p;
+  p.B = T * N; p.N = N; p.V = V; p.F = F; p.H = H; p.W = W;
+  r_calibration(p, cam_K_host);
+  r_carve(p, ws);
+  out->s = p.s; out->w1 = p.w1; out->h1 = p.h1;
+  float range = 2.0f;                                   // r_row_affine
+  if (H > W) range = ((float)H * range) / (float)W;
+  out->rk = (float)H / range;
+  out->ra = (float)H - 0.5f - 0.5f * (float)H;
+  out->thr = (float)p.margin - 0.02f;
+  // half a pixel: the optimiser moves a body by a small fraction of a pixel per cycle; a faster body is scanned
+  out->slack_ndc = 0.5f * 2.0f / (float)(H < W ? H : W);
+  out->slack_y = 0.005f;
+  if (const char* e = getenv("MHHIP_PROJ_SLACK_PX")) out->slack_ndc = (float)atof(e) * 2.0f / (float)(H < W ? H : W);
+  out->ndc = p.ndc; out->rowb = p.rowb;
+  out->bbox = p.fbbox; out->bbox_prev = p.fbbox_prev;
+  out->lowkey = p.flowkey; out->lowkey_prev = p.flowkey_prev;
+  out->moved = p.fmoved;
+  return MH_OK;
 }

@@ -57,6 +57,51 @@ extern "C" int mh_lowest_vertex(const float* verts, int B, int V, int32_t* low_i
   return MH_OK;
 }
 
+// low_idx / low_xyz from the keys the LBS forward's projection epilogue left (mh_lbs_forward_proj: order-preserving bits
+// of y << 32 | ~vertex, reported by the vertices above the previous launch's lowest minus a slack; 0 = nobody reported).
+// One wave per body; a body without a key is scanned like k_lowest_vertex does and its key written back, so that the next
+// forward has an extreme to filter with.
+__global__ __launch_bounds__(64) void k_lowest_resolve(const float* verts, int V, unsigned long long* lowkey, int* low_idx,
+                                                       float* low_xyz) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float* vb = verts + (size_t)b * V * 3;
+  const unsigned long long key = lowkey[b];
+  int bi;
+  if (key != 0ull) {
+    bi = (int)~(unsigned)(key & 0xffffffffull);
+  } else {
+    float best = -INFINITY;
+    bi = 0x7fffffff;
+    for (int v = lane; v < V; v += 64) {
+      const float y = vb[(size_t)v * 3 + 1];
+      if (y > best) { best = y; bi = v; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float oy = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (oy > best || (oy == best && oi < bi)) { best = oy; bi = oi; }
+    }
+    if (bi == 0x7fffffff) bi = 0;                  // nothing compares (NaN everywhere): any vertex
+    if (lane == 0 && best > -INFINITY) {
+      const unsigned u = __float_as_uint(best + 0.0f);
+      lowkey[b] = ((unsigned long long)(u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u)) << 32) | (unsigned)~(unsigned)bi;
+    }
+  }
+  if (lane == 0) low_idx[b] = bi;
+  if (lane < 3) low_xyz[(size_t)b * 3 + lane] = vb[(size_t)bi * 3 + lane];
+}
+
+extern "C" int mh_lowest_resolve(const float* verts, int B, int V, unsigned long long* lowkey, int32_t* low_idx,
+                                 float* low_xyz, void* stream) {
+  MH_CHECK(verts && lowkey && low_idx && low_xyz, "null argument");
+  MH_CHECK(B > 0 && V > 0, "empty input");
+  hipLaunchKernelGGL(k_lowest_resolve, dim3(B), dim3(64), 0, (hipStream_t)stream, verts, V, lowkey, low_idx,
+                     low_xyz);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // k nearest scene points of one query per wave.  A wave keeps the best K squared distances seen
 // so far (K <= 32) in LDS together with the y of those points; a chunk of 64 points only costs

@@ -27,6 +27,15 @@ class ModelHost(ctypes.Structure):
                 ('reg_mupots', c_float_p), ('reg_extra9', c_float_p)]
 
 
+class FwdProj(ctypes.Structure):
+    """mh_fwd_proj of include/mhmocap_hip.h: where the LBS forward's projection epilogue writes for one raster workspace"""
+    _fields_ = [('s', ctypes.c_float), ('w1', ctypes.c_float), ('h1', ctypes.c_float),
+                ('ra', ctypes.c_float), ('rk', ctypes.c_float), ('thr', ctypes.c_float),
+                ('slack_ndc', ctypes.c_float), ('slack_y', ctypes.c_float),
+                ('ndc', vp), ('rowb', vp), ('bbox', vp), ('bbox_prev', vp), ('lowkey', vp), ('lowkey_prev', vp),
+                ('moved', vp)]
+
+
 _lib = None
 
 
@@ -120,6 +129,10 @@ def lib():
         L.mh_raster_pair_counters.argtypes = [ctypes.c_int] * 6 + [vp, ctypes.POINTER(ctypes.c_ulonglong), vp]
         L.mh_raster_sort_counters.argtypes = [ctypes.c_int] * 6 + [vp, ctypes.POINTER(ctypes.c_ulonglong), vp]
         L.mh_raster_terms_phase_log.argtypes = [ctypes.c_int] * 6 + [c_float_p] + [vp] * 12 + [ctypes.c_float] * 3 + [vp] * 8 + [ctypes.c_int, vp, vp, vp]
+        L.mh_raster_terms_projected.argtypes = [ctypes.c_int] * 6 + [c_float_p] + [vp] * 12 + [ctypes.c_float] * 3 + [vp] * 8 + [ctypes.c_int, vp, vp, ctypes.c_int, vp]
+        L.mh_raster_forward_targets.argtypes = [ctypes.c_int] * 6 + [c_float_p, vp, ctypes.POINTER(FwdProj)]
+        L.mh_lbs_forward_proj.argtypes = [vp, ctypes.c_int, ctypes.c_int] + [vp] * 6 + [ctypes.POINTER(FwdProj), vp, vp]
+        L.mh_lowest_resolve.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
         L.mh_raster_workspace_init.argtypes = [ctypes.c_int] * 6 + [vp, vp]
         L.mh_raster_workspace_offsets.argtypes = [ctypes.c_int] * 6 + [ctypes.POINTER(ctypes.c_size_t)]
         L.mh_avg_depth_loss.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_float, vp, vp, vp]

@@ -25,19 +25,30 @@ class RasterTerms(object):
         """mh_raster_workspace_init: once per workspace (again after its bytes were overwritten)"""
         check(_lib.lib().mh_raster_workspace_init(*self.dims, ptr(self.ws), _lib.stream_ptr(self.dev)))
 
+    def forward_targets(self):
+        """mh_fwd_proj of this workspace: what ``SequenceEngine.forward`` hands to mh_lbs_forward_proj so that the skinning
+        epilogue projects the vertices for this rasteriser (the motion threshold follows the current sort margin)."""
+        import ctypes
+        t = _lib.FwdProj()
+        check(_lib.lib().mh_raster_forward_targets(*self.dims, self.K.ctypes.data_as(_lib.c_float_p), ptr(self.ws), ctypes.byref(t)))
+        return t
+
     def __call__(self, e, gverts, log, with_grads=True, zbuf_out=None, alpha_out=None, phases=3):
         """phases: 1 = selection + values (does not touch gverts), 2 = gradients + log entries, 3 = both"""
         L = _lib.lib()
         st = _lib.stream_ptr(e.dev)
         g = e.grads
-        check(L.mh_raster_terms_phase_log(e.T, e.N, e.V, self.faces.shape[0], e.H, e.W, self.K.ctypes.data_as(_lib.c_float_p),
+        # the engine's last forward has projected the vertices into this workspace: no pass over them here
+        projected = 1 if getattr(e, '_projected_into', None) is self else 0
+        check(L.mh_raster_terms_projected(e.T, e.N, e.V, self.faces.shape[0], e.H, e.W, self.K.ctypes.data_as(_lib.c_float_p),
                                       ptr(e.verts), ptr(self.faces), ptr(e.bits), ptr(e.ebits), ptr(e.depths),
                                       ptr(e.leaf('zmin_lin')), ptr(e.leaf('zmax_lin')), ptr(e.p2d_valid), ptr(e.front),
                                       ptr(e.sil_apply), ptr(e.sil_D), ptr(e.sil_S), float(e.c['depth']),
                                       float(e.c['silhouette']), float(e.eps), ptr(gverts) if with_grads else None,
                                       ptr(e.leaf('zmin_lin', g)) if with_grads else None,
                                       ptr(e.leaf('zmax_lin', g)) if with_grads else None, ptr(e.depth_body), ptr(e.sil_body),
-                                      ptr(self.ws), ptr(zbuf_out), ptr(alpha_out), int(phases), ptr(log[1:2]), ptr(log[2:3]), st))
+                                      ptr(self.ws), ptr(zbuf_out), ptr(alpha_out), int(phases), ptr(log[1:2]), ptr(log[2:3]),
+                                      projected, st))
 
 
     def sort_counters(self, e):

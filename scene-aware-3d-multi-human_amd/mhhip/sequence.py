@@ -412,12 +412,24 @@ class SequenceEngine(object):
         return self.scene_pts
 
     # -- forward of all local frames ---------------------------------------------------------------
-    def forward(self, regress=True):
+    def forward(self, regress=True, raster=None):
+        """LBS forward of all local frames.  raster (a ``RasterTerms`` of this engine): the "LBS + projection" form --
+        the skinning epilogue also writes the NDC vertices, screen boxes, motion flags and lowest vertices that
+        ``raster`` / the contact term would otherwise each take a pass over the vertices for (mh_lbs_forward_proj)."""
         m = self.m
         ev = self._tic('lbs_forward')
-        check(_lib.lib().mh_lbs_forward(m.handle, self.B, self.N, ptr(self.leaf('betas')), ptr(self.leaf('poses_smpl')),
-                                        ptr(self.leaf('xscale')), ptr(self.leaf('poses_T')), ptr(self.verts),
-                                        ptr(self.vposed), None, ptr(self.ws), _lib.stream_ptr(self.dev)))
+        self._projected_into = None
+        if raster is not None and os.environ.get('MHHIP_NO_PROJ') != '1' and _lib.lib().mh_lbs_get_mode() != 0:
+            t = raster.forward_targets()
+            check(_lib.lib().mh_lbs_forward_proj(m.handle, self.B, self.N, ptr(self.leaf('betas')), ptr(self.leaf('poses_smpl')),
+                                                 ptr(self.leaf('xscale')), ptr(self.leaf('poses_T')), ptr(self.verts),
+                                                 ptr(self.vposed), ctypes.byref(t), ptr(self.ws), _lib.stream_ptr(self.dev)))
+            self._projected_into = raster
+            self._lowkey = t.lowkey
+        else:
+            check(_lib.lib().mh_lbs_forward(m.handle, self.B, self.N, ptr(self.leaf('betas')), ptr(self.leaf('poses_smpl')),
+                                            ptr(self.leaf('xscale')), ptr(self.leaf('poses_T')), ptr(self.verts),
+                                            ptr(self.vposed), None, ptr(self.ws), _lib.stream_ptr(self.dev)))
         self._toc(ev)
         if regress:
             self._regress(_lib.stream_ptr(self.dev))
@@ -436,10 +448,10 @@ class SequenceEngine(object):
         # the same launch order as the captured form (cycle_graphed): the sums of a cycle are then added in the same order
         # either way, and eager and replayed fits stay bit-identical (deterministic mode) until something else differs
         nj = raster is not None and use_images and self.has_images and self.halo is None
-        self.cycle_begin(join=not nj)
+        self.cycle_begin(join=not nj, raster=raster if (use_images and self.has_images) else None)
         self.cycle_finish(row, use_images, raster)
 
-    def cycle_begin(self, join=True):
+    def cycle_begin(self, join=True, raster=None):
         """zero the gradient buffer and run the LBS forward of all local frames (the frame-sharded
         driver exchanges boundary vertices between this and ``cycle_finish``).  join=False: the leaf-only terms of the side
         branch are NOT waited for here -- the caller's next join covers them (``cycle_graphed``: the one in front of the
@@ -462,7 +474,7 @@ class SequenceEngine(object):
         # the chain's kernels are captured BEFORE the side branch's: a replayed graph keeps the branch whose nodes come first
         # on the queue it was launched on and moves the other one to a second queue, and every hop between queues costs
         # 10-14 us of idle time (rocprofv3 trace: the forward used to start 19 us into the cycle, now 9)
-        self.forward(regress=False)      # (the per-body pose-prior values are summed with the other log entries, _finish_a)
+        self.forward(regress=False, raster=raster)   # (the per-body pose-prior values are summed with the other log entries, _finish_a)
         def leaf_terms():
             if self.has_images:
                 check(L.mh_sil_mask_stats(ptr(self.bits), T, N, self.H, self.W, ptr(pT), ptr(self.p2d_valid),
@@ -608,7 +620,10 @@ class SequenceEngine(object):
         T, N, B = self.T, self.N, self.B
         gpT = self.leaf('poses_T', self.grads)
         gv, log = self._gv_cur, self.tmp_log
-        check(L.mh_lowest_vertex(ptr(self.verts), B, self.V, ptr(self.low_idx), ptr(self.low_xyz), st))
+        if getattr(self, '_projected_into', None) is not None:      # the forward's epilogue has reported the lowest vertices
+            check(L.mh_lowest_resolve(ptr(self.verts), B, self.V, self._lowkey, ptr(self.low_idx), ptr(self.low_xyz), st))
+        else:
+            check(L.mh_lowest_vertex(ptr(self.verts), B, self.V, ptr(self.low_idx), ptr(self.low_xyz), st))
         check(L.mh_contact_knn_grid(ptr(self.scene_grid), self.scene_M, ptr(self.low_xyz), B, 32, ptr(self.dy), st))
         if getattr(self, 'batch_frames', None) is not None:
             check(L.mh_contact_foot_terms_idx(T, N, self.V, self.batch, self.nbatches, ptr(self.batch_frames), ptr(self.verts),
@@ -724,7 +739,7 @@ class SequenceEngine(object):
             # boundary of ~30 us and the chain on the critical path.)
             def body_org():
                 nj = raster is not None and self.has_images and self.halo is None
-                self.cycle_begin(join=not nj)
+                self.cycle_begin(join=not nj, raster=raster if self.has_images else None)
                 self.cycle_finish(None, raster=raster, scene_ready=True)
             self.replay(('full+scene',) + key, body_org)
             if scene_update:
@@ -734,7 +749,7 @@ class SequenceEngine(object):
                 # nothing of the rasteriser's selection half reads what the leaf-only terms of the side branch write: with
                 # gradients asked for, the one join in front of the gradient half covers them
                 nj = raster is not None and self.has_images and self.halo is None
-                self.cycle_begin(join=not nj)
+                self.cycle_begin(join=not nj, raster=raster if self.has_images else None)
                 self.cycle_finish(None, raster=raster)
             self.replay(('full',) + key, body)
             if scene_update:

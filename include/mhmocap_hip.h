@@ -157,6 +157,24 @@ int mh_joints_regress(const mh_model* m, int which, int B, const float* verts /*
                       const float* corr /*(B,3) or NULL*/, int root_relative_to,
                       float* joints /*(B,J,3)*/, void* stream);
 
+/* ---- the 2D key-point term without a pass over the vertices (round 4; csrc/mh_keypoints.hip) -----------------------------
+ * joints_alphapose (smpl.py:374-376), scaled and translated (optimizer.py:701-703), projected (transforms.py:57-95) and
+ * compared with the detections (optimizer.py:364-368, 404, 419-420) -- evaluated from what mh_lbs_forward left in `ws`
+ * (pose features, joint transforms): the regressed key-points are linear in those, the constants per (key-point, bone)
+ * pair are built by mh_model_create.  kp (B,17,3), uv (B,17,2) or NULL, gkp (B,17,3) = dL/dkp or NULL, loss (B).
+ * ws2 != NULL: the term's adjoint (dL/d joint transforms, dL/d pose features, dL/d translation) goes into the extra
+ * chunk slot of the LBS backward's workspace; mh_lbs_backward_kp then runs the skinning adjoint without key-points and
+ * adds that slot.  kp_ws: mh_keypoint_workspace_bytes(m, B) bytes of scratch.                                    */
+size_t mh_keypoint_workspace_bytes(const mh_model* m, int B);
+int mh_keypoint_terms(const mh_model* m, int B, const float* transl /*(B,3) or NULL*/, const float* K_host,
+                      const float* Kd_host /*or NULL*/, const float* joint_w_host /*[17] or NULL*/,
+                      const float* pose2d /*(B,17,3)*/, float thr, float img_w, float img_h, float coef,
+                      float* kp, float* uv, float* gkp, float* loss, const void* ws, void* ws2 /*or NULL*/,
+                      void* kp_ws, void* stream);
+int mh_lbs_backward_kp(const mh_model* m, int B, int NB, const float* betas, const float* poses,
+                       const float* vposed, const float* gverts, float* gposes, float* gtransl,
+                       float* gbetas, float* gxscale, void* ws, void* ws2, void* stream);
+
 /* ---- LBS backward (hand-written adjoint of the above) ---------------------------------------
  * In : gverts (B,V,3) = dL/dverts, gjoints (B,17,3) = dL/d(alphapose joints of the translated,
  *      scaled body) or NULL, vposed from the forward, the same parameters, ws from the forward.

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -83,6 +84,20 @@ struct mh_regressor {
   float* rowsum;   // [J]
 };
 
+// the 2D key-point term from the pose features and joint transforms (mh_keypoints.hip): constants per (key-point, bone) pair
+struct mh_kp_tables {
+  int np;          // pairs (0: no key-point regressor)
+  int rows_pad;    // 3 np rounded up to 32
+  float* Qa;       // [rows_pad/32][112][64] rows of Q in MFMA A-operand order
+  float* Qr;       // [rows_pad][224]        the same, row-major
+  float* M0m;      // [np][4]  (M0 xyz, m)
+  int* pair_j;     // [np]
+  int* pair_k;     // [np]
+  int* jptr;       // [18] pairs by key-point
+  int* kptr;       // [25] pairs by bone ...
+  int* kpairs;     // [np] ... their indices
+};
+
 struct mh_model {
   int V, VP, F, nw;
   float* vt;       // [VP][3]   template, zero padded
@@ -108,7 +123,13 @@ struct mh_model {
   int* kpv_j;      // [nnz]
   float* kpv_w;    // [nnz]
   int* kpv_head;   // [VP][4] (first entry, entry count, first joint, first weight bits)
+  mh_kp_tables kp;
 };
+
+int mh_kp_build(mh_model* m, const mh_model_host* h);
+void mh_kp_free(mh_model* m);
+// the extra chunk slot of the LBS backward's partial sums that mh_keypoint_terms fills (mh_lbs.hip)
+int mh_lbs_backward_extra_slot(const mh_model* m, int B, void* ws2, float** pF, float** pA, float** pS);
 
 static inline int mh_groups(int B) { return (B + 31) / 32; }
 

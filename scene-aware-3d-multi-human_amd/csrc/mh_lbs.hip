@@ -505,10 +505,15 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, 2 * FWD16_WAVES / 4) void k_skin_
   // the stores would be waited for with vmcnt(0), i.e. together with every store in flight (one memory round trip per row)
   float rbv[16];
   if (PROJ) {
-    const unsigned lane_off4 = (unsigned)(4 * lh * p.V + v) * 4u;
+    // (rows of padding bodies read the group's last real row: the array ends with the last body)
+    const int last_row = FULL ? 31 : min(31, p.B - 1 - g * 32);
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      rbv[r] = *(const float*)(rbg + (size_t)(unsigned)(lane_off4 + (unsigned)((r & 3) + 8 * (r >> 2)) * ((unsigned)p.V * 4u)));
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const unsigned off4 = FULL ? (unsigned)(4 * lh * p.V + v) * 4u + (unsigned)((r & 3) + 8 * (r >> 2)) * ((unsigned)p.V * 4u)
+                                 : (unsigned)(min(row, last_row) * p.V + v) * 4u;
+      rbv[r] = *(const float*)(rbg + (size_t)off4);
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
@@ -1690,7 +1695,8 @@ static BwdWs carve_bwd(void* ws, int G, int CH) {
 }
 
 extern "C" size_t mh_lbs_backward_workspace_bytes(int B) {
-  const int G = mh_groups(B < 1 ? 1 : B), CH = std::max(bwd_chunks(2 * G), bwd16_chunks(G));
+  // (+ 1: the chunk slot mh_keypoint_terms fills)
+  const int G = mh_groups(B < 1 ? 1 : B), CH = std::max(bwd_chunks(2 * G), bwd16_chunks(G)) + 1;
   const size_t GB = (size_t)G * 32;
   return align256((size_t)CH * GB * MH_FS * 4) + align256((size_t)CH * GB * 288 * 4) + align256((size_t)CH * GB * 16) +
          align256(GB * MH_NUM_BETAS * 4) + align256(GB * 4);
@@ -1699,7 +1705,29 @@ extern "C" size_t mh_lbs_backward_workspace_bytes(int B) {
 static int lbs_backward_impl(const mh_model* m, int B, int NB, const float* betas, const float* poses, const float* rotmats,
                              const float* vposed, const float* gverts, const float* gjoints, const float* gposed,
                              float* gposes, float* grotmats, float* gtransl, float* gbetas, float* gxscale,
-                             void* ws, void* ws2, void* stream);
+                             void* ws, void* ws2, void* stream, int kp_chunk = 0);
+
+// The backward after mh_keypoint_terms: the key-point term's dL/dA, dL/dfeat and dL/dt are already in the extra chunk slot of
+// ws2 (k_pose_bwd adds it behind the vertex chunks); the skinning kernel runs without key-point adjoints.
+extern "C" int mh_lbs_backward_kp(const mh_model* m, int B, int NB, const float* betas, const float* poses, const float* vposed,
+                                  const float* gverts, float* gposes, float* gtransl, float* gbetas, float* gxscale,
+                                  void* ws, void* ws2, void* stream) {
+  MH_CHECK(poses && gposes, "null argument");
+  return lbs_backward_impl(m, B, NB, betas, poses, nullptr, vposed, gverts, nullptr, nullptr, gposes, nullptr, gtransl, gbetas,
+                           gxscale, ws, ws2, stream, 1);
+}
+
+int mh_lbs_backward_extra_slot(const mh_model* m, int B, void* ws2, float** pF, float** pA, float** pS) {
+  MH_CHECK(m && ws2 && B > 0, "null argument");
+  const bool split16 = lbs_mode() != 0;
+  const int G = mh_groups(B), CH = split16 ? bwd16_chunks(G) : bwd_chunks(2 * G);
+  BwdWs bw = carve_bwd(ws2, G, CH + 1);
+  const size_t GB = (size_t)G * 32;
+  *pF = bw.pF + (size_t)CH * GB * MH_FS;
+  *pA = bw.pA + (size_t)CH * GB * 288;
+  *pS = bw.pS + (size_t)CH * GB * 4;
+  return MH_OK;
+}
 
 extern "C" int mh_lbs_backward(const mh_model* m, int B, int NB, const float* betas, const float* poses,
                                const float* xscale, const float* transl, const float* vposed, const float* gverts,
@@ -1724,16 +1752,16 @@ extern "C" int mh_lbs_backward_ex(const mh_model* m, int B, int NB, const float*
 static int lbs_backward_impl(const mh_model* m, int B, int NB, const float* betas, const float* poses, const float* rotmats,
                              const float* vposed, const float* gverts, const float* gjoints, const float* gposed,
                              float* gposes, float* grotmats, float* gtransl, float* gbetas, float* gxscale,
-                             void* ws, void* ws2, void* stream) {
+                             void* ws, void* ws2, void* stream, int kp_chunk) {
   MH_CHECK(m && betas && vposed && ws && ws2, "null argument");
-  MH_CHECK(gverts || gjoints, "need gverts and/or gjoints");
+  MH_CHECK(gverts || gjoints || kp_chunk, "need gverts and/or gjoints");
   MH_CHECK(B > 0 && NB > 0, "B and NB must be positive");
   MH_CHECK(!gjoints || m->reg[MH_REG_ALPHAPOSE].J == MH_NKP, "gjoints needs the key-point regressor");
   hipStream_t st = (hipStream_t)stream;
   const bool split16 = lbs_mode() != 0;
   const int G = mh_groups(B), G16 = 2 * G, CH = split16 ? bwd16_chunks(G) : bwd_chunks(G16);
   FwdWs fw = carve_fwd(ws, G);
-  BwdWs bw = carve_bwd(ws2, G, CH);
+  BwdWs bw = carve_bwd(ws2, G, CH + 1);      // (+ 1: the chunk slot of mh_keypoint_terms, always laid out)
   if (split16) {
     Bwd16P sp;
     sp.B = B; sp.G = G; sp.V = m->V; sp.VP = m->VP; sp.nw = m->nw; sp.CH = CH;
@@ -1774,7 +1802,7 @@ static int lbs_backward_impl(const mh_model* m, int B, int NB, const float* beta
   mh_prof_mark(MH_PROF_SKIN_BWD, 1, st);
   }
   PoseBwdP pp;
-  pp.B = B; pp.NB = NB; pp.G = G; pp.CH = CH;
+  pp.B = B; pp.NB = NB; pp.G = G; pp.CH = CH + (kp_chunk ? 1 : 0);
   pp.betas = betas; pp.poses = poses; pp.gjoints = gjoints;
   pp.rotmats = rotmats; pp.gposed = gposed; pp.grotmats = grotmats;
   pp.kp_rowsum = m->reg[MH_REG_ALPHAPOSE].rowsum;

@@ -351,6 +351,7 @@ extern "C" int mh_model_create(mh_model** out, const mh_model_host* h) {
     if ((rc = upload(&m->kpv_j, js))) return rc;
     if ((rc = upload(&m->kpv_w, ws))) return rc;
   }
+  if ((rc = mh_kp_build(m, h))) return rc;
   *out = m;
   return MH_OK;
 }
@@ -360,6 +361,7 @@ extern "C" int mh_model_destroy(mh_model* m) {
   void* ptrs[] = {m->vt, m->D, m->Dt, m->D16, m->Dt16, m->W16, m->skidx, m->skw, m->Jt, m->JS, m->faces, m->kpv_ptr, m->kpv_j, m->kpv_w, m->kpv_head};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  mh_kp_free(m);
   for (int i = 0; i < 4; ++i) {
     void* q[] = {m->reg[i].ptr, m->reg[i].vidx, m->reg[i].w, m->reg[i].rowsum};
     for (void* p : q)

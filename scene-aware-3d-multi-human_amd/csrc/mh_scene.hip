@@ -66,10 +66,8 @@ __global__ __launch_bounds__(64) void k_lowest_resolve(const float* verts, int V
   const int b = blockIdx.x, lane = threadIdx.x;
   const float* vb = verts + (size_t)b * V * 3;
   const unsigned long long key = lowkey[b];
-  int bi;
-  if (key != 0ull) {
-    bi = (int)~(unsigned)(key & 0xffffffffull);
-  } else {
+  int bi = (int)~(unsigned)(key & 0xffffffffull);
+  if (key == 0ull || bi < 0 || bi >= V) {       // nobody reported (or not a key at all): scan
     float best = -INFINITY;
     bi = 0x7fffffff;
     for (int v = lane; v < V; v += 64) {

@@ -133,6 +133,10 @@ def lib():
         L.mh_raster_forward_targets.argtypes = [ctypes.c_int] * 6 + [c_float_p, vp, ctypes.POINTER(FwdProj)]
         L.mh_lbs_forward_proj.argtypes = [vp, ctypes.c_int, ctypes.c_int] + [vp] * 6 + [ctypes.POINTER(FwdProj), vp, vp]
         L.mh_lowest_resolve.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
+        L.mh_keypoint_workspace_bytes.restype = ctypes.c_size_t
+        L.mh_keypoint_workspace_bytes.argtypes = [vp, ctypes.c_int]
+        L.mh_keypoint_terms.argtypes = [vp, ctypes.c_int, vp, c_float_p, c_float_p, c_float_p, vp] + [ctypes.c_float] * 4 + [vp] * 8
+        L.mh_lbs_backward_kp.argtypes = [vp, ctypes.c_int, ctypes.c_int] + [vp] * 11
         L.mh_raster_workspace_init.argtypes = [ctypes.c_int] * 6 + [vp, vp]
         L.mh_raster_workspace_offsets.argtypes = [ctypes.c_int] * 6 + [ctypes.POINTER(ctypes.c_size_t)]
         L.mh_avg_depth_loss.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_float, vp, vp, vp]

@@ -85,6 +85,7 @@ class SequenceEngine(object):
         self.shared_lo = int(self.offs[4])          # betas | xscale: the all-reduced tail
         self.ws = model.workspace(B)
         self.ws2 = model.backward_workspace(B)
+        self.kp_ws = torch.empty(max(1, _lib.lib().mh_keypoint_workspace_bytes(model.handle, B)), dtype=torch.uint8, device=self.dev)
         self.fv_ws = torch.empty(_lib.lib().mh_filtered_verts_workspace_bytes(T, N * self.V * 3), dtype=torch.uint8, device=self.dev)
         self.verts = z(B, self.V, 3)
         self.vposed = z(B, self.V, 3)
@@ -539,8 +540,18 @@ class SequenceEngine(object):
         s2 = side.cuda_stream
 
         def regress_project():
-            self._regress(s2)
             jwp = None if self.joint_w is None else self.joint_w.ctypes.data_as(_lib.c_float_p)
+            if self.kp_fused and os.environ.get('MHHIP_NO_KPALG') != '1':
+                # the AlphaPose key-points from the pose features and joint transforms the forward left in its workspace:
+                # value, projection, residual AND the term's adjoint (one more chunk of the LBS backward's partial sums)
+                # in one small launch -- no pass over the vertices either way (csrc/mh_keypoints.hip)
+                check(L.mh_keypoint_terms(self.m.handle, B, ptr(self.leaf('poses_T')), Kp, Kdp, jwp, ptr(self.pose2d), self.thr,
+                                          float(self.W), float(self.H), float(c['proj2d']), ptr(self.kp), ptr(self.uv), ptr(self.gj),
+                                          ptr(self.loss2d), ptr(self.ws), ptr(self.ws2), ptr(self.kp_ws), s2))
+                self._kp_chunk = True
+                return
+            self._kp_chunk = False
+            self._regress(s2)
             check(L.mh_project_joints_loss_w(B, ptr(self.kp), Kp, Kdp, jwp, ptr(self.pose2d), self.thr, 0, float(self.W),
                                              float(self.H), float(c['proj2d']), ptr(self.uv), ptr(self.gj), ptr(self.loss2d), s2))
 
@@ -657,9 +668,13 @@ class SequenceEngine(object):
             self._scene_terms(st)
             self._toc(ev)
         ev = self._tic('lbs_backward')
-        check(L.mh_lbs_backward(self.m.handle, B, N, ptr(self.leaf('betas')), ptr(self.leaf('poses_smpl')),
-                                ptr(self.leaf('xscale')), ptr(pT), ptr(self.vposed), ptr(gv), ptr(self.gj) if self.kp_fused else None, ptr(gposes),
-                                ptr(gpT), ptr(gbetas), ptr(gxs), ptr(self.ws), ptr(self.ws2), st))
+        if getattr(self, '_kp_chunk', False):
+            check(L.mh_lbs_backward_kp(self.m.handle, B, N, ptr(self.leaf('betas')), ptr(self.leaf('poses_smpl')), ptr(self.vposed),
+                                       ptr(gv), ptr(gposes), ptr(gpT), ptr(gbetas), ptr(gxs), ptr(self.ws), ptr(self.ws2), st))
+        else:
+            check(L.mh_lbs_backward(self.m.handle, B, N, ptr(self.leaf('betas')), ptr(self.leaf('poses_smpl')),
+                                    ptr(self.leaf('xscale')), ptr(pT), ptr(self.vposed), ptr(gv), ptr(self.gj) if self.kp_fused else None, ptr(gposes),
+                                    ptr(gpT), ptr(gbetas), ptr(gxs), ptr(self.ws), ptr(self.ws2), st))
         self._toc(ev)
         if row is not None:
             self.log[row].copy_(log)

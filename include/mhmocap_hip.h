@@ -305,6 +305,11 @@ int mh_stage_gates(const float* pose2d /*(B,17,3)*/, const float* area /*(B)*/, 
 int mh_sil_mask_stats(const uint32_t* bits, int T, int N, int H, int W, const float* pT /*(T,N,3)*/,
                       const float* pose2d_valid, const float* mask_valid, uint32_t* front /*(T,N)*/,
                       float* apply /*(T,N)*/, float* D /*(T,N)*/, float* S /*(T,N)*/, void* stream);
+/* the same with the frame's pixel counts kept while the near-to-far ordering of its people is unchanged: tag (T) int32,
+ * zero before the first call on these arrays (and after the masks changed); front / D / S must then persist between calls */
+int mh_sil_mask_stats_cached(const uint32_t* bits, int T, int N, int H, int W, const float* pT,
+                             const float* pose2d_valid, const float* mask_valid, uint32_t* front, float* apply,
+                             float* D, float* S, int32_t* tag, void* stream);
 
 /* ---- a17: priors (optimizer.py:523-532, 535-542) ---------------------------------------------
  * pose prior L1(valid*ref, valid*pose) per body -> body_loss (B), gposes +=;
@@ -343,6 +348,11 @@ int mh_scene_grid_build(const float* points /*(M,3)*/, int M, void* grid_ws, voi
 int mh_scene_grid_build_dev(const float* points, const int* M_dev, int M_cap, void* grid_ws, void* stream);
 int mh_contact_knn_grid(const void* grid_ws, int M, const float* low_xyz, int B, int k,
                         float* dy /*(B)*/, void* stream);
+/* the same with the query = the lowest vertex of each body, taken from the keys mh_lbs_forward_proj reported (as
+ * mh_lowest_resolve; low_idx / low_xyz are outputs) -- one launch instead of two                                  */
+int mh_contact_knn_grid_key(const void* grid_ws, int M, const float* verts /*(B,V,3)*/, int V,
+                            unsigned long long* lowkey /*(B)*/, int B, int k, int32_t* low_idx /*(B)*/,
+                            float* low_xyz /*(B,3)*/, float* dy /*(B)*/, void* stream);
 /* contact: sum |dy+0.02| per batch, gpT.y += coef * (-sign(dy+0.02)); foot sliding between
  * IN-BATCH consecutive frames (batch = frames per batch, optimizer.py:512-518), gverts +=
  * (atomic).  batch_contact / batch_foot: one value per batch (nbatches = ceil(T/batch)).     */
@@ -441,7 +451,10 @@ int mh_raster_terms_phase_log(int T, int N, int V, int F, int H, int W, const fl
                           float* zbuf_out, float* alpha_out, int phases, float* log_depth, float* log_sil, void* stream);
 /* the same after mh_lbs_forward_proj wrote into this workspace (mh_raster_forward_targets): projected != 0 -> the
  * preparation kernel reads the bounding boxes / motion flags the forward left instead of passing over `verts` (which
- * may then be NULL); a body whose box is incomplete is scanned from the projected vertices.  Same results, bit for bit. */
+ * may then be NULL); a body whose box is incomplete is scanned from the projected vertices.  Same results, bit for bit.
+ * phases here is a bit mask: 1 = preparation + selection, 2 = gradients, 4 = preparation only (windows, face lists, work
+ * lists: a chain of small latency-bound launches), 8 = selection only -- so that a caller can start other work between the
+ * two halves of phase 1.                                                                                        */
 int mh_raster_forward_targets(int T, int N, int V, int F, int H, int W, const float* cam_K_host, void* ws,
                               mh_fwd_proj* out);
 int mh_raster_terms_projected(int T, int N, int V, int F, int H, int W, const float* cam_K_host,

@@ -176,6 +176,91 @@ extern "C" int mh_sil_mask_stats(const uint32_t* bits, int T, int N, int H, int 
   return MH_OK;
 }
 
+// The same with the pixel pass taken only when it can change anything (round 4).  D and S are functions of the (constant)
+// instance masks and of WHO IS IN FRONT OF WHOM in the frame; the optimiser changes that ordering a handful of times in a
+// fit.  One workgroup per frame: the front sets are computed from the current translations and compared with the ones the
+// frame's counts were taken for (tag[t] != 0: they exist) -- equal: only the gates are refreshed; different: the frame's
+// pixels are counted again and D / S overwritten (no memsets, no atomics: per-cycle cost 2 launches of 5 us and a 17-us
+// kernel less, all of which ran beside -- and were paid for by -- the selection kernel).
+template <int NMAX>
+__global__ __launch_bounds__(256) void k_sil_stats_cached(const uint32_t* bits, int N, int P, const float* pT,
+                                                          const float* p2d_valid, const float* mask_valid, uint32_t* front,
+                                                          float* apply, float* D, float* S, int* tag) {
+  const int t = blockIdx.x;
+  __shared__ uint32_t sfront[32];
+  __shared__ float sred[2][32][4];
+  __shared__ int s_changed;
+  if (threadIdx.x == 0) s_changed = tag[t] == 0 ? 1 : 0;
+  __syncthreads();
+  if (threadIdx.x < N) {
+    const int n = threadIdx.x;
+    const float z = pT[((size_t)t * N + n) * 3 + 2];
+    uint32_t f = 0;
+    int rank = 0;
+    for (int m = 0; m < N; ++m) {
+      const float zm = pT[((size_t)t * N + m) * 3 + 2];
+      if (zm < z || (zm == z && m < n)) {
+        f |= 1u << m;
+        ++rank;
+      }
+    }
+    sfront[n] = f;
+    if (front[(size_t)t * N + n] != f) s_changed = 1;
+    front[(size_t)t * N + n] = f;
+    apply[(size_t)t * N + n] = mask_valid[(size_t)t * N + rank] * p2d_valid[(size_t)t * N + rank];   // optimizer.py:472 (sic)
+  }
+  __syncthreads();
+  if (!s_changed) return;
+  float d[NMAX], s[NMAX];
+  uint32_t fr[NMAX];
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n) {
+    d[n] = s[n] = 0.f;
+    fr[n] = n < N ? sfront[n] : 0xffffffffu;
+  }
+  for (int p = threadIdx.x; p < P; p += 256) {
+    const uint32_t w = bits[(size_t)t * P + p];
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) {
+      const bool free_px = (w & fr[n]) == 0;
+      d[n] += free_px ? 1.f : 0.f;
+      s[n] += (free_px && ((w >> n) & 1u)) ? 1.f : 0.f;
+    }
+  }
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n) {
+    const float a = mh_wave_sum(d[n]), b = mh_wave_sum(s[n]);     // pixel counts: integers below 2^24, exact in any order
+    if ((threadIdx.x & 63) == 0 && n < N) {
+      sred[0][n][wave] = a;
+      sred[1][n][wave] = b;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < N) {
+    const int n = threadIdx.x;
+    D[(size_t)t * N + n] = sred[0][n][0] + sred[0][n][1] + sred[0][n][2] + sred[0][n][3];
+    S[(size_t)t * N + n] = sred[1][n][0] + sred[1][n][1] + sred[1][n][2] + sred[1][n][3];
+  }
+  if (threadIdx.x == 0) tag[t] = 1;
+}
+
+extern "C" int mh_sil_mask_stats_cached(const uint32_t* bits, int T, int N, int H, int W, const float* pT,
+                                        const float* pose2d_valid, const float* mask_valid, uint32_t* front, float* apply,
+                                        float* D, float* S, int32_t* tag, void* stream) {
+  MH_CHECK(bits && pT && pose2d_valid && mask_valid && front && apply && D && S && tag, "null argument");
+  MH_CHECK(T > 0 && N > 0 && N <= 32, "need 1..32 people per frame");
+#define SIL_LAUNCH(NM) hipLaunchKernelGGL(k_sil_stats_cached<NM>, dim3(T), dim3(256), 0, (hipStream_t)stream, bits, N, \
+                                          H * W, pT, pose2d_valid, mask_valid, front, apply, D, S, tag)
+  if (N <= 4) SIL_LAUNCH(4);
+  else if (N <= 8) SIL_LAUNCH(8);
+  else if (N <= 16) SIL_LAUNCH(16);
+  else SIL_LAUNCH(32);
+#undef SIL_LAUNCH
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // priors (optimizer.py:523-532, 535-542)
 // ---------------------------------------------------------------------------------------------

@@ -21,7 +21,7 @@
 //     key-points, projection, residual, d loss / d key-point
 //     dL/dA_k, dL/dM           element-wise
 //     dL/df = Q^T dL/dM        (224 x 3 np) . (3 np x 32)  exact-fp32 MFMA 32x32x2
-// and leaves dL/dA, dL/df, dL/dt as ONE MORE chunk of the LBS backward's partial sums (k_pose_bwd adds the chunks in fixed
+// (three small launches, see below) and leaves dL/dA, dL/df, dL/dt as ONE MORE chunk of the LBS backward's partial sums (k_pose_bwd adds the chunks in fixed
 // order), so neither the forward nor the backward of the skinning kernels knows about key-points any more.
 #include <vector>
 
@@ -161,30 +161,42 @@ struct KpP {
   float* GM;            // [rows_pad][GB]
 };
 
+// Three launches (the phases need all of a group's rows of the one before; 25 groups alone leave the device idle, and a wave
+// that walks K = 224 alone is a chain of 112 dependent load -> MFMA steps -- the first, single-kernel form took 180 us):
+//   k_kp_p    grid (row tiles, groups): P = Q f.  The four waves of a workgroup split K; every operand of a wave's 28 steps
+//             is requested before its first MFMA; the four partial tiles are added through LDS in fixed order.
+//   k_kp_mid  grid (groups): key-points, projection, residual, dL/dkp; dL/dA, dL/dM, dL/dt (element-wise)
+//   k_kp_gf   grid (feature tiles, groups): dL/df = Q^T dL/dM, K = rows split over the four waves as above
 #define KP_T 256
-__global__ __launch_bounds__(KP_T) void k_kp_terms(KpP p) {
+#define KP_KS (MH_FS / 2 / 4)          // 28 two-k steps per wave
+__global__ __launch_bounds__(KP_T) void k_kp_p(KpP p) {
+  __shared__ float sAcc[4][16][64];
+  const int rt = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float* fb = p.featT + (size_t)g * MH_FS * 32 + lane + (size_t)wave * KP_KS * 64;   // lane l: feature 2 s + (l >> 5), body l & 31
+  const float* qa = p.Qa + ((size_t)rt * (MH_FS / 2) + (size_t)wave * KP_KS) * 64 + lane;
+  float a[KP_KS], f[KP_KS];
+#pragma unroll
+  for (int s = 0; s < KP_KS; ++s) { a[s] = qa[(size_t)s * 64]; f[s] = fb[(size_t)s * 64]; }
+  f32x16 acc = {0};
+#pragma unroll
+  for (int s = 0; s < KP_KS; ++s) acc = MFMA32(a[s], f[s], acc);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sAcc[wave][r][lane] = acc[r];
+  __syncthreads();
+  for (int e = tid; e < 16 * 64; e += KP_T) {
+    const int r = e >> 6, l = e & 63;
+    const float v = ((sAcc[0][r][l] + sAcc[1][r][l]) + sAcc[2][r][l]) + sAcc[3][r][l];
+    const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    p.P[(size_t)row * p.GB + (size_t)g * 32 + (l & 31)] = v;
+  }
+}
+
+__global__ __launch_bounds__(KP_T) void k_kp_mid(KpP p) {
   __shared__ float sGK[MH_NKP * 3][32];      // d loss / d key-point
   __shared__ float sKL[MH_NKP * 3][32];      // key-point before scale and translation
   __shared__ float sL[MH_NKP][32];
-  const int g = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int g = blockIdx.x, tid = threadIdx.x;
   const size_t GB = p.GB;
-  const int ntile = p.rows_pad / 32;
-  // ---- 1. P = Q f: one 32-row tile per wave and trip; K = 224 in steps of two --------------------------------------------
-  {
-    const float* fb = p.featT + (size_t)g * MH_FS * 32 + lane;            // lane l: feature 2 s + (l >> 5), body l & 31
-    for (int rt = wave; rt < ntile; rt += KP_T / 64) {
-      const float* qa = p.Qa + (size_t)rt * (MH_FS / 2) * 64 + lane;
-      f32x16 acc = {0};
-#pragma unroll 8
-      for (int s = 0; s < MH_FS / 2; ++s) acc = MFMA32(qa[(size_t)s * 64], fb[(size_t)s * 64], acc);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        p.P[(size_t)row * GB + (size_t)g * 32 + li] = acc[r];
-      }
-    }
-  }
-  __syncthreads();
   // ---- 2. key-points, projection, residual -----------------------------------------------------------------------------------
   for (int idx = tid; idx < 32 * MH_NKP; idx += KP_T) {
     const int bi = idx & 31, j = idx >> 5, b = g * 32 + bi;
@@ -261,7 +273,7 @@ __global__ __launch_bounds__(KP_T) void k_kp_terms(KpP p) {
     }
   }
   if (!p.pF) return;
-  // ---- 3a. dL/dM per (body, pair) and dL/dA per (body, bone) ----------------------------------------------------------------
+  // ---- dL/dM per (body, pair) and dL/dA per (body, bone) ---------------------------------------------------------------------
   for (int idx = tid; idx < 32 * p.np; idx += KP_T) {
     const int bi = idx & 31, q = idx >> 5, b = g * 32 + bi;
     const int j = p.pair_j[q], k = p.pair_k[q];
@@ -303,19 +315,35 @@ __global__ __launch_bounds__(KP_T) void k_kp_terms(KpP p) {
 #pragma unroll
     for (int e = 0; e < 12; ++e) o[e * MH_NJ] = ga[e];
   }
-  __syncthreads();
-  // ---- 3b. dL/df = Q^T dL/dM: seven 32-feature tiles over the waves; K = rows in steps of two ------------------------------
-  for (int kt = wave; kt < MH_FS / 32; kt += KP_T / 64) {
-    const float* qr = p.Qr + (size_t)lh * MH_FS + kt * 32 + li;          // lane l: row 2 s + (l >> 5), feature 32 kt + (l & 31)
-    const float* gm = p.GM + (size_t)lh * GB + (size_t)g * 32 + li;      //         row 2 s + (l >> 5), body l & 31
-    f32x16 acc = {0};
-#pragma unroll 8
-    for (int s = 0; s < p.rows_pad / 2; ++s) acc = MFMA32(qr[(size_t)2 * s * MH_FS], gm[(size_t)2 * s * GB], acc);
+}
+
+#define KP_GB 16                       // steps whose operands are in flight together
+__global__ __launch_bounds__(KP_T) void k_kp_gf(KpP p) {
+  __shared__ float sAcc[4][16][64];
+  const int kt = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int nstep = p.rows_pad / 2, per = (nstep + 3) / 4, s0 = wave * per, s1 = min(nstep, s0 + per);
+  const float* qr = p.Qr + (size_t)lh * MH_FS + kt * 32 + li;            // lane l: row 2 s + (l >> 5), feature 32 kt + (l & 31)
+  const float* gm = p.GM + (size_t)lh * p.GB + (size_t)g * 32 + li;      //         row 2 s + (l >> 5), body l & 31
+  f32x16 acc = {0};
+  for (int sb = s0; sb < s1; sb += KP_GB) {
+    float a[KP_GB], f[KP_GB];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int f = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      p.pF[((size_t)g * 32 + li) * MH_FS + f] = acc[r];
+    for (int u = 0; u < KP_GB; ++u) {
+      const int s = min(sb + u, s1 - 1);
+      a[u] = qr[(size_t)2 * s * MH_FS];
+      f[u] = (sb + u < s1) ? gm[(size_t)2 * s * p.GB] : 0.f;
     }
+#pragma unroll
+    for (int u = 0; u < KP_GB; ++u) acc = MFMA32(a[u], f[u], acc);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sAcc[wave][r][lane] = acc[r];
+  __syncthreads();
+  for (int e = tid; e < 16 * 64; e += KP_T) {
+    const int r = e >> 6, l = e & 63;
+    const float v = ((sAcc[0][r][l] + sAcc[1][r][l]) + sAcc[2][r][l]) + sAcc[3][r][l];
+    const int f = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    p.pF[((size_t)g * 32 + (l & 31)) * MH_FS + f] = v;
   }
 }
 
@@ -362,7 +390,13 @@ extern "C" int mh_keypoint_terms(const mh_model* m, int B, const float* transl, 
   }
   p.P = (float*)(((uintptr_t)kp_ws + 255) & ~(uintptr_t)255);
   p.GM = p.P + (size_t)p.rows_pad * p.GB;
-  hipLaunchKernelGGL(k_kp_terms, dim3(G), dim3(KP_T), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(k_kp_p, dim3(p.rows_pad / 32, G), dim3(KP_T), 0, (hipStream_t)stream, p);
   MH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_kp_mid, dim3(G), dim3(KP_T), 0, (hipStream_t)stream, p);
+  MH_LAUNCH_CHECK();
+  if (p.pF) {
+    hipLaunchKernelGGL(k_kp_gf, dim3(MH_FS / 32, G), dim3(KP_T), 0, (hipStream_t)stream, p);
+    MH_LAUNCH_CHECK();
+  }
   return MH_OK;
 }

@@ -1941,7 +1941,9 @@ static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const flo
   p.projected = projected ? 1 : 0;
   if (mh_prof_level() < 2) p.pairs = nullptr;
   hipStream_t st = (hipStream_t)stream;
-  if (phases & 1) {
+  // phase bits: 1 = preparation + selection, 4 = preparation only (window, face lists, work lists), 8 = selection only
+  const bool do_prep = (phases & (1 | 4)) != 0, do_sel = (phases & (1 | 8)) != 0;
+  if (do_prep) {
   if (zbuf_out) {   // -1 = empty, like fragments.zbuf
     hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, st, zbuf_out, (size_t)p.B * H * W, -1.f);
     MH_LAUNCH_CHECK();
@@ -1951,6 +1953,8 @@ static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const flo
   MH_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_raster_lists, dim3(1), dim3(RLISTS), 0, st, p);
   MH_LAUNCH_CHECK();
+  }
+  if (do_sel) {
   // persistent grids over the device-side work list (the strip count is only known on the device)
   const int grid = R_STRIP_GRID;
   mh_prof_mark(MH_PROF_RASTER_STRIP, 0, st);
@@ -2045,7 +2049,7 @@ extern "C" int mh_raster_terms_projected(int T, int N, int V, int F, int H, int 
                                          float coef_depth, float coef_sil, float eps, float* gverts, float* gzmin, float* gzmax,
                                          float* depth_body, float* sil_body, void* ws, float* zbuf_out, float* alpha_out,
                                          int phases, float* log_depth, float* log_sil, int projected, void* stream) {
-  MH_CHECK(phases >= 1 && phases <= 3, "phases: 1 = selection + values, 2 = gradients, 3 = both");
+  MH_CHECK(phases >= 1 && phases <= 15, "phases: 1 = preparation + selection + values, 2 = gradients, 4 = preparation only, 8 = selection only");
   return raster_terms_impl(T, N, V, F, H, W, cam_K_host, verts, faces, bits, ebits, depths, zmin_lin, zmax_lin, pose2d_valid, front,
                            sil_apply, sil_D, sil_S, coef_depth, coef_sil, eps, gverts, gzmin, gzmax, depth_body, sil_body, ws, zbuf_out,
                            alpha_out, phases, log_depth, log_sil, stream, projected);

@@ -61,10 +61,8 @@ extern "C" int mh_lowest_vertex(const float* verts, int B, int V, int32_t* low_i
 // of y << 32 | ~vertex, reported by the vertices above the previous launch's lowest minus a slack; 0 = nobody reported).
 // One wave per body; a body without a key is scanned like k_lowest_vertex does and its key written back, so that the next
 // forward has an extreme to filter with.
-__global__ __launch_bounds__(64) void k_lowest_resolve(const float* verts, int V, unsigned long long* lowkey, int* low_idx,
-                                                       float* low_xyz) {
-  const int b = blockIdx.x, lane = threadIdx.x;
-  const float* vb = verts + (size_t)b * V * 3;
+// (one wave) -> the body's lowest vertex, the same in every lane
+__device__ __forceinline__ int mh_lowest_from_key(const float* vb, int V, unsigned long long* lowkey, int b, int lane) {
   const unsigned long long key = lowkey[b];
   int bi = (int)~(unsigned)(key & 0xffffffffull);
   if (key == 0ull || bi < 0 || bi >= V) {       // nobody reported (or not a key at all): scan
@@ -86,6 +84,14 @@ __global__ __launch_bounds__(64) void k_lowest_resolve(const float* verts, int V
       lowkey[b] = ((unsigned long long)(u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u)) << 32) | (unsigned)~(unsigned)bi;
     }
   }
+  return bi;
+}
+
+__global__ __launch_bounds__(64) void k_lowest_resolve(const float* verts, int V, unsigned long long* lowkey, int* low_idx,
+                                                       float* low_xyz) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float* vb = verts + (size_t)b * V * 3;
+  const int bi = mh_lowest_from_key(vb, V, lowkey, b, lane);
   if (lane == 0) low_idx[b] = bi;
   if (lane < 3) low_xyz[(size_t)b * 3 + lane] = vb[(size_t)bi * 3 + lane];
 }
@@ -590,15 +596,29 @@ __device__ __forceinline__ float knn_select(float* sd, float* sy, int lane, int 
 }
 
 // one wave per query
+// (verts != null: the query is the body's lowest vertex, taken from the key the LBS forward's projection epilogue reported --
+// mh_contact_knn_grid_key -- and written to low_idx / low_xyz_out for the contact / foot-sliding kernel)
 __global__ __launch_bounds__(64) void k_contact_knn_grid(const GridHdr* hdr, const int* start, const float* sorted, int M,
-                                                         const float* low_xyz, int K, float* dy) {
+                                                         const float* low_xyz, int K, float* dy, const float* verts, int V,
+                                                         unsigned long long* lowkey, int* low_idx, float* low_xyz_out) {
   __shared__ float sd_s[KNN_CAP];
   __shared__ float sy_s[KNN_CAP];
   __shared__ int s_off[65], s_a0[64], s_la[64], s_b0[64];
   float* sd = sd_s;
   float* sy = sy_s;
   const int b = blockIdx.x, lane = threadIdx.x;
-  const float qx = low_xyz[(size_t)b * 3], qy = low_xyz[(size_t)b * 3 + 1], qz = low_xyz[(size_t)b * 3 + 2];
+  float qx, qy, qz;
+  if (verts) {
+    const float* vb = verts + (size_t)b * V * 3;
+    const int bi = mh_lowest_from_key(vb, V, lowkey, b, lane);
+    qx = vb[(size_t)bi * 3]; qy = vb[(size_t)bi * 3 + 1]; qz = vb[(size_t)bi * 3 + 2];
+    if (lane == 0) {
+      low_idx[b] = bi;
+      low_xyz_out[(size_t)b * 3] = qx; low_xyz_out[(size_t)b * 3 + 1] = qy; low_xyz_out[(size_t)b * 3 + 2] = qz;
+    }
+  } else {
+    qx = low_xyz[(size_t)b * 3]; qy = low_xyz[(size_t)b * 3 + 1]; qz = low_xyz[(size_t)b * 3 + 2];
+  }
   sd[lane] = INFINITY; sd[lane + 64] = INFINITY;
   sy[lane] = 0.f; sy[lane + 64] = 0.f;
   __builtin_amdgcn_wave_barrier();
@@ -734,7 +754,22 @@ extern "C" int mh_contact_knn_grid(const void* grid_ws, int M, const float* low_
   GridWs g = grid_carve((void*)grid_ws, M);
   mh_prof_mark(MH_PROF_CONTACT_KNN, 0, (hipStream_t)stream);
   hipLaunchKernelGGL(k_contact_knn_grid, dim3(B), dim3(64), 0, (hipStream_t)stream, (const GridHdr*)g.hdr, (const int*)g.start,
-                     (const float*)g.sorted, M, low_xyz, k, dy);
+                     (const float*)g.sorted, M, low_xyz, k, dy, (const float*)nullptr, 0, (unsigned long long*)nullptr, (int*)nullptr,
+                     (float*)nullptr);
+  MH_LAUNCH_CHECK();
+  mh_prof_mark(MH_PROF_CONTACT_KNN, 1, (hipStream_t)stream);
+  return MH_OK;
+}
+
+extern "C" int mh_contact_knn_grid_key(const void* grid_ws, int M, const float* verts, int V, unsigned long long* lowkey, int B,
+                                       int k, int32_t* low_idx, float* low_xyz, float* dy, void* stream) {
+  MH_CHECK(grid_ws && verts && lowkey && low_idx && low_xyz && dy, "null argument");
+  MH_CHECK(B > 0 && M > 0 && V > 0, "empty input");
+  MH_CHECK(k >= 1 && k <= 32, "k must be in 1..32");
+  GridWs g = grid_carve((void*)grid_ws, M);
+  mh_prof_mark(MH_PROF_CONTACT_KNN, 0, (hipStream_t)stream);
+  hipLaunchKernelGGL(k_contact_knn_grid, dim3(B), dim3(64), 0, (hipStream_t)stream, (const GridHdr*)g.hdr, (const int*)g.start,
+                     (const float*)g.sorted, M, (const float*)nullptr, k, dy, verts, V, lowkey, low_idx, low_xyz);
   MH_LAUNCH_CHECK();
   mh_prof_mark(MH_PROF_CONTACT_KNN, 1, (hipStream_t)stream);
   return MH_OK;

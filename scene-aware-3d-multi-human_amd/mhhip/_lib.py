@@ -97,6 +97,7 @@ def lib():
         L.mh_erode_bits.argtypes = [u32p, u32p] + [ctypes.c_int] * 3 + [vp]
         L.mh_stage_gates.argtypes = [vp, vp, ctypes.c_int, ctypes.c_float, ctypes.c_float, vp, vp, vp]
         L.mh_sil_mask_stats.argtypes = [u32p] + [ctypes.c_int] * 4 + [vp] * 8
+        L.mh_sil_mask_stats_cached.argtypes = [u32p] + [ctypes.c_int] * 4 + [vp] * 9
         L.mh_prior_terms.argtypes = [ctypes.c_int] * 3 + [vp] * 6 + [ctypes.c_float] * 2 + [vp] * 6
         L.mh_reduce_sum.argtypes = [vp, ctypes.c_size_t, ctypes.c_float, vp, vp]
         L.mh_reduce_sum_multi.argtypes = [ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(vp), vp]
@@ -117,6 +118,7 @@ def lib():
         L.mh_scene_grid_build.argtypes = [vp, ctypes.c_int, vp, vp]
         L.mh_scene_grid_build_dev.argtypes = [vp, vp, ctypes.c_int, vp, vp]
         L.mh_contact_knn_grid.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp]
+        L.mh_contact_knn_grid_key.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
         L.mh_contact_foot_terms.argtypes = [ctypes.c_int] * 4 + [vp] * 4 + [ctypes.c_float] * 2 + [vp] * 5
         L.mh_contact_foot_terms_idx.argtypes = [ctypes.c_int] * 5 + [vp] * 5 + [ctypes.c_float] * 2 + [vp] * 5
         L.mh_scene_unproject.argtypes = [vp, ctypes.c_int, ctypes.c_int, c_float_p, vp, vp]

@@ -219,6 +219,7 @@ class SequenceEngine(object):
             self.sil_apply = torch.zeros(self.B, dtype=torch.float32, device=self.dev)
             self.sil_D = torch.zeros(self.B, dtype=torch.float32, device=self.dev)
             self.sil_S = torch.zeros(self.B, dtype=torch.float32, device=self.dev)
+            self.sil_tag = torch.zeros(T, dtype=torch.int32, device=self.dev)    # 0: the frame's pixel counts do not exist yet
             self.sil_body = torch.zeros(self.B, dtype=torch.float32, device=self.dev)
             self.depth_body = torch.zeros(self.B, dtype=torch.float32, device=self.dev)
             self.has_images = True
@@ -478,9 +479,9 @@ class SequenceEngine(object):
         self.forward(regress=False, raster=raster)   # (the per-body pose-prior values are summed with the other log entries, _finish_a)
         def leaf_terms():
             if self.has_images:
-                check(L.mh_sil_mask_stats(ptr(self.bits), T, N, self.H, self.W, ptr(pT), ptr(self.p2d_valid),
-                                          ptr(self.mask_valid), ptr(self.front), ptr(self.sil_apply), ptr(self.sil_D),
-                                          ptr(self.sil_S), s2))
+                check(L.mh_sil_mask_stats_cached(ptr(self.bits), T, N, self.H, self.W, ptr(pT), ptr(self.p2d_valid),
+                                                 ptr(self.mask_valid), ptr(self.front), ptr(self.sil_apply), ptr(self.sil_D),
+                                                 ptr(self.sil_S), ptr(self.sil_tag), s2))
             check(L.mh_prior_terms(T, N, self.nbatches, ptr(self.leaf('poses_smpl')), ptr(self.poses_ref), ptr(self.valid),
                                    ptr(self.leaf('betas')), ptr(self.betas_ref), ptr(self.leaf('xscale')),
                                    float(c['reg_poses']), float(c['reg_scales']), ptr(self.leaf('poses_smpl', g)),
@@ -606,9 +607,19 @@ class SequenceEngine(object):
         if images:
             if raster is not None:
                 ev = self._tic('raster_terms')
-                raster(self, gv, log, phases=1)
-                if main_first:
+                if main_first and os.environ.get('MHHIP_SIDE_LATE') == '1':     # (measured r04: 0.750 ms against 0.735 -- what runs under the selection kernel costs it one for one; kept as a switch)
+                    # the rasteriser's preparation (windows, kept face lists, work lists: two small launches bound by the latency
+                    # of their dependent loads) first and ALONE: the side branch opens with 200 MB of streaming traffic, beside
+                    # which the one-workgroup list kernel took 38 us instead of 11; behind it everything runs under the
+                    # selection kernel
+                    raster(self, gv, log, phases=4)
+                    side.wait_stream(main)
+                    raster(self, gv, log, phases=8)
                     side_branch()
+                else:
+                    raster(self, gv, log, phases=1)
+                    if main_first:
+                        side_branch()
                 # the whole side branch ends long before the selection does: ONE join here instead of a wait for the
                 # buffer initialisation here and a second join in front of the backward (every cross-stream edge of
                 # the replayed graph costs several us of idle time on the chain, even when its event has long been
@@ -632,10 +643,11 @@ class SequenceEngine(object):
         gpT = self.leaf('poses_T', self.grads)
         gv, log = self._gv_cur, self.tmp_log
         if getattr(self, '_projected_into', None) is not None:      # the forward's epilogue has reported the lowest vertices
-            check(L.mh_lowest_resolve(ptr(self.verts), B, self.V, self._lowkey, ptr(self.low_idx), ptr(self.low_xyz), st))
+            check(L.mh_contact_knn_grid_key(ptr(self.scene_grid), self.scene_M, ptr(self.verts), self.V, self._lowkey, B, 32,
+                                            ptr(self.low_idx), ptr(self.low_xyz), ptr(self.dy), st))
         else:
             check(L.mh_lowest_vertex(ptr(self.verts), B, self.V, ptr(self.low_idx), ptr(self.low_xyz), st))
-        check(L.mh_contact_knn_grid(ptr(self.scene_grid), self.scene_M, ptr(self.low_xyz), B, 32, ptr(self.dy), st))
+            check(L.mh_contact_knn_grid(ptr(self.scene_grid), self.scene_M, ptr(self.low_xyz), B, 32, ptr(self.dy), st))
         if getattr(self, 'batch_frames', None) is not None:
             check(L.mh_contact_foot_terms_idx(T, N, self.V, self.batch, self.nbatches, ptr(self.batch_frames), ptr(self.verts),
                                               ptr(self.low_idx), ptr(self.low_xyz), ptr(self.dy), float(c['reg_contact']),

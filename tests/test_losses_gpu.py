@@ -78,3 +78,41 @@ def test_camera_helpers_match_reference(golden):
     np.testing.assert_allclose(tf.compute_calibration_matrix(1.0, 100.0, K[0], (240, 135)), golden['calib_land'], atol=1e-6)
     np.testing.assert_allclose(tf.compute_calibration_matrix(1.0, 100.0, K[0], (135, 240)), golden['calib_port'], atol=1e-6)
     np.testing.assert_allclose(tf.compute_calibration_matrix(1.0, 100.0, K[0], (256, 256)), golden['calib_sq'], atol=1e-6)
+
+
+def test_cached_mask_statistics_follow_the_depth_ordering():
+    """mh_sil_mask_stats_cached (round 4) keeps a frame's pixel counts while the near-to-far ordering of its people is
+    unchanged: against the uncached kernel over a sequence of translations whose ordering changes in some frames at some
+    steps, stays in others, with ties -- every output equal, every step."""
+    import numpy as np
+    from mhhip import _lib
+    from mhhip._lib import check, ptr
+    L = _lib.lib()
+    dev = torch.device('cuda:0')
+    st = _lib.stream_ptr(dev)
+    rng = np.random.RandomState(5)
+    for T, N, H, W in [(7, 4, 27, 40), (3, 1, 16, 16), (5, 9, 20, 33)]:
+        bits = torch.tensor(rng.randint(0, 2 ** N, size=(T, H, W)).astype(np.int32), device=dev)
+        p2d = torch.tensor(rng.rand(T * N).astype(np.float32) > 0.2, device=dev).float()
+        mv = torch.tensor(rng.rand(T * N).astype(np.float32) > 0.2, device=dev).float()
+        pT = torch.tensor(rng.randn(T, N, 3).astype(np.float32), device=dev)
+        z = lambda dt: torch.zeros(T * N, dtype=dt, device=dev)
+        f0, a0, D0, S0 = z(torch.int32), z(torch.float32), z(torch.float32), z(torch.float32)
+        f1, a1, D1, S1 = z(torch.int32), z(torch.float32), z(torch.float32), z(torch.float32)
+        tag = torch.zeros(T, dtype=torch.int32, device=dev)
+        D1.fill_(-7.0)          # whatever the arrays held
+        recount = 0
+        for step in range(12):
+            if step % 3 == 1:
+                pT[:, :, 2] += torch.tensor(rng.randn(T, N).astype(np.float32) * 0.4, device=dev) * (torch.arange(T, device=dev) % 2 == 0).float()[:, None]
+            if step == 7 and N > 1:
+                pT[0, 1, 2] = pT[0, 0, 2]                    # a tie: the lower index is in front
+            before = f1.clone()
+            check(L.mh_sil_mask_stats(ptr(bits), T, N, H, W, ptr(pT), ptr(p2d), ptr(mv), ptr(f0), ptr(a0), ptr(D0), ptr(S0), st))
+            check(L.mh_sil_mask_stats_cached(ptr(bits), T, N, H, W, ptr(pT), ptr(p2d), ptr(mv), ptr(f1), ptr(a1), ptr(D1), ptr(S1), ptr(tag), st))
+            torch.cuda.synchronize()
+            recount += int((before != f1).view(T, N).any(dim=1).sum())
+            assert torch.equal(f0, f1) and torch.equal(a0, a1) and torch.equal(D0, D1) and torch.equal(S0, S1), (T, N, step)
+        assert int(tag.sum()) == T
+        if N > 1:
+            assert 0 < recount < 12 * T

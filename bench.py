@@ -90,6 +90,23 @@ def counters_fresh(stamp, src):
     return bool(stamp) and stamp.get('sha256', {}).get(src) == file_sha(rel)
 
 
+def load_profile_kernel_us(kernel):
+    """average duration (us) of `kernel` inside REPLAYED cycles from the newest committed rocprofv3 --kernel-trace --stats
+    summary (profiles/rNN_bench_c3_kernel_stats.csv) -- HIP events cannot be read back from inside a replayed graph"""
+    import csv, glob
+    found = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_bench_c3_kernel_stats.csv')))
+    if not found:
+        return None
+    with open(found[-1]) as f:
+        for row in csv.DictReader(f):
+            if row.get('Name', '').startswith(kernel) or (kernel + '(') in row.get('Name', '') or (kernel + '<') in row.get('Name', ''):
+                try:
+                    return float(row['AverageNs']) / 1e3
+                except (KeyError, ValueError):
+                    return None
+    return None
+
+
 def load_pmc_valu(kernel):
     """Vector instructions per launch of `kernel` from the committed SQ counter pass (profiles/README.md)"""
     import glob
@@ -142,8 +159,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fit', action='store_true', help='skip the fit_250 block (wall time of the drop-in fit call)')
     ap.add_argument('--eager', action='store_true', help='launch every kernel from the host instead of replaying captured graphs')
-    ap.add_argument('--cpu-frames', type=int, default=20)
-    ap.add_argument('--cpu-cycles', type=int, default=3)
+    ap.add_argument('--cpu-frames', type=int, default=0, help='frames of the CPU-oracle sample (0 = all of them: no extrapolation)')
+    ap.add_argument('--cpu-cycles', type=int, default=2)
     ap.add_argument('--config', choices=['c3', 'c4'], default='c3', help='c3: 200 frames per GPU (N=1 is BASELINE C3); '
                     'c4: 250 frames per GPU (8 GPUs = BASELINE C4)')
     ap.add_argument('--strong', action='store_true', help='BASELINE C5: fixed 8 humans x 500 frames + 200k-point scene, '
@@ -298,7 +315,8 @@ def main():
     from mhhip import _lib
     L = _lib.lib()
     L.mh_profile_enable(1)
-    prof_names = ['k_raster_strip', 'k_raster_grads', 'lbs_skin_forward', 'lbs_skin_backward', 'k_contact_knn_grid', 'k_raster_sums']
+    prof_names = ['k_raster_strip', 'k_raster_grads', 'lbs_skin_forward', 'lbs_skin_backward', 'k_contact_knn_grid', 'k_raster_sums',
+                  'k_pose_fwd', 'keypoint_terms', 'pose_bwd_reduce', 'raster_prepare_lists']
     prof = {k: [] for k in prof_names}
     for c in range(min(args.steps, 40)):
         one_cycle(args.warmup + args.steps + c, False)
@@ -307,6 +325,28 @@ def main():
             ms1 = ctypes.c_float(0)
             if L.mh_profile_read(i, ctypes.byref(ms1)) == 0:
                 prof[k].append(float(ms1.value))
+    # the kernels of the LBS + projection unit once more ALONE on the device (inside the cycle the small ones run beside --
+    # and are stretched by -- the selection kernel): forward pair, key-point launches, backward chain, 20 calls each
+    alone = {k: [] for k in ('k_pose_fwd', 'lbs_skin_forward', 'keypoint_terms', 'lbs_skin_backward', 'pose_bwd_reduce')}
+    if world == 1 and e.kp_fused:
+        def read(keys):
+            torch.cuda.synchronize()
+            for k in keys:
+                ms1 = ctypes.c_float(0)
+                if L.mh_profile_read(prof_names.index(k), ctypes.byref(ms1)) == 0:
+                    alone[k].append(float(ms1.value))
+        st0 = _lib.stream_ptr(e.dev)
+        for rep in range(22):
+            e.forward(regress=False, raster=raster)
+            if rep >= 2:
+                read(['k_pose_fwd', 'lbs_skin_forward'])
+            e.keypoint_terms(st0)
+            if rep >= 2:
+                read(['keypoint_terms'])
+            e._finish_b(None, raster=raster)          # LBS backward chain on the gradients the last cycle left (timing only)
+            if rep >= 2:
+                read(['lbs_skin_backward', 'pose_bwd_reduce'])
+        e.grads.zero_()
     L.mh_profile_enable(2)                # a few more cycles with the kernel's own work counters on (they cost it ~4 %: not timed)
     for c in range(3):
         one_cycle(args.warmup + args.steps + 40 + c, False)
@@ -349,13 +389,20 @@ def main():
         stamp = profile_stamp()
         roof = None
         if 'k_raster_strip' in kernel_us:
-            us = kernel_us['k_raster_strip']
+            # launch duration INSIDE the cycle: (i) HIP events around the launch in eager cycles of this run -- same kernels,
+            # same two queues, the side branch beside it; (ii) the rocprofv3 average over REPLAYED cycles of the committed
+            # profile (profiles/, only while the kernel source still has the profiled hash).  frac uses the larger one.
+            us_live = kernel_us['k_raster_strip']
+            fresh = counters_fresh(stamp, 'mh_raster.hip')
+            us_prof = load_profile_kernel_us('k_raster_strip') if (fresh and not args.strong and frames_here == 200 and N_PEOPLE == 4) else None
+            us = max(us_live, us_prof or 0.0)
             algo = bodies * (12.0 * V + 4.0 * F) + 40.0 * window_px + 12.0 * F
             gbs = algo / (us * 1e-6) / 1e9
-            fresh = counters_fresh(stamp, 'mh_raster.hip')
             roof = {'kernel': 'k_raster_strip', 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                     'frac': round(gbs / PEAK_HBM_GBS, 4), 'traffic': None, 'traffic_detail': None,
-                    'launch_us': round(us, 1), 'algorithmic_bytes': algo, 'window_pixels': window_px, 'dominant_by_events': dom,
+                    'launch_us': round(us, 1), 'launch_us_events_in_eager_cycles': round(us_live, 1),
+                    'launch_us_rocprof_replayed_cycles': None if us_prof is None else round(us_prof, 1),
+                    'algorithmic_bytes': algo, 'window_pixels': window_px, 'dominant_by_events': dom,
                     'counters_taken_on': stamp.get('git') if fresh else None, 'valu': None, 'pairs': pairs}
             td = traffic.get('k_raster_strip') if fresh else None
             if td and not args.strong and frames_here == 200 and N_PEOPLE == 4:
@@ -377,10 +424,29 @@ def main():
             t_pair = (kernel_us['lbs_skin_forward'] + kernel_us['lbs_skin_backward']) * 1e-6
             by = bodies * 167028.0 + 19.35e6
             fl16 = 3.0 * 2.0 * bodies * V * (2 * 3 * 224.0 + 12 * 32.0)       # issued on the 16-bit matrix pipe (3 products)
-            lbs = {'kernels': 'k_skin_fwd16 | k_skinbwd16 (split-fp16 / split-bf16 contractions)',
+            unit_keys = ['k_pose_fwd', 'lbs_skin_forward', 'keypoint_terms', 'lbs_skin_backward', 'pose_bwd_reduce']
+            in_cycle = {k: kernel_us[k] for k in unit_keys if k in kernel_us}
+            standalone = {k: 1e3 * float(np.mean(v)) for k, v in alone.items() if v}
+            full = None
+            if len(in_cycle) == len(unit_keys):
+                t_in = sum(in_cycle.values()) * 1e-6
+                full = {'what': 'every kernel that makes up SURVEY 8(d)\'s unit (pose features and joint transforms; skinning + '
+                                'NDC projection + screen box + lowest vertex; the 17 key-points with projection, residual and '
+                                'adjoint; the skinning adjoint; the pose adjoint + per-person reduction), summed',
+                        'in_cycle_us': {k: round(v, 1) for k, v in in_cycle.items()},
+                        'in_cycle_note': 'the three key-point launches run in the side branch UNDER the selection kernel, which holds '
+                                         'every vector register of its CUs: their in-cycle time is waiting, not work',
+                        'frac_in_cycle': round(by / t_in / 1e9 / PEAK_HBM_GBS, 4)}
+                if len(standalone) == len(unit_keys):
+                    t_al = sum(standalone.values()) * 1e-6
+                    full['standalone_us'] = {k: round(v, 1) for k, v in standalone.items()}
+                    full['frac_standalone'] = round(by / t_al / 1e9 / PEAK_HBM_GBS, 4)
+            lbs = {'kernels': 'k_skin_fwd16 (projection epilogue) | k_skinbwd16 (split-fp16 / split-bf16 contractions)',
                    'forward_us': round(kernel_us['lbs_skin_forward'], 1), 'backward_us': round(kernel_us['lbs_skin_backward'], 1),
                    'bound': 'hbm', 'algorithmic_bytes': by, 'achieved': round(by / t_pair / 1e9, 1), 'peak': PEAK_HBM_GBS,
                    'unit': 'GB/s', 'frac': round(by / t_pair / 1e9 / PEAK_HBM_GBS, 4),
+                   'frac_note': 'skinning pair only (forward + backward of the two dense kernels); full_unit is SURVEY 8(d)\'s unit',
+                   'full_unit': full,
                    'mfma_16bit': {'issued_tflops': round(fl16 / t_pair / 1e12, 1), 'peak': 2500.0, 'frac': round(fl16 / t_pair / 2.5e15, 4)},
                    'tolerance': 'vertices within 2.4e-7 m and gradients within 6e-6 (relative to the largest entry) of the '
                                 'exact-fp32 MFMA kernels of round 1 (tools/time_lbs.py); fixtures: 1e-5 m / 2e-4',
@@ -392,7 +458,7 @@ def main():
             'value': round(its if args.strong else its * world, 3),
             'unit': 'iterations/s (%d humans x %d frames per iteration unit)' % (N_PEOPLE, unit_frames), 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'strong' if args.strong else 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'launch': 'eager' if args.eager else 'hipGraph replay',
+            'vs_baseline': None, 'dtype': 'f32 (the two dense LBS contractions as split-16-bit MFMA operands -- three products of (hi, lo) fp16 / bf16 terms, fp32 accumulate; everything else plain fp32)', 'data': 'synthetic', 'launch': 'eager' if args.eager else 'hipGraph replay',
             'backend': ('RCCL (nccl)' if args.backend == 'nccl' else 'DRY RUN: gloo, collectives staged through the host%s -- not a '
                         'scaling measurement' % (', all ranks on one device' if args.one_device else '')) if world > 1 else None,
             'config': {'workload': ('BASELINE C5: %d humans x %d frames + 200 000-point scene cloud, %dx%d, batch 10, full nine-term '
@@ -422,17 +488,23 @@ def main():
             ncores = min(ncores, 16)
             torch.set_num_threads(ncores)
             os.environ['ORACLE_THREADS'] = str(ncores)
+            if not args.cpu_frames:
+                args.cpu_frames = T_LOCAL
             o, cpu_s = cpu_baseline(struct, regs, K, seq, pT0, args.cpu_frames, args.cpu_cycles)
             cpu_its = 1.0 / (cpu_s * (T_LOCAL / float(args.cpu_frames)))
+            whole = args.cpu_frames == T_LOCAL
             out['cpu_baseline'] = {
                 'value': round(cpu_its, 6), 'unit': 'iterations/s (4 humans x 200 frames per iteration unit)',
                 'cores': ncores, 'kind': 'port',
-                'sample': '%d cycles of the CPU oracle (torch-CPU LBS/losses on %d threads + C face selection, one body per '
-                          'thread) on the first %d of the 200 frames (x4 humans, 240x135, same nine-term stack); per-cycle time '
-                          'scaled by 200/%d' % (args.cpu_cycles, ncores, args.cpu_frames, args.cpu_frames),
+                'sample': ('%d whole cycles of the CPU oracle (torch-CPU LBS/losses on %d threads + C face selection, one body per '
+                           'thread) on ALL %d frames (x4 humans, 240x135, same nine-term stack): no extrapolation'
+                           % (args.cpu_cycles, ncores, args.cpu_frames)) if whole else
+                          ('%d cycles of the CPU oracle (torch-CPU LBS/losses on %d threads + C face selection, one body per '
+                           'thread) on the first %d of the %d frames (x4 humans, 240x135, same nine-term stack); per-cycle time '
+                           'scaled by %d/%d' % (args.cpu_cycles, ncores, args.cpu_frames, T_LOCAL, T_LOCAL, args.cpu_frames)),
                 'sec_per_cycle_sample': round(cpu_s, 3),
                 'reference_loop_in_build_container': 'the reference\'s own fit loop (PyTorch3D replaced by the oracle rasteriser through '
-                                                     'the stubs) took 1.67 s per cycle on the same 20-frame sample on 8 Xeon threads = '
+                                                     'the stubs) took 1.67 s per cycle on a 20-frame sample on 8 Xeon threads = '
                                                      '0.0598 it/s at 200 frames (BASELINE.md; it cannot run on the GPU box)'}
             out['speedup_vs_cpu_port'] = round(its / cpu_its, 1)
             out.update(mpjpe_block(struct, regs, tmp, device, K, seq, pT0, o, args))
@@ -465,12 +537,14 @@ def fit_block(struct, regs, tmp, device, K, seq):
     opt._stage_from_dataloader(dl)
     torch.cuda.synchronize()
     t_stage = time.perf_counter() - t0
+    params0 = opt.engine.params.clone()
     t0 = time.perf_counter()
     log = opt.fit(dl, num_iter=250)
     torch.cuda.synchronize()
     t_fit = time.perf_counter() - t0
     ov = opt.get_optimized_variables()
-    return {'wall_s': round(t_stage + t_fit, 4), 'staging_s': round(t_stage, 4), 'cycles_s': round(t_fit, 4),
+    early = early_fit_block(opt, dl, params0)
+    return {'early_fit': early, 'wall_s': round(t_stage + t_fit, 4), 'staging_s': round(t_stage, 4), 'cycles_s': round(t_fit, 4),
             'cycles_per_s_incl_everything': round(250.0 / (t_stage + t_fit), 1), 'init_optimized_variables_s': round(t_init, 4),
             'init_note': 'init_optimized_variables(num_iter=100) of a fresh optimiser in a process that has built this body model '
                          'before (what predict_mupots.py does per sequence): content hash of the model arrays (~3-8 ms; the '
@@ -480,6 +554,31 @@ def fit_block(struct, regs, tmp, device, K, seq):
                     '9 one-euro filter updates, 220 device scene updates, scene image; log read back',
             'final_loss_pose24j': float(log[-1]['loss_pose24j']), 'scene_points': int(opt.scene_pcd.shape[2]),
             'scene_img_shape': list(np.asarray(ov['scene_img']).shape)}
+
+
+def early_fit_block(opt, dl, params0, cycles=41):
+    """Cycles 0..40 of a fit from the initial variables, on an optimiser whose graphs exist (captured by the fit_250 call
+    above): RMSprop's first, largest steps move the bodies by more than a pixel row per cycle, so most face lists are
+    re-sorted and the projection epilogue's report filters miss more often than in the steady state the headline is
+    timed in.  The variables are put back to where init_optimized_variables left them, the face lists are invalidated."""
+    e = opt.engine
+    e.params.copy_(params0)                              # (filters stay as the 250-cycle fit left them: same term set, same graphs)
+    raster = e.raster_terms()
+    raster.init_workspace()                              # sort tags cleared: every body sorts in cycle 0
+    keep = opt.scene_update
+    opt.scene_update = 'none'                            # cycles 0..40 never reach the scene update (cycle >= 30 with the device path
+    torch.cuda.synchronize()                             # would only add its set-up to the wall time)
+    seen0, reb0 = raster.sort_counters(e)
+    t0 = time.perf_counter()
+    opt.fit(dl, num_iter=cycles)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    seen1, reb1 = raster.sort_counters(e)
+    opt.scene_update = keep
+    return {'cycles': cycles, 'ms_per_cycle': round(1e3 * dt / cycles, 4), 'iterations_per_s': round(cycles / dt, 1),
+            'bodies_resorted_share': round((reb1 - reb0) / max(1, seen1 - seen0), 4),
+            'what': 'opt.fit(dataloader, num_iter=%d) from the initial variables on staged inputs and existing graphs: wall time / '
+                    'cycles (includes the log read-back), share of (body, cycle) pairs whose face lists were re-sorted' % cycles}
 
 
 def mpjpe_block(struct, regs, tmp, device, K, seq, pT0, o, args):

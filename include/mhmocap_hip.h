@@ -75,7 +75,10 @@ int mh_version(void);
  * switches on the work counters inside the kernels (mh_raster_pair_counters); their stores cost the kernel a few percent. */
 enum mh_profile_kernel {
   MH_PROF_RASTER_STRIP = 0, MH_PROF_RASTER_GRADS = 1, MH_PROF_SKIN_FWD = 2, MH_PROF_SKIN_BWD = 3,
-  MH_PROF_CONTACT_KNN = 4, MH_PROF_RASTER_SUMS = 5, MH_PROF_COUNT = 6
+  MH_PROF_CONTACT_KNN = 4, MH_PROF_RASTER_SUMS = 5,
+  /* the rest of the "LBS + projection" unit of SURVEY 8(d) (round 4) */
+  MH_PROF_POSE_FWD = 6, MH_PROF_KEYPOINTS = 7, MH_PROF_POSE_BWD = 8 /* k_pose_bwd + k_person_reduce */,
+  MH_PROF_RASTER_PREP = 9 /* k_raster_prepare + k_raster_lists */, MH_PROF_COUNT = 10
 };
 int mh_profile_enable(int on);
 int mh_profile_read(int which, float* ms);

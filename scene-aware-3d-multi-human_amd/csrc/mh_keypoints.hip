@@ -390,6 +390,7 @@ extern "C" int mh_keypoint_terms(const mh_model* m, int B, const float* transl, 
   }
   p.P = (float*)(((uintptr_t)kp_ws + 255) & ~(uintptr_t)255);
   p.GM = p.P + (size_t)p.rows_pad * p.GB;
+  mh_prof_mark(MH_PROF_KEYPOINTS, 0, (hipStream_t)stream);
   hipLaunchKernelGGL(k_kp_p, dim3(p.rows_pad / 32, G), dim3(KP_T), 0, (hipStream_t)stream, p);
   MH_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_kp_mid, dim3(G), dim3(KP_T), 0, (hipStream_t)stream, p);
@@ -398,5 +399,6 @@ extern "C" int mh_keypoint_terms(const mh_model* m, int B, const float* transl, 
     hipLaunchKernelGGL(k_kp_gf, dim3(MH_FS / 32, G), dim3(KP_T), 0, (hipStream_t)stream, p);
     MH_LAUNCH_CHECK();
   }
+  mh_prof_mark(MH_PROF_KEYPOINTS, 1, (hipStream_t)stream);
   return MH_OK;
 }

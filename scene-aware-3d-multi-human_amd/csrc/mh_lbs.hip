@@ -337,6 +337,9 @@ __global__ __launch_bounds__(256, 2) void k_skin_fwd(SkinFwdP p) {
 // transforms (36 KB) are staged in LDS once.  Per 16-k step a wave issues 2 ds_read_b128 (A operand: both terms),
 // six 16-byte global loads (B operand: three components x two terms, double buffered) and nine MFMAs.
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef FWD_ABL
+#define FWD_ABL 0        // timing experiments only (tools/ab_fwd_proj.sh): 1 no NDC store, 2 no row loads, 4 no reports, 8 v_rcp instead of the IEEE division
+#endif
 #define MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
 struct SkinFwd16P {
@@ -512,7 +515,11 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, 2 * FWD16_WAVES / 4) void k_skin_
       const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
       const unsigned off4 = FULL ? (unsigned)(4 * lh * p.V + v) * 4u + (unsigned)((r & 3) + 8 * (r >> 2)) * ((unsigned)p.V * 4u)
                                  : (unsigned)(min(row, last_row) * p.V + v) * 4u;
+#if (FWD_ABL & 2)
+      rbv[r] = (float)off4;
+#else
       rbv[r] = *(const float*)(rbg + (size_t)off4);
+#endif
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -559,9 +566,16 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, 2 * FWD16_WAVES / 4) void k_skin_
       if (PROJ) {
         // the same three roundings per coordinate as k_raster_prepare's own projection (multiply, IEEE divide, add)
         const float Zc = o[2];
+#if (FWD_ABL & 8)
+        const float rz_ = __builtin_amdgcn_rcpf(Zc);
+        const float xn = p.P.s * (-o[0]) * rz_ + p.P.w1, yn = p.P.s * (-o[1]) * rz_ + p.P.h1;
+#else
         const float xn = p.P.s * (-o[0]) / Zc + p.P.w1, yn = p.P.s * (-o[1]) / Zc + p.P.h1;
+#endif
         const f32x3 nd = {xn, yn, Zc};
+#if !(FWD_ABL & 1)
         *(f32x3*)(ng + (size_t)off_r) = nd;
+#endif
         const bool mv = !(fabsf(fmaf(-yn, p.P.rk, p.P.ra) - rbv[r]) < p.P.thr);    // NaN-safe: anything odd rebuilds
         const f32x4 th = *(const f32x4*)(sB + 512 + row0 * 16);
         const float ly = *(const float*)(sB + 1024 + row0 * 16);
@@ -570,7 +584,11 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, 2 * FWD16_WAVES / 4) void k_skin_
         const bool c4 = o[1] > ly;
         // ONE wave-uniform branch per row (a scalar test of the combined lane mask): nothing below it is on the path of a row
         // in which no vertex reports -- most rows
+#if (FWD_ABL & 4)
+        if (__builtin_amdgcn_ballot_w64((c0 || c1 || c2 || c3 || c4 || mv) && xn == 12345.f) != 0ull) {
+#else
         if (__builtin_amdgcn_ballot_w64(c0 || c1 || c2 || c3 || c4 || mv) != 0ull) {
+#endif
           // (the asm keeps the sixteen rows' slot addresses from being computed ahead of the matrix phase and spilled)
           int b = g * 32 + row0 + 4 * lh;
           asm volatile("" : "+v"(b));
@@ -684,8 +702,10 @@ static int lbs_forward_impl(const mh_model* m, int B, int NB, const float* betas
   pp.bbox = proj ? proj->bbox : nullptr; pp.bbox_prev = proj ? proj->bbox_prev : nullptr;
   pp.lowkey = proj ? proj->lowkey : nullptr; pp.lowkey_prev = proj ? proj->lowkey_prev : nullptr;
   pp.moved = proj ? proj->moved : nullptr;
+  mh_prof_mark(MH_PROF_POSE_FWD, 0, st);
   hipLaunchKernelGGL(k_pose_fwd, dim3(G * 4), dim3(256), 0, st, pp);
   MH_LAUNCH_CHECK();
+  mh_prof_mark(MH_PROF_POSE_FWD, 1, st);
   if (split16) {
     SkinFwd16P sp;
     sp.B = B; sp.G = G; sp.V = m->V; sp.VP = m->VP; sp.nw = m->nw;
@@ -1811,11 +1831,13 @@ static int lbs_backward_impl(const mh_model* m, int B, int NB, const float* beta
   pp.gposes = gposes; pp.gtransl = gtransl; pp.gbeta_b = bw.gbeta_b; pp.gxs_b = bw.gxs_b;
   pp.scale_from_joint_sums = split16 ? 1 : 0;
   pp.tree = m->tree;
+  mh_prof_mark(MH_PROF_POSE_BWD, 0, st);
   hipLaunchKernelGGL(k_pose_bwd, dim3(G * 32), dim3(256), 0, st, pp);
   MH_LAUNCH_CHECK();
   if (gbetas || gxscale) {
     hipLaunchKernelGGL(k_person_reduce, dim3(NB, 11), dim3(256), 0, st, B, NB, bw.gbeta_b, bw.gxs_b, gbetas, gxscale);
     MH_LAUNCH_CHECK();
   }
+  mh_prof_mark(MH_PROF_POSE_BWD, 1, st);
   return MH_OK;
 }

@@ -1949,10 +1949,12 @@ static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const flo
     MH_LAUNCH_CHECK();
   }
   if (alpha_out) MH_HIP(hipMemsetAsync(alpha_out, 0, (size_t)p.B * H * W * sizeof(float), st));
+  mh_prof_mark(MH_PROF_RASTER_PREP, 0, st);
   hipLaunchKernelGGL(k_raster_prepare, dim3(p.B), dim3(RPREP), (size_t)3 * (H + 1) * sizeof(int), st, p);
   MH_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_raster_lists, dim3(1), dim3(RLISTS), 0, st, p);
   MH_LAUNCH_CHECK();
+  mh_prof_mark(MH_PROF_RASTER_PREP, 1, st);
   }
   if (do_sel) {
   // persistent grids over the device-side work list (the strip count is only known on the device)

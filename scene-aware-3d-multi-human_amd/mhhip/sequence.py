@@ -440,6 +440,18 @@ class SequenceEngine(object):
         check(_lib.lib().mh_joints_regress(self.m.handle, self.joints_reg[0], self.B, ptr(self.verts),
                                            ptr(self.leaf('poses_T')), self.joints_reg[1], ptr(self.kp), st))
 
+    def keypoint_terms(self, st):
+        """The 2D term of the AlphaPose key-points from the pose features and joint transforms the forward left in its
+        workspace: value, projection, residual AND the term's adjoint (one more chunk of the LBS backward's partial sums) in
+        three small launches -- no pass over the vertices in either direction (csrc/mh_keypoints.hip)."""
+        jwp = None if self.joint_w is None else self.joint_w.ctypes.data_as(_lib.c_float_p)
+        Kp = self.K.ctypes.data_as(_lib.c_float_p)
+        Kdp = None if self.Kd is None else self.Kd.ctypes.data_as(_lib.c_float_p)
+        check(_lib.lib().mh_keypoint_terms(self.m.handle, self.B, ptr(self.leaf('poses_T')), Kp, Kdp, jwp, ptr(self.pose2d), self.thr,
+                                           float(self.W), float(self.H), float(self.c['proj2d']), ptr(self.kp), ptr(self.uv),
+                                           ptr(self.gj), ptr(self.loss2d), ptr(self.ws), ptr(self.ws2), ptr(self.kp_ws), st))
+        self._kp_chunk = True
+
     def _side_stream(self):
         if not hasattr(self, '_side'):
             self._side = _shared_stream(self.dev, 'side')
@@ -541,16 +553,10 @@ class SequenceEngine(object):
         s2 = side.cuda_stream
 
         def regress_project():
-            jwp = None if self.joint_w is None else self.joint_w.ctypes.data_as(_lib.c_float_p)
             if self.kp_fused and os.environ.get('MHHIP_NO_KPALG') != '1':
-                # the AlphaPose key-points from the pose features and joint transforms the forward left in its workspace:
-                # value, projection, residual AND the term's adjoint (one more chunk of the LBS backward's partial sums)
-                # in one small launch -- no pass over the vertices either way (csrc/mh_keypoints.hip)
-                check(L.mh_keypoint_terms(self.m.handle, B, ptr(self.leaf('poses_T')), Kp, Kdp, jwp, ptr(self.pose2d), self.thr,
-                                          float(self.W), float(self.H), float(c['proj2d']), ptr(self.kp), ptr(self.uv), ptr(self.gj),
-                                          ptr(self.loss2d), ptr(self.ws), ptr(self.ws2), ptr(self.kp_ws), s2))
-                self._kp_chunk = True
+                self.keypoint_terms(s2)
                 return
+            jwp = None if self.joint_w is None else self.joint_w.ctypes.data_as(_lib.c_float_p)
             self._kp_chunk = False
             self._regress(s2)
             check(L.mh_project_joints_loss_w(B, ptr(self.kp), Kp, Kdp, jwp, ptr(self.pose2d), self.thr, 0, float(self.W),
@@ -561,9 +567,18 @@ class SequenceEngine(object):
             # the rasteriser's preparation, which is bound by latency -- then the key-point terms, the contact chain and, when
             # the caller left them to this branch, the leaf-only terms: everything behind the initialisation lands under
             # the selection kernel.  (With the side branch on the launch queue, round 2, the regression had to come first.)
-            fv_first = self.kp_fused
+            # round 4: the key-point launches (operands in L2) and the leaf-only terms go FIRST -- small kernels beside the
+            # rasteriser's preparation -- and the 200 MB of the vertex-gradient initialisation behind them: beside it the
+            # one-workgroup list kernel of the preparation took 38 us instead of 11 (0.719 -> 0.711 ms same-box)
+            order_old = os.environ.get('MHHIP_SIDE_ORDER') == '0'
+            fv_first = self.kp_fused and order_old
+            later = getattr(self, '_leaf_terms_later', None)
+            self._leaf_terms_later = None
             if not fv_first:
                 regress_project()
+                if later is not None and not order_old:
+                    later()
+                    later = None
             with torch.cuda.stream(side):
                 if need_gv:
                     if filt:
@@ -586,8 +601,6 @@ class SequenceEngine(object):
             if fv_first:
                 regress_project()
             self._scene_done = False
-            later = getattr(self, '_leaf_terms_later', None)
-            self._leaf_terms_later = None
             sums = [(self.loss2d, log[0:1]), (self.prior_body, log[3:4])]
             if scene and (self._scene_dev is None or scene_ready):     # static scene, or its event already waited for
                 self._scene_terms(s2, reduce=False)

@@ -198,8 +198,10 @@ int mh_lbs_backward_ex(const mh_model* m, int B, int NB, const float* betas, con
                        float* gposes, float* grotmats, float* gtransl, float* gbetas, float* gxscale,
                        void* ws, void* ws2, void* stream);
 /* adjoint of mh_joints_regress for any of the four regressors (smpl.py:367-386 under autograd; optimizer.py:41, 75, 695-696
- * with another smpl_sparse_joints_key): gverts (B,V,3) += reg^T gjoints; gcorr (B,3) += (1 - row sums) gjoints (NULL
- * when the joints were regressed without a translation correction).  Deterministic (no atomics). */
+ * with another smpl_sparse_joints_key): gverts (B,V,3) += reg^T gjoints; gcorr (B,3) += the EXPLICIT share of the
+ * translation correction: sum_j (1 - rowsum_j) gjoints_j for plain joints, sum_j (1 - rowsum_j + rowsum_root) gjoints_j
+ * for joints relative to a root (the rest of d/dt reaches the translation through gverts).  NULL when the joints were
+ * regressed without a correction.  Deterministic (no atomics). */
 int mh_joints_regress_backward(const mh_model* m, int which, int B, const float* gjoints /*(B,J,3)*/, int root_relative_to,
                                float* gverts, float* gcorr, void* stream);
 

@@ -839,8 +839,11 @@ __global__ __launch_bounds__(64) void k_joints_regress_bwd(int B, int V, int J, 
       q[1] = fmaf(ww, g1, q[1]);
       q[2] = fmaf(ww, g2, q[2]);
     }
-    // d joint / d corr: (1 - rowsum_j) for plain joints; the root-relative form s (J_j - J_root) + t has exactly 1
-    const float c = root >= 0 ? 1.f : 1.f - rowsum[j];
+    // EXPLICIT d joint / d corr (the share the vertices carry, rowsum . t, reaches the translation through gverts):
+    // plain joints get (1 - rowsum_j) t added; the root-relative form subtracts rowsum_j t and the root's
+    // (rowsum_root - 1) t, i.e. 1 - rowsum_j + rowsum_root (this was 1, 3e-4 off on the translation gradient
+    // for regressors whose rows do not sum to exactly one)
+    const float c = root >= 0 ? 1.f - rowsum[j] + rowsum[root] : 1.f - rowsum[j];
     c0 = fmaf(c, gj[j * 3], c0); c1 = fmaf(c, gj[j * 3 + 1], c1); c2 = fmaf(c, gj[j * 3 + 2], c2);
     __threadfence_block();                         // the next joint's row may touch the same vertices
     __builtin_amdgcn_wave_barrier();

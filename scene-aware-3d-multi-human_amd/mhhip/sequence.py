@@ -733,7 +733,11 @@ class SequenceEngine(object):
             scene = (self.scene_pts.data_ptr(), self.scene_grid.data_ptr(), self.scene_M)
         rast = None if raster is None else (raster.ws.data_ptr(), raster.faces.data_ptr())
         bt = None if getattr(self, 'batch_frames', None) is None else self.batch_frames.data_ptr()
-        return (rast, scene, self.verts_filt is not None and self.pT_filt is not None, self.halo is None, bt)
+        # process-wide switches a capture bakes in: the gradient-scatter kernel (mh_raster_set_deterministic picks it at capture
+        # time), the sort margin (a kernel argument by value) and the LBS arithmetic mode
+        L = _lib.lib()
+        glob = (L.mh_raster_get_deterministic(), L.mh_raster_get_sort_margin(), L.mh_lbs_get_mode()) if raster is not None else None
+        return (rast, scene, self.verts_filt is not None and self.pT_filt is not None, self.halo is None, bt, glob)
 
     def raster_terms(self, znear=1.0, zfar=100.0):
         """The engine's rasteriser binding (workspace + face table), created once and kept alive with the engine:

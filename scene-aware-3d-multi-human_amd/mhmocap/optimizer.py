@@ -272,7 +272,15 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
                                xscale=self._bcast(np.asarray(leaves['xscale'], np.float32)))
         self.sh = sharded.ShardedSequence(self.engine, self.first_frame, self.num_frames, group=self.process_group,
                                           enabled=self.shard_frames)
+        # the whole-sequence leaves this engine was built from ARE the gathered copy until the next fit refreshes it (no
+        # collective needed: every rank was handed the same arrays)
         self._global_cache = None
+        if world > 1:
+            T, N = self.num_frames, self.num_people
+            self._global_cache = dict(
+                poses_T=np.array(leaves['poses_T'], np.float32).reshape(T, N, 1, 3), poses_smpl=np.array(leaves['poses_smpl'], np.float32),
+                betas=np.array(self.engine.leaf('betas').cpu().numpy()), zmin_lin=np.array(leaves['zmin_lin'], np.float32),
+                zmax_lin=np.array(leaves['zmax_lin'], np.float32), xscale=np.array(self.engine.leaf('xscale').cpu().numpy()))
         self._engine_batch = int(batch_size)
         self.valid_smpl = torch.tensor(self._valid, device=self.device)
         self._staged = False
@@ -281,8 +289,14 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
         """Whole-sequence leaves.  In a frame-sharded run this is a COLLECTIVE (all_gather over the group): ``fit`` and
         ``init_optimized_variables`` call it on every rank and keep the result, so that ``get_optimized_variables()``
         (``cached=True``) is a local read -- the usual ``if rank == 0: save(opt.get_optimized_variables())`` works."""
-        if cached and self._world()[0] > 1 and self._global_cache is not None:
-            return self._global_cache
+        if cached and self._world()[0] > 1:
+            if self._global_cache is not None:
+                return self._global_cache
+            # no gathered copy (the engine was rebuilt since the last fit / init): gathering HERE would be a collective
+            # inside what is documented as a local read -- a rank-0-only call would hang the job (ADVICE r03)
+            raise RuntimeError('get_optimized_variables() in a frame-sharded run reads the copy gathered at the end of '
+                               'init_optimized_variables() / fit(); there is none since the engine was rebuilt -- call '
+                               'refresh_global_leaves() on EVERY rank first (a collective)')
         g = self._gather_global()
         if self._world()[0] > 1:
             self._global_cache = g
@@ -402,7 +416,17 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
                     alloc(k, a.shape[lead:], a.dtype)
                 store[k][idx] = a
 
-        rng_state = None if direct else torch.get_rng_state()     # this extra pass must not advance the shuffle of cycle 0
+        # this extra pass must not advance the shuffle of cycle 0: the global generator AND the loader's / sampler's own
+        # generators (a DataLoader built with generator= draws its base seed, a RandomSampler with generator= its
+        # permutation, from those -- ADVICE r03)
+        rng_state = None if direct else torch.get_rng_state()
+        own_gens = []
+        if not direct:
+            for holder in (dataloader, getattr(dataloader, 'sampler', None), getattr(dataloader, 'batch_sampler', None),
+                           getattr(getattr(dataloader, 'batch_sampler', None), 'sampler', None)):
+                gen = getattr(holder, 'generator', None)
+                if isinstance(gen, torch.Generator) and all(gen is not g0 for g0, _ in own_gens):
+                    own_gens.append((gen, gen.get_state()))
         if direct:
             # A plain map-style dataset behind the stock collate function: the frames are read from the dataset itself,
             # straight into the staging buffers.  Going through the loader costs a torch.stack per key and batch plus
@@ -420,6 +444,8 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
                 first = False
         if rng_state is not None:
             torch.set_rng_state(rng_state)
+        for gen, state in own_gens:
+            gen.set_state(state)
         if world > 1 and int(bs) != self._engine_batch:
             # block boundaries are multiples of the batch size: re-shard with the dataloader's
             self._build_engine(int(bs), leaves=self._global_leaves())

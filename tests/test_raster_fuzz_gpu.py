@@ -6,6 +6,8 @@ of scenes: 300 of them had no real difference.)"""
 import numpy as np
 import pytest
 
+from parity_gates import two_precision_gate
+
 import test_raster_gpu as tr
 
 pytestmark = pytest.mark.gpu
@@ -32,7 +34,8 @@ def test_random_scenes_differ_from_the_brute_force_selection_only_in_near_ties(s
 @pytest.mark.parametrize('seed', [303, 404])
 def test_random_scenes_gradients_against_the_oracle_at_both_precisions(smpl_struct, smpl_regs, seed):
     """dL/dverts, the depth-range gradients and the loss values of both rasterised terms against the oracle evaluated on the
-    HIP selection in FLOAT64 and in float32; an entry of dL/dverts is right when it agrees with either.  Neither precision is
+    HIP selection in FLOAT64 and in float32; an entry of dL/dverts is held against float64 first; the few
+    that miss it must agree with float32 and are counted (tests/parity_gates.py).  Neither precision is
     the truth everywhere: on faces of a fraction of a pixel the float32 autograd of the oracle is up to 1e-3 (of the largest
     entry) away from its float64 self where the kernel is not; and where a pixel centre lies within rounding of a face's edge
     the float32 rasteriser -- the reference's, the oracle's, the kernel's -- decides one way and float64 the other (one face
@@ -42,7 +45,7 @@ def test_random_scenes_gradients_against_the_oracle_at_both_precisions(smpl_stru
     Jacobian, pixel centres without fused multiply-add -- the same kind of scene had up to 6e-3 on 16 entries.)"""
     import torch
     rng = np.random.RandomState(seed)
-    nonzero = 0
+    nonzero = second = entries = 0
     for c in range(6):
         W, H = [(96, 54), (64, 96), (80, 80), (160, 90), (48, 135), (240, 135)][rng.randint(6)]
         T, N = int(rng.randint(1, 3)), int(rng.randint(2, 4))
@@ -58,13 +61,15 @@ def test_random_scenes_gradients_against_the_oracle_at_both_precisions(smpl_stru
             continue
         nonzero += 1
         r32 = tr._run_case(smpl_struct, smpl_regs, T, N, W, H, scene_seed, zlo=zlo, zhi=zhi, fov=fov, hip_selection=True)
-        err = np.minimum(np.abs(g - w), np.abs(g - r32['want_gv'].astype(np.float64))) / scale
         where = 'scene %d (%dx%d, T %d, N %d, z %.1f-%.1f, fov %.0f)' % (c, W, H, T, N, zlo, zhi, fov)
-        assert err.max() <= 2e-4, '%s: max %.2e, %d entries > 1e-4' % (where, err.max(), int((err > 1e-4).sum()))
+        worst, n32 = two_precision_gate(g, r32['want_gv'], w, 2e-4, where)
+        second += n32
+        entries += g.size
         np.testing.assert_allclose(r['depth'], r['want_depth'], rtol=2e-4, atol=1e-7, err_msg=where)
         np.testing.assert_allclose(r['sil'], r['want_sil'], rtol=2e-4, atol=1e-7, err_msg=where)
         for k in ('gzmin', 'gzmax'):
             np.testing.assert_allclose(r[k], r['want_' + k], atol=2e-4 * max(np.abs(r['want_' + k]).max(), 1e-12), err_msg=where)
+    print('%d of %d entries of dL/dverts needed the float32 oracle' % (second, entries))
     assert nonzero >= 4
 
 

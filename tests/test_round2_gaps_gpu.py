@@ -519,3 +519,37 @@ def test_body_model_constants_are_shared_per_content_and_device(smpl_struct, smp
     betas, poses = torch.zeros(2, 10), torch.zeros(2, 72)
     va, vd = a(betas=betas, poses=poses)['verts'], d(betas=betas, poses=poses)['verts']
     assert abs(float((vd - va)[0, 5, 1]) - 1e-3) < 1e-6
+
+
+def test_root_relative_regression_passes_the_whole_translation_gradient(smpl_struct, smpl_regs):
+    """joints relative to a root come out as s (J_j - J_root) + t, so d joints / d t is the identity and the
+    translation gradient of ANY function of them is the plain sum of the joint adjoints.  The adjoint kernel splits it in two:
+    what the vertices carry (rowsum . t, through gverts, which the LBS backward sums into the translation) and the explicit
+    share of the correction argument, 1 - rowsum_j + rowsum_root -- which was coded as 1 (3e-4 off for J_regressor_h36m17,
+    whose rows sum to 0.9996..1.00005).  Here with a regressor whose rows are deliberately far from one."""
+    import ctypes
+    from mhhip import engine, _lib
+    from mhhip._lib import check, ptr
+    regs = dict(smpl_regs)
+    rng = np.random.RandomState(3)
+    h36 = np.array(regs['h36m'], np.float32).copy()
+    h36 *= rng.uniform(0.8, 1.25, (h36.shape[0], 1)).astype(np.float32)          # rows no longer sum to one
+    regs['h36m'] = h36
+    m = engine.BodyModel(smpl_struct, regs)
+    B, V = 6, m.V
+    verts = torch.tensor(rng.normal(0, 1, (B, V, 3)).astype(np.float32)).cuda()
+    t = torch.tensor(rng.normal(0, 2, (B, 3)).astype(np.float32)).cuda()
+    gj = torch.tensor(rng.normal(0, 1, (B, 17, 3)).astype(np.float32)).cuda()
+    for root in (14, -1):
+        gv = torch.zeros(B, V, 3, device='cuda')
+        gc = torch.zeros(B, 3, device='cuda')
+        check(_lib.lib().mh_joints_regress_backward(m.handle, engine.REG_H36M17, B, ptr(gj), root, ptr(gv), ptr(gc), _lib.stream_ptr(m.device)))
+        torch.cuda.synchronize()
+        total = (gc + gv.sum(dim=1)).cpu().numpy()          # d/dt with verts = x + t: explicit share + what the vertices carry
+        want = gj.sum(dim=1).cpu().numpy()                   # identity Jacobian in both forms (plain joints: J_j(x) + t)
+        np.testing.assert_allclose(total, want, rtol=0, atol=2e-5 * np.abs(want).max(), err_msg='root %d' % root)
+        # and the forward agrees with that Jacobian: moving t by d moves every joint by d
+        j0 = m.joints_regress(engine.REG_H36M17, verts + t[:, None], corr=t, root=root)
+        d = torch.tensor([0.25, -0.5, 0.125], device='cuda')
+        j1 = m.joints_regress(engine.REG_H36M17, verts + (t + d)[:, None], corr=t + d, root=root)
+        np.testing.assert_allclose((j1 - j0).cpu().numpy(), np.broadcast_to(d.cpu().numpy(), (B, 17, 3)), atol=2e-5)

@@ -171,7 +171,7 @@ def main():
     ap.add_argument('--image', type=str, default=None)
     ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl', help='nccl = RCCL over xGMI (the measured '
                     'configuration).  gloo: DRY RUN of the multi-rank path -- every collective staged through host memory '
-                    '(mhhip/hostdist.py); with --one-device all ranks share cuda:0, so the N-rank orchestration (halos, '
+                    '(tests/hostdist.py); with --one-device all ranks share cuda:0, so the N-rank orchestration (halos, '
                     'all-reduce, filter hand-off) can be executed on a 1-GPU box.  Its numbers are not scaling results.')
     ap.add_argument('--one-device', action='store_true', help='every rank uses cuda:0 (only with --backend gloo)')
     ap.add_argument('--presteps', type=int, default=300, help='untimed steady-state cycles before the warm-up')
@@ -203,7 +203,8 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
         else:
             dist.init_process_group('gloo')
-            from mhhip import hostdist
+            sys.path.insert(0, os.path.join(ROOT, 'tests'))
+            import hostdist                    # test infrastructure (tests/hostdist.py), only reachable through this dry-run switch
             dist = hostdist.install()          # host-staged collectives for the driver, the drop-in and this file
     device = 'cuda:%d' % dev_index
     torch.cuda.set_device(dev_index)

@@ -34,22 +34,19 @@ except Exception:  # pragma: no cover
 
 class SMPLOptimizerBase(object):
     """reference optimizer.py:32-143"""
+    _needs_hip = True          # there is no CPU path (tests/cpu_shard_engine.py subclasses this for the gloo orchestration tests)
 
     def __init__(self, device=None, smpl_model_parameters_path='model_data/parameters',
                  smpl_J_reg_extra_path='J_regressor_extra.npy', smpl_J_reg_h37m_path='J_regressor_h36m.npy',
                  smpl_J_reg_alphapose_path='SMPL_AlphaPose_Regressor_RMSprop_6.npy',
                  smpl_sparse_joints_key='joints_alphapose', pose24j_weights=None, pose17j_weights=None,
-                 smpl_data_struct=None, engine_factory=None):
-        # engine_factory: test hook of the frame-sharded orchestration (tests/test_fit_sharded_cpu.py plugs a torch-CPU
-        # stand-in with SequenceEngine's interface under the gloo backend); the product never passes it, and without
-        # it a HIP device is mandatory
-        self._engine_factory = engine_factory
+                 smpl_data_struct=None):
         if device is None:
             if not torch.cuda.is_available():
                 raise RuntimeError('the MI355X build of mhmocap.optimizer needs a HIP device (no CPU fallback)')
             device = 'cuda:0'
         self.device = torch.device(device)
-        if self.device.type != 'cuda' and engine_factory is None:
+        if self.device.type != 'cuda' and self._needs_hip:
             raise RuntimeError('the MI355X build of mhmocap.optimizer needs a HIP device, got %s' % device)
         self.smpl_model_parameters_path = os.path.abspath(smpl_model_parameters_path)
         p = lambda f: os.path.join(smpl_model_parameters_path, f)
@@ -245,6 +242,12 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
         self.verts_filtered = None
         return init_log
 
+    def _make_engine(self, **kw):
+        """the device-resident state of this rank's frames.  (The gloo tests of the frame-sharded orchestration subclass the
+        optimiser in tests/cpu_shard_engine.py and return a torch-CPU stand-in with the same interface here; nothing in the
+        product does.)"""
+        return SequenceEngine(self.SMPLPY.body_model, **kw)
+
     def _build_engine(self, batch_size, leaves=None):
         """(Re)build the engine for this rank's frames.  ``leaves``: whole-sequence arrays (default: the initial ones)."""
         from mhhip import sharded
@@ -262,10 +265,7 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
                   joint_weights=self._joint_w)
         if self._joints_reg[0] != engine.REG_ALPHAPOSE:
             kw['joints_reg'] = self._joints_reg
-        if self._engine_factory is not None:
-            self.engine = self._engine_factory(**kw)
-        else:
-            self.engine = SequenceEngine(self.SMPLPY.body_model, **kw)
+        self.engine = self._make_engine(**kw)
         self.engine.set_leaves(poses_T=np.asarray(leaves['poses_T'])[sl], poses_smpl=np.asarray(leaves['poses_smpl'])[sl],
                                betas=self._bcast(np.asarray(leaves['betas'], np.float32)),
                                zmin_lin=np.asarray(leaves['zmin_lin'])[sl], zmax_lin=np.asarray(leaves['zmax_lin'])[sl],

@@ -302,3 +302,16 @@ class CpuShardEngine(object):
         nb = float(nbatches_total or self.nbatches)
         return [{'loss_pose24j': r[0] / nb, 'reg_ref_poses': (r[3] + r[9]) / nb, 'reg_scale': r[10] + r[11],
                  'reg_vel': r[7], 'reg_filter_verts': r[8]} for r in raw]
+
+
+def cpu_optimizer_class(model):
+    """the drop-in optimiser with the torch-CPU stand-in above as its engine: what the gloo tests of the frame-sharded
+    orchestration construct (the product class refuses a non-HIP device and always builds a ``SequenceEngine``)"""
+    from mhmocap.optimizer import SMPLDepthSequenceOptimizer
+
+    class CpuShardOptimizer(SMPLDepthSequenceOptimizer):
+        _needs_hip = False
+
+        def _make_engine(self, **kw):
+            return CpuShardEngine.factory(model)(**kw)
+    return CpuShardOptimizer

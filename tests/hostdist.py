@@ -1,4 +1,5 @@
-"""``torch.distributed`` with every tensor operation staged through host memory.
+"""TEST INFRASTRUCTURE (moved out of the product package in round 4): ``torch.distributed`` with every tensor operation
+staged through host memory.
 
 The frame-sharded driver (mhhip/sharded.py) talks to ``torch.distributed`` directly; on the 8-GPU node that is RCCL over
 xGMI (backend "nccl").  The ``gloo`` backend only carries device tensors for broadcast / all_reduce, and RCCL refuses
@@ -63,7 +64,7 @@ def host_staged():
 
 def install():
     """route the sharded driver and the drop-in optimiser through the host-staged operations; returns the shim"""
-    from . import sharded
+    from mhhip import sharded
     import mhmocap.optimizer as mo
     shim = host_staged()
     sharded.dist = shim

@@ -4,7 +4,7 @@ whole-sequence inputs, keeps its contiguous block of frames (block boundaries at
 shape / scale leaves are broadcast from rank 0, each cycle exchanges the halos and all-reduces the shared gradient
 tail (mhhip/sharded.py), the one-euro filter state is handed rank 0 -> 1, ``get_optimized_variables`` gathers the
 whole sequence on every rank.  The compute engine is the torch-CPU stand-in of tests/cpu_shard_engine.py (raster-free
-terms), plugged through the optimiser's ``engine_factory`` test hook; the HIP engine runs the same driver
+terms), plugged in by subclassing the optimiser (tests/cpu_shard_engine.py::cpu_optimizer_class); the HIP engine runs the same driver
 (tests/test_sharded_gpu.py)."""
 import os
 import sys
@@ -58,15 +58,14 @@ class _DS(torch.utils.data.Dataset):
 def _run_fit(tmp):
     """the caller's view: exactly what predict.py does with the optimiser (predict.py:290-306, 332-347)"""
     st, regs, sp, K, pose2d = _inputs()
-    from cpu_shard_engine import CpuShardEngine
-    from mhmocap.optimizer import SMPLDepthSequenceOptimizer
+    from cpu_shard_engine import cpu_optimizer_class
     from oracle import lbs_oracle as lo
     for k, fn in [('extra9', 'J_regressor_extra.npy'), ('h36m', 'J_regressor_h36m.npy'),
                   ('alphapose', 'SMPL_AlphaPose_Regressor_RMSprop_6.npy')]:
         np.save(os.path.join(tmp, fn), regs[k])
     model = lo.BodyModel(st, regs)
-    opt = SMPLDepthSequenceOptimizer(image_size=(W, H), num_frames=T, cam_K=K, device='cpu', smpl_model_parameters_path=tmp,
-                                     smpl_data_struct=st, engine_factory=CpuShardEngine.factory(model), use_rasteriser=False,
+    opt = cpu_optimizer_class(model)(image_size=(W, H), num_frames=T, cam_K=K, device='cpu', smpl_model_parameters_path=tmp,
+                                     smpl_data_struct=st, use_rasteriser=False,
                                      scene_update='none', use_graphs=False, shard_frames=True, **COEFS)
     opt.init_optimized_variables(pose2d, sp['poses_init'], sp['betas_init'], sp['valid'], num_iter=0)
     # a start away from the [0,0,1] of a skipped warm-up: the ground-truth translations, local slice per rank

@@ -26,7 +26,7 @@ def _paths():
 def _host_staged_dist():
     """torch.distributed with the tensor ops going through the host (gloo has no GPU all_gather / send / recv)"""
     _paths()
-    from mhhip import hostdist
+    import hostdist
     return hostdist.host_staged()
 
 

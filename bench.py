@@ -175,6 +175,8 @@ def main():
                     'all-reduce, filter hand-off) can be executed on a 1-GPU box.  Its numbers are not scaling results.')
     ap.add_argument('--one-device', action='store_true', help='every rank uses cuda:0 (only with --backend gloo)')
     ap.add_argument('--presteps', type=int, default=300, help='untimed steady-state cycles before the warm-up')
+    ap.add_argument('--dump-leaves', type=str, default=None, help='(parity tests) save the whole-sequence leaves after the timed '
+                    'region to this .npz (a collective in multi-rank runs; rank 0 writes)')
     args = ap.parse_args()
     global N_PEOPLE, T_LOCAL, IMG
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -265,6 +267,25 @@ def main():
         nstep[0] += 1
 
     use_graphs = not args.eager
+    grad0 = None
+    if args.dump_leaves:
+        # (parity tests) the gradient of one UNSTEPPED cycle at the initial variables, whole sequence: identical inputs in a
+        # one-process and an N-rank run (later cycles are not: RMSprop's sign-like first steps amplify rounding noise)
+        from mhhip.raster import set_deterministic
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()        # --one-device dry runs: no rank may still be starting up (a launch that coincides with
+            time.sleep(1.0)       # another PROCESS' start-up on the same GPU has shown a handful of corrupted selection keys)
+            dist.barrier()
+        old_det = set_deterministic(True)
+        sh.cycle(0, raster=raster, graphs=False)
+        set_deterministic(old_det)
+        tail = e.grads[e.shared_lo:].clone()
+        if world > 1:
+            dist.all_reduce(tail, op=dist.ReduceOp.SUM)
+        grad0 = {'grad0_' + k: opt._gather_frames(e.leaf(k, e.grads)) for k in ('poses_T', 'poses_smpl', 'zmin_lin', 'zmax_lin')}
+        grad0['grad0_tail'] = tail.cpu().numpy()
+        e.grads.zero_()
     # bring the device to its steady state before the W warm-up steps: graph capture, lazy allocations, and enough
     # back-to-back work for the clocks to ramp (a fresh box that idled through the CPU-side set-up was once measured
     # at 0.57x for the first tens of milliseconds)
@@ -289,6 +310,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         opt.check_replicas()
+    if args.dump_leaves:
+        opt._global_cache = None
+        g_all = opt._global_leaves()              # collective
+        if rank == 0:
+            np.savez(args.dump_leaves, **{k: np.asarray(v) for k, v in g_all.items()}, **grad0)
     nsteps_org = min(args.steps, 50)
     # the same cycles with the device-side scene aggregation of optimizer.py:578-584 running every cycle (reported
     # beside the headline, which uses the injected static scene BASELINE.json's C3 names)

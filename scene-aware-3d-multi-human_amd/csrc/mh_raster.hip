@@ -862,6 +862,11 @@ __device__ __forceinline__ void r_tile_depth_sums(const RasterP& p, int s, int b
 }
 
 #define RW (RB / 64)         // waves per tile workgroup
+#ifdef R_SYNC_HARD
+#define R_WAVE_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+#else
+#define R_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
 #ifndef RPL
 #define RPL 512              // pair descriptors per wave and round (sub-pixel face path)
 #endif
@@ -1059,7 +1064,7 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
             int pos = kincl - nk;
             for (unsigned m = keepm; m; m &= m - 1u) pl[pos++] = (unsigned short)(lane | ((__ffs((int)m) - 1) << 6));
           }
-          __builtin_amdgcn_wave_barrier();
+          R_WAVE_SYNC();
           for (int i = lane; i < nkeep; i += 64) {
             const unsigned e = pl[i], lo = e & 63u, k = e >> 6;
             const unsigned d = (unsigned)desc[lo], fw = (unsigned)fid[lo];
@@ -1074,21 +1079,21 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
             r_eval_fast(T, sXf[xi], sYf[yi], &pz, &inside, &dd);
             r_insert((unsigned long long*)((char*)keys + __umul24(__umul24(yi, (unsigned)tw) + xi, 40u)), pz, inside, dd, (int)(fw & 0xfffffu));
           }
-          __builtin_amdgcn_wave_barrier();
+          R_WAVE_SYNC();
         } else if (npairs > 0) {
           // ---- larger faces: the pairs are split evenly over the lanes, every lane walks a contiguous run ----------
           n_cand += (unsigned)npairs; n_eval += (unsigned)npairs;
           pre[lane] = excl;
           if (lane == 63) pre[64] = npairs;
           mark[lane] = -1;
-          __builtin_amdgcn_wave_barrier();
+          R_WAVE_SYNC();
           // run start -> face: face o opens at the first lane whose run starts at or after pre[o]
           const int per = (npairs + 63) >> 6;
           if (cnt > 0) {
             const int tf = (excl + per - 1) / per;
             if (tf < 64) atomicMax(&mark[tf], lane);
           }
-          __builtin_amdgcn_wave_barrier();
+          R_WAVE_SYNC();
           int lo = r_wave_scan_max(mark[lane]);
           const int j0 = lane * per, j1 = min(j0 + per, npairs);
           if (j0 < j1) {
@@ -1120,7 +1125,7 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
               }
             }
           }
-          __builtin_amdgcn_wave_barrier();
+          R_WAVE_SYNC();
         }
         // ---- rotate the pipeline ----------------------------------------------------------------------------------
         e_a = e_b; e_b = e_c; e_c = e_n;

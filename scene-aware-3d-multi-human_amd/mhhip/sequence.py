@@ -440,6 +440,40 @@ class SequenceEngine(object):
         check(_lib.lib().mh_joints_regress(self.m.handle, self.joints_reg[0], self.B, ptr(self.verts),
                                            ptr(self.leaf('poses_T')), self.joints_reg[1], ptr(self.kp), st))
 
+    def _halo_forward(self, h, st):
+        """Frame-sharded run: the vertices of the neighbours' boundary frames (filtered-vertex term, optimizer.py:571-573)
+        are skinned HERE from those frames' leaves -- 75 N floats per frame that arrive with the cycle's one all-reduce
+        (mhhip/sharded.py) -- instead of being exchanged as 83 KB x N of vertices in the middle of the cycle: one small
+        launch pair in the side branch, no communication between the forward and the term that reads its result, the whole
+        cycle one graph.  Same kernel, same inputs as on the owning rank: the same bits.
+        h['poses'] (Bh,72) / h['transl'] (Bh,3): [previous rank's last frame (N) | next rank's first frame (N)], a missing
+        side left out."""
+        Bh = int(h['poses'].shape[0])
+        if getattr(self, '_halo_verts', None) is None or self._halo_verts.shape[0] != Bh:
+            self._halo_verts = torch.empty(Bh, self.V, 3, dtype=torch.float32, device=self.dev)
+            self._halo_ws = self.m.workspace(Bh)
+        check(_lib.lib().mh_lbs_forward(self.m.handle, Bh, self.N, ptr(self.leaf('betas')), ptr(h['poses']), ptr(self.leaf('xscale')),
+                                        ptr(h['transl']), ptr(self._halo_verts), None, None, ptr(self._halo_ws), st))
+        k = 0
+        h['v_prev'] = h['v_next'] = None
+        if h.get('has_prev'):
+            h['v_prev'] = self._halo_verts[:self.N]
+            k = self.N
+        if h.get('has_next'):
+            h['v_next'] = self._halo_verts[k:k + self.N]
+
+    def step_local(self, lr, alpha=0.5, momentum=0.9, eps=1e-8):
+        """RMSprop on the per-frame leaves only (frame-sharded run: they need no other rank's gradients; the shared tail
+        follows the all-reduce, ``step_shared``)"""
+        self._wait_scene_snapshot()
+        self._flush_log()
+        lo = self.shared_lo
+        engine.rmsprop_step(self.params[:lo], self.grads[:lo], self.sq[:lo], self.buf[:lo], float(lr), alpha, momentum, eps)
+
+    def step_shared(self, lr, alpha=0.5, momentum=0.9, eps=1e-8):
+        lo = self.shared_lo
+        engine.rmsprop_step(self.params[lo:], self.grads[lo:], self.sq[lo:], self.buf[lo:], float(lr), alpha, momentum, eps)
+
     def keypoint_terms(self, st):
         """The 2D term of the AlphaPose key-points from the pose features and joint transforms the forward left in its
         workspace: value, projection, residual AND the term's adjoint (one more chunk of the LBS backward's partial sums) in
@@ -461,7 +495,7 @@ class SequenceEngine(object):
     def cycle(self, row, use_images=True, raster=None):
         # the same launch order as the captured form (cycle_graphed): the sums of a cycle are then added in the same order
         # either way, and eager and replayed fits stay bit-identical (deterministic mode) until something else differs
-        nj = raster is not None and use_images and self.has_images and self.halo is None
+        nj = raster is not None and use_images and self.has_images
         self.cycle_begin(join=not nj, raster=raster if (use_images and self.has_images) else None)
         self.cycle_finish(row, use_images, raster)
 
@@ -580,6 +614,8 @@ class SequenceEngine(object):
                     later()
                     later = None
             with torch.cuda.stream(side):
+                if need_gv and filt and h.get('poses') is not None:
+                    self._halo_forward(h, s2)
                 if need_gv:
                     if filt:
                         E = N * self.V * 3
@@ -737,7 +773,8 @@ class SequenceEngine(object):
         # time), the sort margin (a kernel argument by value) and the LBS arithmetic mode
         L = _lib.lib()
         glob = (L.mh_raster_get_deterministic(), L.mh_raster_get_sort_margin(), L.mh_lbs_get_mode()) if raster is not None else None
-        return (rast, scene, self.verts_filt is not None and self.pT_filt is not None, self.halo is None, bt, glob)
+        hk = None if self.halo is None else (bool(self.halo.get('has_prev')), bool(self.halo.get('has_next')), self.halo.get('poses') is not None)
+        return (rast, scene, self.verts_filt is not None and self.pT_filt is not None, hk, bt, glob)
 
     def raster_terms(self, znear=1.0, zfar=100.0):
         """The engine's rasteriser binding (workspace + face table), created once and kept alive with the engine:
@@ -782,7 +819,7 @@ class SequenceEngine(object):
             # static scene.  (Until late in round 2 the cycle was split in two graphs at the contact chain: a graph
             # boundary of ~30 us and the chain on the critical path.)
             def body_org():
-                nj = raster is not None and self.has_images and self.halo is None
+                nj = raster is not None and self.has_images
                 self.cycle_begin(join=not nj, raster=raster if self.has_images else None)
                 self.cycle_finish(None, raster=raster, scene_ready=True)
             self.replay(('full+scene',) + key, body_org)
@@ -792,7 +829,7 @@ class SequenceEngine(object):
             def body():
                 # nothing of the rasteriser's selection half reads what the leaf-only terms of the side branch write: with
                 # gradients asked for, the one join in front of the gradient half covers them
-                nj = raster is not None and self.has_images and self.halo is None
+                nj = raster is not None and self.has_images
                 self.cycle_begin(join=not nj, raster=raster if self.has_images else None)
                 self.cycle_finish(None, raster=raster)
             self.replay(('full',) + key, body)

@@ -2,17 +2,22 @@
 contiguous blocks (block boundaries at multiples of the batch size so the in-batch terms are
 unchanged), per-frame leaves and inputs local to their rank.
 
-Per cycle the ranks exchange, over ``torch.distributed`` (backend "nccl" == RCCL on ROCm, xGMI):
+Per cycle the ranks exchange, over ``torch.distributed`` (backend "nccl" == RCCL on ROCm, xGMI), ONE all-reduce (sum):
 
-  * ONE all-reduce (sum) of the gradient tail of the shared leaves ``betas (N,10) | xscale (N)``
-    -- 11*N floats, latency-bound -- after which every rank applies the identical RMSprop step to
-    its replica of those leaves;
-  * the boundary frame of ``poses_T`` with both neighbours (velocity term, optimizer.py:560), and,
-    once the one-euro filters exist (cycle >= 50), the boundary frame's vertices (filtered-vertex
-    term, optimizer.py:571-573) -- exchanged point-to-point with the two neighbours;
-  * every 25 cycles the one-euro filter state (filtered value + filtered derivative of the last
-    local frame) is handed rank k -> k+1, because the filter is sequential in time
-    (optimizer.py:664-675).
+  * the gradient tail of the shared leaves ``betas (N,10) | xscale (N)`` -- 11*N floats -- after which every rank applies
+    the identical RMSprop step to its replica of those leaves;
+  * riding in the same message (round 4), every rank's two BOUNDARY frames of the per-frame leaves ``poses_T | poses_smpl``
+    (75*N floats per frame, each rank fills its own slots, the others' are zero: the sum is a gather) as they are AFTER this
+    cycle's update -- the per-frame leaves need no other rank's gradients, so they are stepped before the all-reduce.  The
+    next cycle's temporal terms read them: the velocity term the neighbour's translations (optimizer.py:560), the
+    filtered-vertex term (:571-573) the neighbour's boundary VERTICES, which the rank skins itself from those leaves
+    (``SequenceEngine._halo_forward``: one small launch pair in the side branch, bit-identical to the owner's).
+    Rounds 1-3 exchanged the 83 KB x N of vertices point-to-point in the MIDDLE of the cycle, which split the cycle into
+    two graph replays with the exchange on the critical path; now the cycle is one graph and nothing is communicated
+    between its first kernel and its last.
+  * every 25 cycles the one-euro filter state (filtered value + filtered derivative of the last local frame) is handed
+    rank k -> k+1, because the filter is sequential in time (optimizer.py:664-675), and the filtered boundary vertices
+    go to the neighbours once (point-to-point; outside the cycles).
 
 The reference has no distributed path at all; this file is new functionality and is
 parity-tested against the single-process run.  The compute engine is duck-typed (``SequenceEngine``
@@ -50,6 +55,8 @@ class ShardedSequence(object):
         self.is_last = self.first_frame + engine.T >= self.total_frames
         self._vf_halo = None
         self._hbuf = {}
+        self._halo = None             # static halo tensors handed to the engine (world > 1)
+        self._halo_ok = False         # False: the neighbours' boundary leaves must be (re-)gathered before the next cycle
 
     # -- neighbour exchange: the last frame goes to the next rank, the first frame to the previous one -------------------
     # (point-to-point over xGMI: an all_gather of the boundary vertices would move world x 660 KB to every rank for the two
@@ -87,9 +94,83 @@ class ShardedSequence(object):
         buf.copy_(t)
         return buf
 
+    # -- the one message of a cycle: [ gradient tail of betas | xscale (11 N) | world x 2 boundary frames x N x (3 + 72) ] ------
+    def _bufs(self):
+        e = self.e
+        if getattr(self, '_ar', None) is None:
+            N = e.N
+            dev = e.params.device
+            self._nt = int(e.params.numel() - e.shared_lo)
+            self._slot = 2 * N * 75
+            self._ar = torch.zeros(self._nt + self.world * self._slot, dtype=torch.float32, device=dev)
+            nh = (0 if self.is_first else N) + (0 if self.is_last else N)
+            self._halo = dict(has_prev=not self.is_first, has_next=not self.is_last,
+                              poses=torch.zeros(nh, 72, dtype=torch.float32, device=dev) if nh else None,
+                              transl=torch.zeros(nh, 3, dtype=torch.float32, device=dev) if nh else None,
+                              pT_prev=None, pT_next=None, vf_prev=None, vf_next=None)
+            k = 0
+            if not self.is_first:
+                self._halo['pT_prev'] = self._halo['transl'][:N]
+                k = N
+            if not self.is_last:
+                self._halo['pT_next'] = self._halo['transl'][k:k + N]
+        return self._ar
+
+    def _slot_of(self, r):
+        N = self.e.N
+        o = self._nt + r * self._slot
+        return self._ar[o:o + self._slot].view(2, N, 75)          # [first frame | last frame][person][pT(3) | pose(72)]
+
+    def _pack(self, with_grads=True):
+        """own boundary leaves (and the shared gradient tail) into the message; everybody else's slots zero"""
+        e, ar = self.e, self._ar
+        ar.zero_()
+        if with_grads:
+            ar[:self._nt].copy_(e.grads[e.shared_lo:])
+        pT, ps = e.leaf('poses_T'), e.leaf('poses_smpl')
+        own = self._slot_of(self.rank)
+        own[0, :, :3].copy_(pT[0]); own[0, :, 3:].copy_(ps[0])
+        own[1, :, :3].copy_(pT[-1]); own[1, :, 3:].copy_(ps[-1])
+
+    def _unpack(self, with_grads=True):
+        e, h, N = self.e, self._halo, self.e.N
+        if with_grads:
+            e.grads[e.shared_lo:].copy_(self._ar[:self._nt])
+        k = 0
+        if not self.is_first:
+            prev = self._slot_of(self.rank - 1)[1]                # the previous rank's LAST frame
+            h['transl'][:N].copy_(prev[:, :3]); h['poses'][:N].copy_(prev[:, 3:])
+            k = N
+        if not self.is_last:
+            nxt = self._slot_of(self.rank + 1)[0]                 # the next rank's FIRST frame
+            h['transl'][k:k + N].copy_(nxt[:, :3]); h['poses'][k:k + N].copy_(nxt[:, 3:])
+
+    def _run(self, key, fn, graphs):
+        """a fixed sequence of small copies on static buffers: through the engine's captured-graph facility when it has one"""
+        if graphs and hasattr(self.e, 'replay'):
+            self.e.replay(key, fn, wait_scene=False)
+        else:
+            fn()
+
+    def refresh_halo(self):
+        """COLLECTIVE: gather the neighbours' boundary leaves as they are now (first cycle of a fit; after the leaves were
+        set from outside).  Inside a fit every cycle's all-reduce carries them."""
+        if self.world == 1:
+            return
+        self._bufs()
+        self._pack(with_grads=False)
+        dist.all_reduce(self._ar, op=dist.ReduceOp.SUM, group=self.group)
+        self._unpack(with_grads=False)
+        self._halo_ok = True
+
+    def leaves_changed(self):
+        """the per-frame leaves were written from outside a cycle (set_leaves, a test): the next cycle re-gathers the halos"""
+        self._halo_ok = False
+
     def cycle(self, row, raster=None, graphs=False, scene_update=False):
         """scene_update (single process only): launch the device-side scene update of this cycle from inside
-        ``cycle_graphed``; the frame-sharded form calls ``scene_update()`` itself before the cycle"""
+        ``cycle_graphed``; the frame-sharded form calls ``scene_update()`` itself before the cycle.
+        Frame-sharded: the cycle itself communicates nothing -- ``step`` does (one all-reduce)."""
         e = self.e
         if self.world == 1:
             e.halo = None
@@ -100,32 +181,42 @@ class ShardedSequence(object):
                     e.scene_device_update()
                 e.cycle(row, raster=raster)
             return
-        halo = {}
-        pp, pn = self._gather_boundaries(e.leaf('poses_T'))
-        halo['pT_prev'], halo['pT_next'] = self._static('pT_prev', pp), self._static('pT_next', pn)
-        e.halo = halo                      # the velocity term runs inside cycle_begin, beside the forward
-        if graphs:
-            e.replay(('begin',), e.cycle_begin)
+        self._bufs()
+        if not self._halo_ok:
+            self.refresh_halo()
+        h = self._halo
+        h['vf_prev'], h['vf_next'] = self._vf_halo if self._vf_halo is not None else (None, None)
+        e.halo = h
+        self._graphs = bool(graphs)
+        if graphs and hasattr(e, 'cycle_graphed'):
+            e.cycle_graphed(row, raster=raster)                   # ONE graph replay; the log row travels with the next step
         else:
-            e.cycle_begin()
-        if e.verts_filt is not None and e.pT_filt is not None:
-            vp, vn = self._gather_boundaries(e.verts.view(e.T, -1))
-            halo['v_prev'], halo['v_next'] = self._static('v_prev', vp), self._static('v_next', vn)
-            halo['vf_prev'], halo['vf_next'] = self._vf_halo
-        e.halo = halo
-        if graphs:
-            e.replay(('finish',) + e._graph_key(raster), lambda: e.cycle_finish(None, raster=raster))
-            e.log[row].copy_(e.tmp_log)
-        else:
-            e.cycle_finish(row, raster=raster)
-        dist.all_reduce(e.grads[e.shared_lo:], op=dist.ReduceOp.SUM, group=self.group)
+            e.cycle(row, raster=raster)
 
     def step(self, lr=None):
-        """lr given: host-side schedule; lr None: the device-resident schedule (graph friendly)"""
+        """lr given: host-side schedule; lr None: the device-resident schedule (single process only).
+        Frame-sharded: per-frame leaves first (local gradients only), then THE all-reduce of the cycle -- shared gradient
+        tail + everybody's updated boundary leaves -- then the shared leaves."""
+        e = self.e
+        if self.world == 1:
+            if lr is None:
+                e.step_dev()
+            else:
+                e.step(lr)
+            return
         if lr is None:
-            self.e.step_dev()
-        else:
-            self.e.step(lr)
+            # the device-resident schedule of step_dev (lr0 = 0.01, x 0.99 per step, in float32), kept on the host here
+            if getattr(self, '_lr32', None) is None:
+                self._lr32 = np.float32(0.01)
+            lr = float(self._lr32)
+            self._lr32 = np.float32(self._lr32 * np.float32(0.99))
+        g = getattr(self, '_graphs', False)
+        e.step_local(lr)
+        self._run(('shard_pack',), self._pack, g)
+        dist.all_reduce(self._ar, op=dist.ReduceOp.SUM, group=self.group)
+        self._run(('shard_unpack',), self._unpack, g)
+        e.step_shared(lr)
+        self._halo_ok = True
 
     # -- one-euro filters with the state handed down the ranks (optimizer.py:383-392) ----------------
     def _scan(self, x, c, b):

@@ -188,6 +188,7 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
     def refresh_global_leaves(self):
         """collective: re-gather the whole-sequence leaves get_optimized_variables() serves (frame-sharded run only)"""
         self._global_cache = None
+        self.sh.leaves_changed()
         return self._global_leaves()
 
     def check_replicas(self):
@@ -543,6 +544,7 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
         lr = 0.01                                                             # a new RMSprop + ExponentialLR per fit (:355-356):
         e.sq.zero_()                                                          # ... its running squares and momentum buffers
         e.buf.zero_()                                                         # start at zero in EVERY call
+        sh.leaves_changed()                                                   # (sharded: the first cycle gathers the neighbours' boundary leaves)
         cycles = range(num_iter)
         if verbose and tqdm is not None and rank == 0:
             cycles = tqdm(cycles)
@@ -563,7 +565,7 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
                 # the NEXT cycle's contact term: launched on its own stream during this cycle, swapped in after it
                 sh.scene_setup(self._backmasks)
             if world > 1:
-                # frame-sharded: halos + ONE all-reduce of the betas|xscale gradient tail per cycle (mhhip/sharded.py);
+                # frame-sharded: the cycle is one graph; ONE all-reduce per cycle in sh.step (mhhip/sharded.py);
                 # the median of the scene update runs pixel-sharded over all ranks' frames
                 if dev_scene:
                     sh.scene_update()
@@ -575,7 +577,8 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
                 e.scene_device_swap()
             if not self.optim_scale_factor:
                 e.leaf('xscale', e.grads).zero_()
-            e.step(lr)             # RMSprop(lr=.01, alpha=.5, momentum=.9) :355; launched outside the captured cycle, lr by value
+            sh.step(lr)            # RMSprop(lr=.01, alpha=.5, momentum=.9) :355; launched outside the captured cycle, lr by value
+                                   # (frame-sharded: per-frame leaves, THE all-reduce of the cycle, shared leaves -- mhhip/sharded.py)
             lr *= 0.99                                                        # ExponentialLR(0.99) :356
             if check_every and cycle % check_every == 0:
                 self.check_replicas()

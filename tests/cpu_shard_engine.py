@@ -170,7 +170,20 @@ class CpuShardEngine(object):
         lb = T * (self.leaf('betas', p) - self.betas_ref).abs().sum()
         s = torch.pow(torch.tensor(1.1), self.leaf('xscale', p))
         s_avg, s_per = ((s - 1).sum()) ** 2, ((s - 1) ** 2).mean()
-        h = self.halo or {}
+        h = dict(self.halo or {})
+        if h.get('poses') is not None:
+            # the neighbours' boundary frames skinned here from their leaves (SequenceEngine._halo_forward)
+            with torch.no_grad():
+                nh = h['poses'].shape[0]
+                be = self.leaf('betas').repeat(nh // N, 1)
+                hv = lo.smpl_forward(self.model, be, h['poses'])['verts'].view(nh // N, N, -1, 3)
+                hv = torch.pow(torch.tensor(1.1), self.leaf('xscale')).view(1, N, 1, 1) * hv + h['transl'].view(nh // N, N, 1, 3)
+            k = 0
+            if h.get('has_prev'):
+                h['v_prev'] = hv[0]
+                k = 1
+            if h.get('has_next'):
+                h['v_next'] = hv[k]
         pT = self.leaf('poses_T', p)
         seq = [pT] if h.get('pT_prev') is None else [h['pT_prev'].view(1, N, 3), pT]
         own = torch.cat(seq)                                   # pairs (t-1, t) owned by the owner of t
@@ -202,6 +215,14 @@ class CpuShardEngine(object):
 
     def step(self, lr):
         fo.rmsprop_step(self.params, self.grads, self.sq, self.buf, lr)
+
+    def step_local(self, lr):
+        lo_ = self.shared_lo
+        fo.rmsprop_step(self.params[:lo_], self.grads[:lo_], self.sq[:lo_], self.buf[:lo_], lr)
+
+    def step_shared(self, lr):
+        lo_ = self.shared_lo
+        fo.rmsprop_step(self.params[lo_:], self.grads[lo_:], self.sq[lo_:], self.buf[lo_:], lr)
 
     # -- scene aggregation hooks (same contract as SequenceEngine; arithmetic from oracle/scene_oracle.py) ------------
     def main_stream(self):

@@ -136,6 +136,9 @@ typedef struct mh_fwd_proj {
   unsigned long long* lowkey;  /* (B)     out: order-preserving bits of y << 32 | ~vertex, 0 = nobody reported */
   unsigned long long* lowkey_prev; /* (B) */
   int32_t* moved;              /* (B)     out: 1 = some vertex left its band                                 */
+  float* clear;                /* or NULL: clear_n floats zeroed by the launch's first kernel -- the cycle's gradient buffer,
+                                  so that a captured cycle starts with the pose kernel instead of a fill + a gap        */
+  unsigned long long clear_n;
 } mh_fwd_proj;
 int mh_lbs_forward_proj(const mh_model* m, int B, int NB, const float* betas, const float* poses,
                         const float* xscale, const float* transl, float* verts, float* vposed /*or NULL*/,

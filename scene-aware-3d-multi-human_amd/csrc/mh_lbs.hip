@@ -41,6 +41,8 @@ struct PoseFwdP {
   unsigned long long* lowkey;
   unsigned long long* lowkey_prev;
   int* moved;
+  float* clear;            // zeroed here (the cycle's gradient buffer), or null
+  unsigned long long clear_n;
 };
 
 __device__ __forceinline__ void mh_joint_rest(const float* Jt, const float* JS, const float* beta, int j, float J[3]) {
@@ -67,6 +69,8 @@ __device__ __forceinline__ void mh_compose(const float* Gp, const float R[9], co
 __global__ __launch_bounds__(256) void k_pose_fwd(PoseFwdP p) {
   __shared__ float sG[8][MH_NJ][12];
   __shared__ float sJ[8][MH_NJ][3];
+  if (p.clear)           // the cycle's gradient buffer: everything that adds into it is launched behind this kernel
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < p.clear_n; i += (size_t)gridDim.x * 256) p.clear[i] = 0.f;
   const int bl = threadIdx.x >> 5, j = threadIdx.x & 31;
   const int b = blockIdx.x * 8 + bl;
   const bool valid = b < p.B, act = j < MH_NJ;
@@ -702,6 +706,7 @@ static int lbs_forward_impl(const mh_model* m, int B, int NB, const float* betas
   pp.bbox = proj ? proj->bbox : nullptr; pp.bbox_prev = proj ? proj->bbox_prev : nullptr;
   pp.lowkey = proj ? proj->lowkey : nullptr; pp.lowkey_prev = proj ? proj->lowkey_prev : nullptr;
   pp.moved = proj ? proj->moved : nullptr;
+  pp.clear = proj ? proj->clear : nullptr; pp.clear_n = proj ? proj->clear_n : 0ull;
   mh_prof_mark(MH_PROF_POSE_FWD, 0, st);
   hipLaunchKernelGGL(k_pose_fwd, dim3(G * 4), dim3(256), 0, st, pp);
   MH_LAUNCH_CHECK();

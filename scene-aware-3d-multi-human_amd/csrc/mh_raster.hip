@@ -2086,5 +2086,6 @@ extern "C" int mh_raster_forward_targets(int T, int N, int V, int F, int H, int 
   out->bbox = p.fbbox; out->bbox_prev = p.fbbox_prev;
   out->lowkey = p.flowkey; out->lowkey_prev = p.flowkey_prev;
   out->moved = p.fmoved;
+  out->clear = nullptr; out->clear_n = 0ull;
   return MH_OK;
 }

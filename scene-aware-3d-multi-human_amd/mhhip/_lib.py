@@ -33,7 +33,7 @@ class FwdProj(ctypes.Structure):
                 ('ra', ctypes.c_float), ('rk', ctypes.c_float), ('thr', ctypes.c_float),
                 ('slack_ndc', ctypes.c_float), ('slack_y', ctypes.c_float),
                 ('ndc', vp), ('rowb', vp), ('bbox', vp), ('bbox_prev', vp), ('lowkey', vp), ('lowkey_prev', vp),
-                ('moved', vp)]
+                ('moved', vp), ('clear', vp), ('clear_n', ctypes.c_ulonglong)]
 
 
 _lib = None

@@ -414,7 +414,7 @@ class SequenceEngine(object):
         return self.scene_pts
 
     # -- forward of all local frames ---------------------------------------------------------------
-    def forward(self, regress=True, raster=None):
+    def forward(self, regress=True, raster=None, clear=None):
         """LBS forward of all local frames.  raster (a ``RasterTerms`` of this engine): the "LBS + projection" form --
         the skinning epilogue also writes the NDC vertices, screen boxes, motion flags and lowest vertices that
         ``raster`` / the contact term would otherwise each take a pass over the vertices for (mh_lbs_forward_proj)."""
@@ -423,6 +423,8 @@ class SequenceEngine(object):
         self._projected_into = None
         if raster is not None and os.environ.get('MHHIP_NO_PROJ') != '1' and _lib.lib().mh_lbs_get_mode() != 0:
             t = raster.forward_targets()
+            if clear is not None:
+                t.clear, t.clear_n = clear.data_ptr(), clear.numel()
             check(_lib.lib().mh_lbs_forward_proj(m.handle, self.B, self.N, ptr(self.leaf('betas')), ptr(self.leaf('poses_smpl')),
                                                  ptr(self.leaf('xscale')), ptr(self.leaf('poses_T')), ptr(self.verts),
                                                  ptr(self.vposed), ctypes.byref(t), ptr(self.ws), _lib.stream_ptr(self.dev)))
@@ -510,7 +512,13 @@ class SequenceEngine(object):
         g = self.grads
         log = self.tmp_log
         self._flush_log()                # (never inside a capture: cycle_graphed has flushed before it replays)
-        self._grads_log.zero_()
+        # the gradient buffer (+ the staging row of the log) is cleared by the forward's first kernel when the projection form
+        # runs (mh_fwd_proj.clear): the captured cycle starts with k_pose_fwd instead of a fill and a 5-us gap
+        # (only in the single-join form: with join=True the leaf-only terms start beside the forward and add into the buffer)
+        clear_in_fwd = (not join) and raster is not None and os.environ.get('MHHIP_NO_PROJ') != '1' and os.environ.get('MHHIP_CLEAR_FILL') != '1' \
+            and _lib.lib().mh_lbs_get_mode() != 0
+        if not clear_in_fwd:
+            self._grads_log.zero_()
         # the terms that only read the leaves (silhouette mask statistics, priors, velocity) run on the second stream
         # beside the MFMA-bound forward; their scalars land directly in the log row
         main = torch.cuda.current_stream(self.dev)
@@ -522,7 +530,7 @@ class SequenceEngine(object):
         # the chain's kernels are captured BEFORE the side branch's: a replayed graph keeps the branch whose nodes come first
         # on the queue it was launched on and moves the other one to a second queue, and every hop between queues costs
         # 10-14 us of idle time (rocprofv3 trace: the forward used to start 19 us into the cycle, now 9)
-        self.forward(regress=False, raster=raster)   # (the per-body pose-prior values are summed with the other log entries, _finish_a)
+        self.forward(regress=False, raster=raster, clear=self._grads_log if clear_in_fwd else None)   # (the per-body pose-prior values are summed with the other log entries, _finish_a)
         def leaf_terms():
             if self.has_images:
                 check(L.mh_sil_mask_stats_cached(ptr(self.bits), T, N, self.H, self.W, ptr(pT), ptr(self.p2d_valid),

@@ -180,6 +180,12 @@ int mh_keypoint_terms(const mh_model* m, int B, const float* transl /*(B,3) or N
 int mh_lbs_backward_kp(const mh_model* m, int B, int NB, const float* betas, const float* poses,
                        const float* vposed, const float* gverts, float* gposes, float* gtransl,
                        float* gbetas, float* gxscale, void* ws, void* ws2, void* stream);
+/* the same, with the rasteriser's closing job (mh_raster_fin, below; or NULL) carried out by one more workgroup of the pose
+ * kernel */
+typedef struct mh_raster_fin mh_raster_fin;
+int mh_lbs_backward_kp_fin(const mh_model* m, int B, int NB, const float* betas, const float* poses,
+                       const float* vposed, const float* gverts, float* gposes, float* gtransl,
+                       float* gbetas, float* gxscale, void* ws, void* ws2, const mh_raster_fin* fin, void* stream);
 
 /* ---- LBS backward (hand-written adjoint of the above) ---------------------------------------
  * In : gverts (B,V,3) = dL/dverts, gjoints (B,17,3) = dL/d(alphapose joints of the translated,
@@ -463,6 +469,32 @@ int mh_raster_terms_phase_log(int T, int N, int V, int F, int H, int W, const fl
  * phases here is a bit mask: 1 = preparation + selection, 2 = gradients, 4 = preparation only (windows, face lists, work
  * lists: a chain of small latency-bound launches), 8 = selection only -- so that a caller can start other work between the
  * two halves of phase 1.                                                                                        */
+/* The rasterised terms' CLOSING job (per-body values from the tile sums, gradients of the depth-range leaves, the two log
+ * sums: a few microseconds of latency-bound work in one workgroup) as a description that another launch can carry out:
+ * nothing of the LBS backward reads what it writes, so mh_raster_terms_deferred leaves it here instead of launching
+ * k_raster_finish between the gradient kernel and the backward, and mh_lbs_backward_kp_fin runs it as one more workgroup
+ * of its pose kernel -- one launch and one dependent kernel less on the cycle's chain.  Plain pointers into the caller's
+ * buffers and the rasteriser's workspace; valid until those are released. */
+struct mh_raster_fin {
+  int T, N, B, from_partials;
+  float coef_depth;
+  const int* body_first;
+  const int* body_ns;
+  const float* partial;
+  const float* dinv;
+  const float* sil_apply;
+  const float* sil_D;
+  const float* sil_S;
+  float* sil_corr;
+  float* depth_body;
+  float* sil_body;
+  const float* zmin_lin;
+  const float* zmax_lin;
+  float* gzmin;
+  float* gzmax;
+  float* log_depth;
+  float* log_sil;
+};
 int mh_raster_forward_targets(int T, int N, int V, int F, int H, int W, const float* cam_K_host, void* ws,
                               mh_fwd_proj* out);
 int mh_raster_terms_projected(int T, int N, int V, int F, int H, int W, const float* cam_K_host,
@@ -474,6 +506,16 @@ int mh_raster_terms_projected(int T, int N, int V, int F, int H, int W, const fl
                           float* gzmax, float* depth_body, float* sil_body, void* ws,
                           float* zbuf_out, float* alpha_out, int phases, float* log_depth, float* log_sil,
                           int projected, void* stream);
+/* phases & 2 without the closing kernel: its job goes to *fin_out (mh_raster_fin above) */
+int mh_raster_terms_deferred(int T, int N, int V, int F, int H, int W, const float* cam_K_host,
+                          const float* verts, const int32_t* faces, const uint32_t* bits,
+                          const uint32_t* ebits, const float* depths, const float* zmin_lin,
+                          const float* zmax_lin, const float* pose2d_valid, const uint32_t* front,
+                          const float* sil_apply, const float* sil_D, const float* sil_S,
+                          float coef_depth, float coef_sil, float eps, float* gverts, float* gzmin,
+                          float* gzmax, float* depth_body, float* sil_body, void* ws,
+                          float* zbuf_out, float* alpha_out, int phases, float* log_depth, float* log_sil,
+                          int projected, mh_raster_fin* fin_out, void* stream);
 /* Deterministic gradient scatter (default off; MHHIP_DETERMINISTIC=1 in the environment switches it on at first use).
  * The production kernel sums the per-pixel vertex gradients of the rasterised terms with fp32 atomics (LDS table,
  * then global): the summation order, hence the last bits, vary from run to run.  on != 0: one workgroup per body,

@@ -174,3 +174,96 @@ __device__ __forceinline__ int mh_wave_scan_add(int x) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
   return v;
 }
+
+// ---- the rasterised terms' closing job (mh_raster_fin, include/mhmocap_hip.h): carried out by k_raster_finish (mh_raster.hip,
+// one workgroup of its own) or by one extra workgroup of k_pose_bwd (mh_lbs.hip), NT = threads of that workgroup --------------
+//   from_partials != 0 (gradients were requested: k_raster_grads has run): per body, the sums of its tiles in fixed order
+//     -> depth loss, depth-range partials, silhouette loss with the alpha-dependent part k_raster_grads accumulated
+//     (cleared here for the next launch);
+//   from_partials == 0 (values only): k_raster_body_out has done that from k_raster_sums' totals;
+//   then the chain of the depth-range leaves (optimizer.py:683-688: min_z = softplus(zmin), max_z = min_z.detach() + 1 +
+//   softplus(zmax)) and, when asked for, the two loss sums of the log row.
+#define MH_FIN_U 4            // bodies per thread and pass: their dependent loads (tile range -> tile sums) are in flight together
+template <int NT>
+__device__ __forceinline__ void mh_raster_finish_job(const mh_raster_fin& f, float* s_g0 /*[MH_FIN_U * NT]*/, float* s_g1 /*[MH_FIN_U * NT]*/) {
+  const int N = f.N, tid = threadIdx.x, T = f.T;
+  const int fpc = max(1, MH_FIN_U * NT / N);     // whole frames per pass: thread = body (MH_FIN_U of them), then thread = frame
+  for (int t0 = 0; t0 < T; t0 += fpc) {
+    const int nb = min(fpc, T - t0) * N;         // bodies of this pass
+    int first[MH_FIN_U], ns[MH_FIN_U];
+#pragma unroll
+    for (int u = 0; u < MH_FIN_U; ++u) {
+      const int i = tid + u * NT, b = t0 * N + i;
+      first[u] = 0; ns[u] = 0;
+      if (i < nb && b < f.B && f.from_partials) { first[u] = f.body_first[b]; ns[u] = f.body_ns[b]; }
+    }
+    float S[MH_FIN_U][6];
+#pragma unroll
+    for (int u = 0; u < MH_FIN_U; ++u) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) S[u][k] = 0.f;
+      for (int s = first[u]; s < first[u] + ns[u]; ++s)      // fixed order over the body's tiles
+#pragma unroll
+        for (int k = 0; k < 6; ++k) S[u][k] += f.partial[(size_t)s * 6 + k];
+    }
+#pragma unroll
+    for (int u = 0; u < MH_FIN_U; ++u) {
+      const int i = tid + u * NT, b = t0 * N + i;
+      float g0 = 0.f, g1 = 0.f;
+      if (i < nb && b < f.B) {
+        if (f.from_partials) {
+          const float cnt = S[u][2] + 1.f;
+          const float diff = S[u][0] / cnt - S[u][1] / cnt;                                            // losses.py:24-27
+          f.depth_body[b] = diff * diff;
+          const float gB = f.coef_depth * (-2.f) * diff / cnt;
+          g0 = gB * S[u][3];                        // d/d(1/min_z) through the target disparity
+          g1 = gB * S[u][4];                        // d/d(1/max_z)
+          f.sil_body[b] = f.sil_apply[b] * (f.sil_S[b] + f.sil_corr[b]) / (f.sil_D[b] + 1.f);        // losses.py:35-38
+          f.sil_corr[b] = 0.f;
+        } else {
+          g0 = f.dinv[(size_t)b * 2];
+          g1 = f.dinv[(size_t)b * 2 + 1];
+          f.sil_corr[b] = 0.f;                      // (gradients AND images in one call: k_raster_grads ran after k_raster_body_out)
+        }
+      }
+      s_g0[i] = g0; s_g1[i] = g1;
+    }
+    __syncthreads();
+    if (f.gzmin)
+      for (int fr = tid; fr < fpc && t0 + fr < T; fr += NT) {
+        const int t = t0 + fr;
+        float a0 = 0.f, a1 = 0.f;
+        for (int n = 0; n < N; ++n) { a0 += s_g0[fr * N + n]; a1 += s_g1[fr * N + n]; }
+        const float e0 = expf(f.zmin_lin[t]), e1 = expf(f.zmax_lin[t]);
+        const float min_z = logf(1.f + e0);
+        const float max_z = min_z + 1.f + logf(1.f + e1);
+        f.gzmin[t] += a0 * (-1.f / (min_z * min_z)) * (e0 / (1.f + e0));
+        f.gzmax[t] += a1 * (-1.f / (max_z * max_z)) * (e1 / (1.f + e1));
+      }
+    __syncthreads();
+  }
+  if (f.log_depth || f.log_sil) {
+    // sums of the per-body values in an order that does not depend on NT: aligned groups of 64 bodies by a wave butterfly,
+    // then the groups in turn -- the log row is bit-identical whichever launch carries the job.  (The values were written
+    // by this workgroup, behind the barriers above; every wave's loads are in flight together.)
+    const int ngr = (f.B + 63) / 64, lane = tid & 63;
+    float ta = 0.f, tc = 0.f;                      // thread 0: the running totals
+    for (int g0 = 0; g0 < ngr; g0 += MH_FIN_U * NT) {
+      const int nh = min(MH_FIN_U * NT, ngr - g0);
+      for (int gr = tid >> 6; gr < nh; gr += NT / 64) {
+        const int b = (g0 + gr) * 64 + lane;
+        float a = b < f.B ? f.depth_body[b] : 0.f, c = b < f.B ? f.sil_body[b] : 0.f;
+        a = mh_wave_sum(a); c = mh_wave_sum(c);
+        if (lane == 0) { s_g0[gr] = a; s_g1[gr] = c; }
+      }
+      __syncthreads();
+      if (tid == 0)
+        for (int gr = 0; gr < nh; ++gr) { ta += s_g0[gr]; tc += s_g1[gr]; }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      if (f.log_depth) *f.log_depth = ta;
+      if (f.log_sil) *f.log_sil = tc;
+    }
+  }
+}

@@ -21,6 +21,28 @@
 // =============================================================================================
 // forward
 // =============================================================================================
+// timing builds (tools/mkvariant.sh x mh_lbs.hip -DLBS_TIMING; tools/time_lbs_phases.py): wave-elapsed shader cycles of the two
+// skinning kernels by phase, summed over the waves.  forward: 0 staging, 1 constants + matrix phase, 2 epilogue, 3 everything,
+// 4 waves; backward: 8 staging, 9 stage, 10 wait A, 11 blend, 12 wait B, 13 matrix phase, 14 everything, 15 waves
+#ifdef LBS_TIMING
+__device__ unsigned long long g_lbs_t[16];
+#define L_T0() unsigned long long lt_ = __builtin_readcyclecounter(); const unsigned long long lt_begin = lt_; unsigned lacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define L_MARK(c) do { const unsigned long long t1_ = __builtin_readcyclecounter(); lacc[c] += (unsigned)(t1_ - lt_); lt_ = t1_; } while (0)
+#define L_OUT(base, n) do { if ((threadIdx.x & 63) == 0) { for (int c_ = 0; c_ < (n); ++c_) atomicAdd(&g_lbs_t[(base) + c_], (unsigned long long)lacc[c_]); \
+    atomicAdd(&g_lbs_t[(base) + (n)], __builtin_readcyclecounter() - lt_begin); atomicAdd(&g_lbs_t[(base) + (n) + 1], 1ull); } } while (0)
+extern "C" int mh_lbs_debug_timing(unsigned long long* out16) {
+  MH_HIP(hipDeviceSynchronize());
+  MH_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_lbs_t), sizeof(g_lbs_t)));
+  unsigned long long z[16] = {0};
+  MH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_lbs_t), z, sizeof(z)));
+  return MH_OK;
+}
+#else
+#define L_T0() do { } while (0)
+#define L_MARK(c) do { } while (0)
+#define L_OUT(base, n) do { } while (0)
+#endif
+
 struct PoseFwdP {
   int B, NB, G;
   const float* betas;
@@ -406,6 +428,7 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, 2 * FWD16_WAVES / 4) void k_skin_
   const int g = blockIdx.y;
   const int ntiles = p.VP / 32;
   if ((int)blockIdx.x * p.tpb >= ntiles) return;
+  L_T0();
   {
     const f32x4* srcF = (const f32x4*)(p.F16 + (size_t)g * (MH_FS / 16) * 2 * 64 * 8);
     for (int i = threadIdx.x; i < FWD16_SF_BYTES / 16; i += FWD16_WAVES * 64) ((f32x4*)sF)[i] = srcF[i];
@@ -436,11 +459,12 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, 2 * FWD16_WAVES / 4) void k_skin_
     }
   }
   __syncthreads();
+  L_MARK(0);
   // tile k of the workgroup goes to wave k % WAVES: with tpb = 11 three waves take two tiles, five take one
   for (int rep_ = 0; rep_ < FWD16_TPW; ++rep_) {
-  if (wave + rep_ * FWD16_WAVES >= p.tpb) return;
+  if (wave + rep_ * FWD16_WAVES >= p.tpb) break;
   const int tile = blockIdx.x * p.tpb + wave + rep_ * FWD16_WAVES;
-  if (tile >= ntiles) return;
+  if (tile >= ntiles) break;
   const int v = tile * 32 + li;
   // this lane's vertex constants: issued before the matrix phase, consumed after it
   const bool vok = v < p.V;
@@ -494,6 +518,7 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, 2 * FWD16_WAVES / 4) void k_skin_
     az = MFMA_F16(al, bq[cur][4], az);
     __builtin_amdgcn_sched_barrier(0);
   }
+  L_MARK(1);
   if (!vok) continue;
   const float us = p.unscale;
   // per-lane LDS bases (bytes): the row part (r&3)+8(r>>2) is a compile-time offset, the half-wave part 4*lh is here
@@ -607,7 +632,9 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, 2 * FWD16_WAVES / 4) void k_skin_
       }
     }
   }
+  L_MARK(2);
   }   // tiles of this wave
+  L_OUT(0, 3);
 }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1187,6 +1214,7 @@ __global__ __launch_bounds__(256, SB_OCC) void k_skinbwd16(Bwd16P p) {
   if (item >= p.G * p.CH) return;
   const int g = item % p.G, ch = item / p.G;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  L_T0();
   for (int i = tid; i < 32 * MH_NJ * 12; i += 256) {
     const int bb = i / (MH_NJ * 12), e = i % (MH_NJ * 12);
     sA[bb * BWD_AS + e] = p.A[(size_t)(g * 32 + bb) * MH_NJ * 12 + e];
@@ -1244,6 +1272,7 @@ __global__ __launch_bounds__(256, SB_OCC) void k_skinbwd16(Bwd16P p) {
     }
   };
   if (b0 < bend) fetch(b0);
+  L_MARK(0);
   for (int blk = b0; blk < bend; ++blk) {
     // ---- stage ----
     fetch_rows(blk);
@@ -1265,7 +1294,9 @@ __global__ __launch_bounds__(256, SB_OCC) void k_skinbwd16(Bwd16P p) {
     fetch_b(2);
     const int vp = blk * 16 + 2 * vs;            // first vertex of the thread's pair
     SB_FENCE;
+    L_MARK(1);
     __syncthreads();                             // (A) adjoint tile complete; every wave is past the last mfma phase
+    L_MARK(2);
 #pragma unroll
     for (int k = 0; k < 2; ++k)
 #pragma unroll
@@ -1349,7 +1380,9 @@ __global__ __launch_bounds__(256, SB_OCC) void k_skinbwd16(Bwd16P p) {
         *(f32x2a*)(sGx + (c * 32 + bi) * BW_TS + 2 * vs) = (f32x2a){gxp[c][0], gxp[c][1]};
       }
     }
+    L_MARK(3);
     __syncthreads();                             // (B) fragments, s g and posed vertices of the block are in LDS
+    L_MARK(4);
     // ---- mfma ----
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -1380,6 +1413,7 @@ __global__ __launch_bounds__(256, SB_OCC) void k_skinbwd16(Bwd16P p) {
       accA[k] = MFMA_BF16(al, bW[0], accA[k]);
       SB_FENCE2;
     }
+    L_MARK(5);
   }
   // ---- write the chunk's partial sums; element r of lane l is C[body (r&3) + 8 (r>>2) + 4 (l>>5)][column l&31] ----
   const size_t GB = (size_t)p.G * 32;
@@ -1407,6 +1441,7 @@ __global__ __launch_bounds__(256, SB_OCC) void k_skinbwd16(Bwd16P p) {
       for (int k = 0; k < 8; ++k) s += sTr[(k * 32 + bb) * 3 + c];
     p.pS[base * 4 + tid] = s;                    // [3] (the scale term) comes from the joint sums, see k_pose_bwd
   }
+  L_OUT(8, 6);
 }
 
 struct PoseBwdP {
@@ -1431,9 +1466,20 @@ struct PoseBwdP {
   float* gxs_b;     // [G*32]
   int scale_from_joint_sums;   // 1: d/dlog-scale = sum_j <A_j, dL/dA_j> (pS[3] is not filled by the split kernels)
   mh_tree tree;
+  int has_fin;                 // the FIRST workgroup of the launch carries the rasteriser's closing job instead of a body
+                               // (first: the body workgroups outnumber the slots of the device, the last one starts late)
+  mh_raster_fin fin;
 };
 
 __global__ __launch_bounds__(256) void k_pose_bwd(PoseBwdP p) {
+  if (p.has_fin && blockIdx.x == 0) {
+    // the rasterised terms' closing job (mh_raster_fin): nothing in this launch reads what it writes, it only has to be
+    // over before the update -- beside 800 body workgroups its 12 us of dependent loads cost nothing, as a launch of its
+    // own between the gradient kernel and the backward they cost the chain 16
+    __shared__ float f_g0[MH_FIN_U * 256], f_g1[MH_FIN_U * 256];
+    mh_raster_finish_job<256>(p.fin, f_g0, f_g1);
+    return;
+  }
   __shared__ float sGA[1][12 * MH_NJ];   // summed dL/dA  [e][j]
   __shared__ float sGF[1][MH_FS];        // summed dL/dfeat
   __shared__ float sG[1][MH_NJ][12];
@@ -1448,7 +1494,7 @@ __global__ __launch_bounds__(256) void k_pose_bwd(PoseBwdP p) {
   // goes on from there (a barrier only waits for the waves that are still alive).
   __shared__ float sP[8][12 * MH_NJ + MH_FS + 4];
   const int g = threadIdx.x >> 5, j = threadIdx.x & 31, bl = 0;
-  const int b = blockIdx.x;
+  const int b = (int)blockIdx.x - p.has_fin;
   const bool valid = b < p.B, act = j < MH_NJ;
   // the state of the forward, asked for before the chunk partials so that its round trip hides behind theirs: rest joints,
   // rotations, and the rotation part of the global transforms as k_pose_fwd left it in A = [G.R | G.t - G.R.J] (the chain
@@ -1733,7 +1779,7 @@ extern "C" size_t mh_lbs_backward_workspace_bytes(int B) {
 static int lbs_backward_impl(const mh_model* m, int B, int NB, const float* betas, const float* poses, const float* rotmats,
                              const float* vposed, const float* gverts, const float* gjoints, const float* gposed,
                              float* gposes, float* grotmats, float* gtransl, float* gbetas, float* gxscale,
-                             void* ws, void* ws2, void* stream, int kp_chunk = 0);
+                             void* ws, void* ws2, void* stream, int kp_chunk = 0, const mh_raster_fin* fin = nullptr);
 
 // The backward after mh_keypoint_terms: the key-point term's dL/dA, dL/dfeat and dL/dt are already in the extra chunk slot of
 // ws2 (k_pose_bwd adds it behind the vertex chunks); the skinning kernel runs without key-point adjoints.
@@ -1743,6 +1789,14 @@ extern "C" int mh_lbs_backward_kp(const mh_model* m, int B, int NB, const float*
   MH_CHECK(poses && gposes, "null argument");
   return lbs_backward_impl(m, B, NB, betas, poses, nullptr, vposed, gverts, nullptr, nullptr, gposes, nullptr, gtransl, gbetas,
                            gxscale, ws, ws2, stream, 1);
+}
+
+extern "C" int mh_lbs_backward_kp_fin(const mh_model* m, int B, int NB, const float* betas, const float* poses, const float* vposed,
+                                      const float* gverts, float* gposes, float* gtransl, float* gbetas, float* gxscale,
+                                      void* ws, void* ws2, const mh_raster_fin* fin, void* stream) {
+  MH_CHECK(poses && gposes, "null argument");
+  return lbs_backward_impl(m, B, NB, betas, poses, nullptr, vposed, gverts, nullptr, nullptr, gposes, nullptr, gtransl, gbetas,
+                           gxscale, ws, ws2, stream, 1, fin);
 }
 
 int mh_lbs_backward_extra_slot(const mh_model* m, int B, void* ws2, float** pF, float** pA, float** pS) {
@@ -1780,7 +1834,7 @@ extern "C" int mh_lbs_backward_ex(const mh_model* m, int B, int NB, const float*
 static int lbs_backward_impl(const mh_model* m, int B, int NB, const float* betas, const float* poses, const float* rotmats,
                              const float* vposed, const float* gverts, const float* gjoints, const float* gposed,
                              float* gposes, float* grotmats, float* gtransl, float* gbetas, float* gxscale,
-                             void* ws, void* ws2, void* stream, int kp_chunk) {
+                             void* ws, void* ws2, void* stream, int kp_chunk, const mh_raster_fin* fin) {
   MH_CHECK(m && betas && vposed && ws && ws2, "null argument");
   MH_CHECK(gverts || gjoints || kp_chunk, "need gverts and/or gjoints");
   MH_CHECK(B > 0 && NB > 0, "B and NB must be positive");
@@ -1839,8 +1893,10 @@ static int lbs_backward_impl(const mh_model* m, int B, int NB, const float* beta
   pp.gposes = gposes; pp.gtransl = gtransl; pp.gbeta_b = bw.gbeta_b; pp.gxs_b = bw.gxs_b;
   pp.scale_from_joint_sums = split16 ? 1 : 0;
   pp.tree = m->tree;
+  pp.has_fin = (fin && fin->B > 0) ? 1 : 0;
+  if (pp.has_fin) pp.fin = *fin; else memset(&pp.fin, 0, sizeof(pp.fin));
   mh_prof_mark(MH_PROF_POSE_BWD, 0, st);
-  hipLaunchKernelGGL(k_pose_bwd, dim3(G * 32), dim3(256), 0, st, pp);
+  hipLaunchKernelGGL(k_pose_bwd, dim3(G * 32 + pp.has_fin), dim3(256), 0, st, pp);
   MH_LAUNCH_CHECK();
   if (gbetas || gxscale) {
     hipLaunchKernelGGL(k_person_reduce, dim3(NB, 11), dim3(256), 0, st, B, NB, bw.gbeta_b, bw.gxs_b, gbetas, gxscale);

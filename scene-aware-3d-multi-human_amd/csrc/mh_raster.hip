@@ -287,10 +287,12 @@ __device__ __forceinline__ void r_insert(unsigned long long* q, float pz, bool i
   if (pz < 0.f || (!inside && d >= BLUR_D)) return;
   unsigned long long key = ((unsigned long long)__float_as_uint(pz) << 32) | (unsigned)f;
   if (key < q[0]) atomicMin(&q[0], key);
-  if (inside || d < BLUR_S) {
+  // a candidate behind the pixel's current 4th key changes nothing (the keys only ever decrease, and a key still travelling
+  // down another lane's cascade can only make the 4th slot smaller than what is read here): ONE read instead of three
+  // atomics that leave their slots as they were
+  if ((inside || d < BLUR_S) && key < q[4]) {
 #pragma unroll
     for (int k = 1; k < 5; ++k) {
-      if (k == 4 && key >= q[4]) break;
       const unsigned long long old = atomicMin(&q[k], key);
       if (old == RS_EMPTY) break;
       key = old > key ? old : key;
@@ -331,10 +333,20 @@ __device__ __forceinline__ void r_tiling(int ww, int wh, int* tw, int* th, int* 
 // squared distance to segment ab with the staged 1/|ab|^2, parametrised from b: il = 0 marks a degenerate segment and
 // then yields |p - b|^2, the reference's answer for that case, without a branch
 __device__ __forceinline__ float r_seg_fast(float px, float py, float ax, float ay, float bx, float by, float il) {
+#pragma clang fp contract(off)
   const float abx = ax - bx, aby = ay - by, dx = px - bx, dy = py - by;
-  const float tt = fminf(fmaxf((abx * dx + aby * dy) * il, 0.f), 1.f);
-  const float qx = tt * abx - dx, qy = tt * aby - dy;
-  return qx * qx + qy * qy;
+  const float tt = fminf(fmaxf(fmaf(abx, dx, aby * dy) * il, 0.f), 1.f);
+  const float qx = fmaf(tt, abx, -dx), qy = fmaf(tt, aby, -dy);
+  return fmaf(qx, qx, qy * qy);
+}
+
+// max(x, 0) as ONE v_max_f32: fmaxf(x, 0.f) compiles to two (the first only quiets a signalling NaN, which no
+// arithmetic result is), and v_max_f32 is a full-rate-only instruction on gfx950 (tools/ubench/valu_rate.hip: 4.1 cycles
+// against 2.3 for fma / mul / add)
+__device__ __forceinline__ float r_max0(float x) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
 }
 
 // the selection-time twin of r_eval: per-face reciprocals are staged once per face, the only
@@ -344,15 +356,24 @@ __device__ __forceinline__ float r_seg_fast(float px, float py, float ax, float 
 // (An early exit for candidates provably outside the blur band -- distance to the line of a violated
 // edge -- was measured and does not pay inside a 64-wide divergent loop: some lane always survives.)
 __device__ __forceinline__ bool r_eval_fast(const float* T, float xf, float yf, float* pz, bool* inside, float* dist) {
+  // Every multiply-add of this function is spelled out and the compiler's own contraction is off: the function is inlined
+  // into two loops of k_raster_strip (pair list / even split), and left to itself hipcc fused a * b - c * d one way in
+  // one copy and the other way in the other -- the same (face, pixel) pair then got a depth one ulp apart depending on
+  // which path its round took (found in round 4 by moving rounds from one path to the other: 47 753 of 1.2 M window
+  // pixels changed a last bit).
+#pragma clang fp contract(off)
   const float x0 = T[0], y0 = T[1], z0 = T[2], x1 = T[3], y1 = T[4], z1 = T[5], x2 = T[6], y2 = T[7], z2 = T[8];
   const float ia = T[9];
-  const float e0 = r_edge(xf, yf, x1, y1, x2, y2), e1 = r_edge(xf, yf, x2, y2, x0, y0), e2 = r_edge(xf, yf, x0, y0, x1, y1);
+  const float d0x = xf - x0, d0y = yf - y0, d1x = xf - x1, d1y = yf - y1, d2x = xf - x2, d2y = yf - y2;
+  const float e0 = fmaf(d1x, y2 - y1, -(d1y * (x2 - x1)));      // edge(p; v1, v2)
+  const float e1 = fmaf(d2x, y0 - y2, -(d2y * (x0 - x2)));      // edge(p; v2, v0)
+  const float e2 = fmaf(d0x, y1 - y0, -(d0y * (x1 - x0)));      // edge(p; v0, v1)
   const float w0 = e0 * ia, w1 = e1 * ia, w2 = e2 * ia;
   const bool in = w0 > 0.f && w1 > 0.f && w2 > 0.f;
   *inside = in;
-  const float c0 = fmaxf(w0, 0.f), c1 = fmaxf(w1, 0.f), c2 = fmaxf(w2, 0.f);
-  const float ics = __builtin_amdgcn_rcpf(fmaxf(c0 + c1 + c2, 1e-5f));
-  *pz = (c0 * ics) * z0 + (c1 * ics) * z1 + (c2 * ics) * z2;
+  const float c0 = r_max0(w0), c1 = r_max0(w1), c2 = r_max0(w2);
+  const float ics = __builtin_amdgcn_rcpf(fmaxf((c0 + c1) + c2, 1e-5f));
+  *pz = fmaf(c2 * ics, z2, fmaf(c1 * ics, z1, (c0 * ics) * z0));
   *dist = in ? 0.f
              : fminf(fminf(r_seg_fast(xf, yf, x0, y0, x1, y1, T[10]), r_seg_fast(xf, yf, x0, y0, x2, y2, T[11])),
                      r_seg_fast(xf, yf, x1, y1, x2, y2, T[12]));
@@ -853,15 +874,33 @@ __device__ __forceinline__ void r_tile_depth_sums(const RasterP& p, int s, int b
       }
     }
   }
-  lA = r_block_sum(lA, sh); lB = r_block_sum(lB, sh); lC = r_block_sum(lC, sh);
-  lS1 = r_block_sum(lS1, sh); lS2 = r_block_sum(lS2, sh);
-  if (tid == 0) {
-    float* o = p.partial + (size_t)s * 6;
-    o[0] = lA; o[1] = lB; o[2] = lC; o[3] = lS1; o[4] = lS2; o[5] = 0.f;
+  // the five sums behind ONE pair of barriers (same order of additions as five r_block_sum calls: lanes by xor
+  // butterflies, then the waves in turn)
+  lA = mh_wave_sum(lA); lB = mh_wave_sum(lB); lC = mh_wave_sum(lC); lS1 = mh_wave_sum(lS1); lS2 = mh_wave_sum(lS2);
+  __syncthreads();
+  if ((tid & 63) == 0) {
+    float* w = sh + (tid >> 6) * 5;
+    w[0] = lA; w[1] = lB; w[2] = lC; w[3] = lS1; w[4] = lS2;
   }
+  __syncthreads();
+  if (tid < 5) {
+    float a = 0.f;
+    for (int w = 0; w < RB / 64; ++w) a += sh[w * 5 + tid];
+    p.partial[(size_t)s * 6 + tid] = a;
+  }
+  if (tid == 5) p.partial[(size_t)s * 6 + 5] = 0.f;
 }
 
 #define RW (RB / 64)         // waves per tile workgroup
+// timing builds (tools/mkvariant.sh ... -DR_TIMING=1|2): wave-elapsed shader cycles per phase of k_raster_strip, summed over
+// the waves into the pair-counter slots (units of 1024 cycles; four phases per build, two 32-bit halves per counter):
+// 0 tile prologue, 1 round head (gathers issued, box, staging, scan), 2 cull walk + pair list, 3 pair evaluation,
+// 4 even-split path, 5 wait for the tile's other waves, 6 tile epilogue, 7 everything
+#ifdef R_TIMING
+#define R_TMARK(c) do { const unsigned long long t1_ = __builtin_readcyclecounter(); tacc[c] += (unsigned)(t1_ - tlast); tlast = t1_; } while (0)
+#else
+#define R_TMARK(c) do { } while (0)
+#endif
 #ifdef R_SYNC_HARD
 #define R_WAVE_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
 #else
@@ -869,9 +908,6 @@ __device__ __forceinline__ void r_tile_depth_sums(const RasterP& p, int s, int b
 #endif
 #ifndef RPL
 #define RPL 512              // pair descriptors per wave and round (sub-pixel face path)
-#endif
-#ifndef R_SUBMAX
-#define R_SUBMAX 16          // most candidate pixels of a face on the sub-pixel path (<= 32: one mask word, k * M >> 10 exact)
 #endif
 
 // One workgroup per tile.  Every wave runs its own rounds of 64 candidate faces with no workgroup barrier in
@@ -888,7 +924,7 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
   __shared__ int wFid[RW][64];
   __shared__ int wMark[RW][64];
   __shared__ unsigned short wPl[RW][RPL];   // pair list of the sub-pixel path: face slot | pair index << 6
-  __shared__ float s_sums[RB / 64];
+  __shared__ float s_sums[RB / 64 * 5];
   __shared__ float sXf[R_CAP];              // NDC x of the tile columns
   __shared__ float sYf[R_CAP];              // NDC y of the tile rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -907,6 +943,12 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
   int* mark = wMark[wave];
   unsigned short* pl = wPl[wave];
   unsigned long long n_cand = 0ull, n_eval = 0ull;        // wave-uniform
+#ifdef R_TIMING
+  unsigned tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_readcyclecounter();
+  const unsigned long long tbegin = tlast;
+  const unsigned long long twall = wall_clock64();
+#endif
   for (int si = blockIdx.x; si < total; si += gridDim.x) {
     const int s = p.strip_order[si];
     const int b = p.strip_body[s];
@@ -929,6 +971,7 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
     const int nab = na + nbk, i1 = nab + nc;
     auto fs_at = [&](int j) { return fs[j < na ? a0 + j : (j < nab ? b0 + (j - na) : c0 + (j - nab))]; };
     __syncthreads();
+    R_TMARK(0);
     if (i1 > 0) {
       const int last = i1 - 1, stride = RW * 64;
       int idx = wave * 64 + lane;
@@ -959,7 +1002,7 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
         }
         // ---- this round: bbox against the tile, candidate count, staging -----------------------------------
         int cnt = 0;
-        int f_pix = 0, f_nx = 1;                 // first window pixel (tile-relative index) and width of the face's pixel box
+        int f_pix = 0, f_nx = 1, f_ny = 1;       // first window pixel (tile-relative index), width and height of the face's pixel box
         unsigned f_zb = 0u;                      // bits of its nearest vertex depth (minus the margin below)
         if (idx < i1 && (int)(e_a >> 20) + p.margin >= sy0) {
           const float bxmin = fminf(ca[0], fminf(ca[3], ca[6])) - blur_d, bxmax = fmaxf(ca[0], fmaxf(ca[3], ca[6])) + blur_d;
@@ -999,9 +1042,8 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
             desc[lane] = (xa - x0) | ((ya - sy0) << 10) | ((xb - xa + 1) << 20);
             f_pix = (int)__umul24((unsigned)(ya - sy0), (unsigned)tw) + (xa - x0);
             f_nx = xb - xa + 1;
-            // face id | M << 20 with M = floor(1024 / nx) + 1: for a box of up to 16 pixels (nx <= 16, k < 16)
-            // (k * M) >> 10 == k / nx exactly (k * (M * nx - 1024) <= 15 * 16 < 1024); wider boxes never use M
-            fid[lane] = (int)((e_a & 0xfffffu) | ((unsigned)((int)(1024.f * __builtin_amdgcn_rcpf((float)f_nx)) + 1) << 20));
+            f_ny = yb - ya + 1;
+            fid[lane] = (int)(e_a & 0xfffffu);
             {
               // nearest vertex depth MINUS 16 ulps: the interpolated depth (normalised weights through v_rcp_f32) can fall a
               // few ulps short of the nearest vertex, and on such a tie the depth cull below dropped a candidate or not
@@ -1012,75 +1054,68 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
             }
           }
         }
-        const int incl = r_wave_scan_add(cnt);
-        const int npairs = __builtin_amdgcn_readlane(incl, 63);
-        const int excl = incl - cnt;
-        if (npairs > 0 && npairs <= RPL && __ballot(cnt > R_SUBMAX) == 0ull) {
-          // ---- sub-pixel faces (a few candidates each).  Depth cull first, per face lane: the clipped-barycentric depth
-          // of a face is never below its nearest vertex, so a pair whose face lies entirely behind both the pixel's current
-          // nearest key and its current 4th silhouette key cannot change the window (the keys only ever decrease).  A lane
-          // walks the <= 16 pixels of its own face (box position, width and depth bound are its registers) and keeps a bit
-          // per survivor; only the survivors are written to the pair list, behind a wave prefix sum of the counts, and
-          // evaluated with full lanes.  (Round 1 listed every pair, then culled the list 64 pairs at a time with a decode
-          // per pair: 324 vector instructions per round against ~220 now, the kernel is bound by their issue.)
+        // ---- small boxes (at most 4 columns x 8 rows: nearly every face at this resolution) go through the depth cull and
+        // the compacted pair list; the others -- and everything when the list could overflow: the 3 x 3 boxes of the bodies
+        // nearest to the camera -- through the even split below, whose cost per pair is lower when a face has many
+        // (staged face in registers, no pair list).  A round may take both paths.  (Filling the list in several passes
+        // instead of falling back was measured in round 4: 3 % fewer pairs evaluated, kernel 3 % slower.)
+        int cnt_s = (cnt > 0 && f_nx <= 4 && f_ny <= 8) ? cnt : 0;
+        int npairs_s = __builtin_amdgcn_readlane(r_wave_scan_add(cnt_s), 63);
+        if (npairs_s > RPL) { cnt_s = 0; npairs_s = 0; }
+        const int cnt_g = cnt - cnt_s;
+        R_TMARK(1);
+        if (npairs_s > 0) {
+          // Depth cull first, per face lane: the clipped-barycentric depth of a face is never below its nearest vertex, so
+          // a pair whose face lies entirely behind the pixel's current 4th silhouette key cannot change the window (the keys
+          // only ever decrease; the nearest key of the wide pass never lies behind it: every key of the K=4 list was
+          // offered to slot 0 first -- r_insert -- and a face inside the narrow band is inside the wide one).  A lane walks
+          // the rows of its own box, four pixels per trip from ONE address (columns past the box read other LDS words and
+          // are masked out), and keeps a bit per survivor at position 4 * row + column; only the survivors are written to
+          // the pair list, behind a wave prefix sum of the counts, and evaluated with full lanes.
+          // (Round 1 listed every pair, then culled the list 64 pairs at a time with a decode per pair; rounds 2-3 walked the
+          // box in pixel order, four pixels per trip with a wrap test per pixel and a division by the box width per pair.)
           unsigned keepm = 0u;
-          if (cnt > 0) {
-            // byte offset of the pixel's key block; the walk over the box is branch-free and multiply-free, reads past the
-            // box (the last trip) land on other LDS words and are masked out below
-            unsigned a = __umul24((unsigned)f_pix, 40u);
-            const unsigned wrap = __umul24((unsigned)(tw - f_nx), 40u);
-            const char* kb = (const char*)keys;
-            int kx = 0;
-            for (int k0 = 0; k0 < cnt; k0 += 4) {          // four pixels per trip: their eight key words are in flight together
-              unsigned ad[4], q1[4], q9[4];
-#pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                ad[u] = a;
-                ++kx;
-                const bool w = kx == f_nx;
-                a += 40u + (w ? wrap : 0u);
-                kx = w ? 0 : kx;
-              }
-#pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                const unsigned* qh = (const unsigned*)(kb + ad[u]);
-                q1[u] = qh[1]; q9[u] = qh[9];
-              }
-              unsigned mx[4];
-#pragma unroll
-              for (int u = 0; u < 4; ++u) mx[u] = max(q1[u], q9[u]);       // behind BOTH keys <=> behind the farther one
-              unsigned bits = 0u;
-#pragma unroll
-              for (int u = 0; u < 4; ++u) bits |= (f_zb <= mx[u] ? 1u : 0u) << u;
-              keepm |= bits << k0;
+          if (cnt_s > 0) {
+            const char* kb = (const char*)keys + __umul24((unsigned)f_pix, 40u);
+            const unsigned rowstep = __umul24((unsigned)tw, 40u);
+            const unsigned colm = (1u << f_nx) - 1u;
+            for (int r4 = 0; r4 < 4 * f_ny; r4 += 4) {
+              const unsigned* qh = (const unsigned*)kb;
+              const unsigned q0 = qh[9], q1 = qh[19], q2 = qh[29], q3 = qh[39];
+              const unsigned bits = (f_zb <= q0 ? 1u : 0u) | (f_zb <= q1 ? 2u : 0u) | (f_zb <= q2 ? 4u : 0u) | (f_zb <= q3 ? 8u : 0u);
+              keepm |= (bits & colm) << r4;
+              kb += rowstep;
             }
-            keepm &= cnt >= 32 ? ~0u : (1u << cnt) - 1u;
           }
           const int nk = __popc(keepm);
           const int kincl = r_wave_scan_add(nk);
           const int nkeep = __builtin_amdgcn_readlane(kincl, 63);
-          n_cand += (unsigned)npairs; n_eval += (unsigned)nkeep;
+          n_cand += (unsigned)npairs_s; n_eval += (unsigned)nkeep;
           {
             int pos = kincl - nk;
             for (unsigned m = keepm; m; m &= m - 1u) pl[pos++] = (unsigned short)(lane | ((__ffs((int)m) - 1) << 6));
           }
           R_WAVE_SYNC();
+          R_TMARK(2);
           for (int i = lane; i < nkeep; i += 64) {
             const unsigned e = pl[i], lo = e & 63u, k = e >> 6;
             const unsigned d = (unsigned)desc[lo], fw = (unsigned)fid[lo];
-            const unsigned nx = d >> 20;
-            const unsigned ky_ = __umul24(k, fw >> 20) >> 10, kx_ = k - __umul24(ky_, nx);
-            const unsigned xi = (d & 1023u) + kx_, yi = ((d >> 10) & 1023u) + ky_;
+            const unsigned xi = (d & 1023u) + (k & 3u), yi = ((d >> 10) & 1023u) + (k >> 2);
             float T[RT];
 #pragma unroll
             for (int q = 0; q < RT; ++q) T[q] = T_[lo * RT + q];
             float pz, dd;
             bool inside;
             r_eval_fast(T, sXf[xi], sYf[yi], &pz, &inside, &dd);
-            r_insert((unsigned long long*)((char*)keys + __umul24(__umul24(yi, (unsigned)tw) + xi, 40u)), pz, inside, dd, (int)(fw & 0xfffffu));
+            r_insert((unsigned long long*)((char*)keys + __umul24(__umul24(yi, (unsigned)tw) + xi, 40u)), pz, inside, dd, (int)fw);
           }
           R_WAVE_SYNC();
-        } else if (npairs > 0) {
+          R_TMARK(3);
+        }
+        if (__ballot(cnt_g > 0) != 0ull) {
+          const int incl = r_wave_scan_add(cnt_g);
+          const int npairs = __builtin_amdgcn_readlane(incl, 63);
+          const int excl = incl - cnt_g;
           // ---- larger faces: the pairs are split evenly over the lanes, every lane walks a contiguous run ----------
           n_cand += (unsigned)npairs; n_eval += (unsigned)npairs;
           pre[lane] = excl;
@@ -1089,7 +1124,7 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
           R_WAVE_SYNC();
           // run start -> face: face o opens at the first lane whose run starts at or after pre[o]
           const int per = (npairs + 63) >> 6;
-          if (cnt > 0) {
+          if (cnt_g > 0) {
             const int tf = (excl + per - 1) / per;
             if (tf < 64) atomicMax(&mark[tf], lane);
           }
@@ -1100,7 +1135,7 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
             float T[RT];
 #pragma unroll
             for (int q = 0; q < RT; ++q) T[q] = T_[lo * RT + q];
-            int d = desc[lo], f = fid[lo] & 0xfffff;
+            int d = desc[lo], f = fid[lo];
             int nx = d >> 20, xa = d & 1023, ya = (d >> 10) & 1023;
             const int k = j0 - pre[lo];
             int ky_ = k / nx, kx_ = k - ky_ * nx;
@@ -1118,7 +1153,7 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
                 while (pre[lo + 1] <= j) ++lo;
 #pragma unroll
                 for (int q = 0; q < RT; ++q) T[q] = T_[lo * RT + q];
-                d = desc[lo]; f = fid[lo] & 0xfffff;
+                d = desc[lo]; f = fid[lo];
                 nx = d >> 20; xa = d & 1023; ya = (d >> 10) & 1023;
                 kx_ = 0; ky_ = 0;
                 nextp = pre[lo + 1];
@@ -1126,6 +1161,7 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
             }
           }
           R_WAVE_SYNC();
+          R_TMARK(4);
         }
         // ---- rotate the pipeline ----------------------------------------------------------------------------------
         e_a = e_b; e_b = e_c; e_c = e_n;
@@ -1135,17 +1171,44 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
         for (int k = 0; k < 9; ++k) ca[k] = cn[k];
       }
     }
+    R_TMARK(1);
     __syncthreads();
+    R_TMARK(5);
     // finished tile -> HBM (40 B per pixel), window row-major
     const int wx0 = p.win[b * 4], wy0 = p.win[b * 4 + 1], ww = p.win[b * 4 + 2];
     unsigned long long* gk = p.gkeys + (size_t)p.body_koff[b] * 5;
-    for (int i = tid; i < npx * 5; i += RB) {
-      const int px = i / 5, c = i - px * 5;
-      const int r = px / tw, cc = px - r * tw;
-      gk[((size_t)(sy0 - wy0 + r) * ww + (x0 - wx0 + cc)) * 5 + c] = keys[i];
+    if (tw == ww && x0 == wx0) {   // a full-width strip of rows (the usual tiling) is one contiguous range of the body's keys
+      unsigned long long* dst = gk + (size_t)(sy0 - wy0) * ww * 5;
+      for (int i = tid; i < npx * 5; i += RB) dst[i] = keys[i];
+    } else {
+      for (int i = tid; i < npx * 5; i += RB) {
+        const int px = i / 5, c = i - px * 5;
+        const int r = px / tw, cc = px - r * tw;
+        gk[((size_t)(sy0 - wy0 + r) * ww + (x0 - wx0 + cc)) * 5 + c] = keys[i];
+      }
     }
     r_tile_depth_sums(p, s, b, keys, tw, x0, sy0, npx, s_sums);
+    R_TMARK(6);
   }
+#if defined(R_TIMING) && R_TIMING == 3
+  if (p.pairs && tid == 0 && (int)blockIdx.x < total) {      // life span of the workgroup on the 100 MHz clock (last launch wins)
+    unsigned long long* slot = p.pairs + 2 + 2 * (size_t)blockIdx.x;
+    slot[0] = twall; slot[1] = wall_clock64();
+    if (blockIdx.x == 0) p.pairs[0] += 1ull;
+  }
+#elif defined(R_TIMING) && R_TIMING >= 4
+#elif defined(R_TIMING)
+  if (p.pairs) {
+    tacc[7] = (unsigned)(__builtin_readcyclecounter() - tbegin);
+    if (lane == 0) {
+      unsigned long long* slot = p.pairs + 2 + 2 * (size_t)blockIdx.x;
+      const int c = (R_TIMING - 1) * 4;
+      atomicAdd(slot, (unsigned long long)(tacc[c] >> 10) | ((unsigned long long)(tacc[c + 1] >> 10) << 32));
+      atomicAdd(slot + 1, (unsigned long long)(tacc[c + 2] >> 10) | ((unsigned long long)(tacc[c + 3] >> 10) << 32));
+      if (blockIdx.x == 0 && wave == 0) p.pairs[0] += 1ull;
+    }
+  }
+#else
   if (p.pairs) {
     // per-workgroup slots, plain adds (49 000 same-address atomics at the end of the kernel doubled its duration)
     __shared__ unsigned long long s_cnt[RW][2];
@@ -1160,6 +1223,7 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
       if (blockIdx.x == 0) p.pairs[0] += 1ull;
     }
   }
+#endif
 }
 
 // =============================================================================================
@@ -1268,67 +1332,14 @@ __global__ void k_raster_body_out(RasterP p) {
   p.sil_corr[b] = 0.f;                        // accumulated by k_raster_grads, consumed and cleared by k_raster_finish
 }
 
-// Last kernel of the rasterised terms, one thread per FRAME (a single workgroup: a few microseconds of work that used to
-// be three launches -- k_raster_body_out between selection and gradients, this kernel, and a reduction for the log):
-//   from_partials != 0 (gradients were requested: k_raster_grads has run): per body, the sums of its tiles in fixed order
-//     -> depth loss, depth-range partials, silhouette loss with the alpha-dependent part k_raster_grads accumulated
-//     (cleared here for the next launch);
-//   from_partials == 0 (values only): k_raster_body_out has done that from k_raster_sums' totals;
-//   then the chain of the depth-range leaves (optimizer.py:683-688: min_z = softplus(zmin), max_z = min_z.detach() + 1 +
-//   softplus(zmax)) and, when asked for, the two loss sums of the log row.
+// Last kernel of the rasterised terms (a single workgroup: a few microseconds of work that used to be three launches --
+// k_raster_body_out between selection and gradients, this kernel, and a reduction for the log): the closing job of
+// mh_common.h / mh_raster_fin.  In the optimisation cycle the job rides in the LBS backward's pose kernel instead
+// (mh_raster_terms_deferred + mh_lbs_backward_kp_fin) and this kernel is not launched.
 #define RFIN 1024
-__global__ __launch_bounds__(RFIN) void k_raster_finish(RasterP p, int T, int from_partials, const float* zmin_lin, const float* zmax_lin,
-                                                        float* gzmin, float* gzmax, float* log_depth, float* log_sil) {
-  __shared__ float sh[RFIN / 64];
-  __shared__ float s_g0[RFIN], s_g1[RFIN];
-  const int N = p.N, tid = threadIdx.x;
-  const int fpc = max(1, RFIN / N);              // frames per pass: thread = body, then thread = frame
-  float ld = 0.f, ls = 0.f;
-  for (int t0 = 0; t0 < T; t0 += fpc) {
-    const int b = t0 * N + tid;
-    float g0 = 0.f, g1 = 0.f;
-    if (tid < fpc * N && b < p.B) {
-      if (from_partials) {
-        float S[6];
-        r_body_sums(p, b, S);
-        const float cnt = S[2] + 1.f;
-        const float diff = S[0] / cnt - S[1] / cnt;                                                  // losses.py:24-27
-        p.depth_body[b] = diff * diff;
-        const float gB = p.coef_depth * (-2.f) * diff / cnt;
-        g0 = gB * S[3];                           // d/d(1/min_z) through the target disparity
-        g1 = gB * S[4];                           // d/d(1/max_z)
-        p.sil_body[b] = p.sil_apply[b] * (p.sil_S[b] + p.sil_corr[b]) / (p.sil_D[b] + 1.f);        // losses.py:35-38
-        p.sil_corr[b] = 0.f;
-      } else {
-        g0 = p.dinv[(size_t)b * 2];
-        g1 = p.dinv[(size_t)b * 2 + 1];
-        p.sil_corr[b] = 0.f;                      // (gradients AND images in one call: k_raster_grads ran after k_raster_body_out)
-      }
-      ld += p.depth_body[b];
-      ls += p.sil_body[b];
-    }
-    s_g0[tid] = g0; s_g1[tid] = g1;
-    __syncthreads();
-    const int t = t0 + tid;
-    if (gzmin && tid < fpc && t < T) {
-      float a0 = 0.f, a1 = 0.f;
-      for (int n = 0; n < N; ++n) { a0 += s_g0[tid * N + n]; a1 += s_g1[tid * N + n]; }
-      const float e0 = expf(zmin_lin[t]), e1 = expf(zmax_lin[t]);
-      const float min_z = logf(1.f + e0);
-      const float max_z = min_z + 1.f + logf(1.f + e1);
-      gzmin[t] += a0 * (-1.f / (min_z * min_z)) * (e0 / (1.f + e0));
-      gzmax[t] += a1 * (-1.f / (max_z * max_z)) * (e1 / (1.f + e1));
-    }
-    __syncthreads();
-  }
-  if (log_depth || log_sil) {
-    ld = r_block_sum(ld, sh);
-    ls = r_block_sum(ls, sh);
-    if (tid == 0) {
-      if (log_depth) *log_depth = ld;
-      if (log_sil) *log_sil = ls;
-    }
-  }
+__global__ __launch_bounds__(RFIN) void k_raster_finish(mh_raster_fin f) {
+  __shared__ float s_g0[MH_FIN_U * RFIN], s_g1[MH_FIN_U * RFIN];
+  mh_raster_finish_job<RFIN>(f, s_g0, s_g1);
 }
 
 // per-body constants of the gradient kernels
@@ -1559,6 +1570,16 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
   int* plist = (int*)(gtab + (use_tab ? p.V * 3 : 0));
   int* s_n = plist + RG_LIST;
   const int nunits = p.gunit_total[0];
+#if defined(R_TIMING) && R_TIMING >= 4
+  // timing builds 4 / 5: wave-elapsed cycles of the gradient kernel by phase: 0 unit header + body sums, 1 classification
+  // loads + table clear, 2 compaction, 3 pixels, 4 reductions + flush, 7 everything
+  unsigned tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_readcyclecounter();
+  const unsigned long long tbegin = tlast;
+#define RG_TMARK(c) R_TMARK(c)
+#else
+#define RG_TMARK(c) do { } while (0)
+#endif
   for (int u = blockIdx.x; u < nunits; u += gridDim.x) {
     const unsigned long long ue = p.gunit_list[u];
     const int b = (int)(ue >> 32), up0 = (int)(ue & 0xffffffffu) * RG_UNIT;
@@ -1589,6 +1610,7 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
     // The classification loads of all of a thread's pixels are issued first, and the table is cleared while they
     // are in flight.
     bool table_clear = !use_tab;
+    RG_TMARK(0);
     for (int cbase = up0; cbase < npx; cbase += RG_LIST) {
     constexpr int NPT = (RG_LIST + RGB - 1) / RGB;
     unsigned long long c0[NPT], c1[NPT];
@@ -1610,6 +1632,7 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
       table_clear = true;
     }
     __syncthreads();
+    RG_TMARK(1);
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
       const int i = cbase + tid + j * RGB;
@@ -1626,12 +1649,14 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
       }
     }
     __syncthreads();
+    RG_TMARK(2);
     const int nlive = *s_n;
     for (int li_ = tid; li_ < nlive; li_ += RGB) {
       const int i = plist[li_];
       rg_pixel<TAB ? 1 : 0>(p, bd, i, lcorr, dc);
     }
     __syncthreads();
+    RG_TMARK(3);
     }   // classification pass
     lcorr = r_block_sum(lcorr, s_red);
     if (tid == 0 && lcorr != 0.f) atomicAdd(&p.sil_corr[b], lcorr);
@@ -1640,7 +1665,20 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
         const float g = gtab[i];
         if (g != 0.f) atomicAdd(&gvb[i], g);      // several units of one body may flush concurrently
       }
+    RG_TMARK(4);
   }
+#if defined(R_TIMING) && R_TIMING >= 4
+  if (p.pairs) {
+    tacc[7] = (unsigned)(__builtin_readcyclecounter() - tbegin);
+    if ((tid & 63) == 0) {
+      unsigned long long* slot = p.pairs + 2 + 2 * (size_t)(blockIdx.x % R_STRIP_GRID);
+      const int c = (R_TIMING - 4) * 4;
+      atomicAdd(slot, (unsigned long long)(tacc[c] >> 10) | ((unsigned long long)(tacc[c + 1] >> 10) << 32));
+      atomicAdd(slot + 1, (unsigned long long)(tacc[c + 2] >> 10) | ((unsigned long long)(tacc[c + 3] >> 10) << 32));
+      if (blockIdx.x == 0 && tid == 0) p.pairs[0] += 1ull;
+    }
+  }
+#endif
 }
 
 // Deterministic form of the gradient scatter (mh_raster_set_deterministic / MHHIP_DETERMINISTIC=1): one workgroup per
@@ -1880,6 +1918,19 @@ extern "C" int mh_raster_pair_counters(int T, int N, int V, int F, int H, int W,
   MH_HIP(hipMemcpyAsync(host, p.pairs, sizeof(host), hipMemcpyDeviceToHost, (hipStream_t)stream));
   MH_HIP(hipStreamSynchronize((hipStream_t)stream));
   out_host[0] = host[0]; out_host[1] = 0ull; out_host[2] = 0ull;
+#if defined(R_TIMING) && R_TIMING == 3
+  {   // timing build 3: {launches, span of the last launch, sum of the workgroups' life spans} in 10 ns ticks
+    unsigned long long t0 = ~0ull, t1 = 0ull;
+    for (int i = 0; i < R_STRIP_GRID; ++i) {
+      const unsigned long long a = host[2 + 2 * i], b = host[3 + 2 * i];
+      if (!a || b < a) continue;
+      t0 = a < t0 ? a : t0; t1 = b > t1 ? b : t1;
+      out_host[2] += b - a;
+    }
+    out_host[1] = t1 > t0 ? t1 - t0 : 0ull;
+    return MH_OK;
+  }
+#endif
   for (int i = 0; i < R_STRIP_GRID; ++i) { out_host[1] += host[2 + 2 * i]; out_host[2] += host[3 + 2 * i]; }
   return MH_OK;
 }
@@ -1926,7 +1977,8 @@ static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const flo
                              const uint32_t* front, const float* sil_apply, const float* sil_D, const float* sil_S,
                              float coef_depth, float coef_sil, float eps, float* gverts, float* gzmin, float* gzmax,
                              float* depth_body, float* sil_body, void* ws, float* zbuf_out, float* alpha_out,
-                             int phases, float* log_depth, float* log_sil, void* stream, int projected = 0) {
+                             int phases, float* log_depth, float* log_sil, void* stream, int projected = 0,
+                             mh_raster_fin* fin_out = nullptr) {
   MH_CHECK(cam_K_host && (verts || projected) && faces && bits && ebits && depths && zmin_lin && zmax_lin && pose2d_valid && front &&
                sil_apply && sil_D && sil_S && depth_body && sil_body && ws,
            "null argument");
@@ -2001,12 +2053,24 @@ static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const flo
     MH_LAUNCH_CHECK();
     mh_prof_mark(MH_PROF_RASTER_GRADS, 1, st);
   }
+  if (fin_out) memset(fin_out, 0, sizeof(*fin_out));
   if (gverts || (gzmin && gzmax) || log_depth || log_sil) {
     // values-only launches with images requested went through k_raster_body_out (sums of k_raster_sums): then only the chain
-    const int from_partials = (gverts && !zbuf_out && !alpha_out) ? 1 : 0;
-    hipLaunchKernelGGL(k_raster_finish, dim3(1), dim3(RFIN), 0, st, p, T, from_partials, zmin_lin, zmax_lin,
-                       (gzmin && gzmax) ? gzmin : (float*)nullptr, gzmax, log_depth, log_sil);
-    MH_LAUNCH_CHECK();
+    mh_raster_fin f;
+    f.T = T; f.N = N; f.B = p.B; f.from_partials = (gverts && !zbuf_out && !alpha_out) ? 1 : 0;
+    f.coef_depth = p.coef_depth;
+    f.body_first = p.body_first; f.body_ns = p.body_ns; f.partial = p.partial; f.dinv = p.dinv;
+    f.sil_apply = p.sil_apply; f.sil_D = p.sil_D; f.sil_S = p.sil_S; f.sil_corr = p.sil_corr;
+    f.depth_body = p.depth_body; f.sil_body = p.sil_body;
+    f.zmin_lin = zmin_lin; f.zmax_lin = zmax_lin;
+    f.gzmin = (gzmin && gzmax) ? gzmin : (float*)nullptr; f.gzmax = gzmax;
+    f.log_depth = log_depth; f.log_sil = log_sil;
+    if (fin_out) {
+      *fin_out = f;            // the caller's next launch carries the job (mh_lbs_backward_kp_fin)
+    } else {
+      hipLaunchKernelGGL(k_raster_finish, dim3(1), dim3(RFIN), 0, st, f);
+      MH_LAUNCH_CHECK();
+    }
   }
   return MH_OK;
 }
@@ -2060,6 +2124,20 @@ extern "C" int mh_raster_terms_projected(int T, int N, int V, int F, int H, int 
   return raster_terms_impl(T, N, V, F, H, W, cam_K_host, verts, faces, bits, ebits, depths, zmin_lin, zmax_lin, pose2d_valid, front,
                            sil_apply, sil_D, sil_S, coef_depth, coef_sil, eps, gverts, gzmin, gzmax, depth_body, sil_body, ws, zbuf_out,
                            alpha_out, phases, log_depth, log_sil, stream, projected);
+}
+
+extern "C" int mh_raster_terms_deferred(int T, int N, int V, int F, int H, int W, const float* cam_K_host, const float* verts,
+                                         const int32_t* faces, const uint32_t* bits, const uint32_t* ebits, const float* depths,
+                                         const float* zmin_lin, const float* zmax_lin, const float* pose2d_valid,
+                                         const uint32_t* front, const float* sil_apply, const float* sil_D, const float* sil_S,
+                                         float coef_depth, float coef_sil, float eps, float* gverts, float* gzmin, float* gzmax,
+                                         float* depth_body, float* sil_body, void* ws, float* zbuf_out, float* alpha_out,
+                                         int phases, float* log_depth, float* log_sil, int projected, mh_raster_fin* fin_out, void* stream) {
+  MH_CHECK(phases >= 1 && phases <= 15, "phases: 1 = preparation + selection + values, 2 = gradients, 4 = preparation only, 8 = selection only");
+  MH_CHECK(fin_out, "null argument");
+  return raster_terms_impl(T, N, V, F, H, W, cam_K_host, verts, faces, bits, ebits, depths, zmin_lin, zmax_lin, pose2d_valid, front,
+                           sil_apply, sil_D, sil_S, coef_depth, coef_sil, eps, gverts, gzmin, gzmax, depth_body, sil_body, ws, zbuf_out,
+                           alpha_out, phases, log_depth, log_sil, stream, projected, fin_out);
 }
 
 // where mh_lbs_forward_proj writes for this workspace, and the constants of the projection / motion test (the host-side

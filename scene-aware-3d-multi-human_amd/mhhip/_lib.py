@@ -36,6 +36,15 @@ class FwdProj(ctypes.Structure):
                 ('moved', vp), ('clear', vp), ('clear_n', ctypes.c_ulonglong)]
 
 
+class RasterFin(ctypes.Structure):
+    """mh_raster_fin of include/mhmocap_hip.h: the rasterised terms' closing job, left by mh_raster_terms_deferred for the
+    LBS backward's pose kernel (mh_lbs_backward_kp_fin)"""
+    _fields_ = [('T', ctypes.c_int), ('N', ctypes.c_int), ('B', ctypes.c_int), ('from_partials', ctypes.c_int),
+                ('coef_depth', ctypes.c_float)] + [(k, vp) for k in (
+                    'body_first', 'body_ns', 'partial', 'dinv', 'sil_apply', 'sil_D', 'sil_S', 'sil_corr', 'depth_body',
+                    'sil_body', 'zmin_lin', 'zmax_lin', 'gzmin', 'gzmax', 'log_depth', 'log_sil')]
+
+
 _lib = None
 
 
@@ -139,6 +148,9 @@ def lib():
         L.mh_keypoint_workspace_bytes.argtypes = [vp, ctypes.c_int]
         L.mh_keypoint_terms.argtypes = [vp, ctypes.c_int, vp, c_float_p, c_float_p, c_float_p, vp] + [ctypes.c_float] * 4 + [vp] * 8
         L.mh_lbs_backward_kp.argtypes = [vp, ctypes.c_int, ctypes.c_int] + [vp] * 11
+        L.mh_lbs_backward_kp_fin.argtypes = [vp, ctypes.c_int, ctypes.c_int] + [vp] * 10 + [ctypes.POINTER(RasterFin), vp]
+        L.mh_raster_terms_deferred.argtypes = [ctypes.c_int] * 6 + [c_float_p] + [vp] * 12 + [ctypes.c_float] * 3 + [vp] * 8 + [
+            ctypes.c_int, vp, vp, ctypes.c_int, ctypes.POINTER(RasterFin), vp]
         L.mh_raster_workspace_init.argtypes = [ctypes.c_int] * 6 + [vp, vp]
         L.mh_raster_workspace_offsets.argtypes = [ctypes.c_int] * 6 + [ctypes.POINTER(ctypes.c_size_t)]
         L.mh_avg_depth_loss.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_float, vp, vp, vp]

@@ -1,4 +1,5 @@
 """Binding of the fused rasteriser + depth / silhouette residual kernel (``mh_raster_terms``)."""
+import ctypes
 import numpy as np
 import torch
 
@@ -33,23 +34,29 @@ class RasterTerms(object):
         check(_lib.lib().mh_raster_forward_targets(*self.dims, self.K.ctypes.data_as(_lib.c_float_p), ptr(self.ws), ctypes.byref(t)))
         return t
 
-    def __call__(self, e, gverts, log, with_grads=True, zbuf_out=None, alpha_out=None, phases=3):
-        """phases: 1 = selection + values (does not touch gverts), 2 = gradients + log entries, 3 = both"""
+    def __call__(self, e, gverts, log, with_grads=True, zbuf_out=None, alpha_out=None, phases=3, defer=False):
+        """phases: 1 = selection + values (does not touch gverts), 2 = gradients + log entries, 3 = both.
+        defer (with phases & 2): the closing kernel is NOT launched; its job is returned (a ``_lib.RasterFin``) for the
+        caller's LBS backward to carry out (mh_lbs_backward_kp_fin)."""
         L = _lib.lib()
         st = _lib.stream_ptr(e.dev)
         g = e.grads
         # the engine's last forward has projected the vertices into this workspace: no pass over them here
         projected = 1 if getattr(e, '_projected_into', None) is self else 0
-        check(L.mh_raster_terms_projected(e.T, e.N, e.V, self.faces.shape[0], e.H, e.W, self.K.ctypes.data_as(_lib.c_float_p),
-                                      ptr(e.verts), ptr(self.faces), ptr(e.bits), ptr(e.ebits), ptr(e.depths),
-                                      ptr(e.leaf('zmin_lin')), ptr(e.leaf('zmax_lin')), ptr(e.p2d_valid), ptr(e.front),
-                                      ptr(e.sil_apply), ptr(e.sil_D), ptr(e.sil_S), float(e.c['depth']),
-                                      float(e.c['silhouette']), float(e.eps), ptr(gverts) if with_grads else None,
-                                      ptr(e.leaf('zmin_lin', g)) if with_grads else None,
-                                      ptr(e.leaf('zmax_lin', g)) if with_grads else None, ptr(e.depth_body), ptr(e.sil_body),
-                                      ptr(self.ws), ptr(zbuf_out), ptr(alpha_out), int(phases), ptr(log[1:2]), ptr(log[2:3]),
-                                      projected, st))
-
+        args = (e.T, e.N, e.V, self.faces.shape[0], e.H, e.W, self.K.ctypes.data_as(_lib.c_float_p),
+                ptr(e.verts), ptr(self.faces), ptr(e.bits), ptr(e.ebits), ptr(e.depths),
+                ptr(e.leaf('zmin_lin')), ptr(e.leaf('zmax_lin')), ptr(e.p2d_valid), ptr(e.front),
+                ptr(e.sil_apply), ptr(e.sil_D), ptr(e.sil_S), float(e.c['depth']),
+                float(e.c['silhouette']), float(e.eps), ptr(gverts) if with_grads else None,
+                ptr(e.leaf('zmin_lin', g)) if with_grads else None,
+                ptr(e.leaf('zmax_lin', g)) if with_grads else None, ptr(e.depth_body), ptr(e.sil_body),
+                ptr(self.ws), ptr(zbuf_out), ptr(alpha_out), int(phases), ptr(log[1:2]), ptr(log[2:3]), projected)
+        if defer:
+            fin = _lib.RasterFin()
+            check(L.mh_raster_terms_deferred(*args, ctypes.byref(fin), st))
+            return fin
+        check(L.mh_raster_terms_projected(*args, st))
+        return None
 
     def sort_counters(self, e):
         """(bodies seen, bodies whose face lists were re-sorted), cumulative over the launches on this workspace"""

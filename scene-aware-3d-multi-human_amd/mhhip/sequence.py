@@ -683,7 +683,10 @@ class SequenceEngine(object):
                 # signalled: +0.5 % same-box)
                 main.wait_stream(side)
                 joined = True
-                raster(self, gv, log, phases=2)
+                # the closing kernel's job rides in the LBS backward's pose kernel when that is the fused form
+                # (_finish_b): one launch and one dependent kernel less on the chain
+                defer = bool(getattr(self, '_kp_chunk', False)) and os.environ.get('MHHIP_NO_DEFER') != '1'
+                self._raster_fin = raster(self, gv, log, phases=2, defer=defer)
                 self._toc(ev)
             else:
                 # no rasteriser: alpha = 0, zbuf empty -> the mask-only silhouette term (tests only)
@@ -737,9 +740,11 @@ class SequenceEngine(object):
             self._scene_terms(st)
             self._toc(ev)
         ev = self._tic('lbs_backward')
+        fin, self._raster_fin = getattr(self, '_raster_fin', None), None
         if getattr(self, '_kp_chunk', False):
-            check(L.mh_lbs_backward_kp(self.m.handle, B, N, ptr(self.leaf('betas')), ptr(self.leaf('poses_smpl')), ptr(self.vposed),
-                                       ptr(gv), ptr(gposes), ptr(gpT), ptr(gbetas), ptr(gxs), ptr(self.ws), ptr(self.ws2), st))
+            check(L.mh_lbs_backward_kp_fin(self.m.handle, B, N, ptr(self.leaf('betas')), ptr(self.leaf('poses_smpl')), ptr(self.vposed),
+                                           ptr(gv), ptr(gposes), ptr(gpT), ptr(gbetas), ptr(gxs), ptr(self.ws), ptr(self.ws2),
+                                           ctypes.byref(fin) if fin is not None else None, st))
         else:
             check(L.mh_lbs_backward(self.m.handle, B, N, ptr(self.leaf('betas')), ptr(self.leaf('poses_smpl')),
                                     ptr(self.leaf('xscale')), ptr(pT), ptr(self.vposed), ptr(gv), ptr(self.gj) if self.kp_fused else None, ptr(gposes),

@@ -538,6 +538,10 @@ int mh_raster_workspace_offsets(int T, int N, int V, int F, int H, int W, size_t
 int mh_raster_pair_counters(int T, int N, int V, int F, int H, int W, void* ws, unsigned long long* out_host /*[3]*/, void* stream);
 int mh_raster_set_sort_margin(int rows);
 int mh_raster_get_sort_margin(void);
+/* test aid: all_even != 0 sends every round of the selection kernel down its even-split path (no depth cull, no pair list);
+ * the selection keys must not depend on the path a round takes.  Process-wide; part of the cycle graphs' key. */
+int mh_raster_set_path(int all_even);
+int mh_raster_get_path(void);
 int mh_raster_sort_counters(int T, int N, int V, int F, int H, int W, void* ws, unsigned long long* out_host /*[2]*/, void* stream);
 int mh_raster_set_deterministic(int on);
 int mh_raster_get_deterministic(void);

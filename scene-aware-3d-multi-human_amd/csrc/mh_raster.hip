@@ -93,6 +93,7 @@ struct RasterP {
   // temporal coherence of the face sort (see k_raster_face_sort): the sorted lists of a body are kept until one of its
   // vertices has moved `margin` pixel rows away from where it was when the lists were built
   int margin;                // rows (0: rebuild every launch)
+  int all_even;              // test aid (mh_raster_set_path): 1 = every round of k_raster_strip takes the even-split path
   float* rowb;               // [B][V] continuous pixel-row coordinate of every vertex at the body's last sort
   unsigned long long* sort_tag;   // [B] validity tag of the body's lists (a fresh workspace holds anything)
   char* ctl_end;             // (host) end of the control words
@@ -1059,7 +1060,7 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
         // nearest to the camera -- through the even split below, whose cost per pair is lower when a face has many
         // (staged face in registers, no pair list).  A round may take both paths.  (Filling the list in several passes
         // instead of falling back was measured in round 4: 3 % fewer pairs evaluated, kernel 3 % slower.)
-        int cnt_s = (cnt > 0 && f_nx <= 4 && f_ny <= 8) ? cnt : 0;
+        int cnt_s = (cnt > 0 && f_nx <= 4 && f_ny <= 8 && !p.all_even) ? cnt : 0;
         int npairs_s = __builtin_amdgcn_readlane(r_wave_scan_add(cnt_s), 63);
         if (npairs_s > RPL) { cnt_s = 0; npairs_s = 0; }
         const int cnt_g = cnt - cnt_s;
@@ -1090,7 +1091,11 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
           const int nk = __popc(keepm);
           const int kincl = r_wave_scan_add(nk);
           const int nkeep = __builtin_amdgcn_readlane(kincl, 63);
+#ifdef R_COUNT_PATHS          // counter A = pairs of the even-split path, counter B = survivors of the pair-list path
+          n_eval += (unsigned)nkeep;
+#else
           n_cand += (unsigned)npairs_s; n_eval += (unsigned)nkeep;
+#endif
           {
             int pos = kincl - nk;
             for (unsigned m = keepm; m; m &= m - 1u) pl[pos++] = (unsigned short)(lane | ((__ffs((int)m) - 1) << 6));
@@ -1117,7 +1122,11 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
           const int npairs = __builtin_amdgcn_readlane(incl, 63);
           const int excl = incl - cnt_g;
           // ---- larger faces: the pairs are split evenly over the lanes, every lane walks a contiguous run ----------
+#ifdef R_COUNT_PATHS
+          n_cand += (unsigned)npairs;
+#else
           n_cand += (unsigned)npairs; n_eval += (unsigned)npairs;
+#endif
           pre[lane] = excl;
           if (lane == 63) pre[64] = npairs;
           mark[lane] = -1;
@@ -1800,6 +1809,14 @@ extern "C" int mh_raster_set_sort_margin(int rows) {
   return MH_OK;
 }
 extern "C" int mh_raster_get_sort_margin(void) { return raster_sort_margin(); }
+// test aid: 1 sends every round of the selection kernel down the even-split path (no depth cull, no pair list).  The keys
+// must not depend on the path a round takes (tests/test_raster_paths_gpu.py): the pair arithmetic is spelled out for that.
+static int g_raster_all_even = 0;
+extern "C" int mh_raster_set_path(int all_even) {
+  g_raster_all_even = all_even ? 1 : 0;
+  return MH_OK;
+}
+extern "C" int mh_raster_get_path(void) { return g_raster_all_even; }
 
 static size_t r_align(size_t x) { return (x + 255) & ~(size_t)255; }
 static size_t r_max_units(size_t B, int H, int W) { return B + B * (size_t)H * W / RG_UNIT + 1; }
@@ -1835,6 +1852,7 @@ static size_t r_carve(RasterP& p, void* ws) {
   p.body_koff = (long long*)c; c += r_align(B * 8);
   p.rowb = (float*)c; c += r_align(B * V * 4);
   p.margin = raster_sort_margin();
+  p.all_even = g_raster_all_even;
   p.max_units = (int)r_max_units(B, H, W);
   p.strip_cls = (int*)c; c += r_align(ms * 4);
   p.strip_order = (int*)c; c += r_align(ms * 4);

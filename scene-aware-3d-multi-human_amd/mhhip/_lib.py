@@ -137,6 +137,7 @@ def lib():
         L.mh_raster_terms_phase.argtypes = [ctypes.c_int] * 6 + [c_float_p] + [vp] * 12 + [ctypes.c_float] * 3 + [vp] * 8 + [ctypes.c_int, vp]
         L.mh_raster_set_deterministic.argtypes = [ctypes.c_int]
         L.mh_raster_set_sort_margin.argtypes = [ctypes.c_int]
+        L.mh_raster_set_path.argtypes = [ctypes.c_int]
         L.mh_raster_pair_counters.argtypes = [ctypes.c_int] * 6 + [vp, ctypes.POINTER(ctypes.c_ulonglong), vp]
         L.mh_raster_sort_counters.argtypes = [ctypes.c_int] * 6 + [vp, ctypes.POINTER(ctypes.c_ulonglong), vp]
         L.mh_raster_terms_phase_log.argtypes = [ctypes.c_int] * 6 + [c_float_p] + [vp] * 12 + [ctypes.c_float] * 3 + [vp] * 8 + [ctypes.c_int, vp, vp, vp]

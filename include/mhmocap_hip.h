@@ -494,6 +494,10 @@ struct mh_raster_fin {
   float* gzmax;
   float* log_depth;
   float* log_sil;
+  /* phases & 128 of mh_raster_terms_deferred: the carrier also rebuilds the rasteriser's work lists (tile and gradient-unit
+   * order: a schedule for the NEXT launch on that workspace) -- the parameter block it needs, opaque to the caller */
+  int has_lists;
+  unsigned long long lists[75];
 };
 int mh_raster_forward_targets(int T, int N, int V, int F, int H, int W, const float* cam_K_host, void* ws,
                               mh_fwd_proj* out);

@@ -15,6 +15,7 @@
 #include <algorithm>
 
 #include "mh_common.h"
+#include "mh_raster_p.h"
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -1466,7 +1467,8 @@ struct PoseBwdP {
   float* gxs_b;     // [G*32]
   int scale_from_joint_sums;   // 1: d/dlog-scale = sum_j <A_j, dL/dA_j> (pS[3] is not filled by the split kernels)
   mh_tree tree;
-  int has_fin;                 // the FIRST workgroup of the launch carries the rasteriser's closing job instead of a body
+  int has_fin;                 // 1: the FIRST workgroup of the launch carries the rasteriser's closing job instead of a body;
+                               // 2: and the second one rebuilds its work lists
                                // (first: the body workgroups outnumber the slots of the device, the last one starts late)
   mh_raster_fin fin;
 };
@@ -1478,6 +1480,12 @@ __global__ __launch_bounds__(256) void k_pose_bwd(PoseBwdP p) {
     // own between the gradient kernel and the backward they cost the chain 16
     __shared__ float f_g0[MH_FIN_U * 256], f_g1[MH_FIN_U * 256];
     mh_raster_finish_job<256>(p.fin, f_g0, f_g1);
+    return;
+  }
+  if (p.has_fin == 2 && blockIdx.x == 1) {
+    // ... and the rasteriser's work lists for the next launch on that workspace (a schedule: tile and unit order), which
+    // used to be a launch of their own between the preparation and the selection kernel
+    r_finalize_lists<256>(*(const RasterP*)p.fin.lists);
     return;
   }
   __shared__ float sGA[1][12 * MH_NJ];   // summed dL/dA  [e][j]
@@ -1893,7 +1901,7 @@ static int lbs_backward_impl(const mh_model* m, int B, int NB, const float* beta
   pp.gposes = gposes; pp.gtransl = gtransl; pp.gbeta_b = bw.gbeta_b; pp.gxs_b = bw.gxs_b;
   pp.scale_from_joint_sums = split16 ? 1 : 0;
   pp.tree = m->tree;
-  pp.has_fin = (fin && fin->B > 0) ? 1 : 0;
+  pp.has_fin = (fin && fin->B > 0) ? (fin->has_lists ? 2 : 1) : 0;
   if (pp.has_fin) pp.fin = *fin; else memset(&pp.fin, 0, sizeof(pp.fin));
   mh_prof_mark(MH_PROF_POSE_BWD, 0, st);
   hipLaunchKernelGGL(k_pose_bwd, dim3(G * 32 + pp.has_fin), dim3(256), 0, st, pp);

@@ -10,8 +10,11 @@
 //                         face and counting sort by first row (a tile's candidate faces become contiguous ranges) -- only
 //                         when a vertex has moved more than `margin` rows since the body's last sort (temporal coherence);
 //                         the body's tiles of <= R_CAP pixels with their cost classes
-//   k_raster_lists        one workgroup: where each body's keys live, tiles ordered by cost class (longest first),
-//                         work units of the gradient kernel -- device-side lists, no host sync
+//   k_raster_lists        one workgroup: tiles ordered by cost class (longest first), work units of the gradient kernel --
+//                         device-side lists, no host sync.  A SCHEDULE only: every body's keys live in a region of their
+//                         own, and the kernels below find every tile / unit with lists that are a launch old (or empty);
+//                         in the optimisation cycle the lists are therefore rebuilt off the chain, by a workgroup of the
+//                         LBS backward's pose kernel (mh_raster_p.h, mh_raster_fin), and this kernel is not launched
 //   k_raster_strip        one workgroup per tile; every wave runs barrier-free rounds of 64 faces (3-deep gather
 //                         pipeline, bbox, pair list / even split, depth cull) and inserts 64-bit (z, face) keys into
 //                         the tile's LDS window with ds_min_u64: slot 0 = nearest face of the blur 1e-4 pass (all
@@ -20,11 +23,13 @@
 //                         The finished window is written to HBM once (40 B per window pixel).
 //   k_raster_sums         per tile: residual sums of the depth and silhouette terms
 //   k_raster_finish       per frame: per-body loss values from the tile sums, chain of the depth-range leaves, log sums
+//                         (the closing job of mh_common.h; in the cycle it rides in the pose kernel too)
 //   k_raster_grads        per work unit (2048 window pixels of one body): live-pixel compaction, exact re-evaluation
 //                         of the selected faces, gradients scattered to an LDS vertex table, flushed with atomics
 // No (b,N,H,W,K) fragment tensor, z-buffer or alpha image is materialised (the reference builds
 // two of them per batch).
 #include "mh_common.h"
+#include "mh_raster_p.h"
 
 #define RS_EMPTY 0xffffffffffffffffull
 #define R_KEPS 1e-8f
@@ -40,75 +45,6 @@
 #define R_CAP 640            // window pixels per tile (5 x u64 each = 25.6 KB of LDS; 2 workgroups per CU)
 #define RT 13                // floats staged per face: 9 NDC coordinates, 1/area, 1/|edge|^2 x 3
 
-struct RasterP {
-  int B, N, V, F, H, W;
-  float s, w1, h1;           // x_ndc = -s*x/z + w1, y_ndc = -s*y/z + h1 (transforms.py:222-255, R=diag(-1,-1,1))
-  const float* verts;
-  const int* faces;
-  const uint32_t* bits;
-  const uint32_t* ebits;
-  const float* depths;
-  const float* zmin_lin;
-  const float* zmax_lin;
-  const float* p2d_valid;
-  const uint32_t* front;
-  const float* sil_apply;
-  const float* sil_D;
-  const float* sil_S;
-  float coef_depth, coef_sil, eps;
-  float* gverts;
-  float* depth_body;
-  float* sil_body;
-  float* zbuf_out;           // (B,H,W) or null
-  float* alpha_out;          // (B,H,W) or null
-  // workspace
-  int max_strips;
-  int* win;                  // [B][4] x0,y0,ww,wh (ww <= 0: nothing on screen)
-  int* body_first;           // [B] first tile slot of the body (b * max_strips / B)
-  int* body_ns;              // [B] tiles of the body
-  int* strip_body;           // [max_strips]
-  int* strip_row0;           // [max_strips] first image row of the tile
-  int* strip_rows;           // [max_strips]
-  int* strip_col0;           // [max_strips] first image column of the tile
-  int* strip_cols;           // [max_strips]
-  long long* body_koff;      // [B] first window pixel of the body in gkeys (window row-major)
-  float* partial;            // [max_strips][6]
-  float* dinv;               // [B][2]
-  unsigned long long* gkeys; // [sum of window pixels][5]
-  float* ndc;                // [B][V][3] projected vertices (NDC x, y, view z)
-  unsigned* frows;           // [B][F] conservative pixel-row range of every face: lo | hi << 16 (lo > hi: skip)
-  unsigned* fsort;           // [B][F] faces ordered by their first row: hi << 20 | face
-  int* row_start;            // [B][3][H+1] (+1): per list (near short, far short, tall), first entry of fsort with lo >= row
-  int* maxh;                 // [B] tallest face (rows) of the body
-  // work lists (put together by the last workgroup of k_raster_prepare)
-  int max_units;
-  unsigned* ctl;             // (reserved control words)
-  int* total;                // [1] number of tiles
-  int* strip_cls;            // [max_strips] cost class of a tile (by slot)
-  int* strip_order;          // [max_strips] tile slots, most expensive class first
-  int* gunit_total;          // [1]
-  unsigned long long* gunit_list;   // [max_units] body << 32 | piece: RG_UNIT window pixels of one body, full pieces first
-  int* stale;                // [B] 1 = the body's face lists were rebuilt this launch
-  float* sil_corr;           // [B] sum over the silhouette pixels of alpha^2 - 2 alpha seg (accumulated by k_raster_grads)
-  // temporal coherence of the face sort (see k_raster_face_sort): the sorted lists of a body are kept until one of its
-  // vertices has moved `margin` pixel rows away from where it was when the lists were built
-  int margin;                // rows (0: rebuild every launch)
-  int all_even;              // test aid (mh_raster_set_path): 1 = every round of k_raster_strip takes the even-split path
-  float* rowb;               // [B][V] continuous pixel-row coordinate of every vertex at the body's last sort
-  unsigned long long* sort_tag;   // [B] validity tag of the body's lists (a fresh workspace holds anything)
-  char* ctl_end;             // (host) end of the control words
-  unsigned long long* sort_count;  // [2] launches x bodies seen, bodies rebuilt (cumulative)
-  unsigned long long* pairs;       // [2 + 2 x R_STRIP_GRID]: launches, -, then per workgroup: candidate (face, pixel-centre) pairs,
-                                   // pairs evaluated after the depth cull (cumulative); NULL unless mh_profile_enable(1)
-  // what mh_lbs_forward_proj leaves here (include/mhmocap_hip.h, mh_fwd_proj): with projected != 0 the preparation reads
-  // these instead of passing over the vertices
-  int projected;
-  int* fbbox;                // [B][4] order-preserving ints of the NDC extremes (min x, min y, max x, max y); INT_MAX / INT_MIN = unset
-  int* fbbox_prev;           // [B][4]
-  unsigned long long* flowkey;       // [B]
-  unsigned long long* flowkey_prev;  // [B]
-  int* fmoved;               // [B]
-};
 // order-preserving int of a float (and back): a < b <=> r_ord(a) < r_ord(b)
 __device__ __forceinline__ int r_ord(float x) { const int i = __float_as_int(x); return i ^ ((i >> 31) & 0x7fffffff); }
 __device__ __forceinline__ float r_unord(int o) { return __int_as_float(o ^ ((o >> 31) & 0x7fffffff)); }
@@ -204,9 +140,6 @@ __device__ __forceinline__ float r_seg_rcp(float px, float py, float ax, float a
 // atomics), then added to dL/dverts with plain coalesced read-modify-writes -- no global atomics.
 // Bodies whose table does not fit in LDS (V > RG_MAXV) scatter with global atomics instead.
 #define RG_MAXV 11500
-#ifndef RG_UNIT
-#define RG_UNIT 3072           // window pixels per work unit of the gradient kernel (one classification pass; swept 1536..4096)
-#endif
 #define RG_LIST RG_UNIT
 // dynamic LDS of the gradient kernel: [V][3] gradient table when it fits, then the live-pixel list.  The scatter
 // goes through this symbol (not through a pointer chosen at run time) so that the compiler emits ds_add_f32 rather
@@ -457,11 +390,6 @@ __device__ __forceinline__ unsigned r_face_rows_xyz(const RasterP& p, float ra, 
 // chain of dependent loads per tile, 45 us of serial work that the face sort used to hide and the kept face lists
 // exposed; a first version of this round appended to per-class lists with atomics from every workgroup: four
 // same-address round trips on every workgroup's tail, 30 us slower than the serial pass it replaced.)
-#define R_SHORT 2            // faces of up to R_SHORT + 1 rows go to the two short lists, taller ones to the third
-#define R_NCLS 64            // cost classes of the tiles (0 = most expensive)
-#define R_STRIP_GRID (256 * 3 * 4)   // persistent grid of the selection kernel
-#define R_NGCLS 33           // gradient work units: class 0 = full units, 1..32 = partial units by decreasing size
-__device__ __forceinline__ int r_cap(const RasterP& p) { return p.max_strips / p.B; }
 
 // cost class of a tile from the body's face lists: ~7 ns per candidate face and ~76 ns per window pixel (measured, C3)
 __device__ __forceinline__ int r_tile_class(const RasterP& p, const int* rs, int mh, int sy0, int nrows, int ncols) {
@@ -594,118 +522,6 @@ __device__ __forceinline__ void r_face_sort(const RasterP& p, int b, int* hist /
   __syncthreads();             // rs / maxh of this body are read by the tile classes below (same workgroup: L2-coherent stores + barrier)
 }
 
-// k_raster_lists (ONE workgroup of NT threads, its own launch behind k_raster_prepare): dense work lists from the per-body
-// tables.  (Measured on the way, MI355X: doing this in the workgroup of k_raster_prepare that finishes last -- a ticket
-// behind __threadfence() -- cost 14 us for the fence + ticket of 800 workgroups and 26 us for this function reading the
-// other workgroups' tables with device-scope loads: the eight XCDs have their own L2s, so device-scope ordering inside a
-// kernel means write-backs and L2 bypasses; a kernel boundary is cheaper than that.)
-#define R_FCLS 16            // tile classes of a body kept in registers between the histogram and the placement
-#define RLISTS 1024
-template <int NT>
-__device__ __forceinline__ void r_finalize_lists(const RasterP& p) {
-  __shared__ long long f_wave[NT / 64];
-  __shared__ long long f_carry;
-  __shared__ int f_hist[R_NCLS], f_cur[R_NCLS], f_ghist[64], f_gcur[64];
-  __shared__ int f_stale;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cap = r_cap(p);
-  if (tid == 0) { f_carry = 0; f_stale = 0; }
-  if (tid < R_NCLS) { f_hist[tid] = 0; f_ghist[tid] = 0; }
-  __syncthreads();
-  auto unit_class = [&](int rem) { return 1 + (31 - min(31, rem * 32 / RG_UNIT)); };
-  const int nchunk = (p.B + NT - 1) / NT;
-  // per-thread body of a chunk: window size, tile count, the first R_FCLS tile classes (all loads issued together)
-  int ns = 0, cls[R_FCLS];
-  long long v = 0;
-  auto load_body = [&](int b) {
-    int ww = 0, wh = 0, st = 0;
-    ns = 0;
-    if (b < p.B) { ww = p.win[b * 4 + 2]; wh = p.win[b * 4 + 3]; ns = p.body_ns[b]; st = p.stale[b]; }
-#pragma unroll
-    for (int k = 0; k < R_FCLS; ++k) cls[k] = (b < p.B && k < ns) ? p.strip_cls[(size_t)b * cap + k] : 0;
-    v = (ww > 0 && wh > 0) ? (long long)ww * wh : 0ll;
-    return st;
-  };
-  for (int ch = 0; ch < nchunk; ++ch) {
-    const int b = ch * NT + tid;
-    const int st = load_body(b);
-    // ---- where a body's keys live: exclusive prefix of the window sizes in body order (wave scan + wave totals) ----------
-    long long incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const long long u = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += u;
-    }
-    if (lane == 63) f_wave[wave] = incl;
-    __syncthreads();
-    long long before = f_carry;
-    for (int w = 0; w < wave; ++w) before += f_wave[w];
-    if (b < p.B) p.body_koff[b] = before + incl - v;
-    // ---- class histograms ----------------------------------------------------------------------------------------------
-#pragma unroll
-    for (int k = 0; k < R_FCLS; ++k)
-      if (k < ns) atomicAdd(&f_hist[cls[k]], 1);
-    for (int k = R_FCLS; k < ns; ++k) atomicAdd(&f_hist[p.strip_cls[(size_t)b * cap + k]], 1);
-    const long long nfull = v / RG_UNIT;
-    const int rem = (int)(v % RG_UNIT);
-    if (nfull) atomicAdd(&f_ghist[0], (int)min(nfull, (long long)p.max_units));
-    if (rem) atomicAdd(&f_ghist[unit_class(rem)], 1);
-    if (st) atomicAdd(&f_stale, 1);
-    __syncthreads();
-    if (tid == 0) {
-      long long a = f_carry;
-      for (int w = 0; w < NT / 64; ++w) a += f_wave[w];
-      f_carry = a;
-    }
-    __syncthreads();
-  }
-  // ---- class offsets: exclusive scans of the two histograms by the first two waves --------------------------------------
-  if (wave < 2) {
-    int* hist = wave == 0 ? f_hist : f_ghist;
-    int* cur = wave == 0 ? f_cur : f_gcur;
-    const int h = hist[lane];
-    const int incl = mh_wave_scan_add(h);
-    cur[lane] = incl - h;
-    if (lane == 63) {
-      if (wave == 0) {
-        p.total[0] = min(incl, p.max_strips);
-        p.sort_count[0] += (unsigned long long)p.B;
-        p.sort_count[1] += (unsigned long long)f_stale;
-      } else {
-        p.gunit_total[0] = min(incl, p.max_units);
-      }
-    }
-  }
-  __syncthreads();
-  // ---- placement (up to NT bodies: still in registers) ---------------------------------------------------------------------
-  for (int ch = 0; ch < nchunk; ++ch) {
-    const int b = ch * NT + tid;
-    if (nchunk > 1) load_body(b);
-    if (b >= p.B) continue;
-#pragma unroll
-    for (int k = 0; k < R_FCLS; ++k)
-      if (k < ns) {
-        const int pos = atomicAdd(&f_cur[cls[k]], 1);
-        if (pos < p.max_strips) p.strip_order[pos] = b * cap + k;
-      }
-    for (int k = R_FCLS; k < ns; ++k) {
-      const int pos = atomicAdd(&f_cur[p.strip_cls[(size_t)b * cap + k]], 1);
-      if (pos < p.max_strips) p.strip_order[pos] = b * cap + k;
-    }
-    const long long nfull = v / RG_UNIT;
-    const int rem = (int)(v % RG_UNIT);
-    if (nfull) {
-      const int n = (int)min(nfull, (long long)p.max_units);
-      const int pos = atomicAdd(&f_gcur[0], n);
-      for (int k = 0; k < n; ++k)
-        if (pos + k < p.max_units) p.gunit_list[pos + k] = ((unsigned long long)(unsigned)b << 32) | (unsigned)k;
-    }
-    if (rem) {
-      const int pos = atomicAdd(&f_gcur[unit_class(rem)], 1);
-      if (pos < p.max_units) p.gunit_list[pos] = ((unsigned long long)(unsigned)b << 32) | (unsigned)nfull;
-    }
-  }
-}
-
 // One workgroup per body: NDC projection of the vertices (kept in HBM, 12 B per vertex) + screen window, how far the
 // vertices have moved since the body's face lists were sorted, the sort itself when they moved too far (temporal
 // coherence: the optimiser moves a body by a small fraction of a pixel per cycle; the lists stay a SUPERSET of every
@@ -827,7 +643,12 @@ __global__ __launch_bounds__(RPREP) void k_raster_prepare(RasterP p) {
   int tw = 1, th = 1, ncol = 0, nrow = 0;
   if (ww > 0) r_tiling(ww, wh, &tw, &th, &ncol, &nrow);
   const int cap = r_cap(p), ns = min(ncol * nrow, cap), first = b * cap;
-  if (tid == 0) { p.body_first[b] = first; p.body_ns[b] = ns; p.stale[b] = any_moved; }
+  if (tid == 0) {
+    p.body_first[b] = first; p.body_ns[b] = ns; p.stale[b] = any_moved;
+    // a body's keys live in a region of its own (the key array has room for a full image per body): where they are does not
+    // depend on the other bodies' windows, so the work lists -- which may be a launch old -- carry no addresses
+    p.body_koff[b] = (long long)b * p.H * p.W;
+  }
   const int* rs = p.row_start + (size_t)b * (3 * (p.H + 1) + 1);
   const int mh = p.maxh[b];
   for (int k = tid; k < ns; k += RPREP) {
@@ -950,9 +771,29 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
   const unsigned long long tbegin = tlast;
   const unsigned long long twall = wall_clock64();
 #endif
-  for (int si = blockIdx.x; si < total; si += gridDim.x) {
-    const int s = p.strip_order[si];
-    const int b = p.strip_body[s];
+  // Work items: the listed tiles first (most expensive class first), then, per body, the tiles its window has gained since
+  // the lists were put together -- the lists may be a launch old (mh_raster_fin): a listed tile that no longer exists is
+  // skipped, a new one is picked up by the workgroup that looks at its body (none in a steady sequence).
+  const int cap_ = r_cap(p);
+  int xb = -1, xk = 0, xend = 0;               // body whose new tiles this workgroup is working through
+  for (int si = blockIdx.x;;) {
+    int s;
+    if (xk < xend) {
+      s = xb * cap_ + xk++;
+    } else if (si < total) {
+      s = p.strip_order[si];
+      si += gridDim.x;
+      const int b_ = s / cap_;
+      if (s - b_ * cap_ >= p.body_ns[b_]) continue;      // (the same for every thread of the workgroup)
+    } else if (si < total + p.B) {
+      xb = si - total;
+      si += gridDim.x;
+      xk = min(p.ns_listed[xb], p.body_ns[xb]); xend = p.body_ns[xb];
+      continue;
+    } else {
+      break;
+    }
+    const int b = s / cap_;
     const int x0 = p.strip_col0[s], tw = p.strip_cols[s], x1 = x0 + tw - 1;
     const int sy0 = p.strip_row0[s], nrows = p.strip_rows[s], sy1 = sy0 + nrows - 1;
     const int npx = nrows * tw;
@@ -1589,11 +1430,31 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
 #else
 #define RG_TMARK(c) do { } while (0)
 #endif
-  for (int u = blockIdx.x; u < nunits; u += gridDim.x) {
-    const unsigned long long ue = p.gunit_list[u];
-    const int b = (int)(ue >> 32), up0 = (int)(ue & 0xffffffffu) * RG_UNIT;
+  // Work items as in k_raster_strip: the listed units (the lists may be a launch old: a listed piece beyond the body's
+  // current window is skipped), then per body the pieces its window has gained since (none in a steady sequence).
+  int xb = -1, xk = 0, xend = 0;
+  for (int u = blockIdx.x;;) {
+    int b, piece;
+    if (xk < xend) {
+      b = xb; piece = xk++;
+    } else if (u < nunits) {
+      const unsigned long long ue = p.gunit_list[u];
+      u += gridDim.x;
+      b = (int)(ue >> 32); piece = (int)(ue & 0xffffffffu);
+    } else if (u < nunits + p.B) {
+      xb = u - nunits;
+      u += gridDim.x;
+      const int wx = p.win[xb * 4 + 2], wy = p.win[xb * 4 + 3];
+      const int nu = (wx > 0 && wy > 0) ? (wx * wy + RG_UNIT - 1) / RG_UNIT : 0;
+      xk = min(p.nu_listed[xb], nu); xend = nu;
+      continue;
+    } else {
+      break;
+    }
+    const int up0 = piece * RG_UNIT;
     const int t = b / p.N, n = b % p.N;
     const int x0 = p.win[b * 4], ww = p.win[b * 4 + 2], y0 = p.win[b * 4 + 1], wh = p.win[b * 4 + 3];
+    if (ww <= 0 || wh <= 0 || up0 >= ww * wh) continue;          // a listed piece the window no longer has
     const int npx = min(ww * wh, up0 + RG_UNIT);
     const int sy0 = y0;
     const float* vb = p.ndc + (size_t)b * p.V * 3;
@@ -1858,10 +1719,13 @@ static size_t r_carve(RasterP& p, void* ws) {
   p.strip_order = (int*)c; c += r_align(ms * 4);
   p.gunit_list = (unsigned long long*)c; c += r_align((size_t)p.max_units * 8);
   p.stale = (int*)c; c += r_align(B * 4);
+  // control words: everything mh_raster_workspace_init clears, contiguous (the work lists' totals and coverage among them: an
+  // untouched workspace lists nothing, and the selection / gradient kernels then take every tile / unit from the bodies)
+  p.ctl = (unsigned*)c; c += r_align(16);
   p.total = (int*)c; c += r_align(4);
   p.gunit_total = (int*)c; c += r_align(4);
-  // control words: everything mh_raster_workspace_init clears, contiguous
-  p.ctl = (unsigned*)c; c += r_align(16);
+  p.ns_listed = (int*)c; c += r_align(B * 4);
+  p.nu_listed = (int*)c; c += r_align(B * 4);
   p.sort_count = (unsigned long long*)c; c += r_align(16);
   p.pairs = (unsigned long long*)c; c += r_align((2 + 2 * (size_t)R_STRIP_GRID) * 8);
   p.sort_tag = (unsigned long long*)c; c += r_align(B * 8);
@@ -2027,8 +1891,14 @@ static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const flo
   mh_prof_mark(MH_PROF_RASTER_PREP, 0, st);
   hipLaunchKernelGGL(k_raster_prepare, dim3(p.B), dim3(RPREP), (size_t)3 * (H + 1) * sizeof(int), st, p);
   MH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_raster_lists, dim3(1), dim3(RLISTS), 0, st, p);
-  MH_LAUNCH_CHECK();
+  // The work lists are a schedule (the selection and gradient kernels find every tile and unit with lists that are a launch
+  // old, or empty).  phases & 128: they are NOT rebuilt here, between the preparation and the selection, but by whoever
+  // carries the closing job of this launch's gradient half (mh_raster_fin.lists, beside the LBS backward): 16 us off the
+  // chain.  Values-only launches read the lists in k_raster_sums: always rebuilt here.
+  if (!(phases & 128) || !gverts || zbuf_out || alpha_out) {
+    hipLaunchKernelGGL(k_raster_lists, dim3(1), dim3(RLISTS), 0, st, p);
+    MH_LAUNCH_CHECK();
+  }
   mh_prof_mark(MH_PROF_RASTER_PREP, 1, st);
   }
   if (do_sel) {
@@ -2085,6 +1955,11 @@ static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const flo
     f.log_depth = log_depth; f.log_sil = log_sil;
     if (fin_out) {
       *fin_out = f;            // the caller's next launch carries the job (mh_lbs_backward_kp_fin)
+      if (phases & 128) {      // ... and rebuilds the work lists for the next launch on this workspace
+        static_assert(sizeof(RasterP) <= sizeof(fin_out->lists), "mh_raster_fin.lists too small for the parameter block");
+        memcpy(fin_out->lists, &p, sizeof(RasterP));
+        fin_out->has_lists = 1;
+      }
     } else {
       hipLaunchKernelGGL(k_raster_finish, dim3(1), dim3(RFIN), 0, st, f);
       MH_LAUNCH_CHECK();
@@ -2138,7 +2013,7 @@ extern "C" int mh_raster_terms_projected(int T, int N, int V, int F, int H, int 
                                          float coef_depth, float coef_sil, float eps, float* gverts, float* gzmin, float* gzmax,
                                          float* depth_body, float* sil_body, void* ws, float* zbuf_out, float* alpha_out,
                                          int phases, float* log_depth, float* log_sil, int projected, void* stream) {
-  MH_CHECK(phases >= 1 && phases <= 15, "phases: 1 = preparation + selection + values, 2 = gradients, 4 = preparation only, 8 = selection only");
+  MH_CHECK(phases >= 1 && (phases & ~(15 | 128)) == 0, "phases: 1 = preparation + selection + values, 2 = gradients, 4 = preparation only, 8 = selection only, 128 = work lists deferred");
   return raster_terms_impl(T, N, V, F, H, W, cam_K_host, verts, faces, bits, ebits, depths, zmin_lin, zmax_lin, pose2d_valid, front,
                            sil_apply, sil_D, sil_S, coef_depth, coef_sil, eps, gverts, gzmin, gzmax, depth_body, sil_body, ws, zbuf_out,
                            alpha_out, phases, log_depth, log_sil, stream, projected);
@@ -2151,7 +2026,7 @@ extern "C" int mh_raster_terms_deferred(int T, int N, int V, int F, int H, int W
                                          float coef_depth, float coef_sil, float eps, float* gverts, float* gzmin, float* gzmax,
                                          float* depth_body, float* sil_body, void* ws, float* zbuf_out, float* alpha_out,
                                          int phases, float* log_depth, float* log_sil, int projected, mh_raster_fin* fin_out, void* stream) {
-  MH_CHECK(phases >= 1 && phases <= 15, "phases: 1 = preparation + selection + values, 2 = gradients, 4 = preparation only, 8 = selection only");
+  MH_CHECK(phases >= 1 && (phases & ~(15 | 128)) == 0, "phases: 1 = preparation + selection + values, 2 = gradients, 4 = preparation only, 8 = selection only, 128 = work lists deferred");
   MH_CHECK(fin_out, "null argument");
   return raster_terms_impl(T, N, V, F, H, W, cam_K_host, verts, faces, bits, ebits, depths, zmin_lin, zmax_lin, pose2d_valid, front,
                            sil_apply, sil_D, sil_S, coef_depth, coef_sil, eps, gverts, gzmin, gzmax, depth_body, sil_body, ws, zbuf_out,

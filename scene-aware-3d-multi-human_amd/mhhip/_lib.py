@@ -42,7 +42,8 @@ class RasterFin(ctypes.Structure):
     _fields_ = [('T', ctypes.c_int), ('N', ctypes.c_int), ('B', ctypes.c_int), ('from_partials', ctypes.c_int),
                 ('coef_depth', ctypes.c_float)] + [(k, vp) for k in (
                     'body_first', 'body_ns', 'partial', 'dinv', 'sil_apply', 'sil_D', 'sil_S', 'sil_corr', 'depth_body',
-                    'sil_body', 'zmin_lin', 'zmax_lin', 'gzmin', 'gzmax', 'log_depth', 'log_sil')]
+                    'sil_body', 'zmin_lin', 'zmax_lin', 'gzmin', 'gzmax', 'log_depth', 'log_sil')] + [
+                    ('has_lists', ctypes.c_int), ('lists', ctypes.c_ulonglong * 75)]
 
 
 _lib = None

@@ -85,12 +85,11 @@ class RasterTerms(object):
         first = self.ws[off[1]:off[1] + B * 8].view(torch.int64).cpu().numpy()
         npix = np.maximum(win[:, 2], 0).astype(np.int64) * np.maximum(win[:, 3], 0)
         total = int(npix.sum())
-        raw = self.ws[off[2]:off[2] + total * 40].cpu().numpy().view(np.uint64).reshape(-1, 5)
-        # the bodies' key windows lie in the array in the order their workgroups got there: back into body order
+        # every body's keys lie in a region of their own (first[b]): gathered into body order on the device
         koff = np.concatenate([[0], np.cumsum(npix)])
-        keys = np.empty_like(raw)
-        for b in range(B):
-            keys[koff[b]:koff[b + 1]] = raw[first[b]:first[b] + npix[b]]
+        src = np.concatenate([first[b] + np.arange(npix[b], dtype=np.int64) for b in range(B)]) if total else np.zeros(0, np.int64)
+        raw = self.ws[off[2]:off[2] + B * e.H * e.W * 40].view(torch.int64).view(-1, 5)
+        keys = raw[torch.as_tensor(src, device=self.ws.device)].cpu().numpy().view(np.uint64).reshape(-1, 5)
         return win, koff, keys
 
 

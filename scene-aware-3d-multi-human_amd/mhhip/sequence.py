@@ -664,17 +664,27 @@ class SequenceEngine(object):
         if images:
             if raster is not None:
                 ev = self._tic('raster_terms')
-                if main_first and os.environ.get('MHHIP_SIDE_LATE') == '1':     # (measured r04: 0.750 ms against 0.735 -- what runs under the selection kernel costs it one for one; kept as a switch)
-                    # the rasteriser's preparation (windows, kept face lists, work lists: two small launches bound by the latency
-                    # of their dependent loads) first and ALONE: the side branch opens with 200 MB of streaming traffic, beside
-                    # which the one-workgroup list kernel took 38 us instead of 11; behind it everything runs under the
-                    # selection kernel
-                    raster(self, gv, log, phases=4)
+                # the rasteriser's work lists (a schedule) are rebuilt beside the LBS backward, for the NEXT cycle, when the
+                # backward is the fused form that carries the closing job (one launch and 16 us less between the forward and
+                # the selection kernel); the kernels find every tile with lists that are a cycle old
+                ldef = 128 if (self.kp_fused and os.environ.get('MHHIP_NO_KPALG') != '1' and os.environ.get('MHHIP_NO_DEFER') != '1'
+                               and os.environ.get('MHHIP_LISTS_ONCHAIN') != '1') else 0
+                side_late = os.environ.get('MHHIP_SIDE_LATE', '1' if ldef else '0') == '1'
+                if main_first and side_late:
+                    # The side branch opens BEHIND the rasteriser's preparation, with the selection kernel already launched.
+                    # With the work lists on the chain (two small launches between the forward and the selection) this order
+                    # loses (r04: 0.750 ms against 0.735: the side branch starts 20 us later and ends under the selection
+                    # kernel's tail).  With the lists deferred it is the one that wins: the selection kernel must get its
+                    # first 512 workgroups -- the longest tiles -- onto the CUs before the side branch's kernels arrive; forked
+                    # behind the forward they arrive together with it, take their slots at full speed (the key-point kernels
+                    # ran in 9 us instead of 65) and the selection kernel pays 34 us for it (0.700 ms against 0.679 with the lists
+                    # on the chain, 0.676 this way: same box).
+                    raster(self, gv, log, phases=4 | ldef)
                     side.wait_stream(main)
                     raster(self, gv, log, phases=8)
                     side_branch()
                 else:
-                    raster(self, gv, log, phases=1)
+                    raster(self, gv, log, phases=(4 | 8 | ldef) if ldef else 1)
                     if main_first:
                         side_branch()
                 # the whole side branch ends long before the selection does: ONE join here instead of a wait for the
@@ -686,7 +696,7 @@ class SequenceEngine(object):
                 # the closing kernel's job rides in the LBS backward's pose kernel when that is the fused form
                 # (_finish_b): one launch and one dependent kernel less on the chain
                 defer = bool(getattr(self, '_kp_chunk', False)) and os.environ.get('MHHIP_NO_DEFER') != '1'
-                self._raster_fin = raster(self, gv, log, phases=2, defer=defer)
+                self._raster_fin = raster(self, gv, log, phases=2 | (ldef if defer else 0), defer=defer)
                 self._toc(ev)
             else:
                 # no rasteriser: alpha = 0, zbuf empty -> the mask-only silhouette term (tests only)

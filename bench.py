@@ -452,7 +452,12 @@ def main():
             nv = load_pmc_valu('k_raster_strip') if fresh else None
             if nv and not args.strong and frames_here == 200 and N_PEOPLE == 4:
                 gi = nv / (us * 1e-6) / 1e9
-                roof['valu'] = {'what': 'vector-instruction issue utilisation (not a roofline fraction of useful work)',
+                roof['valu'] = {'what': 'vector-instruction issue utilisation (not a roofline fraction of useful work); the peak prices every '
+                                        'wave64 instruction at 4 cycles per SIMD -- measured on gfx950 (tools/ubench/valu_rate.hip, '
+                                        'profiles/r04_ubench_valu_lds.txt) fp32 fma / mul / add, integer add / logic, moves and cndmask '
+                                        'issue every 2.3 cycles from two or more waves, everything else every 4.1-4.6: with the '
+                                        "kernel's mix the issue bound is ~1.3x this peak and the kernel sits at ~60 % of it "
+                                        '(DESIGN.md 4.1: the rest is the dependent chain of a 64-pair batch)',
                                 'achieved': round(gi, 1), 'peak': PEAK_VALU_GIPS, 'unit': 'G wave-instr/s',
                                 'utilisation': round(gi / PEAK_VALU_GIPS, 3), 'wave_instructions_per_launch': nv}
         # SURVEY 8(d) unit of the LBS + projection pair: 167 028 B per human.frame.iteration + the 19.35 MB of constants

@@ -42,7 +42,15 @@
 #ifndef RMINW
 #define RMINW 4
 #endif
-#define R_CAP 640            // window pixels per tile (5 x u64 each = 25.6 KB of LDS; 2 workgroups per CU)
+// window pixels per tile (5 x u64 each = 28 KB of LDS; 2 workgroups per CU).  Larger tiles = fewer of them: less work repeated
+// for the faces that reach across tiles, more rounds per wave and tile; but the selection kernel shares its CUs' LDS with the
+// side branch's kernels.  Round 4 sweep with the pair list's size (same box, ms per cycle): 448 / 512 px 0.707 / 0.694, 640 px
+// with 512 entries (rounds 2-4) 0.679 and 0.669 on a second box, 704 / 384 0.670 and 0.658, 704 / 256 0.671, 768 / 384 0.665,
+// 800 / 512 0.667 (kernel alone 333 us instead of 357: the side branch then waits for LDS), 1408 px in 1024-thread
+// workgroups 0.725.
+#ifndef R_CAP
+#define R_CAP 704
+#endif
 #define RT 13                // floats staged per face: 9 NDC coordinates, 1/area, 1/|edge|^2 x 3
 
 // order-preserving int of a float (and back): a < b <=> r_ord(a) < r_ord(b)
@@ -729,7 +737,7 @@ __device__ __forceinline__ void r_tile_depth_sums(const RasterP& p, int s, int b
 #define R_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 #endif
 #ifndef RPL
-#define RPL 512              // pair descriptors per wave and round (sub-pixel face path)
+#define RPL 384              // pair descriptors per wave and round (pair-list path; see R_CAP for the sweep)
 #endif
 
 // One workgroup per tile.  Every wave runs its own rounds of 64 candidate faces with no workgroup barrier in
@@ -741,14 +749,15 @@ __device__ __forceinline__ void r_tile_depth_sums(const RasterP& p, int s, int b
 __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       // 4 waves/SIMD: two workgroups per CU
   __shared__ unsigned long long keys[R_CAP * 5];
   __shared__ float wT[RW][64 * RT];         // staged faces of the wave's current round
-  __shared__ int wPre[RW][65];              // exclusive prefix of the candidate counts
   __shared__ int wDesc[RW][64];             // xa | ya << 10 | nx << 20 (tile-relative)
   __shared__ int wFid[RW][64];
-  __shared__ int wMark[RW][64];
-  __shared__ unsigned short wPl[RW][RPL];   // pair list of the sub-pixel path: face slot | pair index << 6
+  // pair list of the pair-list path (face slot | pair index << 6) and, in the same bytes, the even-split path's prefix
+  // and run-start tables (a round that takes both paths takes them one after the other); the tile's pixel-centre
+  // coordinates share one array (columns + rows <= pixels + 1): LDS the side branch's kernels can have
+  static_assert(RPL * 2 >= (65 + 64) * 4, "the pair list must cover the even-split path's tables");
+  __shared__ __attribute__((aligned(8))) unsigned short wPl[RW][RPL];
   __shared__ float s_sums[RB / 64 * 5];
-  __shared__ float sXf[R_CAP];              // NDC x of the tile columns
-  __shared__ float sYf[R_CAP];              // NDC y of the tile rows
+  __shared__ float sXY[R_CAP + 2];          // NDC x of the tile's columns, then NDC y of its rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = p.H, W = p.W;
   const float blur_d = sqrtf(BLUR_D);
@@ -759,11 +768,11 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
   // moving LDS accesses across it, and LDS executes one wave's accesses in order (a fence would also wait for the
   // prefetched global loads and serialise the gather pipeline)
   float* T_ = wT[wave];
-  int* pre = wPre[wave];
   int* desc = wDesc[wave];
   int* fid = wFid[wave];
-  int* mark = wMark[wave];
   unsigned short* pl = wPl[wave];
+  int* pre = (int*)wPl[wave];               // [65]
+  int* mark = pre + 65;                     // [64]
   unsigned long long n_cand = 0ull, n_eval = 0ull;        // wave-uniform
 #ifdef R_TIMING
   unsigned tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -797,6 +806,8 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
     const int x0 = p.strip_col0[s], tw = p.strip_cols[s], x1 = x0 + tw - 1;
     const int sy0 = p.strip_row0[s], nrows = p.strip_rows[s], sy1 = sy0 + nrows - 1;
     const int npx = nrows * tw;
+    float* const sXf = sXY;
+    float* const sYf = sXY + tw;
     const float* nb = p.ndc + (size_t)b * p.V * 3;
     const unsigned* fs = p.fsort + (size_t)b * p.F;
     const int* rs = p.row_start + (size_t)b * (3 * (H + 1) + 1);

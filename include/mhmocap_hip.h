@@ -468,7 +468,9 @@ int mh_raster_terms_phase_log(int T, int N, int V, int F, int H, int W, const fl
  * may then be NULL); a body whose box is incomplete is scanned from the projected vertices.  Same results, bit for bit.
  * phases here is a bit mask: 1 = preparation + selection, 2 = gradients, 4 = preparation only (windows, face lists, work
  * lists: a chain of small latency-bound launches), 8 = selection only -- so that a caller can start other work between the
- * two halves of phase 1.                                                                                        */
+ * two halves of phase 1. 128 (with 4 / 2, mh_raster_terms_deferred): the work lists -- a schedule: the kernels find every
+ * tile and gradient unit with lists that are a launch old, or empty -- are not rebuilt between preparation and selection
+ * but by the carrier of the closing job (mh_raster_fin.lists), for the next launch on the workspace. */
 /* The rasterised terms' CLOSING job (per-body values from the tile sums, gradients of the depth-range leaves, the two log
  * sums: a few microseconds of latency-bound work in one workgroup) as a description that another launch can carry out:
  * nothing of the LBS backward reads what it writes, so mh_raster_terms_deferred leaves it here instead of launching

@@ -417,8 +417,17 @@ __device__ __forceinline__ int r_tile_class(const RasterP& p, const int* rs, int
 // Two classes per row: the faces whose class (sign of the screen-space area) is nearer to the camera on average (for a
 // closed mesh: the ones looking at it) come first in fsort, so that a tile rasterises them first and the depth cull of
 // k_raster_strip then removes most of the far-side candidates.  row_start: [2][H+1] (+ total), class-major in that order.
+// timing builds 6 / 7 (-DR_TIMING=6|7, tools/pair_stats.py): elapsed shader cycles of k_raster_prepare's workgroups that SORT,
+// by phase: 0 window + motion test, 1 histogram clear + row coordinates, 2 first pass (gathers, row ranges, histogram),
+// 3 reductions + scan, 4 second pass (placement), 5 tiles, 6 everything, 7 number of sorting workgroups
+#if defined(R_TIMING) && R_TIMING >= 6
+__device__ unsigned long long g_prep_t[8];
+#define P_MARK(c) do { const unsigned long long t1_ = __builtin_readcyclecounter(); pacc[c] += (unsigned)(t1_ - plast); plast = t1_; } while (0)
+#else
+#define P_MARK(c) do { } while (0)
+#endif
 template <int NT>
-__device__ __forceinline__ void r_face_sort(const RasterP& p, int b, int* hist /*LDS [3][H+1]*/) {
+__device__ __forceinline__ void r_face_sort(const RasterP& p, int b, int* hist /*LDS [3][H+1]*/, unsigned* pacc, unsigned long long& plast) {
   __shared__ int s_maxh, s_flip;
   __shared__ float s_z[2];
   __shared__ int s_n[2];
@@ -430,6 +439,7 @@ __device__ __forceinline__ void r_face_sort(const RasterP& p, int b, int* hist /
   for (int i = tid; i < 3 * HB; i += NT) hist[i] = 0;
   if (tid == 0) { s_maxh = 0; s_z[0] = s_z[1] = 0.f; s_n[0] = s_n[1] = 0; }
   __syncthreads();
+  (void)pacc; (void)plast;
   int mh = 0, n0 = 0, n1 = 0;
   float z0 = 0.f, z1 = 0.f, ra, rk;
   r_row_affine(p, &ra, &rk);
@@ -444,6 +454,7 @@ __device__ __forceinline__ void r_face_sort(const RasterP& p, int b, int* hist /
   // reading a list `tallest face of the list` rows above its first row; one list for all faces made every tile wade through
   // the faces of the nine rows above it (the mean tallest face) to find the handful that reach down -- 1.44x the entries
   // that really overlap a tile, 1.13x with the tall ones in a list of their own
+  P_MARK(1);
   auto tally = [&](unsigned r, float zm, bool live) {
     const int lo = (int)(r & 0x7fffu), hi = (int)(r >> 16), sg = (int)((r >> 15) & 1u);
     if (live && lo <= hi) {
@@ -480,6 +491,7 @@ __device__ __forceinline__ void r_face_sort(const RasterP& p, int b, int* hist /
       tally(r, zm, f < p.F);
     }
   }
+  P_MARK(2);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     mh = max(mh, __shfl_xor(mh, o, 64));
@@ -516,6 +528,7 @@ __device__ __forceinline__ void r_face_sort(const RasterP& p, int b, int* hist /
     if (tid == 0) { p.maxh[b] = s_maxh; rs[3 * HB] = carry; }
   }
   __syncthreads();
+  P_MARK(3);
   auto place = [&](unsigned r, int f, bool live) {
     const int lo = (int)(r & 0x7fffu), hi = (int)(r >> 16), sg = (int)((r >> 15) & 1u);
     if (live && lo <= hi) fs[atomicAdd(&hist[(hi - lo > R_SHORT ? 2 : sg) * HB + lo], 1)] = ((unsigned)hi << 20) | (unsigned)f;
@@ -528,6 +541,7 @@ __device__ __forceinline__ void r_face_sort(const RasterP& p, int b, int* hist /
     for (int u = 0; u < RFS_V; ++u) place(r[u], f0 + u * NT, f0 + u * NT < p.F);
   }
   __syncthreads();             // rs / maxh of this body are read by the tile classes below (same workgroup: L2-coherent stores + barrier)
+  P_MARK(4);
 }
 
 // One workgroup per body: NDC projection of the vertices (kept in HBM, 12 B per vertex) + screen window, how far the
@@ -544,6 +558,9 @@ __device__ __forceinline__ void r_face_sort(const RasterP& p, int b, int* hist /
 #endif
 __global__ __launch_bounds__(RPREP) void k_raster_prepare(RasterP p) {
   extern __shared__ int hist[];                     // [3][H + 1] of the sort
+  unsigned pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long plast = __builtin_readcyclecounter();
+  const unsigned long long pbegin = plast;
   __shared__ float sbb[RPREP / 64][4];
   __shared__ int s_win[4];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -644,7 +661,8 @@ __global__ __launch_bounds__(RPREP) void k_raster_prepare(RasterP p) {
     if (ww <= 0 || wh <= 0) ww = wh = 0;
     s_win[0] = x0; s_win[1] = y0; s_win[2] = ww; s_win[3] = wh;
   }
-  if (p.margin == 0 || any_moved) r_face_sort<RPREP>(p, b, hist);       // (ends with a barrier)
+  P_MARK(0);
+  if (p.margin == 0 || any_moved) r_face_sort<RPREP>(p, b, hist, pacc, plast);       // (ends with a barrier)
   else __syncthreads();
   // ---- tiles of the window: geometry and cost class into the body's own slots -------------------------------------------
   const int x0 = s_win[0], y0 = s_win[1], ww = s_win[2], wh = s_win[3];
@@ -667,6 +685,18 @@ __global__ __launch_bounds__(RPREP) void k_raster_prepare(RasterP p) {
     p.strip_col0[s] = c0; p.strip_cols[s] = nc;
     p.strip_cls[s] = r_tile_class(p, rs, mh, r0, nr, nc);
   }
+#if defined(R_TIMING) && R_TIMING >= 6
+  if (p.pairs && tid == 0 && (p.margin == 0 || any_moved)) {
+    P_MARK(5);
+    pacc[6] = (unsigned)(__builtin_readcyclecounter() - pbegin);
+    pacc[7] = 1;
+    unsigned long long* slot = p.pairs + 2 + 2 * (size_t)(blockIdx.x % R_STRIP_GRID);
+    const int c = (R_TIMING - 6) * 4;
+    atomicAdd(slot, (unsigned long long)pacc[c] | ((unsigned long long)pacc[c + 1] << 32));
+    atomicAdd(slot + 1, (unsigned long long)pacc[c + 2] | ((unsigned long long)pacc[c + 3] << 32));
+    if (blockIdx.x == 0) p.pairs[0] += 1ull;
+  }
+#endif
 }
 
 __global__ __launch_bounds__(RLISTS) void k_raster_lists(RasterP p) { r_finalize_lists<RLISTS>(p); }
@@ -1548,7 +1578,7 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
       }
     RG_TMARK(4);
   }
-#if defined(R_TIMING) && R_TIMING >= 4
+#if defined(R_TIMING) && R_TIMING >= 4 && R_TIMING <= 5
   if (p.pairs) {
     tacc[7] = (unsigned)(__builtin_readcyclecounter() - tbegin);
     if ((tid & 63) == 0) {

@@ -22,6 +22,10 @@ torch.cuda.synchronize()
 L.mh_profile_enable(2)
 gv = torch.zeros_like(e.verts); log = torch.zeros(16, device=e.dev)
 a0 = r.pair_counters(e)
+if os.environ.get('R_TIMING') in ('6', '7'):
+    from mhhip.raster import set_sort_margin
+    e.leaf('poses_T')[::7, :, 1] += 0.05      # every seventh frame moves: its bodies sort, the others keep their lists
+    e.forward(regress=False, raster=r)
 for _ in range(4): r(e, gv, log, phases=3 if os.environ.get('R_TIMING') in ('4', '5') else 1)
 torch.cuda.synchronize()
 a1 = r.pair_counters(e)
@@ -30,6 +34,9 @@ print('launches', n, 'counter A per launch %.0f' % ((a1[1] - a0[1]) / n), 'count
 if os.environ.get('R_TIMING') == '3':
     a = r.pair_counters(e)
     print('timing build 3: last launch spans %.1f us, workgroup life spans sum to %.1f us = %.1f %% of 512 slots' % (a[1] / 100., a[2] / 100., 100. * a[2] / max(1, a[1]) / 512))
+elif os.environ.get('R_TIMING') in ('6', '7'):
+    A = a1[1] - a0[1]; B = a1[2] - a0[2]
+    print('timing build %s (k_raster_prepare, sorting workgroups, cycles summed over %d launches): %s' % (os.environ['R_TIMING'], n, [A & 0xffffffff, A >> 32, B & 0xffffffff, B >> 32]))
 elif os.environ.get('R_TIMING'):
     # timing builds: two 32-bit halves per counter, units of 1024 wave-cycles (csrc/mh_raster.hip, R_TMARK)
     A = a1[1] - a0[1]; B = a1[2] - a0[2]

@@ -589,7 +589,11 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, 2 * FWD16_WAVES / 4) void k_skin_
     if (FULL || g * 32 + row0 + 4 * lh < p.B) {
       const unsigned off_r = lane_off + (unsigned)row0 * row_b32;
       *(f32x3*)(vg + (size_t)off_r) = o;
+#ifdef ABL_NOQ_STORE
+      if (qg && vp0 == 12345.f) {
+#else
       if (qg) {
+#endif
         const f32x3 q = {vp0, vp1, vp2};
         *(f32x3*)(qg + (size_t)off_r) = q;
       }
@@ -1252,9 +1256,14 @@ __global__ __launch_bounds__(256, SB_OCC) void k_skinbwd16(Bwd16P p) {
       // vertex has zero rows in Dt16 / W16; only the plain sum of g (the translation gradient) masks them, below.
       const int b = g * 32 + fr + 16 * k;
       const size_t o = ((size_t)(b < p.B ? b : p.B - 1) * p.V + (v < p.V ? v : p.V - 1)) * 3;
+#ifndef ABL_NOQ_LOAD
       rq[k] = *(const f32x3*)(p.vposed + o);
+#endif
       rg[k] = (f32x3){0.f, 0.f, 0.f};
       if (p.gverts) rg[k] = *(const f32x3*)(p.gverts + o);
+#ifdef ABL_NOQ_LOAD
+      rq[k] = rg[k] + 1.f;
+#endif
     }
   };
   // skinning rows and key-point head rows of the thread's vertex pair: requested AHEAD of the block's B operands

@@ -79,6 +79,7 @@ __global__ __launch_bounds__(64) void k_scene_median(int T, int P, const float* 
 // all (the column form above pins 51 KB of LDS per wave for T = 200 and crowds the concurrently running loss kernels
 // off the CUs) and ~6x less time.  T <= 64 * SMT_NV (8: 512 frames; 32: 2048, the whole sequence of a pixel-sharded
 // multi-GPU run).
+typedef float f32x2s __attribute__((ext_vector_type(2)));
 template <int SMT_NV>
 __global__ __launch_bounds__(256) void k_scene_median_t(int T, int P, const float* depths_t, const unsigned char* backmask_t,
                                                         const float* invz, float* ma_depth, float* ma_mask) {
@@ -89,20 +90,50 @@ __global__ __launch_bounds__(256) void k_scene_median_t(int T, int P, const floa
   const unsigned char* bp = backmask_t + (size_t)p * T;
   unsigned v[SMT_NV];
   int n = 0;
+  if (SMT_NV <= 8) {
+    // every load of the pixel asked for at once, unconditionally (clamped frame index): behind the mask test they were
+    // two dependent round trips per 64 frames, and beside the optimiser's own kernels a wave waits long for each
+    unsigned char bm[SMT_NV];
+    float dv[SMT_NV];
+    f32x2s iz[SMT_NV];
 #pragma unroll
-  for (int j = 0; j < SMT_NV; ++j) {
-    const int t = j * 64 + lane;
-    v[j] = SM_INVALID;
-    if (t < T && bp[t] != 0) {
-      if (invz) {
-        const float inv_min = invz[2 * t], inv_max = invz[2 * t + 1];
-        const float disp = dp[t] * (inv_min - inv_max) + inv_max;      // optimizer.py:425
-        v[j] = __float_as_uint(1.0f / disp);                           // :426
-      } else {
-        v[j] = __float_as_uint(dp[t]);                                 // raw non-negative values (colour planes)
-      }
+    for (int j = 0; j < SMT_NV; ++j) {
+      const int t = min(j * 64 + lane, T - 1);
+      bm[j] = bp[t];
+      dv[j] = dp[t];
+      iz[j] = invz ? *(const f32x2s*)(invz + 2 * t) : (f32x2s){0.f, 0.f};
     }
-    n += __popcll(__ballot(v[j] != SM_INVALID));
+#pragma unroll
+    for (int j = 0; j < SMT_NV; ++j) {
+      const int t = j * 64 + lane;
+      v[j] = SM_INVALID;
+      if (t < T && bm[j] != 0) {
+        if (invz) {
+          const float inv_min = iz[j][0], inv_max = iz[j][1];
+          const float disp = dv[j] * (inv_min - inv_max) + inv_max;      // optimizer.py:425
+          v[j] = __float_as_uint(1.0f / disp);                           // :426
+        } else {
+          v[j] = __float_as_uint(dv[j]);                                 // raw non-negative values (colour planes)
+        }
+      }
+      n += __popcll(__ballot(v[j] != SM_INVALID));
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < SMT_NV; ++j) {
+      const int t = j * 64 + lane;
+      v[j] = SM_INVALID;
+      if (t < T && bp[t] != 0) {
+        if (invz) {
+          const float inv_min = invz[2 * t], inv_max = invz[2 * t + 1];
+          const float disp = dp[t] * (inv_min - inv_max) + inv_max;      // optimizer.py:425
+          v[j] = __float_as_uint(1.0f / disp);                           // :426
+        } else {
+          v[j] = __float_as_uint(dp[t]);                                 // raw non-negative values (colour planes)
+        }
+      }
+      n += __popcll(__ballot(v[j] != SM_INVALID));
+    }
   }
   if (n == 0) {
     if (lane == 0) { ma_depth[p] = 0.f; ma_mask[p] = 0.f; }
@@ -119,7 +150,7 @@ __global__ __launch_bounds__(256) void k_scene_median_t(int T, int P, const floa
     all_and &= (unsigned)__shfl_xor((int)all_and, o, 64);
   }
   const unsigned vary = all_or ^ all_and;
-  int k = n >> 1;
+  int k = n >> 1, left = n;                            // left: values that match the prefix so far
   unsigned prefix = 0u;
   for (int bit = 31; bit >= 0; --bit) {
     if (((vary >> bit) & 1u) == 0u) {                  // wave-uniform
@@ -130,7 +161,17 @@ __global__ __launch_bounds__(256) void k_scene_median_t(int T, int P, const floa
     int c0 = 0;
 #pragma unroll
     for (int j = 0; j < SMT_NV; ++j) c0 += __popcll(__ballot((v[j] & m) == prefix));
-    if (k >= c0) { k -= c0; prefix |= 1u << bit; }
+    if (k >= c0) { k -= c0; prefix |= 1u << bit; left -= c0; } else { left = c0; }
+    if (left == 1) {
+      // one value is left under this prefix: it is the answer (distinct depths part ways after ~log2 n of their ~25
+      // varying bits; the counting passes over the rest were two thirds of the kernel)
+#pragma unroll
+      for (int j = 0; j < SMT_NV; ++j) {
+        const unsigned long long bal = __ballot((v[j] & m) == prefix);
+        if (bal) prefix = (unsigned)__builtin_amdgcn_readlane((int)v[j], __builtin_ctzll(bal));
+      }
+      break;
+    }
   }
   float med = __uint_as_float(prefix);
   if ((n & 1) == 0) {

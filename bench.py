@@ -274,22 +274,29 @@ def main():
         from mhhip.raster import set_deterministic
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()        # --one-device dry runs: no rank may still be starting up (a launch that coincides with
-            time.sleep(1.0)       # another PROCESS' start-up on the same GPU has shown a handful of corrupted selection keys)
             dist.barrier()
         old_det = set_deterministic(True)
         if world > 1 and args.one_device:
-            # the dry run's ranks take turns: this cycle is the one the parity test holds against the one-process run, and
-            # eight PROCESSES launching on one GPU at the same instant disturb each other -- not what it tests
+            # the dry run's ranks take turns for the cycle the parity test holds against the one-process run (what used to
+            # look like the processes disturbing each other was packed fp32 arithmetic beside matrix instructions: DESIGN 7)
             if not getattr(sh, '_halo_ok', True):
                 sh.refresh_halo()                 # (the first cycle's collective: everybody, before anybody waits)
             for r_turn in range(world):
                 if r_turn == rank:
                     sh.cycle(0, raster=raster, graphs=False)
                     torch.cuda.synchronize()
+                    if os.environ.get('MHHIP_C4_PROBE'):      # developer aid (tools/c4_probe.sh): is the cycle self-consistent?
+                        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools'))
+                        import c4_probe
+                        c4_probe.repeat_and_compare(rank, e, sh, raster)
                 dist.barrier()
         else:
             sh.cycle(0, raster=raster, graphs=False)
+            if os.environ.get('MHHIP_C4_PROBE'):
+                torch.cuda.synchronize()
+                sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools'))
+                import c4_probe
+                c4_probe.repeat_and_compare(rank, e, sh, raster)
         set_deterministic(old_det)
         tail = e.grads[e.shared_lo:].clone()
         if world > 1:

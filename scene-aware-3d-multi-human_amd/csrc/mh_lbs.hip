@@ -416,7 +416,10 @@ typedef float f32x3 __attribute__((ext_vector_type(3)));
 // launch's box / lowest-vertex extremes minus a slack -- plain compares against per-body thresholds in LDS, atomics only
 // from the few vertices near an extreme, no cross-lane reduction (include/mhmocap_hip.h, mh_fwd_proj).
 template <bool FULL, bool NW4, bool PROJ>
-__global__ __launch_bounds__(FWD16_WAVES * 64, 2 * FWD16_WAVES / 4) void k_skin_fwd16(SkinFwd16P p) {
+#ifndef FWD16_MINB
+#define FWD16_MINB (2 * FWD16_WAVES / 4)
+#endif
+__global__ __launch_bounds__(FWD16_WAVES * 64, FWD16_MINB) void k_skin_fwd16(SkinFwd16P p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
   f16x8* sF = (f16x8*)smem16;                                           // [14][2][64]
   float* sA = (float*)(smem16 + FWD16_SF_BYTES);                        // [32][24][12]
@@ -508,6 +511,15 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, 2 * FWD16_WAVES / 4) void k_skin_
     }
     __builtin_amdgcn_sched_barrier(0);   // keep the ring: the scheduler otherwise sinks each load next to its first use
     const f16x8 ah = sF[(s16 * 2) * 64 + lane], al = sF[(s16 * 2 + 1) * 64 + lane];
+#if (FWD_ABL & 16)      // experiment build: no matrix instructions in the form WITHOUT the projection epilogue (sums of operand bits keep the loads alive)
+    if (!PROJ) {
+    ax[0] += (float)ah[0] + (float)bq[cur][0][0] + (float)bq[cur][1][0];
+    ay[0] += (float)al[0] + (float)bq[cur][2][0] + (float)bq[cur][3][0];
+    az[0] += (float)bq[cur][4][0] + (float)bq[cur][5][0];
+    } else {
+#else
+    {
+#endif
     ax = MFMA_F16(ah, bq[cur][0], ax);
     ay = MFMA_F16(ah, bq[cur][2], ay);
     az = MFMA_F16(ah, bq[cur][4], az);
@@ -517,6 +529,7 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, 2 * FWD16_WAVES / 4) void k_skin_
     ax = MFMA_F16(al, bq[cur][0], ax);
     ay = MFMA_F16(al, bq[cur][2], ay);
     az = MFMA_F16(al, bq[cur][4], az);
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
   L_MARK(1);
@@ -751,7 +764,11 @@ static int lbs_forward_impl(const mh_model* m, int B, int NB, const float* betas
     sp.D16 = m->D16; sp.vt = m->vt; sp.skidx = m->skidx; sp.skw = m->skw;
     sp.verts = verts; sp.vposed = vposed;
     MH_CHECK((size_t)32 * m->V * 12 < ((size_t)1 << 32), "model too large for 32-bit lane offsets");
+#ifdef FWD16_LDS_PAD      // experiment builds (tools/c4_probe.py): more LDS than the form without the epilogue uses -- with 30000 no
+    const size_t lds = FWD16_LDS_BYTES + (proj ? 0 : FWD16_LDS_PAD);      // selection workgroup fits on a CU beside it
+#else
     const size_t lds = FWD16_LDS_BYTES;
+#endif
     const bool full = (B % 32) == 0, nw4 = m->nw <= 4;
     auto kern = proj ? (full ? (nw4 ? k_skin_fwd16<true, true, true> : k_skin_fwd16<true, false, true>)
                              : (nw4 ? k_skin_fwd16<false, true, true> : k_skin_fwd16<false, false, true>))

@@ -913,15 +913,19 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
           }
           if (cnt > 0) {
             float* T = T_ + lane * RT;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) T[k] = ca[k];
-            T[9] = __builtin_amdgcn_rcpf(farea + R_KEPS);
+            const float ia_ = __builtin_amdgcn_rcpf(farea + R_KEPS);
             const float l01 = (ca[3] - ca[0]) * (ca[3] - ca[0]) + (ca[4] - ca[1]) * (ca[4] - ca[1]);
             const float l02 = (ca[6] - ca[0]) * (ca[6] - ca[0]) + (ca[7] - ca[1]) * (ca[7] - ca[1]);
             const float l12 = (ca[6] - ca[3]) * (ca[6] - ca[3]) + (ca[7] - ca[4]) * (ca[7] - ca[4]);
-            T[10] = l01 <= R_KEPS ? 0.f : __builtin_amdgcn_rcpf(l01);
-            T[11] = l02 <= R_KEPS ? 0.f : __builtin_amdgcn_rcpf(l02);
-            T[12] = l12 <= R_KEPS ? 0.f : __builtin_amdgcn_rcpf(l12);
+            const float r01_ = l01 <= R_KEPS ? 0.f : __builtin_amdgcn_rcpf(l01);
+            const float r02_ = l02 <= R_KEPS ? 0.f : __builtin_amdgcn_rcpf(l02);
+            const float r12_ = l12 <= R_KEPS ? 0.f : __builtin_amdgcn_rcpf(l12);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) T[k] = ca[k];
+            T[9] = ia_;
+            T[10] = r01_;
+            T[11] = r02_;
+            T[12] = r12_;
             desc[lane] = (xa - x0) | ((ya - sy0) << 10) | ((xb - xa + 1) << 20);
             f_pix = (int)__umul24((unsigned)(ya - sy0), (unsigned)tw) + (xa - x0);
             f_nx = xb - xa + 1;

@@ -3,13 +3,16 @@
 Every ``csrc/*.hip`` is compiled to its own object (in parallel, only when stale) and the objects are linked into
 ``mhhip/libmhmocap_hip.so``.  Per-file flags:
 
-* ``mh_lbs.hip`` is built with ``-fno-slp-vectorize``.  With SLP on, hipcc (ROCm 7.2) packs the fp32 epilogue arithmetic
-  that consumes the accumulators of ``v_mfma_f32_32x32x16_f16`` into ``v_pk_fma_f32`` / ``v_pk_mul_f32``; that code
-  produced WRONG values on lanes 48-63 of the first / last accumulator rows of some waves of some launches (run-to-run
-  non-deterministic, more often under back-to-back launches; every input of the affected expression verified
-  deterministic and correct; tools/stress_lbs.py).  Without SLP the same source is exact and deterministic
-  over thousands of launches.  Nothing is lost: beside MFMAs the packed forms cost more than the two plain VALU ops they
-  replace (MI355X_MICROARCH.md, price of fillers), and these epilogues are not bound by vector issue.
+* EVERY file is built with ``-fno-slp-vectorize -fno-vectorize``: no packed fp32 arithmetic (``v_pk_fma_f32`` /
+  ``v_pk_mul_f32`` / ``v_pk_add_f32``) anywhere in the library.  On the MI355X boxes of this pool a packed fp32 instruction
+  can return WRONG values while ``v_mfma_f32_32x32x16_f16`` instructions are in flight on the same SIMD -- from the same
+  wave (round 2: hipcc packed the fp32 epilogue that consumes the accumulators in ``mh_lbs.hip``; wrong values on lanes
+  48-63 of some waves of some launches, tools/stress_lbs.py) AND from another kernel's wave that shares the CU (round 4:
+  k_raster_strip, whose face staging hipcc had packed, lost ~1 face per 1000 bodies and launch whenever the frame-sharded
+  run's neighbour-frame LBS forward ran beside it; tools/c4_probe.py).  Every input of the affected
+  expressions was verified deterministic and correct; the same source without packed instructions is bit-stable.
+  Nothing is lost: packed fp32 issues at half the rate of the plain instructions on this chip
+  (profiles/r04_ubench_valu_lds.txt).  tests/test_build_flags.py holds the disassembly to zero packed fp32 instructions.
 """
 import concurrent.futures
 import glob
@@ -21,8 +24,9 @@ CSRC = os.path.join(os.path.dirname(HERE), 'csrc')
 OBJ = os.path.join(os.path.dirname(HERE), 'build')
 LIB = os.path.join(HERE, 'libmhmocap_hip.so')
 
-COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result', '-munsafe-fp-atomics']
-PER_FILE = {'mh_lbs.hip': ['-fno-slp-vectorize']}
+COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result', '-munsafe-fp-atomics',
+          '-fno-slp-vectorize', '-fno-vectorize']
+PER_FILE = {}
 
 
 def sources():
@@ -56,8 +60,8 @@ def _stamp(src):
 
 def _flags_changed(src, extra=None):
     """an object is only reused when it was compiled with exactly the flags this build would use (experiments through
-    MHHIP_CXXFLAGS must not leave objects behind that a later plain build links silently -- mh_lbs.hip without
-    -fno-slp-vectorize computes wrong vertices)"""
+    MHHIP_CXXFLAGS must not leave objects behind that a later plain build links silently -- a file compiled
+    without -fno-slp-vectorize -fno-vectorize computes wrong values beside matrix instructions)"""
     try:
         with open(_stamp(src)) as f:
             return f.read() != ' '.join(_flags(src, extra))

@@ -64,12 +64,12 @@ def test_c4_at_full_size_eight_ranks_equal_one_process(tmp_path):
     (1) THE MATHS: the gradient of every leaf of one unstepped cycle at identical variables (deterministic scatter).
     (2) THE TRAJECTORIES, 18 cycles and a one-euro filter update later, against what two runs of the one-process job part by.
 
-    Eight PROCESSES time-sharing one GPU is not the product's configuration (one process per device), and it has an
-    artefact of its own: a launch that coincides with another process being scheduled in or out has -- in about one of
-    several hundred launches, tools/race_hunt.py -- a handful of selection keys of a few bodies come out different (same
-    kernels, same inputs, bit-stable over thousands of launches and every poison pattern of uninitialised memory when the
-    process has the device to itself: tools/poison_check.py).  The eight-rank run is therefore repeated
-    (at most three times) until its first-cycle gradient is undisturbed; every attempt is printed."""
+    Until round 4 this test had to repeat the eight-rank run: a few frames -- different ones every time -- came out with
+    different selection keys.  It was not the eight processes: the frame-sharded cycle skins its neighbours' boundary frames
+    in the side branch, beside the selection kernel, and hipcc had packed part of that kernel's fp32 arithmetic
+    (``v_pk_*_f32``), which returns wrong values while another wave's matrix instructions are in flight on the same SIMD
+    (mhhip/build.py, tests/test_corunner_gpu.py).  Without packed instructions the FIRST run must be
+    right in every entry."""
     import numpy as np
     common = ['--steps', '12', '--warmup', '2', '--presteps', '4', '--no-cpu-baseline', '--no-fit']
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='2')
@@ -95,29 +95,13 @@ def test_c4_at_full_size_eight_ranks_equal_one_process(tmp_path):
     GRADS = ('grad0_poses_T', 'grad0_poses_smpl', 'grad0_zmin_lin', 'grad0_zmax_lin', 'grad0_tail')
     for k in GRADS:
         assert np.array_equal(a[k], c[k]), k                   # one process: bit-identical from run to run
-    b, runs = None, []
-    for attempt in range(3):
-        b = run_eight(str(tmp_path / ('eight%d.npz' % attempt)), 29851 + attempt)
-        runs.append(b)
-        # the LBS backward cuts the vertices into 500 / (groups of 32 bodies) chunks and adds the chunk sums in order: 2 chunks for
-        # the one process' 250 groups, 16 for a rank's 32, so sums of 6890 cancelling terms round differently; the shared tail is
-        # additionally summed per rank and then across ranks
-        worst = {k: float(np.abs(a[k] - b[k]).max() / np.abs(a[k]).max()) for k in GRADS}
-        print('attempt %d, first-cycle gradients, max |eight ranks - one process| / largest entry: %s' % (
-            attempt, ', '.join('%s %.1e' % (k[6:], v) for k, v in worst.items())))
-        if max(worst.values()) <= 2e-5:
-            break
-    else:
-        # No attempt was undisturbed (round 4: the disturbance does not need simultaneous launches -- it shows with the ranks
-        # taking turns, bench.py --dump-leaves -- and it hits a few frames, different ones every time: tools/c4_diff.sh).  A
-        # mistake in the sharded maths hits the SAME entries every time: every entry must be right in at least one attempt,
-        # and no attempt may have more than 2 % of its frames disturbed.
-        worst = {k: float(np.min(np.stack([np.abs(a[k] - r[k]) for r in runs]), axis=0).max() / np.abs(a[k]).max()) for k in GRADS}
-        print('per-entry best of the three attempts: %s' % ', '.join('%s %.1e' % (k[6:], v) for k, v in worst.items()))
-        assert max(worst.values()) <= 2e-5, 'first-cycle gradients of the eight-rank run differ from the one-process run: %s' % worst
-        for r in runs:
-            d = np.abs(a['grad0_zmin_lin'] - r['grad0_zmin_lin']) / np.abs(a['grad0_zmin_lin']).max()
-            assert (d > 2e-5).mean() <= 0.02, 'disturbed frames: %d of %d' % (int((d > 2e-5).sum()), d.size)
+    b = run_eight(str(tmp_path / 'eight.npz'), 29851)
+    # the LBS backward cuts the vertices into 500 / (groups of 32 bodies) chunks and adds the chunk sums in order: 2 chunks for
+    # the one process' 250 groups, 16 for a rank's 32, so sums of 6890 cancelling terms round differently; the shared tail is
+    # additionally summed per rank and then across ranks
+    worst = {k: float(np.abs(a[k] - b[k]).max() / np.abs(a[k]).max()) for k in GRADS}
+    print('first-cycle gradients, max |eight ranks - one process| / largest entry: %s' % ', '.join('%s %.1e' % (k[6:], v) for k, v in worst.items()))
+    assert max(worst.values()) <= 2e-5, 'first-cycle gradients of the eight-rank run differ from the one-process run: %s' % worst
     for k in ('poses_T', 'poses_smpl', 'betas', 'zmin_lin', 'zmax_lin', 'xscale'):
         assert a[k].shape == b[k].shape, k
         d, d1 = np.abs(a[k] - b[k]), np.abs(a[k] - c[k])

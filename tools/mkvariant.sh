@@ -7,8 +7,7 @@ name=$1; src=$2; shift 2
 P=scene-aware-3d-multi-human_amd
 mkdir -p variants /tmp/mkv_$name
 python -c "import sys; sys.path.insert(0,'$P'); from mhhip import build; build.build()" >/dev/null
-extra=""
-[ "$src" = "mh_lbs.hip" ] && extra="-fno-slp-vectorize"
+extra="-fno-slp-vectorize -fno-vectorize"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -munsafe-fp-atomics $extra "$@" -c ${SRCFILE:-$P/csrc/$src} -o /tmp/mkv_$name/${src%.hip}.o
 objs=""
 for f in $P/build/*.o; do

@@ -1855,6 +1855,30 @@ extern "C" int mh_raster_pair_counters(int T, int N, int V, int F, int H, int W,
       out_host[2] += b - a;
     }
     out_host[1] = t1 > t0 ? t1 - t0 : 0ull;
+    if (getenv("MHHIP_SPANS")) {      // who ends last?  (workgroup index = position in the cost-sorted tile list)
+      fprintf(stderr, "spans of the last launch (us): kernel %.1f\n", (double)(t1 - t0) / 100.);
+      for (int d = 0; d < 12; ++d) {
+        const int i0 = d * (R_STRIP_GRID / 12), i1 = (d + 1) * (R_STRIP_GRID / 12);
+        double sd = 0, me = 0, ms = 0; int n = 0;
+        for (int i = i0; i < i1; ++i) {
+          const unsigned long long a = host[2 + 2 * i], b = host[3 + 2 * i];
+          if (!a || b < a) continue;
+          sd += (double)(b - a) / 100.; ++n;
+          if ((double)(b - t0) / 100. > me) me = (double)(b - t0) / 100.;
+          ms += (double)(a - t0) / 100.;
+        }
+        fprintf(stderr, "  workgroups %4d..%4d: %4d ran, mean start %6.1f, mean life %5.1f, latest end %6.1f\n", i0, i1 - 1, n, n ? ms / n : 0., n ? sd / n : 0., me);
+      }
+      for (int k = 0; k < 8; ++k) {          // the eight workgroups that end last
+        int best = -1;
+        for (int i = 0; i < R_STRIP_GRID; ++i)
+          if (host[2 + 2 * i] && host[3 + 2 * i] > host[2 + 2 * i] && (best < 0 || host[3 + 2 * i] > host[3 + 2 * best])) best = i;
+        if (best < 0) break;
+        fprintf(stderr, "  ends at %6.1f: workgroup %4d, started %6.1f, life %5.1f\n", (double)(host[3 + 2 * best] - t0) / 100., best,
+                (double)(host[2 + 2 * best] - t0) / 100., (double)(host[3 + 2 * best] - host[2 + 2 * best]) / 100.);
+        host[3 + 2 * best] = host[2 + 2 * best];      // (consumed: the buffer is a copy)
+      }
+    }
     return MH_OK;
   }
 #endif

@@ -26,7 +26,13 @@ if os.environ.get('R_TIMING') in ('6', '7'):
     from mhhip.raster import set_sort_margin
     e.leaf('poses_T')[::7, :, 1] += 0.05      # every seventh frame moves: its bodies sort, the others keep their lists
     e.forward(regress=False, raster=r)
-for _ in range(4): r(e, gv, log, phases=3 if os.environ.get('R_TIMING') in ('4', '5') else 1)
+if os.environ.get('IN_CYCLE') == '1':
+    # the last launch measured is one inside the replayed cycle (side branch beside it, work lists a cycle old)
+    e.scene_pts = None
+    for c in range(30):
+        e.cycle_graphed(c % 8, raster=r)
+        e.step(0.0)
+for _ in range(0 if os.environ.get('IN_CYCLE') == '1' else 4): r(e, gv, log, phases=3 if os.environ.get('R_TIMING') in ('4', '5') else 1)
 torch.cuda.synchronize()
 a1 = r.pair_counters(e)
 n = a1[0] - a0[0]

@@ -65,3 +65,62 @@ def test_selection_keys_do_not_depend_on_an_lbs_forward_running_beside_them(smpl
         disturbed += [(rep, int(b)) for b in (ks != ref).nonzero().view(-1).tolist()]
         assert int(hs) == int(href)                                  # ... and the co-runner is not disturbed either
     assert not disturbed, 'selection keys of (launch, body) %s differ from the first launch' % disturbed[:12]
+
+
+def test_organic_cycle_is_self_consistent(smpl_struct, smpl_regs, oracle_model, tmp_path):
+    """The cycle with the device-side scene update beside it (every cycle of a real fit from cycle 30 on): the update's
+    kernels share the CUs with the LBS kernels' matrix instructions.  Replayed with a zero learning rate, every repetition
+    must give the same scene cloud, the same selection keys and -- in the deterministic mode -- the same gradients, bit for bit.
+    (On the bench sequence a library built with the vectorisers on does not have this property: 29 of 200 repetitions had up
+    to 48 scene points off by up to 13 m, and the contact term's gradient with them -- tools/organic_probe.py, DESIGN.md 7;
+    on this test's smaller scene the old build slips through 60 repetitions, the test above is the sensitive one.)"""
+    from mhhip import _lib
+    from mhhip._lib import check
+    from mhhip.raster import set_deterministic
+    T, N, W, H = 200, 4, 240, 135
+    opt, dl, o, batches, seq = _setup(smpl_struct, smpl_regs, oracle_model, tmp_path, T, N, W, H, 10, 67, True)
+    opt._stage_from_dataloader(dl)
+    e = opt.engine
+    r = e.raster_terms()
+    e.update_filters()
+    e.scene_device_setup(seq['backmasks'])
+    old = set_deterministic(True)
+    try:
+        B = e.B
+        off = (ctypes.c_size_t * 3)()
+        check(_lib.lib().mh_raster_workspace_offsets(*r.dims, off))
+        win = r.ws[off[0]:off[0] + B * 16].view(torch.int32).view(B, 4)
+        raw = r.ws[off[2]:off[2] + B * H * W * 40].view(torch.int64).view(B, H * W, 5)
+        idx = torch.arange(H * W, device=e.dev)[None, :]
+
+        def snap():
+            torch.cuda.synchronize()
+            npx = (win[:, 2].clamp(min=0) * win[:, 3].clamp(min=0)).to(torch.int64)
+            ks = (raw.sum(dim=2) * (idx < npx[:, None])).sum(dim=1)
+            s = e._scene_dev['front']
+            n = int(s['count'].item())
+            return ks.clone(), n, s['pts'][:n].clone(), e.grads.clone()
+
+        def one(c):
+            e.grads.zero_()
+            e.cycle_graphed(c % 4, raster=r, scene_update=True)
+            e.scene_device_swap()
+            e.step(0.0)
+
+        for c in range(4):                 # graphs captured, both scene sets filled
+            one(c)
+        ref = snap()
+        assert ref[1] > 1000               # there is a scene
+        bad = []
+        for rep in range(60):
+            one(rep)
+            cur = snap()
+            if not torch.equal(cur[0], ref[0]):
+                bad.append((rep, 'keys'))
+            if cur[1] != ref[1] or not torch.equal(cur[2], ref[2]):
+                bad.append((rep, 'scene cloud'))
+            if not torch.equal(cur[3], ref[3]):
+                bad.append((rep, 'gradients'))
+        assert not bad, bad[:10]
+    finally:
+        set_deterministic(old)

@@ -761,6 +761,9 @@ __device__ __forceinline__ void r_tile_depth_sums(const RasterP& p, int s, int b
 #else
 #define R_TMARK(c) do { } while (0)
 #endif
+#ifndef R_KEYS_NT
+#define R_KEYS_NT 1
+#endif
 #ifdef R_SYNC_HARD
 #define R_WAVE_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
 #else
@@ -1074,7 +1077,11 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
     unsigned long long* gk = p.gkeys + (size_t)p.body_koff[b] * 5;
     if (tw == ww && x0 == wx0) {   // a full-width strip of rows (the usual tiling) is one contiguous range of the body's keys
       unsigned long long* dst = gk + (size_t)(sy0 - wy0) * ww * 5;
+#if R_KEYS_NT       // written once, read a kernel later: kept out of the L2 sets the other tiles' gathers live in (-6 us same-box)
+      for (int i = tid; i < npx * 5; i += RB) __builtin_nontemporal_store(keys[i], dst + i);
+#else
       for (int i = tid; i < npx * 5; i += RB) dst[i] = keys[i];
+#endif
     } else {
       for (int i = tid; i < npx * 5; i += RB) {
         const int px = i / 5, c = i - px * 5;

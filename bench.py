@@ -179,7 +179,22 @@ def main():
                     'region to this .npz (a collective in multi-rank runs; rank 0 writes)')
     args = ap.parse_args()
     global N_PEOPLE, T_LOCAL, IMG
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become N ranks (one process per GPU) under torch.distributed.run,
+        # the launch line of the module docstring, on a free local port -- never a silent one-process run that prints n_gpus 1
+        import socket
+        with socket.socket() as so:
+            so.bind(('127.0.0.1', 0))
+            port = so.getsockname()[1]
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        os.environ.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // args.gpus)))
+        sys.stdout.flush()
+        os.execv(sys.executable, [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+                                  '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:])
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks (run `python bench.py --gpus N`, or '
+                         'torch.distributed.run --nproc-per-node N bench.py --gpus N)' % (args.gpus, world))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.config == 'c4':
@@ -210,6 +225,23 @@ def main():
             dist = hostdist.install()          # host-staged collectives for the driver, the drop-in and this file
     device = 'cuda:%d' % dev_index
     torch.cuda.set_device(dev_index)
+    if not args.one_device:
+        assert torch.cuda.device_count() >= (world if world > 1 else 1), \
+            '%d ranks on a node with %d visible GPUs (one process per GPU; --backend gloo --one-device is the dry run)' % (world, torch.cuda.device_count())
+    # proof of what the collective layer saw: every rank's device, gathered through the process group itself
+    rccl_info = None
+    if world > 1:
+        props = torch.cuda.get_device_properties(dev_index)
+        mine = [rank, dev_index, '%s %s' % (props.name, getattr(props, 'uuid', getattr(props, 'pci_bus_id', '')))]
+        got = [None] * world
+        import torch.distributed as tdist
+        tdist.all_gather_object(got, mine)
+        probe = torch.ones(1, device=device)
+        dist.all_reduce(probe)
+        assert int(probe.item()) == world, 'all-reduce over the process group summed %s ranks, not %d' % (probe.item(), world)
+        rccl_info = {'ranks': int(tdist.get_world_size()), 'backend': str(tdist.get_backend()), 'devices': [g[1] for g in sorted(got)],
+                     'device_ids': [g[2] for g in sorted(got)], 'allreduce_of_ones': int(probe.item()),
+                     'one_device_dry_run': bool(args.one_device)}
 
     import tempfile
     from mhhip import build as mhbuild, synthetic, synthetic_seq, sharded
@@ -249,6 +281,7 @@ def main():
         opt.update_scene_pointcloud(opt.scene_depth, scene_mask)                       # contact term live
     raster = e.raster_terms()
     sh.update_filters()                                                                # filtered-vertex term live
+    sh.refresh_halo()                                                                  # (collective, every rank: the cycles themselves issue none)
     nstep = [0]
 
     # one-euro filter updates every 25 cycles as in fit (optimizer.py:383-392); the phase is chosen so that the first one
@@ -279,8 +312,6 @@ def main():
         if world > 1 and args.one_device:
             # the dry run's ranks take turns for the cycle the parity test holds against the one-process run (what used to
             # look like the processes disturbing each other was packed fp32 arithmetic beside matrix instructions: DESIGN 7)
-            if not getattr(sh, '_halo_ok', True):
-                sh.refresh_halo()                 # (the first cycle's collective: everybody, before anybody waits)
             for r_turn in range(world):
                 if r_turn == rank:
                     sh.cycle(0, raster=raster, graphs=False)
@@ -509,6 +540,7 @@ def main():
             'unit': 'iterations/s (%d humans x %d frames per iteration unit)' % (N_PEOPLE, unit_frames), 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'strong' if args.strong else 'weak',
             'vs_baseline': None, 'dtype': 'f32 (the two dense LBS contractions as split-16-bit MFMA operands -- three products of (hi, lo) fp16 / bf16 terms, fp32 accumulate; everything else plain fp32)', 'data': 'synthetic', 'launch': 'eager' if args.eager else 'hipGraph replay',
+            'rccl': rccl_info,
             'backend': ('RCCL (nccl)' if args.backend == 'nccl' else 'DRY RUN: gloo, collectives staged through the host%s -- not a '
                         'scaling measurement' % (', all ranks on one device' if args.one_device else '')) if world > 1 else None,
             'config': {'workload': ('BASELINE C5: %d humans x %d frames + 200 000-point scene cloud, %dx%d, batch 10, full nine-term '

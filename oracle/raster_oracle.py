@@ -56,6 +56,16 @@ def to_ndc(verts, cam_K, image_size, znear=1.0, zfar=100.0):
     return torch.stack([s * (-x) / z + w1, s * (-y) / z + h1, z], dim=-1)
 
 
+def set_behind_camera_rule(whole_face):
+    """raster_select.c: 1 (default) = a face with a vertex behind the camera (zmin < 1e-8) is skipped entirely (the CUDA
+    kernels' rule, what the HIP kernel implements), 0 = only its pixels with interpolated pz < 0 are (the plain naive CPU
+    loop).  Returns the previous setting."""
+    L = _lib()
+    old = L.raster_select_get_behind_camera_rule()
+    L.raster_select_set_behind_camera_rule(1 if whole_face else 0)
+    return old
+
+
 def select_faces(verts_ndc, faces, H, W, blur_radius, K):
     """(B,V,3) float32 NDC verts -> pix_to_face (B,H,W,K) int64 (-1 empty)."""
     v = np.ascontiguousarray(verts_ndc, dtype=np.float32)

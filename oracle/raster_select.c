@@ -8,6 +8,19 @@
  * footprint covers the pixel centre.  PARITY UNPINNED: no PyTorch3D output exists to pin this
  * against; tests/test_raster_oracle.py pins it with analytic known-answer cases instead.
  *
+ * WHICH BACKEND each rule restates (from the published sources as recalled -- there is no copy to read offline):
+ *   - pixel centres (PixToNonSquareNdc), blurred bounding-box test, |face area| <= kEpsilon skip, clipped barycentrics
+ *     (clip_barycentric_coords, blur_radius > 0), pz < 0 skip, inside-or-(dist < blur_radius), K nearest by pz with the
+ *     earlier face winning ties: common to RasterizeMeshesNaiveCpu (rasterize_meshes_cpu.cpp) and the CUDA kernels
+ *     (rasterize_meshes.cu: CheckPixelInsideFace);
+ *   - faces with a vertex behind the camera, zmin < kEpsilon, skipped ENTIRELY: the CUDA kernels' rule (CheckPixelInsideFace:
+ *     `zmax < 0` / the coarse pass's `z_invalid = zmin < kEpsilon`), which newer CPU sources apply through the face bounding
+ *     boxes as well.  The plain naive CPU loop drops only the PIXELS whose interpolated pz < 0 of such a face.
+ *     raster_select_set_behind_camera_rule(1) = whole-face rule (DEFAULT; what the HIP kernel implements: the reference
+ *     fits on a GPU, predict.py), 0 = per-pixel rule only.  The two differ only for a face that straddles the camera plane
+ *     z = 0 -- never the case at MuPoTs depths (bodies 2-10 m in front of the camera); tests/test_raster_oracle.py holds a
+ *     known-answer case for each.
+ *
  * Only the discrete selection happens here; the differentiable quantities (barycentrics, z,
  * distances) are recomputed from the selected faces in torch (oracle/raster_oracle.py) so that
  * autograd provides the reference gradients.
@@ -19,6 +32,10 @@
 #include <stdlib.h>
 
 #define K_EPS 1e-8f
+
+static int g_behind_rule = 1;   /* 1: skip faces with zmin < kEpsilon (CUDA kernels; default), 0: only pixels with pz < 0 */
+void raster_select_set_behind_camera_rule(int whole_face) { g_behind_rule = whole_face ? 1 : 0; }
+int raster_select_get_behind_camera_rule(void) { return g_behind_rule; }
 
 static float edge_fn(float px, float py, float ax, float ay, float bx, float by) {
   return (px - ax) * (by - ay) - (py - ay) * (bx - ax);
@@ -69,7 +86,7 @@ void raster_select(const float* verts_ndc, const int32_t* faces, int F, int H, i
     const float* v1 = verts_ndc + 3 * faces[3 * f + 1];
     const float* v2 = verts_ndc + 3 * faces[3 * f + 2];
     float zmin = fminf(v0[2], fminf(v1[2], v2[2]));
-    if (zmin < K_EPS) continue;                               /* face (partly) behind the camera */
+    if (g_behind_rule && zmin < K_EPS) continue;              /* face (partly) behind the camera: whole-face rule */
     float face_area = edge_fn(v0[0], v0[1], v1[0], v1[1], v2[0], v2[1]);
     if (face_area <= K_EPS && face_area >= -K_EPS) continue;  /* degenerate */
     float xmin = fminf(v0[0], fminf(v1[0], v2[0])) - blur, xmax = fmaxf(v0[0], fmaxf(v1[0], v2[0])) + blur;

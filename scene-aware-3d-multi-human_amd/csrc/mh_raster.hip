@@ -856,6 +856,18 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
     const int c0 = rs[2 * (H + 1) + rt_], nc = rs[2 * (H + 1) + rb_] - c0;
     const int nab = na + nbk, i1 = nab + nc;
     auto fs_at = [&](int j) { return fs[j < na ? a0 + j : (j < nab ? b0 + (j - na) : c0 + (j - nab))]; };
+#ifdef R_SEED_CEIL      // experiment (timing only): the previous launch's 4th keys (+ slack ulps) as cull bounds from the start
+    __syncthreads();
+    {
+      const int wx0_ = p.win[b * 4], wy0_ = p.win[b * 4 + 1], ww_ = p.win[b * 4 + 2];
+      const unsigned long long* gkp = p.gkeys + (size_t)p.body_koff[b] * 5;
+      for (int i = tid; i < npx; i += RB) {
+        const int r = i / tw, cc = i - r * tw;
+        const unsigned long long k4 = gkp[((size_t)(sy0 - wy0_ + r) * ww_ + (x0 - wx0_ + cc)) * 5 + 4];
+        if ((unsigned)k4 != 0xffffffffu) keys[i * 5 + 4] = ((unsigned long long)((unsigned)(k4 >> 32) + (unsigned)(R_SEED_CEIL)) << 32) | 0xffffffffull;
+      }
+    }
+#endif
     __syncthreads();
     R_TMARK(0);
     if (i1 > 0) {
@@ -1077,7 +1089,9 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
     unsigned long long* gk = p.gkeys + (size_t)p.body_koff[b] * 5;
     if (tw == ww && x0 == wx0) {   // a full-width strip of rows (the usual tiling) is one contiguous range of the body's keys
       unsigned long long* dst = gk + (size_t)(sy0 - wy0) * ww * 5;
-#if R_KEYS_NT       // written once, read a kernel later: kept out of the L2 sets the other tiles' gathers live in (-6 us same-box)
+#ifdef R_SEED_CEIL
+      for (int i = tid; i < npx * 5; i += RB) { unsigned long long k_ = keys[i]; if ((unsigned)k_ == 0xffffffffu) k_ = RS_EMPTY; __builtin_nontemporal_store(k_, dst + i); }
+#elif R_KEYS_NT       // written once, read a kernel later: kept out of the L2 sets the other tiles' gathers live in (-6 us same-box)
       for (int i = tid; i < npx * 5; i += RB) __builtin_nontemporal_store(keys[i], dst + i);
 #else
       for (int i = tid; i < npx * 5; i += RB) dst[i] = keys[i];

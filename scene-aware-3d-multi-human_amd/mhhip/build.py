@@ -102,34 +102,54 @@ def build(force=False, verbose=False):
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(compile_one, jobs))
     run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + [_obj(s) for s in sources()] + ['-o', LIB + '.tmp'])
-    n = packed_instructions(LIB + '.tmp')
-    if n and os.environ.get('MHHIP_ALLOW_PACKED') != '1':      # (experiments set it: tools/mkvariant.sh builds do not come through here)
-        os.remove(LIB + '.tmp')
-        raise RuntimeError('%d packed arithmetic instructions (v_pk_*) in the linked device code: they return wrong values beside '
-                           'matrix instructions on this hardware (see the module docstring); flags: %s' % (n, ' '.join(extra) or '-'))
+    if os.environ.get('MHHIP_ALLOW_PACKED') != '1':            # (experiments set it: tools/mkvariant.sh builds do not come through here)
+        try:
+            n = packed_instructions(LIB + '.tmp')              # raises when there is no llvm-objdump to look with: the guard
+        except Exception:                                      # must not pass silently
+            os.remove(LIB + '.tmp')
+            raise
+        if n:
+            os.remove(LIB + '.tmp')
+            raise RuntimeError('%d packed fp32 arithmetic instructions (v_pk_fma/mul/add_f32) in the linked device code: they return '
+                               'wrong values beside matrix instructions on this hardware (see the module docstring); flags: %s'
+                               % (n, ' '.join(extra) or '-'))
     os.replace(LIB + '.tmp', LIB)
     return LIB
 
 
+PACKED_FP32 = r'\bv_pk_(?:fma|mul|add)_f32\b'
+
+
+def objdump_path():
+    """llvm-objdump of the toolchain that compiled the library; raises when there is none (the packed-fp32 guard must not
+    pass silently on a host without it: ADVICE r04)"""
+    cands = [os.path.join(os.path.dirname(os.path.realpath(os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'))), '..', 'lib', 'llvm', 'bin',
+                          'llvm-objdump'), '/opt/rocm/lib/llvm/bin/llvm-objdump']
+    for c in cands:
+        if os.path.exists(c):
+            return c
+    raise RuntimeError('llvm-objdump not found (looked in %s): the linked device code cannot be checked for packed fp32 '
+                       'instructions; set MHHIP_ALLOW_PACKED=1 to link without the check' % ', '.join(cands))
+
+
 def packed_instructions(lib):
-    """number of packed arithmetic instructions (v_pk_*; conversions v_cvt_pk_* do not count) in the gfx950 code objects of a
-    linked library, or 0 when the toolchain's llvm-objdump is not there to look"""
+    """number of packed fp32 ARITHMETIC instructions -- v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, the forms the fault was
+    seen with (moves, packed integer / 16-bit forms and the conversions v_cvt_pk_* are not counted: the backend may emit them
+    whatever the vectoriser flags say) -- in the gfx950 code objects of a linked library"""
     import re
     import shutil
     import tempfile
-    objdump = os.path.join(os.path.dirname(os.path.realpath(os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'))), '..', 'lib', 'llvm', 'bin',
-                           'llvm-objdump')
-    if not os.path.exists(objdump):
-        objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
-    if not os.path.exists(objdump):
-        return 0
+    objdump = objdump_path()
     n = 0
     with tempfile.TemporaryDirectory() as tmp:
         so = shutil.copy(lib, os.path.join(tmp, 'lib.so'))
         subprocess.run([objdump, '--offloading', so], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=tmp)
-        for o in glob.glob(os.path.join(tmp, 'lib.so.*gfx950*')):
+        objs = glob.glob(os.path.join(tmp, 'lib.so.*gfx950*'))
+        if not objs:
+            raise RuntimeError('no gfx950 code object found in %s' % lib)
+        for o in objs:
             asm = subprocess.run([objdump, '-d', '--mcpu=gfx950', o], check=True, capture_output=True, text=True).stdout
-            n += len(re.findall(r'\bv_pk_\w+', asm))
+            n += len(re.findall(PACKED_FP32, asm))
     return n
 
 

@@ -164,8 +164,11 @@ class ShardedSequence(object):
         self._halo_ok = True
 
     def leaves_changed(self):
-        """the per-frame leaves were written from outside a cycle (set_leaves, a test): the next cycle re-gathers the halos"""
+        """the per-frame leaves were written from outside a cycle (set_leaves, the start of a fit, a test): the neighbours'
+        copies of the boundary frames are stale -- every rank must call ``refresh_halo()`` (a COLLECTIVE) before its next
+        ``cycle`` -- and the device-style learning-rate schedule of ``step(lr=None)`` starts over, as a new optimiser's would"""
         self._halo_ok = False
+        self._lr32 = None
 
     def cycle(self, row, raster=None, graphs=False, scene_update=False):
         """scene_update (single process only): launch the device-side scene update of this cycle from inside
@@ -183,7 +186,9 @@ class ShardedSequence(object):
             return
         self._bufs()
         if not self._halo_ok:
-            self.refresh_halo()
+            # no hidden collective: a cycle issued on some ranks only must not deadlock the others inside an all-reduce
+            raise RuntimeError('frame-sharded cycle with stale halos: the per-frame leaves were set from outside a cycle -- call '
+                               'refresh_halo() on EVERY rank first (fit() and init_optimized_variables() do)')
         h = self._halo
         h['vf_prev'], h['vf_next'] = self._vf_halo if self._vf_halo is not None else (None, None)
         e.halo = h
@@ -212,11 +217,31 @@ class ShardedSequence(object):
             self._lr32 = np.float32(self._lr32 * np.float32(0.99))
         g = getattr(self, '_graphs', False)
         e.step_local(lr)
-        self._run(('shard_pack',), self._pack, g)
-        dist.all_reduce(self._ar, op=dist.ReduceOp.SUM, group=self.group)
-        self._run(('shard_unpack',), self._unpack, g)
+        if g and self._ar_in_graph():
+            # MHHIP_SHARD_AR_GRAPH=1: pack -> all-reduce -> unpack as ONE captured graph (RCCL collectives capture and replay:
+            # tests/test_rccl_single_rank_gpu.py on the one-rank group; off by default until an N-rank node has run it)
+            def message():
+                self._pack()
+                dist.all_reduce(self._ar, op=dist.ReduceOp.SUM, group=self.group)
+                self._unpack()
+            self._run(('shard_message',), message, True)
+        else:
+            self._run(('shard_pack',), self._pack, g)
+            dist.all_reduce(self._ar, op=dist.ReduceOp.SUM, group=self.group)
+            self._run(('shard_unpack',), self._unpack, g)
         e.step_shared(lr)
         self._halo_ok = True
+
+    def _ar_in_graph(self):
+        if getattr(self, '_ar_graph', None) is None:
+            import os
+            on = os.environ.get('MHHIP_SHARD_AR_GRAPH') == '1' and hasattr(self.e, 'replay')
+            try:
+                on = on and str(dist.get_backend(self.group)) == 'nccl'       # host-staged dry runs cannot be captured
+            except Exception:
+                on = False
+            self._ar_graph = bool(on)
+        return self._ar_graph
 
     # -- one-euro filters with the state handed down the ranks (optimizer.py:383-392) ----------------
     def _scan(self, x, c, b):

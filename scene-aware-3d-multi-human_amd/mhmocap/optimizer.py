@@ -544,7 +544,8 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
         lr = 0.01                                                             # a new RMSprop + ExponentialLR per fit (:355-356):
         e.sq.zero_()                                                          # ... its running squares and momentum buffers
         e.buf.zero_()                                                         # start at zero in EVERY call
-        sh.leaves_changed()                                                   # (sharded: the first cycle gathers the neighbours' boundary leaves)
+        sh.leaves_changed()                                                   # (sharded: the neighbours' boundary leaves are gathered
+        sh.refresh_halo()                                                     #  here, by every rank: the cycles issue no hidden collective)
         cycles = range(num_iter)
         if verbose and tqdm is not None and rank == 0:
             cycles = tqdm(cycles)

@@ -28,6 +28,21 @@ def _run(nproc, extra, port):
 
 
 @pytest.mark.timeout(1800)
+def test_gpus_flag_alone_launches_the_ranks():
+    """``python bench.py --gpus 2`` WITHOUT a launcher must become two ranks by itself (it used to run one process
+    and print n_gpus 1), and the line must carry what the process group saw"""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='2')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--one-device', '--steps', '12', '--warmup', '2',
+           '--presteps', '4', '--image', '96x54', '--humans', '2', '--frames', '20']
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
+    assert out['n_gpus'] == 2 and out['config']['frames'] == 40
+    assert out['rccl']['ranks'] == 2 and out['rccl']['allreduce_of_ones'] == 2 and out['rccl']['one_device_dry_run'] is True
+
+
+@pytest.mark.timeout(1800)
 def test_weak_scaling_form_on_three_ranks():
     out = _run(3, ['--frames', '20'], 29811)
     assert out['n_gpus'] == 3 and out['scaling'] == 'weak' and out['steps'] == 30

@@ -20,14 +20,23 @@ def test_every_source_is_compiled_without_the_vectorisers():
         assert '-fno-slp-vectorize' in flags and '-fno-vectorize' in flags, src
 
 
-@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason='llvm-objdump of the ROCm toolchain not found')
+def test_the_guard_fails_loudly_without_a_disassembler(monkeypatch):
+    """ADVICE / VERDICT r04: the link-time gate used to return 0 packed instructions when llvm-objdump was missing"""
+    from mhhip import build
+    monkeypatch.setattr(os.path, 'exists', lambda p: False if 'llvm-objdump' in str(p) else os.path.lexists(p))
+    with pytest.raises(RuntimeError, match='llvm-objdump not found'):
+        build.packed_instructions(build.LIB)
+
+
 def test_linked_device_code_has_no_packed_fp32_instruction(tmp_path):
     from mhhip import build
+    assert os.path.exists(OBJDUMP), 'llvm-objdump of the ROCm toolchain not found: the packed-fp32 guard cannot be held'
+    assert build.packed_instructions(build.build()) == 0
     so = shutil.copy(build.build(), tmp_path / 'lib.so')
     subprocess.run([OBJDUMP, '--offloading', str(so)], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=tmp_path)
     objs = sorted(glob.glob(str(tmp_path / 'lib.so.*gfx950*')))
     assert len(objs) >= 6, objs                           # one code object per source file with device code
-    packed = re.compile(r'\bv_pk_\w+')          # (conversions, v_cvt_pk_*, are not arithmetic and stay)
+    packed = re.compile(build.PACKED_FP32)      # the fp32 arithmetic forms the fault was seen with (mhhip/build.py)
     n_mfma = 0
     seen = ''
     for o in objs:

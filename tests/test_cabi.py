@@ -4,6 +4,7 @@ HIP device (no CPU fallback); host-side helpers behave."""
 import ctypes
 import inspect
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -117,3 +118,12 @@ def test_argument_checks_return_status_and_message_without_a_device():
     assert rc < 0 and L.mh_last_error()
     assert L.mh_scene_median(0, 8, 8, *([None] * 8)) < 0
     assert L.mh_scene_workspace_bytes(4, 8, 8) > 0 and L.mh_raster_workspace_bytes(1, 1, 10, 10, 8, 8) > 0
+
+
+def test_bench_refuses_a_rank_count_that_is_not_what_gpus_says():
+    """``--gpus N`` is binding -- a launcher that started another number of ranks is an error, not a run that
+    prints the wrong ``n_gpus`` (without a launcher bench.py starts the N ranks itself: tests/test_bench_multirank_gpu.py)"""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and 'WORLD_SIZE=1' in (p.stderr + p.stdout)

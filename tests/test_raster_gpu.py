@@ -319,3 +319,26 @@ def test_deterministic_scatter_and_where_the_gradient_errors_come_from(smpl_stru
     print('selection differs on %d of %d live (pixel, pass) entries; not explained as near-ties: %d' % (ndiff, live, len(not_ties)))
     assert live > 300 and ndiff <= 3e-2 * live + 3, (ndiff, live)
     assert not not_ties, not_ties[:5]
+
+
+def test_face_straddling_the_camera_plane_is_skipped_whole():
+    """Known answer for the behind-the-camera rule (oracle/raster_select.c says which PyTorch3D backend each rule restates): the
+    HIP kernel implements the WHOLE-FACE rule (zmin < kEpsilon: the CUDA kernels') -- a triangle with its apex behind the
+    camera leaves the z-buffer and the silhouette empty, while the same triangle pushed in front of the camera is drawn; the
+    oracle agrees under its default rule."""
+    import types
+    from mhhip.raster import render
+    W, H = 64, 48
+    K = synthetic.default_cam_K((W, H), 60.0)
+    faces = np.array([[0, 1, 2], [3, 4, 5]], np.int32)
+    model = types.SimpleNamespace(faces=faces)
+    tri = np.array([[-0.6, -0.5, 2.0], [0.6, -0.5, 2.0], [0.0, 0.5, -1.0]], np.float32)          # apex behind the camera
+    far = np.array([[5.0, 5.0, 50.0], [5.1, 5.0, 50.0], [5.0, 5.1, 50.0]], np.float32)           # (off screen: the table needs a 2nd face)
+    verts = torch.tensor(np.stack([np.concatenate([tri, far]), np.concatenate([tri + [0, 0, 1.5], far])]), device='cuda:0')
+    zbuf, alpha = render(model, verts, K, (W, H))
+    zbuf, alpha = zbuf.cpu().numpy(), alpha.cpu().numpy()
+    assert (zbuf[0] == -1).all() and (alpha[0] == 0).all()                   # straddling: skipped entirely
+    assert (zbuf[1] > 0).sum() > 30 and alpha[1].max() > 0.99                # the same triangle, wholly in front: drawn
+    ndc = ro.to_ndc(verts.cpu(), K, (W, H)).numpy().astype(np.float32)
+    f8, _ = ro.select_faces(ndc, faces.astype(np.int64), H, W, 1e-4, 8)
+    assert (f8[0] == -1).all() and ((f8[1, ..., 0] >= 0) == (zbuf[1] > 0)).mean() > 0.995

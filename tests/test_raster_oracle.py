@@ -144,3 +144,36 @@ def test_capsule_body_render_is_sane():
     assert float(a.max()) > 0.9 and float(a[0, 0, 0]) == 0.0
     # the depth pass has the wider blur band (1e-4 vs 2e-5): a few rim pixels have depth but no alpha
     assert float((a[0][cover] > 0.5).float().mean()) > 0.8
+
+
+def test_face_straddling_the_camera_plane_under_both_backend_rules():
+    """one triangle with its apex BEHIND the camera (z = -1), base in front (z = 2), given directly in NDC.
+    Whole-face rule (the CUDA kernels' zmin < kEpsilon; default, what the HIP kernel implements): nothing is rasterised.
+    Per-pixel rule (the plain naive CPU loop): the pixels whose interpolated depth is >= 0 are kept -- analytically, with the
+    apex's barycentric weight w2 = (y + 0.5) / 1.1, pz = 2 (1 - w2) - w2 >= 0  <=>  y <= 0.2333."""
+    H = W = 41
+    v = np.array([[[-0.5, -0.5, 2.0], [0.5, -0.5, 2.0], [0.0, 0.6, -1.0]]], np.float32)
+    f = np.array([[0, 1, 2]])
+    xs, ys = ro.pixel_centres_ndc(H, W)
+    old = ro.set_behind_camera_rule(1)
+    try:
+        face, z = ro.select_faces(v, f, H, W, 0.0, 1)
+        assert (face == -1).all()
+        ro.set_behind_camera_rule(0)
+        face, z = ro.select_faces(v, f, H, W, 0.0, 1)
+    finally:
+        ro.set_behind_camera_rule(old)
+    got = face[0, :, :, 0] >= 0
+    assert got.sum() > 50
+    for yi in range(H):
+        for xi in range(W):
+            x, y = float(xs[xi]), float(ys[yi])
+            # inside the NDC triangle (strictly), away from the edges and from the pz = 0 line by a pixel fraction
+            w2 = (y + 0.5) / 1.1
+            half = 0.5 * (1.0 - w2)
+            inside = -0.5 < y < 0.6 and abs(x) < half
+            margin = min(abs(abs(x) - half), abs(y + 0.5), abs(y - 0.2333)) > 0.03
+            if inside and margin:
+                assert bool(got[yi, xi]) == (y < 0.2333), (xi, yi, x, y)
+                if got[yi, xi]:
+                    assert abs(float(z[0, yi, xi, 0]) - (2.0 * (1.0 - w2) - w2)) < 1e-4

@@ -217,37 +217,43 @@ def test_models_with_more_than_four_bones_per_vertex(smpl_struct, smpl_regs, nbo
     np.testing.assert_allclose(gbetas.cpu().numpy(), gb, atol=2e-4 * np.abs(gb).max())
 
 
-def _cycle_vs_oracle(opt, dl, o, batches, frac=0.01):
-    from mhhip.raster import RasterTerms
+def _cycle_vs_oracle(opt, dl, o, batches, N, smpl_struct):
+    """one full cycle at a BASELINE shape, held like C3 (tests/test_full_size_gpu.py): deterministic scatter, the oracle rendering
+    the faces the kernel selected at the vertices the kernel produced, the loss log and EVERY entry of EVERY leaf gradient within
+    2e-4 of the leaf's largest entry (rounds 2-4 allowed 1 % of the entries to miss 5e-3 here)"""
+    from mhhip.raster import RasterTerms, set_deterministic
+    from test_fit_full_gpu import _HipSelectionRasteriser
+    from test_full_size_gpu import _compare_grads_everywhere
     opt._stage_from_dataloader(dl)
     e = opt.engine
-    e.cycle(0, raster=RasterTerms(e))
-    log = e.read_log(1)[0]
-    want = o.cycle_grads(batches)
+    raster = RasterTerms(e)
+    hsel = _HipSelectionRasteriser(np.asarray(smpl_struct.f).astype(np.int64), np.asarray(opt.cam_K, np.float32).reshape(3, 3), (e.W, e.H), N)
+    o.rasteriser = hsel
+    old = set_deterministic(True)
+    try:
+        e.cycle(0, raster=raster)
+        hsel.take(raster, e, oracle=o)
+        log = e.read_log(1)[0]
+        want = o.cycle_grads(batches)
+    finally:
+        set_deterministic(old)
     for k in ['loss_pose24j', 'loss_depth', 'loss_silhouette', 'reg_ref_poses', 'reg_scale', 'reg_contact', 'reg_foot_sliding', 'reg_vel']:
-        np.testing.assert_allclose(log[k], want[k], rtol=3e-3, atol=1e-6, err_msg=k)
+        np.testing.assert_allclose(log[k], want[k], rtol=1e-3, atol=1e-6, err_msg=k)
     assert want['loss_depth'] > 0 and want['loss_silhouette'] > 0
-    for name, ename in LEAF_MAP:
-        w = _oracle_grad(o, name)
-        g = e.leaf(ename, e.grads).cpu().numpy().reshape(w.shape)
-        scale = max(np.abs(w).max(), 1e-8)
-        err = np.abs(g - w)
-        bad = float((err > 5e-3 * scale).mean())
-        assert bad < frac and np.median(err) < 1e-3 * scale, '%s: %.4f of entries above 5e-3*max, median %.2e (scale %.2e)' % (
-            name, bad, np.median(err), scale)
+    _compare_grads_everywhere(e, o)
     return e, want
 
 
 def test_c2_two_humans_100_frames_at_size(smpl_struct, smpl_regs, oracle_model, tmp_path):
     """BASELINE config C2: 2 humans x 100 frames, 240x135, batch 10 -- one full nine-term cycle against the oracle"""
     opt, dl, o, batches, seq = _setup(smpl_struct, smpl_regs, oracle_model, tmp_path, 100, 2, 240, 135, 10, 52, True)
-    _cycle_vs_oracle(opt, dl, o, batches)
+    _cycle_vs_oracle(opt, dl, o, batches, 2, smpl_struct)
 
 
 def test_c1_shape_one_human_square_image(smpl_struct, smpl_regs, oracle_model, tmp_path):
     """C1's shape (MuPoTs TS1: 2048^2 x 0.125 = 256x256, one human, 50 frames, batch 10) on the device"""
     opt, dl, o, batches, seq = _setup(smpl_struct, smpl_regs, oracle_model, tmp_path, 50, 1, 256, 256, 10, 53, True)
-    _cycle_vs_oracle(opt, dl, o, batches)
+    _cycle_vs_oracle(opt, dl, o, batches, 1, smpl_struct)
 
 
 def test_c4_shard_of_250_frames_with_halos(smpl_struct, smpl_regs, oracle_model, tmp_path):
@@ -270,12 +276,30 @@ def test_c4_shard_of_250_frames_with_halos(smpl_struct, smpl_regs, oracle_model,
     e.scene_from_depth(opt.scene_depth, seq['backmasks'].min(axis=0) > 0)
     dev = e.dev
     e.halo = {'pT_prev': torch.tensor(full['poses_T'][f0 - 1]).view(N, 3).to(dev), 'pT_next': torch.tensor(full['poses_T'][f1]).view(N, 3).to(dev)}
-    e.cycle_begin()
-    e.cycle_finish(0, raster=RasterTerms(e))
-    log = e.read_log(1)[0]
-    want = o.cycle_grads(batches[f0 // batch:f1 // batch])          # the shard's 25 batches + the full-sequence temporal term
+    # held like C3: deterministic scatter, the oracle rendering the kernel's selection at the kernel's vertices, every entry
+    from mhhip.raster import set_deterministic
+    from test_fit_full_gpu import _HipSelectionRasteriser
+    raster = RasterTerms(e)
+    hsel = _HipSelectionRasteriser(np.asarray(smpl_struct.f).astype(np.int64), np.asarray(opt.cam_K, np.float32).reshape(3, 3), (W, H), N)
+    old = set_deterministic(True)
+    try:
+        e.cycle_begin()
+        e.cycle_finish(0, raster=raster)
+        log = e.read_log(1)[0]
+        # the shard's selection and vertices in the frames of the WHOLE sequence the oracle works on
+        from test_raster_gpu import _hip_selection
+        sel = np.full((T, N, H, W, 5), -1, np.int64)
+        sel[sl] = _hip_selection(raster.selection(e), e.B, H, W).reshape(f1 - f0, N, H, W, 5)
+        hsel.sel = sel
+        o.rasteriser = hsel
+        vo = torch.zeros(T, N, e.V, 3)
+        vo[sl] = e.verts.view(f1 - f0, N, -1, 3).cpu()
+        o.verts_value_override = vo
+        want = o.cycle_grads(batches[f0 // batch:f1 // batch])          # the shard's 25 batches + the full-sequence temporal term
+    finally:
+        set_deterministic(old)
     for k in ['loss_pose24j', 'loss_depth', 'loss_silhouette', 'reg_contact', 'reg_foot_sliding']:
-        np.testing.assert_allclose(log[k], want[k], rtol=3e-3, atol=1e-6, err_msg=k)
+        np.testing.assert_allclose(log[k], want[k], rtol=1e-3, atol=1e-6, err_msg=k)
     for name, ename in LEAF_MAP:
         w = _oracle_grad(o, name)
         if name in ('poses_T', 'poses_smpl', 'zmin_lin', 'zmax_lin'):
@@ -283,8 +307,8 @@ def test_c4_shard_of_250_frames_with_halos(smpl_struct, smpl_regs, oracle_model,
         g = e.leaf(ename, e.grads).cpu().numpy().reshape(w.shape)
         scale = max(np.abs(w).max(), 1e-8)
         err = np.abs(g - w)
-        bad = float((err > 5e-3 * scale).mean())
-        assert bad < 0.01 and np.median(err) < 1e-3 * scale, '%s: %.4f of entries above 5e-3*max, median %.2e' % (name, bad, np.median(err))
+        print('%-10s max %.2e  median %.2e (x largest entry)' % (name, err.max() / scale, np.median(err) / scale))
+        np.testing.assert_allclose(g, w, atol=2e-4 * scale, rtol=0, err_msg=name)
     # the halo matters: the boundary frames' translation gradient contains the pull of frames 9 and 260
     gT = e.leaf('poses_T', e.grads).cpu().numpy()
     vel_pull = 2 * gi.COEFS['reg_velocity'] * (full['poses_T'][f0, :, 0] - full['poses_T'][f0 - 1, :, 0])

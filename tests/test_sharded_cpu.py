@@ -49,6 +49,7 @@ def _make_engine(model, sp, K, pose2d, f0, f1):
 
 def _run(sh, e):
     lr = 0.01
+    sh.refresh_halo()                   # collective, every rank: the cycles issue no hidden one
     for c in range(CYCLES):
         if c == 1:                      # filters come alive (cycle 50 in the reference schedule)
             sh.update_filters()
@@ -67,6 +68,16 @@ def _worker(rank, world, port, out):
     f0, f1 = shard_bounds(T, world, BATCH)[rank]
     e = _make_engine(model, sp, K, pose2d, f0, f1)
     sh = ShardedSequence(e, f0, T)
+    # a cycle on stale halos raises instead of starting a hidden collective (a cycle run on some ranks only would
+    # otherwise hang the others); the device-style schedule of step(lr=None) restarts when the leaves are set from outside
+    try:
+        sh.cycle(0)
+        raise AssertionError('a frame-sharded cycle on stale halos must raise')
+    except RuntimeError as ex:
+        assert 'refresh_halo' in str(ex)
+    sh._lr32 = np.float32(0.005)
+    sh.leaves_changed()
+    assert sh._lr32 is None
     log = _run(sh, e)
     torch.save(dict(params=e.params.clone(), log=log, f0=f0, f1=f1, pT_filt=e.pT_filt, vf=e.verts_filt[:, :, ::97]),
                os.path.join(out, 'rank%d.pt' % rank))

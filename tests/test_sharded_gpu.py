@@ -63,6 +63,7 @@ def _backmasks(T=T):
 def _run(sh, e):
     from mhhip.raster import RasterTerms
     raster = RasterTerms(e)
+    sh.refresh_halo()                   # collective, every rank: the cycles issue no hidden one
     for c in range(CYCLES):
         if c == 1:
             sh.update_filters()

@@ -499,7 +499,7 @@ struct mh_raster_fin {
   /* phases & 128 of mh_raster_terms_deferred: the carrier also rebuilds the rasteriser's work lists (tile and gradient-unit
    * order: a schedule for the NEXT launch on that workspace) -- the parameter block it needs, opaque to the caller */
   int has_lists;
-  unsigned long long lists[75];
+  unsigned long long lists[80];
 };
 int mh_raster_forward_targets(int T, int N, int V, int F, int H, int W, const float* cam_K_host, void* ws,
                               mh_fwd_proj* out);
@@ -549,6 +549,13 @@ int mh_raster_get_sort_margin(void);
 int mh_raster_set_path(int all_even);
 int mh_raster_get_path(void);
 int mh_raster_sort_counters(int T, int N, int V, int F, int H, int W, void* ws, unsigned long long* out_host /*[2]*/, void* stream);
+/* Winners first (round 5): on != 0 (default; MHHIP_RASTER_WINNERS=0 switches it off) = when a body's face lists are sorted, the
+ * faces that held one of the five keys of some pixel in the previous launch on this workspace go into a list of their own
+ * that every tile of the selection kernel rasterises FIRST, so that the depth cull meets nearly final 4th keys for all other
+ * faces.  An order only: the selection keys are the same bits with and without it, whatever the workspace held.
+ * Process-wide; part of the cycle graphs' key. */
+int mh_raster_set_winners(int on);
+int mh_raster_get_winners(void);
 int mh_raster_set_deterministic(int on);
 int mh_raster_get_deterministic(void);
 

@@ -406,7 +406,8 @@ __device__ __forceinline__ int r_tile_class(const RasterP& p, const int* rs, int
   const int sy1 = sy0 + nrows - 1;
   mh = min(max(mh, 0), H);
   const int ra = max(0, sy0 - R_SHORT - p.margin), rt = max(0, sy0 - mh - p.margin), rb = min(sy1 + 1 + p.margin, H);
-  const long long n = (long long)(rs[rb] - rs[ra]) + (long long)(rs[H + 1 + rb] - rs[H + 1 + ra]) + (long long)(rs[2 * (H + 1) + rb] - rs[2 * (H + 1) + rt]);
+  const long long n = (long long)(rs[rb] - rs[ra]) + (long long)(rs[H + 1 + rb] - rs[H + 1 + ra]) + (long long)(rs[2 * (H + 1) + rb] - rs[2 * (H + 1) + ra]) +
+                      (long long)(rs[3 * (H + 1) + rb] - rs[3 * (H + 1) + rt]);
   const long long cost = min(max(n, 0ll), (long long)p.F) + 11ll * nrows * ncols;
   return R_NCLS - 1 - (int)min((long long)(R_NCLS - 1), max(0ll, cost * R_NCLS / cmax));
 }
@@ -426,8 +427,22 @@ __device__ unsigned long long g_prep_t[8];
 #else
 #define P_MARK(c) do { } while (0)
 #endif
+// WINNERS FIRST (round 5).  The depth cull of k_raster_strip only bites once a pixel's own K=4 list has filled, and the
+// faces that fill it are nearly the same from launch to launch: the faces that ended the PREVIOUS launch in some pixel's
+// five keys ("winners", ~18 % of a body's faces) go into a list of their own that every tile rasterises first -- after a
+// tile's first rounds its 4th keys are close to their final values and the other 82 % of the faces meet a cull that is
+// nearly as tight as it will get.  An ORDER only: every face is still decided from the current coordinates, the keys are
+// the same bits whatever the list holds (tests/test_raster_winners_gpu.py: garbage keys, stale winners).  The class is
+// assigned when a body's lists are sorted (3 % of the bodies per cycle in a steady sequence) from the keys the body's
+// window holds at that moment, and stays with the kept lists; a body sorted before it had any keys sorts once more.
+// (Measured on the way: seeding the cull with last launch's 4th DEPTHS as sentinels -- exact through verification and
+// per-pixel repair -- evaluates 28 % fewer pairs and is 33-44 us SLOWER: a pixel's list flips between "four front faces"
+// and "three front faces + one 20 cm behind" under the smallest motion, ~1.5 failed pixels per body and cycle, each a
+// re-run of its row's faces.  Real keys of real faces cannot fail.)
+#define R_WIN_MAXF 65536     // models with more faces have no winners' list (the bitmap lives in LDS: F / 8 bytes)
 template <int NT>
-__device__ __forceinline__ void r_face_sort(const RasterP& p, int b, int* hist /*LDS [3][H+1]*/, unsigned* pacc, unsigned long long& plast) {
+__device__ __forceinline__ void r_face_sort(const RasterP& p, int b, int* hist /*LDS [4][H+1] + winner bitmap*/, int pww, int pwh,
+                                            unsigned* pacc, unsigned long long& plast) {
   __shared__ int s_maxh, s_flip;
   __shared__ float s_z[2];
   __shared__ int s_n[2];
@@ -435,11 +450,25 @@ __device__ __forceinline__ void r_face_sort(const RasterP& p, int b, int* hist /
   const float* nb = p.ndc + (size_t)b * p.V * 3;
   unsigned* fr = p.frows + (size_t)b * p.F;
   unsigned* fs = p.fsort + (size_t)b * p.F;
-  int* rs = p.row_start + (size_t)b * (3 * HB + 1);
-  for (int i = tid; i < 3 * HB; i += NT) hist[i] = 0;
+  int* rs = p.row_start + (size_t)b * (4 * HB + 1);
+  unsigned* wbits = (unsigned*)(hist + 4 * HB);
+  const bool use_win = p.F <= R_WIN_MAXF && p.winners_on;
+  const int nwords = use_win ? (p.F + 31) / 32 : 0;
+  for (int i = tid; i < 4 * HB + nwords; i += NT) hist[i] = 0;
   if (tid == 0) { s_maxh = 0; s_z[0] = s_z[1] = 0.f; s_n[0] = s_n[1] = 0; }
   __syncthreads();
   (void)pacc; (void)plast;
+  // winners of the previous launch on this workspace: every face id in the five keys of the body's (previous) window pixels
+  const bool have_prev = use_win && p.kvalid[b] != 0 && pww > 0 && pwh > 0 && pww <= p.W && pwh <= p.H;
+  if (have_prev) {
+    const unsigned long long* gk = p.gkeys + (size_t)p.body_koff[b] * 5;
+    const int nk = pww * pwh * 5;
+    for (int i = tid; i < nk; i += NT) {
+      const unsigned f = (unsigned)gk[i];                  // (an empty key has face id all ones)
+      if (f < (unsigned)p.F) atomicOr(&wbits[f >> 5], 1u << (f & 31u));
+    }
+  }
+  if (tid == 0) p.wstate[b] = have_prev ? 1 : 0;
   int mh = 0, n0 = 0, n1 = 0;
   float z0 = 0.f, z1 = 0.f, ra, rk;
   r_row_affine(p, &ra, &rk);
@@ -450,15 +479,22 @@ __device__ __forceinline__ void r_face_sort(const RasterP& p, int b, int* hist /
   } else if (tid == 0) {
     p.sort_tag[b] = 0ull;                  // lists without the margin's slack: never to be kept by a later launch
   }
-  // third list: the few TALL faces (more than R_SHORT rows: 5 % of them at C3, slivers and close-ups).  A tile must start
+  __syncthreads();                         // (the bitmap is complete)
+  // fourth list: the few TALL faces (more than R_SHORT rows: 5 % of them at C3, slivers and close-ups).  A tile must start
   // reading a list `tallest face of the list` rows above its first row; one list for all faces made every tile wade through
   // the faces of the nine rows above it (the mean tallest face) to find the handful that reach down -- 1.44x the entries
   // that really overlap a tile, 1.13x with the tall ones in a list of their own
   P_MARK(1);
+  // row word of a face: lo (15 bits) | sign of the screen-space area << 15 | hi << 16 (15 bits) | winner << 31
+  // histogram bins: 0 / 1 = short faces by the sign of their area, 2 = tall, 3 = winners (short)
+  auto bin_of = [&](unsigned r) {
+    const int lo = (int)(r & 0x7fffu), hi = (int)((r >> 16) & 0x7fffu);
+    return hi - lo > R_SHORT ? 2 : ((r >> 31) ? 3 : (int)((r >> 15) & 1u));
+  };
   auto tally = [&](unsigned r, float zm, bool live) {
-    const int lo = (int)(r & 0x7fffu), hi = (int)(r >> 16), sg = (int)((r >> 15) & 1u);
+    const int lo = (int)(r & 0x7fffu), hi = (int)((r >> 16) & 0x7fffu), sg = (int)((r >> 15) & 1u);
     if (live && lo <= hi) {
-      atomicAdd(&hist[(hi - lo > R_SHORT ? 2 : sg) * HB + lo], 1);
+      atomicAdd(&hist[bin_of(r) * HB + lo], 1);
       mh = max(mh, hi - lo);
       if (sg) { z1 += zm; ++n1; } else { z0 += zm; ++n0; }
     }
@@ -486,8 +522,11 @@ __device__ __forceinline__ void r_face_sort(const RasterP& p, int b, int* hist /
     for (int u = 0; u < RFS_U; ++u) {
       const int f = f0 + u * NT;
       float zm;
-      const unsigned r = r_face_rows_xyz(p, ra, rk, x[u], y[u], z[u], &zm);
-      if (f < p.F) fr[f] = r;
+      unsigned r = r_face_rows_xyz(p, ra, rk, x[u], y[u], z[u], &zm);
+      if (f < p.F) {
+        if (use_win && ((wbits[f >> 5] >> (f & 31)) & 1u)) r |= 0x80000000u;
+        fr[f] = r;
+      }
       tally(r, zm, f < p.F);
     }
   }
@@ -511,27 +550,27 @@ __device__ __forceinline__ void r_face_sort(const RasterP& p, int b, int* hist /
   }
   __syncthreads();
   const int flip = s_flip;
-  if (tid < 64) {                                   // exclusive scan of the (class order, row) histogram by one wave
+  if (tid < 64) {                                   // exclusive scan of the (list order, row) histogram by one wave
     int carry = 0;
-    for (int base = 0; base < 3 * HB; base += 64) {
-      const int i = base + tid;                     // position in the output order: near short, far short, tall
-      const int o = min(i / HB, 2), rrow = i - o * HB;
-      const int bin = (o < 2 ? ((o ^ flip) & 1) : 2) * HB + rrow;
-      const int v = i < 3 * HB ? hist[bin] : 0;
+    for (int base = 0; base < 4 * HB; base += 64) {
+      const int i = base + tid;                     // position in the output order: winners, near short, far short, tall
+      const int o = min(i / HB, 3), rrow = i - o * HB;
+      const int bin = (o == 0 ? 3 : (o == 3 ? 2 : ((o - 1) ^ flip) & 1)) * HB + rrow;
+      const int v = i < 4 * HB ? hist[bin] : 0;
       const int incl = r_wave_scan_add(v);
-      if (i < 3 * HB) {
+      if (i < 4 * HB) {
         hist[bin] = carry + incl - v;
         rs[i] = carry + incl - v;
       }
       carry += __builtin_amdgcn_readlane(incl, 63);
     }
-    if (tid == 0) { p.maxh[b] = s_maxh; rs[3 * HB] = carry; }
+    if (tid == 0) { p.maxh[b] = s_maxh; rs[4 * HB] = carry; }
   }
   __syncthreads();
   P_MARK(3);
   auto place = [&](unsigned r, int f, bool live) {
-    const int lo = (int)(r & 0x7fffu), hi = (int)(r >> 16), sg = (int)((r >> 15) & 1u);
-    if (live && lo <= hi) fs[atomicAdd(&hist[(hi - lo > R_SHORT ? 2 : sg) * HB + lo], 1)] = ((unsigned)hi << 20) | (unsigned)f;
+    const int lo = (int)(r & 0x7fffu), hi = (int)((r >> 16) & 0x7fffu);
+    if (live && lo <= hi) fs[atomicAdd(&hist[bin_of(r) * HB + lo], 1)] = ((unsigned)hi << 20) | (unsigned)f;
   };
   for (int f0 = tid; f0 < p.F; f0 += RFS_V * NT) {        // the row words of RFS_V faces are fetched together
     unsigned r[RFS_V];
@@ -557,13 +596,14 @@ __device__ __forceinline__ void r_face_sort(const RasterP& p, int b, int* hist /
 #define RPV 7                // vertices per thread whose loads are in flight together (6890 = 2 x 7 x 512 - 278)
 #endif
 __global__ __launch_bounds__(RPREP) void k_raster_prepare(RasterP p) {
-  extern __shared__ int hist[];                     // [3][H + 1] of the sort
+  extern __shared__ int hist[];                     // [4][H + 1] of the sort + the winners' bitmap (r_prepare_lds)
   unsigned pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long plast = __builtin_readcyclecounter();
   const unsigned long long pbegin = plast;
   __shared__ float sbb[RPREP / 64][4];
   __shared__ int s_win[4];
   const int b = blockIdx.x, tid = threadIdx.x;
+  const int pww = p.win[b * 4 + 2], pwh = p.win[b * 4 + 3];      // the window of the previous launch (its keys: the winners)
   // extremes in NDC; the (monotonically decreasing) NDC -> pixel map is applied once to the four results
   float mnx = 1e30f, mny = 1e30f, mxx = -1e30f, mxy = -1e30f;
   float ra, rk;
@@ -571,6 +611,8 @@ __global__ __launch_bounds__(RPREP) void k_raster_prepare(RasterP p) {
   const float* rowb = p.rowb + (size_t)b * p.V;
   const bool tagged = p.margin > 0 && p.sort_tag[b] == RS_TAG(b, p.margin);
   bool moved = !tagged;
+  // lists that were sorted before the body had any keys carry no winners' list: one more sort now that it has
+  if (tagged && p.winners_on && p.F <= R_WIN_MAXF && p.wstate[b] == 0 && p.kvalid[b] != 0) moved = true;
   const float thr = (float)p.margin - 0.02f;
   float* nbo = p.ndc + (size_t)b * p.V * 3;
   // projected: mh_lbs_forward_proj has written the NDC vertices, the motion flag and -- unless nobody reported one of the
@@ -662,7 +704,7 @@ __global__ __launch_bounds__(RPREP) void k_raster_prepare(RasterP p) {
     s_win[0] = x0; s_win[1] = y0; s_win[2] = ww; s_win[3] = wh;
   }
   P_MARK(0);
-  if (p.margin == 0 || any_moved) r_face_sort<RPREP>(p, b, hist, pacc, plast);       // (ends with a barrier)
+  if (p.margin == 0 || any_moved) r_face_sort<RPREP>(p, b, hist, pww, pwh, pacc, plast);       // (ends with a barrier)
   else __syncthreads();
   // ---- tiles of the window: geometry and cost class into the body's own slots -------------------------------------------
   const int x0 = s_win[0], y0 = s_win[1], ww = s_win[2], wh = s_win[3];
@@ -675,7 +717,7 @@ __global__ __launch_bounds__(RPREP) void k_raster_prepare(RasterP p) {
     // depend on the other bodies' windows, so the work lists -- which may be a launch old -- carry no addresses
     p.body_koff[b] = (long long)b * p.H * p.W;
   }
-  const int* rs = p.row_start + (size_t)b * (3 * (p.H + 1) + 1);
+  const int* rs = p.row_start + (size_t)b * (4 * (p.H + 1) + 1);
   const int mh = p.maxh[b];
   for (int k = tid; k < ns; k += RPREP) {
     const int tr = k / ncol, tc = k - tr * ncol, s = first + k;
@@ -843,7 +885,7 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
     float* const sYf = sXY + tw;
     const float* nb = p.ndc + (size_t)b * p.V * 3;
     const unsigned* fs = p.fsort + (size_t)b * p.F;
-    const int* rs = p.row_start + (size_t)b * (3 * (H + 1) + 1);
+    const int* rs = p.row_start + (size_t)b * (4 * (H + 1) + 1);
     __syncthreads();
     for (int i = tid; i < npx * 5; i += RB) keys[i] = RS_EMPTY;
     for (int i = tid; i < tw; i += RB) sXf[i] = r_pix_to_ndc(W - 1 - (x0 + i), W, H);
@@ -852,22 +894,12 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
     // three contiguous ranges of fsort: near short faces, far short faces, tall faces.  Kept lists: a face's first row may
     // have moved by up to `margin` rows either way since the sort
     const int ra_ = max(0, sy0 - R_SHORT - p.margin), rt_ = max(0, sy0 - min(max(p.maxh[b], 0), H) - p.margin), rb_ = min(sy1 + 1 + p.margin, H);
-    const int a0 = rs[ra_], na = rs[rb_] - a0, b0 = rs[H + 1 + ra_], nbk = rs[H + 1 + rb_] - b0;
-    const int c0 = rs[2 * (H + 1) + rt_], nc = rs[2 * (H + 1) + rb_] - c0;
-    const int nab = na + nbk, i1 = nab + nc;
-    auto fs_at = [&](int j) { return fs[j < na ? a0 + j : (j < nab ? b0 + (j - na) : c0 + (j - nab))]; };
-#ifdef R_SEED_CEIL      // experiment (timing only): the previous launch's 4th keys (+ slack ulps) as cull bounds from the start
-    __syncthreads();
-    {
-      const int wx0_ = p.win[b * 4], wy0_ = p.win[b * 4 + 1], ww_ = p.win[b * 4 + 2];
-      const unsigned long long* gkp = p.gkeys + (size_t)p.body_koff[b] * 5;
-      for (int i = tid; i < npx; i += RB) {
-        const int r = i / tw, cc = i - r * tw;
-        const unsigned long long k4 = gkp[((size_t)(sy0 - wy0_ + r) * ww_ + (x0 - wx0_ + cc)) * 5 + 4];
-        if ((unsigned)k4 != 0xffffffffu) keys[i * 5 + 4] = ((unsigned long long)((unsigned)(k4 >> 32) + (unsigned)(R_SEED_CEIL)) << 32) | 0xffffffffull;
-      }
-    }
-#endif
+    // four contiguous ranges of fsort: last launch's winners (see r_face_sort), near short faces, far short faces, tall faces
+    const int w0 = rs[ra_], nw = rs[rb_] - w0;
+    const int a0 = rs[H + 1 + ra_], nwa = nw + rs[H + 1 + rb_] - a0, b0 = rs[2 * (H + 1) + ra_], nab = nwa + rs[2 * (H + 1) + rb_] - b0;
+    const int c0 = rs[3 * (H + 1) + rt_], nc = rs[3 * (H + 1) + rb_] - c0;
+    const int i1 = nab + nc;
+    auto fs_at = [&](int j) { return fs[j < nwa ? (j < nw ? w0 + j : a0 + (j - nw)) : (j < nab ? b0 + (j - nwa) : c0 + (j - nab))]; };
     __syncthreads();
     R_TMARK(0);
     if (i1 > 0) {
@@ -963,20 +995,14 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
         // instead of falling back was measured in round 4: 3 % fewer pairs evaluated, kernel 3 % slower.)
         int cnt_s = (cnt > 0 && f_nx <= 4 && f_ny <= 8 && !p.all_even) ? cnt : 0;
         int npairs_s = __builtin_amdgcn_readlane(r_wave_scan_add(cnt_s), 63);
+        // (Round 5, measured: deciding whether a round fits the list on the SURVIVORS of the cull instead of on its candidates --
+        // the walk for every round, the even split only when more than RPL pairs survive -- evaluates 6 % fewer pairs and is
+        // 4 us slower: the rounds that overflow are mostly the winners' own, which meet empty lists and lose the walk.)
         if (npairs_s > RPL) { cnt_s = 0; npairs_s = 0; }
-        const int cnt_g = cnt - cnt_s;
         R_TMARK(1);
+        unsigned keepm = 0u;
+        int nk = 0, kincl = 0, nkeep = 0;
         if (npairs_s > 0) {
-          // Depth cull first, per face lane: the clipped-barycentric depth of a face is never below its nearest vertex, so
-          // a pair whose face lies entirely behind the pixel's current 4th silhouette key cannot change the window (the keys
-          // only ever decrease; the nearest key of the wide pass never lies behind it: every key of the K=4 list was
-          // offered to slot 0 first -- r_insert -- and a face inside the narrow band is inside the wide one).  A lane walks
-          // the rows of its own box, four pixels per trip from ONE address (columns past the box read other LDS words and
-          // are masked out), and keeps a bit per survivor at position 4 * row + column; only the survivors are written to
-          // the pair list, behind a wave prefix sum of the counts, and evaluated with full lanes.
-          // (Round 1 listed every pair, then culled the list 64 pairs at a time with a decode per pair; rounds 2-3 walked the
-          // box in pixel order, four pixels per trip with a wrap test per pixel and a division by the box width per pair.)
-          unsigned keepm = 0u;
           if (cnt_s > 0) {
             const char* kb = (const char*)keys + __umul24((unsigned)f_pix, 40u);
             const unsigned rowstep = __umul24((unsigned)tw, 40u);
@@ -989,9 +1015,21 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
               kb += rowstep;
             }
           }
-          const int nk = __popc(keepm);
-          const int kincl = r_wave_scan_add(nk);
-          const int nkeep = __builtin_amdgcn_readlane(kincl, 63);
+          nk = __popc(keepm);
+          kincl = r_wave_scan_add(nk);
+          nkeep = __builtin_amdgcn_readlane(kincl, 63);
+        }
+        const int cnt_g = cnt - cnt_s;
+        if (npairs_s > 0) {
+          // Depth cull first, per face lane: the clipped-barycentric depth of a face is never below its nearest vertex, so
+          // a pair whose face lies entirely behind the pixel's current 4th silhouette key cannot change the window (the keys
+          // only ever decrease; the nearest key of the wide pass never lies behind it: every key of the K=4 list was
+          // offered to slot 0 first -- r_insert -- and a face inside the narrow band is inside the wide one).  A lane walks
+          // the rows of its own box, four pixels per trip from ONE address (columns past the box read other LDS words and
+          // are masked out), and keeps a bit per survivor at position 4 * row + column; only the survivors are written to
+          // the pair list, behind a wave prefix sum of the counts, and evaluated with full lanes.
+          // (Round 1 listed every pair, then culled the list 64 pairs at a time with a decode per pair; rounds 2-3 walked the
+          // box in pixel order, four pixels per trip with a wrap test per pixel and a division by the box width per pair.)
 #ifdef R_COUNT_PATHS          // counter A = pairs of the even-split path, counter B = survivors of the pair-list path
           n_eval += (unsigned)nkeep;
 #else
@@ -1089,9 +1127,7 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
     unsigned long long* gk = p.gkeys + (size_t)p.body_koff[b] * 5;
     if (tw == ww && x0 == wx0) {   // a full-width strip of rows (the usual tiling) is one contiguous range of the body's keys
       unsigned long long* dst = gk + (size_t)(sy0 - wy0) * ww * 5;
-#ifdef R_SEED_CEIL
-      for (int i = tid; i < npx * 5; i += RB) { unsigned long long k_ = keys[i]; if ((unsigned)k_ == 0xffffffffu) k_ = RS_EMPTY; __builtin_nontemporal_store(k_, dst + i); }
-#elif R_KEYS_NT       // written once, read a kernel later: kept out of the L2 sets the other tiles' gathers live in (-6 us same-box)
+#if R_KEYS_NT       // written once, read a kernel later: kept out of the L2 sets the other tiles' gathers live in (-6 us same-box)
       for (int i = tid; i < npx * 5; i += RB) __builtin_nontemporal_store(keys[i], dst + i);
 #else
       for (int i = tid; i < npx * 5; i += RB) dst[i] = keys[i];
@@ -1103,6 +1139,7 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
         gk[((size_t)(sy0 - wy0 + r) * ww + (x0 - wx0 + cc)) * 5 + c] = keys[i];
       }
     }
+    if (tid == 0) p.kvalid[b] = 1;               // the body has keys: its next face sort finds its winners
     r_tile_depth_sums(p, s, b, keys, tw, x0, sy0, npx, s_sums);
     R_TMARK(6);
   }
@@ -1745,6 +1782,26 @@ extern "C" int mh_raster_set_path(int all_even) {
 }
 extern "C" int mh_raster_get_path(void) { return g_raster_all_even; }
 
+// winners' list of the face sort (r_face_sort): 1 (default; MHHIP_RASTER_WINNERS=0 switches it off) = the faces that held a
+// key in the previous launch are rasterised first by every tile.  An order only: the keys are the same bits either way.
+static int g_raster_winners = -1;
+static int raster_winners() {
+  if (g_raster_winners < 0) {
+    const char* e = getenv("MHHIP_RASTER_WINNERS");
+    g_raster_winners = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_raster_winners;
+}
+extern "C" int mh_raster_set_winners(int on) {
+  g_raster_winners = on ? 1 : 0;
+  return MH_OK;
+}
+extern "C" int mh_raster_get_winners(void) { return raster_winners(); }
+// dynamic LDS of k_raster_prepare: the sort's [4][H+1] histogram + the winners' bitmap
+static size_t r_prepare_lds(const RasterP& p) {
+  return ((size_t)4 * (p.H + 1) + (p.F <= R_WIN_MAXF ? (size_t)(p.F + 31) / 32 : 0)) * sizeof(int);
+}
+
 static size_t r_align(size_t x) { return (x + 255) & ~(size_t)255; }
 static size_t r_max_units(size_t B, int H, int W) { return B + B * (size_t)H * W / RG_UNIT + 1; }
 static int r_max_strips(int B, int H, int W) {
@@ -1774,7 +1831,7 @@ static size_t r_carve(RasterP& p, void* ws) {
   p.ndc = (float*)c; c += r_align(B * V * 3 * 4);
   p.frows = (unsigned*)c; c += r_align(B * F * 4);
   p.fsort = (unsigned*)c; c += r_align(B * F * 4);
-  p.row_start = (int*)c; c += r_align(B * (size_t)(3 * (H + 1) + 1) * 4);
+  p.row_start = (int*)c; c += r_align(B * (size_t)(4 * (H + 1) + 1) * 4);
   p.maxh = (int*)c; c += r_align(B * 4);
   p.body_koff = (long long*)c; c += r_align(B * 8);
   p.rowb = (float*)c; c += r_align(B * V * 4);
@@ -1796,6 +1853,9 @@ static size_t r_carve(RasterP& p, void* ws) {
   p.pairs = (unsigned long long*)c; c += r_align((2 + 2 * (size_t)R_STRIP_GRID) * 8);
   p.sort_tag = (unsigned long long*)c; c += r_align(B * 8);
   p.sil_corr = (float*)c; c += r_align(B * 4);
+  p.kvalid = (int*)c; c += r_align(B * 4);
+  p.wstate = (int*)c; c += r_align(B * 4);
+  p.winners_on = raster_winners();
   p.ctl_end = c;
   p.fbbox = (int*)c; c += r_align(B * 4 * 4);
   p.fbbox_prev = (int*)c; c += r_align(B * 4 * 4);
@@ -1841,7 +1901,17 @@ extern "C" int mh_raster_workspace_offsets(int T, int N, int V, int F, int H, in
   return MH_OK;
 }
 
-// (developer aid, not in the public header) more offsets: ndc, frows, fsort, row_start, maxh, rowb
+// (developer aid, not in the public header) more offsets: ndc, frows, fsort, row_start, maxh, rowb; mh_raster_debug_offsets2:
+// kvalid, wstate (B int32 each), sort_tag (B uint64)
+extern "C" int mh_raster_debug_offsets2(int T, int N, int V, int F, int H, int W, size_t* out /*[3]*/) {
+  RasterP p;
+  p.B = T * N; p.N = N; p.V = V; p.F = F; p.H = H; p.W = W;
+  r_carve(p, nullptr);
+  out[0] = (size_t)((char*)p.kvalid - (char*)nullptr);
+  out[1] = (size_t)((char*)p.wstate - (char*)nullptr);
+  out[2] = (size_t)((char*)p.sort_tag - (char*)nullptr);
+  return MH_OK;
+}
 extern "C" int mh_raster_debug_offsets(int T, int N, int V, int F, int H, int W, size_t* out /*[6]*/) {
   RasterP p;
   p.B = T * N; p.N = N; p.V = V; p.F = F; p.H = H; p.W = W;
@@ -1979,7 +2049,7 @@ static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const flo
   }
   if (alpha_out) MH_HIP(hipMemsetAsync(alpha_out, 0, (size_t)p.B * H * W * sizeof(float), st));
   mh_prof_mark(MH_PROF_RASTER_PREP, 0, st);
-  hipLaunchKernelGGL(k_raster_prepare, dim3(p.B), dim3(RPREP), (size_t)3 * (H + 1) * sizeof(int), st, p);
+  hipLaunchKernelGGL(k_raster_prepare, dim3(p.B), dim3(RPREP), r_prepare_lds(p), st, p);
   MH_LAUNCH_CHECK();
   // The work lists are a schedule (the selection and gradient kernels find every tile and unit with lists that are a launch
   // old, or empty).  phases & 128: they are NOT rebuilt here, between the preparation and the selection, but by whoever

@@ -45,7 +45,7 @@ struct RasterP {
   float* ndc;                // [B][V][3] projected vertices (NDC x, y, view z)
   unsigned* frows;           // [B][F] conservative pixel-row range of every face: lo | hi << 16 (lo > hi: skip)
   unsigned* fsort;           // [B][F] faces ordered by their first row: hi << 20 | face
-  int* row_start;            // [B][3][H+1] (+1): per list (near short, far short, tall), first entry of fsort with lo >= row
+  int* row_start;            // [B][4][H+1] (+1): per list (winners, near short, far short, tall), first entry of fsort with lo >= row
   int* maxh;                 // [B] tallest face (rows) of the body
   // work lists (put together by the last workgroup of k_raster_prepare)
   int max_units;
@@ -80,6 +80,10 @@ struct RasterP {
   unsigned long long* flowkey;       // [B]
   unsigned long long* flowkey_prev;  // [B]
   int* fmoved;               // [B]
+  // winners' list of the face sort (round 5, r_face_sort)
+  int winners_on;            // mh_raster_set_winners / MHHIP_RASTER_WINNERS (default 1)
+  int* kvalid;               // [B] 1 = the body's key region holds the keys of a launch on this workspace
+  int* wstate;               // [B] 1 = the body's lists were sorted with a winners' list
 };
 
 #define R_SHORT 2            // faces of up to R_SHORT + 1 rows go to the two short lists, taller ones to the third

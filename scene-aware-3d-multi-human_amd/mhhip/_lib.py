@@ -43,7 +43,7 @@ class RasterFin(ctypes.Structure):
                 ('coef_depth', ctypes.c_float)] + [(k, vp) for k in (
                     'body_first', 'body_ns', 'partial', 'dinv', 'sil_apply', 'sil_D', 'sil_S', 'sil_corr', 'depth_body',
                     'sil_body', 'zmin_lin', 'zmax_lin', 'gzmin', 'gzmax', 'log_depth', 'log_sil')] + [
-                    ('has_lists', ctypes.c_int), ('lists', ctypes.c_ulonglong * 75)]
+                    ('has_lists', ctypes.c_int), ('lists', ctypes.c_ulonglong * 80)]
 
 
 _lib = None
@@ -139,6 +139,7 @@ def lib():
         L.mh_raster_set_deterministic.argtypes = [ctypes.c_int]
         L.mh_raster_set_sort_margin.argtypes = [ctypes.c_int]
         L.mh_raster_set_path.argtypes = [ctypes.c_int]
+        L.mh_raster_set_winners.argtypes = [ctypes.c_int]
         L.mh_raster_pair_counters.argtypes = [ctypes.c_int] * 6 + [vp, ctypes.POINTER(ctypes.c_ulonglong), vp]
         L.mh_raster_sort_counters.argtypes = [ctypes.c_int] * 6 + [vp, ctypes.POINTER(ctypes.c_ulonglong), vp]
         L.mh_raster_terms_phase_log.argtypes = [ctypes.c_int] * 6 + [c_float_p] + [vp] * 12 + [ctypes.c_float] * 3 + [vp] * 8 + [ctypes.c_int, vp, vp, vp]

@@ -101,6 +101,14 @@ def set_sort_margin(rows):
     return int(old)
 
 
+def set_winners(on):
+    """mh_raster_set_winners: winners' list of the face sort on / off (same keys either way); returns the previous setting"""
+    L = _lib.lib()
+    old = L.mh_raster_get_winners()
+    check(L.mh_raster_set_winners(1 if on else 0))
+    return bool(old)
+
+
 def set_deterministic(on):
     """mh_raster_set_deterministic: bit-reproducible gradient scatter (64-bit fixed-point accumulation, one workgroup per
     body) instead of fp32 atomics; returns the previous setting"""

@@ -795,7 +795,8 @@ class SequenceEngine(object):
         # process-wide switches a capture bakes in: the gradient-scatter kernel (mh_raster_set_deterministic picks it at capture
         # time), the sort margin (a kernel argument by value) and the LBS arithmetic mode
         L = _lib.lib()
-        glob = (L.mh_raster_get_deterministic(), L.mh_raster_get_sort_margin(), L.mh_lbs_get_mode(), L.mh_raster_get_path()) if raster is not None else None
+        glob = (L.mh_raster_get_deterministic(), L.mh_raster_get_sort_margin(), L.mh_lbs_get_mode(), L.mh_raster_get_path(),
+                L.mh_raster_get_winners()) if raster is not None else None
         hk = None if self.halo is None else (bool(self.halo.get('has_prev')), bool(self.halo.get('has_next')), self.halo.get('poses') is not None)
         return (rast, scene, self.verts_filt is not None and self.pT_filt is not None, hk, bt, glob)
 

@@ -48,7 +48,7 @@ for c in range(int(os.environ.get('CYCLES', 3))):
     B, V, F, H = e.B, e.V, int(raster.faces.shape[0]), e.H
     seg = lambda o, n: raster.ws[off[o]:off[o] + n]
     fsort = seg(2, B * F * 4).view(torch.int32).view(B, F)
-    rs = seg(3, B * (3 * (H + 1) + 1) * 4).view(torch.int32).view(B, -1)
+    rs = seg(3, B * (4 * (H + 1) + 1) * 4).view(torch.int32).view(B, -1)
     # the face lists as SETS per body (their order inside a row is whatever the sort's atomics gave)
     nf = rs[:, -1].clamp(0, F)
     fs_sorted = torch.where(torch.arange(F, device=e.dev)[None] < nf[:, None], fsort, torch.full_like(fsort, 2 ** 31 - 1)).sort(dim=1).values

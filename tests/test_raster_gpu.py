@@ -334,7 +334,8 @@ def test_face_straddling_the_camera_plane_is_skipped_whole():
     model = types.SimpleNamespace(faces=faces)
     tri = np.array([[-0.6, -0.5, 2.0], [0.6, -0.5, 2.0], [0.0, 0.5, -1.0]], np.float32)          # apex behind the camera
     far = np.array([[5.0, 5.0, 50.0], [5.1, 5.0, 50.0], [5.0, 5.1, 50.0]], np.float32)           # (off screen: the table needs a 2nd face)
-    verts = torch.tensor(np.stack([np.concatenate([tri, far]), np.concatenate([tri + [0, 0, 1.5], far])]), device='cuda:0')
+    front = tri + np.array([0, 0, 1.5], np.float32)
+    verts = torch.tensor(np.stack([np.concatenate([tri, far]), np.concatenate([front, far])]).astype(np.float32), device='cuda:0')
     zbuf, alpha = render(model, verts, K, (W, H))
     zbuf, alpha = zbuf.cpu().numpy(), alpha.cpu().numpy()
     assert (zbuf[0] == -1).all() and (alpha[0] == 0).all()                   # straddling: skipped entirely

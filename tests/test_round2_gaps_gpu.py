@@ -295,20 +295,23 @@ def test_c4_shard_of_250_frames_with_halos(smpl_struct, smpl_regs, oracle_model,
         vo = torch.zeros(T, N, e.V, 3)
         vo[sl] = e.verts.view(f1 - f0, N, -1, 3).cpu()
         o.verts_value_override = vo
-        want = o.cycle_grads(batches[f0 // batch:f1 // batch])          # the shard's 25 batches + the full-sequence temporal term
+        # the shard's 25 batches + the full-sequence temporal term, the oracle's renderer in float32 (what the reference runs) and
+        # in float64: every entry is held against float64; the few that miss it (a sub-pixel face's float32 edge decision, which
+        # the kernel shares with the float32 oracle) must agree with float32 and are counted and capped (tests/parity_gates.py)
+        from parity_gates import two_precision_gate
+        from test_fit_full_gpu import _oracle_grads_both
+        want, both = _oracle_grads_both(o, hsel, batches[f0 // batch:f1 // batch])
     finally:
         set_deterministic(old)
     for k in ['loss_pose24j', 'loss_depth', 'loss_silhouette', 'reg_contact', 'reg_foot_sliding']:
         np.testing.assert_allclose(log[k], want[k], rtol=1e-3, atol=1e-6, err_msg=k)
     for name, ename in LEAF_MAP:
-        w = _oracle_grad(o, name)
+        w32, w64 = both[name]
         if name in ('poses_T', 'poses_smpl', 'zmin_lin', 'zmax_lin'):
-            w = w[sl]
-        g = e.leaf(ename, e.grads).cpu().numpy().reshape(w.shape)
-        scale = max(np.abs(w).max(), 1e-8)
-        err = np.abs(g - w)
-        print('%-10s max %.2e  median %.2e (x largest entry)' % (name, err.max() / scale, np.median(err) / scale))
-        np.testing.assert_allclose(g, w, atol=2e-4 * scale, rtol=0, err_msg=name)
+            w32, w64 = w32[sl], w64[sl]
+        g = e.leaf(ename, e.grads).cpu().numpy().reshape(w64.shape)
+        worst, n32 = two_precision_gate(g, w32, w64, 2e-4, 'C4 shard, leaf %s' % name)
+        print('%-10s worst entry %.2e of the largest, %d of %d entries needed the float32 oracle' % (name, worst, n32, g.size))
     # the halo matters: the boundary frames' translation gradient contains the pull of frames 9 and 260
     gT = e.leaf('poses_T', e.grads).cpu().numpy()
     vel_pull = 2 * gi.COEFS['reg_velocity'] * (full['poses_T'][f0, :, 0] - full['poses_T'][f0 - 1, :, 0])

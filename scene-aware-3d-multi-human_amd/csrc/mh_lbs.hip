@@ -1865,6 +1865,11 @@ extern "C" int mh_lbs_backward_ex(const mh_model* m, int B, int NB, const float*
                            gxscale, ws, ws2, stream);
 }
 
+// (developer aid for scheduling experiments, not in the public header) 0 = the whole backward, 1 = the skinning adjoint only,
+// 2 = the pose adjoint + per-person reduction only: lets a caller put a stream join between the two halves
+static int g_bwd_phase = 0;
+extern "C" int mh_lbs_debug_backward_phase(int phase) { g_bwd_phase = phase; return MH_OK; }
+
 static int lbs_backward_impl(const mh_model* m, int B, int NB, const float* betas, const float* poses, const float* rotmats,
                              const float* vposed, const float* gverts, const float* gjoints, const float* gposed,
                              float* gposes, float* grotmats, float* gtransl, float* gbetas, float* gxscale,
@@ -1878,7 +1883,8 @@ static int lbs_backward_impl(const mh_model* m, int B, int NB, const float* beta
   const int G = mh_groups(B), G16 = 2 * G, CH = split16 ? bwd16_chunks(G) : bwd_chunks(G16);
   FwdWs fw = carve_fwd(ws, G);
   BwdWs bw = carve_bwd(ws2, G, CH + 1);      // (+ 1: the chunk slot of mh_keypoint_terms, always laid out)
-  if (split16) {
+  if (g_bwd_phase == 2) {
+  } else if (split16) {
     Bwd16P sp;
     sp.B = B; sp.G = G; sp.V = m->V; sp.VP = m->VP; sp.nw = m->nw; sp.CH = CH;
     sp.PB = (m->VP / 16 + CH - 1) / CH;
@@ -1917,6 +1923,7 @@ static int lbs_backward_impl(const mh_model* m, int B, int NB, const float* beta
   MH_LAUNCH_CHECK();
   mh_prof_mark(MH_PROF_SKIN_BWD, 1, st);
   }
+  if (g_bwd_phase == 1) return MH_OK;
   PoseBwdP pp;
   pp.B = B; pp.NB = NB; pp.G = G; pp.CH = CH + (kp_chunk ? 1 : 0);
   pp.betas = betas; pp.poses = poses; pp.gjoints = gjoints;

@@ -1,4 +1,4 @@
 cd /root/repo
 export PYTHONPATH=/root/repo/scene-aware-3d-multi-human_amd
-python tools/raster_keys.py 2>&1 | grep "sha1" | cut -c1-80
-REPS=4 bash tools/ab_rotate.sh default variants/lib_e0q0.so variants/lib_e1q0.so 2>&1 | tail -3
+MHHIP_SIDE_SPLIT=1 python -m pytest tests/test_fit_full_gpu.py tests/test_optimizer_raster_gpu.py -q -x 2>&1 | tail -3
+REPS=5 bash tools/ab_rotate.sh default "MHHIP_SIDE_SPLIT=1" 2>&1 | tail -2

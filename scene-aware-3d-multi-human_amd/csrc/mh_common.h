@@ -130,6 +130,8 @@ int mh_kp_build(mh_model* m, const mh_model_host* h);
 void mh_kp_free(mh_model* m);
 // the extra chunk slot of the LBS backward's partial sums that mh_keypoint_terms fills (mh_lbs.hip)
 int mh_lbs_backward_extra_slot(const mh_model* m, int B, void* ws2, float** pF, float** pA, float** pS);
+// the pose features, bone transforms and scales the last mh_lbs_forward* on `ws` left there (mh_lbs.hip owns the layout)
+int mh_lbs_forward_views(int B, const void* ws, const float** featT, const float** A, const float** scale);
 
 static inline int mh_groups(int B) { return (B + 31) / 32; }
 

@@ -354,8 +354,6 @@ extern "C" size_t mh_keypoint_workspace_bytes(const mh_model* m, int B) {
   return 2 * (size_t)(m->kp.rows_pad > 0 ? m->kp.rows_pad : 32) * GB * sizeof(float) + 512;
 }
 
-int mh_lbs_backward_extra_slot(const mh_model* m, int B, void* ws2, float** pF, float** pA, float** pS);
-
 extern "C" int mh_keypoint_terms(const mh_model* m, int B, const float* transl, const float* K_host, const float* Kd_host,
                                  const float* joint_w_host, const float* pose2d, float thr, float img_w, float img_h,
                                  float coef, float* kp, float* uv, float* gkp, float* loss, const void* ws, void* ws2,
@@ -368,14 +366,8 @@ extern "C" int mh_keypoint_terms(const mh_model* m, int B, const float* transl, 
   p.B = B; p.G = G; p.np = m->kp.np; p.rows_pad = m->kp.rows_pad; p.GB = (size_t)G * 32;
   p.Qa = m->kp.Qa; p.Qr = m->kp.Qr; p.M0m = m->kp.M0m; p.pair_j = m->kp.pair_j; p.pair_k = m->kp.pair_k;
   p.jptr = m->kp.jptr; p.kptr = m->kp.kptr; p.kpairs = m->kp.kpairs;
-  // the forward's workspace as mh_lbs_forward left it: featT | A | scale (carve_fwd in mh_lbs.hip)
-  {
-    const char* c = (const char*)ws;
-    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    p.featT = (const float*)c; c += al((size_t)G * MH_FS * 32 * 4);
-    p.A = (const float*)c; c += al((size_t)G * 32 * MH_NJ * 12 * 4);
-    p.scale = (const float*)c;
-  }
+  // the forward's workspace as the immediately preceding mh_lbs_forward* on it left it (the layout is mh_lbs.hip's: one accessor)
+  if (int rc = mh_lbs_forward_views(B, ws, &p.featT, &p.A, &p.scale)) return rc;
   p.transl = transl;
   p.has_kd = Kd_host != nullptr;
   for (int i = 0; i < 9; ++i) p.K[i] = K_host[i];

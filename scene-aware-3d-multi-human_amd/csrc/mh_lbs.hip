@@ -13,6 +13,7 @@
 //                adjoints ARE the MFMA A operands: gfeat += g_vposed x Dt, gA += gT x W
 //   k_pose_bwd   per body: adjoint of the chain and of rodrigues, priors-free
 #include <algorithm>
+#include <mutex>
 
 #include "mh_common.h"
 #include "mh_raster_p.h"
@@ -365,7 +366,8 @@ __global__ __launch_bounds__(256, 2) void k_skin_fwd(SkinFwdP p) {
 // six 16-byte global loads (B operand: three components x two terms, double buffered) and nine MFMAs.
 // ---------------------------------------------------------------------------------------------------------------
 #ifndef FWD_ABL
-#define FWD_ABL 0        // timing experiments only (tools/ab_fwd_proj.sh): 1 no NDC store, 2 no row loads, 4 no reports, 8 v_rcp instead of the IEEE division
+#define FWD_ABL 0        // timing experiments only (tools/ab_fwd_proj.sh, with MHHIP_LBS_SELFCHECK=0): 1 no NDC store, 2 no row loads, 4 no reports, 8 v_rcp instead of
+                         // the IEEE division, 32 one bone transform per row instead of four, 64 no vertex store, 256 one k-step instead of fourteen
 #endif
 #define MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
@@ -503,7 +505,7 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, FWD16_MINB) void k_skin_fwd16(Ski
 #pragma unroll
     for (int i = 0; i < 6; ++i) bq[st][i] = Dw[(st * 6 + i) * 64];
 #pragma unroll
-  for (int s16 = 0; s16 < MH_KD / 16; ++s16) {
+  for (int s16 = 0; s16 < ((FWD_ABL & 256) ? 1 : MH_KD / 16); ++s16) {      // (FWD_ABL & 256, timing only: one k-step instead of fourteen)
     const int cur = s16 % FWD16_STAGES, nxt = (s16 + FWD16_STAGES - 1) % FWD16_STAGES;
     if (s16 + FWD16_STAGES - 1 < MH_KD / 16) {
 #pragma unroll
@@ -576,6 +578,9 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, FWD16_MINB) void k_skin_fwd16(Ski
     for (int e = 0; e < 12; ++e) T[e] = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+#if (FWD_ABL & 32)      // timing only: ONE transform per row instead of four gathers (no blend traffic)
+      if (k > 0) continue;
+#endif
       const f32x4* Aj = (const f32x4*)(aB[k] + row0 * (MH_NJ * 48));
       const f32x4 q0 = Aj[0], q1 = Aj[1], q2 = Aj[2];
 #pragma unroll
@@ -601,6 +606,9 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, FWD16_MINB) void k_skin_fwd16(Ski
     const f32x3 o = {fmaf(st[0], x0, st[1]), fmaf(st[0], x1, st[2]), fmaf(st[0], x2, st[3])};
     if (FULL || g * 32 + row0 + 4 * lh < p.B) {
       const unsigned off_r = lane_off + (unsigned)row0 * row_b32;
+#if (FWD_ABL & 64)      // timing only: no vertex store (kept alive by an impossible condition)
+      if (o[0] == 12345.f)
+#endif
       *(f32x3*)(vg + (size_t)off_r) = o;
 #ifdef ABL_NOQ_STORE
       if (qg && vp0 == 12345.f) {
@@ -676,6 +684,36 @@ static FwdWs carve_fwd(void* ws, int G) {
   return w;
 }
 
+// What other translation units may read of a forward workspace (mh_keypoints.hip: the key-point term is computed from the pose
+// features and bone transforms the LAST forward on that workspace left): ONE definition of the layout, and a record of which
+// workspaces hold a forward of how many bodies (the layout was re-derived by hand over there).
+static std::mutex g_fwd_seen_mu;
+static struct { const void* ws; int B; } g_fwd_seen[64];
+static void fwd_note(const void* ws, int B) {
+  std::lock_guard<std::mutex> lk(g_fwd_seen_mu);
+  int slot = -1;
+  for (int i = 0; i < 64; ++i) {
+    if (g_fwd_seen[i].ws == ws) { slot = i; break; }
+    if (slot < 0 && !g_fwd_seen[i].ws) slot = i;
+  }
+  if (slot < 0) slot = (int)(((uintptr_t)ws >> 8) & 63);          // (table full: overwrite)
+  g_fwd_seen[slot].ws = ws; g_fwd_seen[slot].B = B;
+}
+int mh_lbs_forward_views(int B, const void* ws, const float** featT, const float** A, const float** scale) {
+  MH_CHECK(ws && B > 0 && featT && A && scale, "null argument");
+  {
+    std::lock_guard<std::mutex> lk(g_fwd_seen_mu);
+    int found = 0;
+    for (int i = 0; i < 64; ++i)
+      if (g_fwd_seen[i].ws == ws) found = g_fwd_seen[i].B;
+    MH_CHECK(found == B, "this workspace does not hold an LBS forward of this many bodies: the key-point term reads the pose features "
+                         "and bone transforms of the forward that immediately preceded it on the same workspace");
+  }
+  FwdWs w = carve_fwd(const_cast<void*>(ws), mh_groups(B));
+  *featT = w.featT; *A = w.A; *scale = w.scale;
+  return MH_OK;
+}
+
 // 1 (default): split-fp16 / split-bf16 contractions on the 16-bit matrix pipe; 0: exact-fp32 MFMA (A/B reference)
 static int g_lbs_mode = -1;
 static int lbs_mode() {
@@ -740,6 +778,7 @@ static int lbs_forward_impl(const mh_model* m, int B, int NB, const float* betas
   hipStream_t st = (hipStream_t)stream;
   const int G = mh_groups(B);
   FwdWs w = carve_fwd(ws, G);
+  fwd_note(ws, B);
   PoseFwdP pp;
   pp.B = B; pp.NB = NB; pp.G = G;
   pp.betas = betas; pp.poses = poses; pp.rotmats = rotmats; pp.xscale = xscale;

@@ -41,8 +41,13 @@ class RasterTerms(object):
         L = _lib.lib()
         st = _lib.stream_ptr(e.dev)
         g = e.grads
-        # the engine's last forward has projected the vertices into this workspace: no pass over them here
+        # the engine's last forward has projected the vertices into this workspace: no pass over them here.  A ONE-SHOT token
+        # (ADVICE r04): the launch that runs the preparation consumes it, so that a caller who writes e.verts afterwards -- or
+        # launches the rasteriser a second time -- gets the projection from the vertices as they are, not the forward's
         projected = 1 if getattr(e, '_projected_into', None) is self else 0
+        if int(phases) & (1 | 4):
+            e._projected_into = None
+            self.last_projected = projected
         args = (e.T, e.N, e.V, self.faces.shape[0], e.H, e.W, self.K.ctypes.data_as(_lib.c_float_p),
                 ptr(e.verts), ptr(self.faces), ptr(e.bits), ptr(e.ebits), ptr(e.depths),
                 ptr(e.leaf('zmin_lin')), ptr(e.leaf('zmax_lin')), ptr(e.p2d_valid), ptr(e.front),

@@ -420,7 +420,8 @@ class SequenceEngine(object):
         ``raster`` / the contact term would otherwise each take a pass over the vertices for (mh_lbs_forward_proj)."""
         m = self.m
         ev = self._tic('lbs_forward')
-        self._projected_into = None
+        self._projected_into = None       # one-shot tokens of what this forward's epilogue left behind: consumed by the
+        self._lowkey_fresh = False        # rasteriser's preparation (mhhip/raster.py) and by the contact term (_scene_terms)
         if raster is not None and os.environ.get('MHHIP_NO_PROJ') != '1' and _lib.lib().mh_lbs_get_mode() != 0:
             t = raster.forward_targets()
             if clear is not None:
@@ -429,6 +430,7 @@ class SequenceEngine(object):
                                                  ptr(self.leaf('xscale')), ptr(self.leaf('poses_T')), ptr(self.verts),
                                                  ptr(self.vposed), ctypes.byref(t), ptr(self.ws), _lib.stream_ptr(self.dev)))
             self._projected_into = raster
+            self._lowkey_fresh = True
             self._lowkey = t.lowkey
         else:
             check(_lib.lib().mh_lbs_forward(m.handle, self.B, self.N, ptr(self.leaf('betas')), ptr(self.leaf('poses_smpl')),
@@ -737,7 +739,8 @@ class SequenceEngine(object):
         T, N, B = self.T, self.N, self.B
         gpT = self.leaf('poses_T', self.grads)
         gv, log = self._gv_cur, self.tmp_log
-        if getattr(self, '_projected_into', None) is not None:      # the forward's epilogue has reported the lowest vertices
+        fresh, self._lowkey_fresh = getattr(self, '_lowkey_fresh', False), False
+        if fresh:                                                   # the forward's epilogue has reported the lowest vertices
             check(L.mh_contact_knn_grid_key(ptr(self.scene_grid), self.scene_M, ptr(self.verts), self.V, self._lowkey, B, 32,
                                             ptr(self.low_idx), ptr(self.low_xyz), ptr(self.dy), st))
         else:

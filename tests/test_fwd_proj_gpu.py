@@ -56,7 +56,7 @@ def test_projection_epilogue_equals_the_passes_over_the_vertices(smpl_struct, sm
         for c in range(30):
             e.cycle(c, raster=proj)                      # forward with the projection epilogue -> preparation without a vertex pass
             torch.cuda.synchronize()
-            assert e._projected_into is proj
+            assert proj.last_projected == 1 and e._projected_into is None     # used by the preparation, and used up (one-shot)
             win1, koff1, k1 = proj.selection(e)
             ndc1 = _ndc(proj, e)
             i0, x0, i1, x1 = _lowest(e)
@@ -98,3 +98,32 @@ def test_forward_proj_is_the_plain_forward_for_the_vertices(smpl_struct, smpl_re
     torch.cuda.synchronize()
     assert torch.equal(v1.view(torch.int32), e.verts.view(torch.int32))
     assert torch.equal(q1.view(torch.int32), e.vposed.view(torch.int32))
+
+
+def test_halo_forward_gives_the_owners_bits(smpl_struct, smpl_regs, oracle_model, tmp_path):
+    """the frame-sharded cycle skins its neighbours' boundary frames itself (``SequenceEngine._halo_forward``: the
+    plain, non-FULL instantiation of the skinning kernel over N or 2N bodies with its own workspace) and relies on the result
+    being the OWNER's vertices bit for bit (the owner runs the projecting, FULL instantiation over all its bodies).  One
+    process is enough to hold the two instantiations against each other: the engine's own first and last frame as "halo"."""
+    from mhhip.raster import RasterTerms
+    T, N, W, H, batch = 32, 4, 96, 54, 4                    # 128 bodies: the owner's launch is the FULL form
+    opt, dl, o, batches, seq = _setup(smpl_struct, smpl_regs, oracle_model, tmp_path, T, N, W, H, batch, 71, True)
+    opt._stage_from_dataloader(dl)
+    e = opt.engine
+    r = RasterTerms(e)
+    gen = torch.Generator(device=e.dev); gen.manual_seed(3)
+    e.leaf('poses_smpl').add_(torch.randn(e.leaf('poses_smpl').shape, device=e.dev, generator=gen) * 0.2)
+    e.leaf('betas').add_(torch.randn(e.leaf('betas').shape, device=e.dev, generator=gen) * 0.5)
+    e.leaf('xscale').add_(0.3)
+    e.forward(regress=False, raster=r)                       # the owner: projection epilogue, all bodies
+    torch.cuda.synchronize()
+    owner = e.verts.view(T, N, -1, 3)
+    pT, ps = e.leaf('poses_T').view(T, N, 3), e.leaf('poses_smpl').view(T, N, 72)
+    for frames in ([0], [T - 1], [T - 1, 0]):                # a first rank, a last rank, a middle rank (previous | next)
+        h = dict(poses=torch.cat([ps[f] for f in frames]).contiguous(), transl=torch.cat([pT[f] for f in frames]).contiguous(),
+                 has_prev=True, has_next=len(frames) == 2)
+        e._halo_forward(h, torch.cuda.current_stream(e.dev).cuda_stream)
+        torch.cuda.synchronize()
+        got = [h['v_prev']] + ([h['v_next']] if len(frames) == 2 else [])
+        for f, v in zip(frames, got):
+            assert torch.equal(v.view(torch.int32), owner[f].view(torch.int32)), 'halo of frame %d differs from the owner\'s vertices' % f

@@ -1,4 +1,2 @@
 cd /root/repo
-export PYTHONPATH=/root/repo/scene-aware-3d-multi-human_amd
-MHHIP_SIDE_SPLIT=1 python -m pytest tests/test_fit_full_gpu.py tests/test_optimizer_raster_gpu.py -q -x 2>&1 | tail -3
-REPS=5 bash tools/ab_rotate.sh default "MHHIP_SIDE_SPLIT=1" 2>&1 | tail -2
+python -m pytest tests -m gpu -q --timeout=2400 --deselect tests/test_bench_multirank_gpu.py::test_c4_at_full_size_eight_ranks_equal_one_process 2>&1 | tail -12

@@ -474,7 +474,9 @@ def main():
             us = max(us_live, us_prof or 0.0)
             algo = bodies * (12.0 * V + 4.0 * F) + 40.0 * window_px + 12.0 * F
             gbs = algo / (us * 1e-6) / 1e9
-            roof = {'kernel': 'k_raster_strip', 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+            roof = {'kernel': 'k_raster_strip', 'bound': 'hbm',
+                    'bound_note': 'the contract\'s roofline of the dominant kernel against HBM; the kernel itself is bound by vector-instruction '
+                                  'issue (face-parallel z-buffer selection in LDS): see "valu"', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                     'frac': round(gbs / PEAK_HBM_GBS, 4), 'traffic': None, 'traffic_detail': None,
                     'launch_us': round(us, 1), 'launch_us_events_in_eager_cycles': round(us_live, 1),
                     'launch_us_rocprof_replayed_cycles': None if us_prof is None else round(us_prof, 1),
@@ -550,6 +552,10 @@ def main():
                                     'filtered vertices) + RMSprop; scene injected (ground plane), one-euro filters live '
                                     '(updated every 25 cycles inside the timed region)' % (N_PEOPLE, T_TOTAL, IMG[0], IMG[1])),
                        'humans': N_PEOPLE, 'frames': T_TOTAL, 'frames_per_gpu': frames_here, 'image': list(IMG),
+                       'presteps': args.presteps,
+                       'state': 'steady state: %d untimed optimisation cycles (+ %d warm-up) precede the timed ones -- bodies nearly at rest, '
+                                'few face lists re-sorted; fit_250_ms_per_cycle / early_fit_ms_per_cycle are the drop-in call from the '
+                                'initial variables' % (args.presteps, args.warmup),
                        'parallelism': 'one contiguous sequence, frames sharded x%d by the drop-in (mhmocap.optimizer under '
                                       'torch.distributed), one RCCL all-reduce on the betas/scale gradients + one-frame halos per cycle' % world},
             'timed_region_s': round(dt, 4),
@@ -565,6 +571,10 @@ def main():
         }
         if not args.no_fit and world == 1 and not args.strong:
             out['fit_250'] = fit_block(struct, regs, tmp, device, K, seq)
+            # what a caller of the drop-in sees, beside the steady-state headline: the whole fit(250) call of
+            # predict.py:343 per cycle (staging, captures, scene updates, filter updates included) and its first 41 cycles
+            out['fit_250_ms_per_cycle'] = round(1e3 * out['fit_250']['cycles_s'] / 250.0, 4)
+            out['early_fit_ms_per_cycle'] = out['fit_250']['early_fit']['ms_per_cycle']
         if not args.no_cpu_baseline and world == 1 and not args.strong:
             ncores = os.cpu_count() or 1
             ncores = min(ncores, 16)

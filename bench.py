@@ -370,15 +370,17 @@ def main():
     organic = None
     if world == 1 and not args.strong:
         e.scene_device_setup(seq['backmasks'])
-        for c in range(3):
+        for c in range(12):       # two captures (the injected scene, then the device-built sets) + the lane test of mhhip/queues.py
             one_cycle(args.warmup + args.steps + c, use_graphs, scene=True)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for c in range(nsteps_org):
-            one_cycle(args.warmup + args.steps + 3 + c, use_graphs, scene=True)
+            one_cycle(args.warmup + args.steps + 12 + c, use_graphs, scene=True)
         torch.cuda.synchronize()
         dt1 = time.perf_counter() - t1
         organic = {'value': round(nsteps_org / dt1, 3), 'ms_per_step': round(1e3 * dt1 / nsteps_org, 4), 'steps': nsteps_org,
+                   'lane_test': [{'replay_ms': [round(x, 3) for x in getattr(lt, 'ms', [])], 'busy_lanes': len(getattr(lt, 'busy', [])),
+                                  'candidates': len(lt.cand)} for lt in getattr(e, '_lane_tests', {}).values()],
                    'what': 'per-cycle masked median over the 200 frames + bilateral/Sobel/erode/median-fill + un-projection '
                            '+ grid rebuild on a second stream, overlapped with the next cycle'}
         opt.scene_depth = ground_scene(K, W, H)
@@ -630,13 +632,31 @@ def fit_block(struct, regs, tmp, device, K, seq):
     torch.cuda.synchronize()
     t_stage = time.perf_counter() - t0
     params0 = opt.engine.params.clone()
+    # where the fit's time goes: an event in front of every cycle's launch (GPU time between consecutive cycle launches)
+    e = opt.engine
+    evs, orig = [], e.cycle_graphed
+
+    def traced(*a, **k):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        evs.append(ev)
+        return orig(*a, **k)
+    e.cycle_graphed = traced
     t0 = time.perf_counter()
     log = opt.fit(dl, num_iter=250)
     torch.cuda.synchronize()
     t_fit = time.perf_counter() - t0
+    e.cycle_graphed = orig
+    gaps = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1)])
+    phases = {'cycle_0_ms': round(float(gaps[0]), 3), 'cycles_1_29_ms': round(float(gaps[1:30].mean()), 4),
+              'cycles_30_59_ms': round(float(gaps[30:60].mean()), 4), 'cycles_60_248_ms': round(float(gaps[60:].mean()), 4),
+              'graphs_captured': len(getattr(e, '_graphs', {})),
+              'lane_test': [{'replay_ms': [round(x, 3) for x in getattr(lt, 'ms', [])], 'busy_lanes': len(getattr(lt, 'busy', [])),
+                             'candidates': len(lt.cand)} for lt in getattr(e, '_lane_tests', {}).values()],
+              'what': 'GPU time between consecutive cycle launches of this fit (events): cycle 0 holds the eager run + the one capture'}
     ov = opt.get_optimized_variables()
     early = early_fit_block(opt, dl, params0)
-    return {'early_fit': early, 'wall_s': round(t_stage + t_fit, 4), 'staging_s': round(t_stage, 4), 'cycles_s': round(t_fit, 4),
+    return {'early_fit': early, 'phases': phases, 'wall_s': round(t_stage + t_fit, 4), 'staging_s': round(t_stage, 4), 'cycles_s': round(t_fit, 4),
             'cycles_per_s_incl_everything': round(250.0 / (t_stage + t_fit), 1), 'init_optimized_variables_s': round(t_init, 4),
             'init_note': 'init_optimized_variables(num_iter=100) of a fresh optimiser in a process that has built this body model '
                          'before (what predict_mupots.py does per sequence): content hash of the model arrays (~3-8 ms; the '

@@ -85,6 +85,22 @@ int mh_profile_read(int which, float* ms);
 /* number of visible HIP devices (0 on a CPU-only host; never fails) */
 int mh_device_count(void);
 
+/* Streams and the hardware queues behind them (csrc/mh_streams.hip).  The captured cycle (optimizer.py:375-602 as one
+ * hipGraph) runs its chain, its side branch and the scene update of optimizer.py:578-584 on three streams; the runtime
+ * multiplexes streams onto a few hardware queues, and two of the three on one queue run one after the other.
+ * mh_stream_create: a NEW runtime stream (non-blocking), already bound to its queue; mh_streams_share_queue: shared = 1
+ * when a and b (NULL = the default stream) drain through the same hardware queue (a spin kernel of spin_us on a, an
+ * empty one on b: in-order queues show it); both synchronise.                                                        */
+int mh_stream_create(void** out_stream);
+int mh_stream_destroy(void* stream);
+int mh_streams_share_queue(void* stream_a, void* stream_b, float spin_us, int* shared);
+/* one spin kernel (one thread) of ~spin_us on the stream, asynchronous: keeps the stream's hardware queue busy */
+int mh_stream_spin(void* stream, float spin_us);
+/* shared = 1 when x drains through the hardware queue of ANY of busy[0 .. n), n <= 8 (all spin at once: one probe) */
+int mh_stream_shares_any(void* const* busy, int n, void* x, float spin_us, int* shared);
+/* the same for m <= 32 candidates in one probe: shared[j] = 1 when cand[j] shares a hardware queue with any busy stream */
+int mh_streams_classify(void* const* busy, int n, void* const* cand, int m, float spin_us, int* shared);
+
 /* replaces SMPL.__init__ (smpl.py:124-275): uploads and re-lays the constants once. */
 int mh_model_create(mh_model** out, const mh_model_host* host);
 int mh_model_destroy(mh_model* m);
@@ -254,6 +270,14 @@ int mh_rmsprop_step(float* params, const float* grads, float* square_avg, float*
 int mh_rmsprop_step_log(float* params, const float* grads, float* square_avg, float* momentum_buf,
                         size_t n, float lr, float alpha, float momentum, float eps,
                         const float* log_src, float* log_dst, int nlog, void* stream);
+/* mh_rmsprop_step_log, and in the same launch up to two 32-bit words written to poke_dst[0 .. npoke): the
+ * device-resident switches the NEXT captured cycle reads (which of the two scene grids is live: the scene
+ * is rebuilt every cycle from cycle 30 on, optimizer.py:578-584, and one captured graph serves the whole
+ * fit) travel with the update instead of in a launch of their own.  npoke = 0: mh_rmsprop_step_log.     */
+int mh_rmsprop_step_log_poke(float* params, const float* grads, float* square_avg, float* momentum_buf,
+                             size_t n, float lr, float alpha, float momentum, float eps,
+                             const float* log_src, float* log_dst, int nlog, int32_t* poke_dst, int npoke,
+                             int32_t poke0, int32_t poke1, void* stream);
 /* the same update with the learning rate resident on the device (lr_dev[0]); afterwards
  * lr_dev[0] *= gamma (ExponentialLR).  No host scalar changes between calls, so the whole cycle can
  * be captured in a hipGraph and replayed.                                                      */
@@ -300,6 +324,13 @@ int mh_filtered_verts_term_init(int T, size_t E, const float* verts, const float
                                 const float* prev_v, const float* prev_vf, const float* next_v,
                                 const float* next_vf, float coef, float* gverts, float* loss_out,
                                 void* ws, void* stream);
+/* mh_filtered_verts_term_init behind a device-resident switch: while live_dev[0] == 0 the term does not exist yet
+ * (optimizer.py:383-392: the one-euro filters first run at cycle 50; :571-573 `if self.verts_filtered is not None`)
+ * -- gverts is cleared, loss_out = 0 -- so that ONE captured launch sequence serves every phase of a fit.    */
+int mh_filtered_verts_term_init_gated(int T, size_t E, const float* verts, const float* verts_filt,
+                                      const float* prev_v, const float* prev_vf, const float* next_v,
+                                      const float* next_vf, float coef, float* gverts, float* loss_out,
+                                      const int32_t* live_dev, void* ws, void* stream);
 
 /* ---- staging of the constant per-frame inputs (once per sequence; optimizer.py:396-409, 434) --
  * The N float {0,1} instance masks of a frame become ONE 32-bit word per pixel (bit n = person n,
@@ -367,6 +398,13 @@ int mh_contact_knn_grid(const void* grid_ws, int M, const float* low_xyz, int B,
 int mh_contact_knn_grid_key(const void* grid_ws, int M, const float* verts /*(B,V,3)*/, int V,
                             unsigned long long* lowkey /*(B)*/, int B, int k, int32_t* low_idx /*(B)*/,
                             float* low_xyz /*(B,3)*/, float* dy /*(B)*/, void* stream);
+/* mh_contact_knn_grid_key over one of TWO grids of the same capacity M, chosen by device-resident words: sel_dev[0] = 0 --
+ * there is no scene yet (optimizer.py:485 `if self.scene_pcd is not None`), nothing is read or written; otherwise grid_ws0
+ * (sel_dev[1] = 0) or grid_ws1.  The scene update of cycle c builds the grid cycle c does not read (optimizer.py:578-584);
+ * the words change between cycles, the captured launch does not.  lowkey NULL: the queries are low_xyz (input).     */
+int mh_contact_knn_grid_sel(const void* grid_ws0, const void* grid_ws1, int M, const int32_t* sel_dev,
+                            const float* verts /*(B,V,3)*/, int V, unsigned long long* lowkey /*(B)*/, int B, int k,
+                            int32_t* low_idx /*(B)*/, float* low_xyz /*(B,3)*/, float* dy /*(B)*/, void* stream);
 /* contact: sum |dy+0.02| per batch, gpT.y += coef * (-sign(dy+0.02)); foot sliding between
  * IN-BATCH consecutive frames (batch = frames per batch, optimizer.py:512-518), gverts +=
  * (atomic).  batch_contact / batch_foot: one value per batch (nbatches = ceil(T/batch)).     */
@@ -383,6 +421,12 @@ int mh_contact_foot_terms_idx(int T, int N, int V, int batch, int nbatches, cons
                               const float* verts, const int32_t* low_idx, const float* low_xyz, const float* dy,
                               float coef_contact, float coef_foot, float* gpT, float* gverts, float* batch_contact,
                               float* batch_foot, void* stream);
+/* mh_contact_foot_terms[_idx] (batch_frames NULL: contiguous batches) behind the same switch as mh_contact_knn_grid_sel:
+ * live_dev[0] = 0 -> both sums are 0 and no gradient is touched.                                                    */
+int mh_contact_foot_terms_gated(int T, int N, int V, int batch, int nbatches, const int32_t* batch_frames,
+                                const float* verts, const int32_t* low_idx, const float* low_xyz, const float* dy,
+                                float coef_contact, float coef_foot, float* gpT, float* gverts, float* batch_contact,
+                                float* batch_foot, const int32_t* live_dev, void* stream);
 /* a21: pixel centres + depth -> camera-space points (H*W,3) (optimizer.py:605-612,
  * transforms.py:114-130).  K_host: HOST 3x3 intrinsics.                                       */
 int mh_scene_unproject(const float* depth /*(H,W)*/, int H, int W, const float* K_host,

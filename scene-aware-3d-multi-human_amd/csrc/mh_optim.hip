@@ -170,9 +170,13 @@ __global__ void k_rmsprop(float* p, const float* g, float* sq, float* buf, size_
 // the same update and, riding along in its first workgroup, the cycle's log entries copied from the staging row the captured
 // graph wrote them to into their row of the log (one small launch less behind every graph replay)
 __global__ void k_rmsprop_log(float* p, const float* g, float* sq, float* buf, size_t n, float lr, float alpha,
-                              float mom, float eps, const float* log_src, float* log_dst, int nlog) {
-  if (blockIdx.x == 0)
+                              float mom, float eps, const float* log_src, float* log_dst, int nlog, int* poke_dst, int npoke,
+                              int poke0, int poke1) {
+  if (blockIdx.x == 0) {
     for (int i = threadIdx.x; i < nlog; i += blockDim.x) log_dst[i] = log_src[i];
+    // (mh_rmsprop_step_log_poke) up to two device-resident switch words of the NEXT captured cycle, set in this launch
+    if (threadIdx.x == 0 && npoke > 0) { poke_dst[0] = poke0; if (npoke > 1) poke_dst[1] = poke1; }
+  }
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const float gi = g[i];
     const float s = alpha * sq[i] + (1.f - alpha) * gi * gi;
@@ -183,17 +187,25 @@ __global__ void k_rmsprop_log(float* p, const float* g, float* sq, float* buf, s
   }
 }
 
+extern "C" int mh_rmsprop_step_log_poke(float* params, const float* grads, float* square_avg, float* momentum_buf, size_t n,
+                                        float lr, float alpha, float momentum, float eps, const float* log_src, float* log_dst,
+                                        int nlog, int32_t* poke_dst, int npoke, int32_t poke0, int32_t poke1, void* stream) {
+  MH_CHECK(params && grads && square_avg && momentum_buf, "null argument");
+  MH_CHECK(nlog == 0 || (log_src && log_dst && nlog > 0), "log_src / log_dst / nlog");
+  MH_CHECK(npoke >= 0 && npoke <= 2 && (npoke == 0 || poke_dst), "poke_dst / npoke");
+  if (n == 0 && nlog == 0 && npoke == 0) return MH_OK;
+  const int blocks = n == 0 ? 1 : (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(k_rmsprop_log, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, square_avg,
+                     momentum_buf, n, lr, alpha, momentum, eps, log_src, log_dst, nlog, (int*)poke_dst, npoke, (int)poke0, (int)poke1);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
 extern "C" int mh_rmsprop_step_log(float* params, const float* grads, float* square_avg, float* momentum_buf, size_t n,
                                    float lr, float alpha, float momentum, float eps, const float* log_src, float* log_dst,
                                    int nlog, void* stream) {
-  MH_CHECK(params && grads && square_avg && momentum_buf, "null argument");
-  MH_CHECK(nlog == 0 || (log_src && log_dst && nlog > 0), "log_src / log_dst / nlog");
-  if (n == 0 && nlog == 0) return MH_OK;
-  const int blocks = n == 0 ? 1 : (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-  hipLaunchKernelGGL(k_rmsprop_log, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, square_avg,
-                     momentum_buf, n, lr, alpha, momentum, eps, log_src, log_dst, nlog);
-  MH_LAUNCH_CHECK();
-  return MH_OK;
+  return mh_rmsprop_step_log_poke(params, grads, square_avg, momentum_buf, n, lr, alpha, momentum, eps, log_src, log_dst, nlog,
+                                  nullptr, 0, 0, 0, stream);
 }
 
 extern "C" int mh_rmsprop_step(float* params, const float* grads, float* square_avg, float* momentum_buf, size_t n,
@@ -422,12 +434,23 @@ extern "C" int mh_velocity_term(int T, int N, const float* pT, const float* prev
 template <typename VEC, bool OVERWRITE>
 __global__ __launch_bounds__(256) void k_filtered_verts(int T, size_t E, const float* v, const float* vf, const float* pv,
                                                            const float* pvf, const float* nv, const float* nvf, float coef,
-                                                           float* gv, float* partial) {
+                                                           float* gv, float* partial, const int* live) {
   __shared__ float s[256];
   constexpr int L = sizeof(VEC) / sizeof(float);
   const size_t EV = E / L;
   const int t0 = blockIdx.y * FV_TB, t1 = min(t0 + FV_TB, T);
   float acc = 0.f;
+  // gated form (mh_filtered_verts_term_init_gated): while the device-resident switch is 0 the term does not exist yet
+  // (optimizer.py:383-392: the filters first run at cycle 50) -- the overwriting form then only clears its rows of the
+  // gradient buffer, the adding form does nothing, the sum is 0; the SAME captured launch serves both phases of a fit
+  const bool off = live != nullptr && *live == 0;
+  if (off) {
+    if (OVERWRITE) {
+      VEC z = {};
+      for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < EV; e += (size_t)gridDim.x * 256)
+        for (int t = t0; t < t1; ++t) ((VEC*)(gv + (size_t)t * E))[e] = z;
+    }
+  } else
   for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < EV; e += (size_t)gridDim.x * 256) {
 #if FV_NT
     typedef float fv_x4 __attribute__((ext_vector_type(4)));
@@ -525,7 +548,7 @@ extern "C" size_t mh_filtered_verts_workspace_bytes(int T, size_t E) {
 
 static int filtered_verts_term(int T, size_t E, const float* verts, const float* verts_filt, const float* prev_v,
                                const float* prev_vf, const float* next_v, const float* next_vf, float coef, float* gverts,
-                               float* loss_out, bool overwrite, void* ws, void* stream) {
+                               float* loss_out, bool overwrite, void* ws, void* stream, const int32_t* live = nullptr) {
   MH_CHECK(verts && verts_filt && gverts && loss_out && ws, "null argument");
   float* g_fv_partial = (float*)ws;
   MH_CHECK(T >= 1 && E >= 1, "empty input");
@@ -542,7 +565,7 @@ static int filtered_verts_term(int T, size_t E, const float* verts, const float*
 #define FV_KERNEL k_filtered_verts
 #define FV_LAUNCH(VEC, OW)                                                                                       \
   hipLaunchKernelGGL((FV_KERNEL<VEC, OW>), grid, blk, 0, st, T, E, verts, verts_filt, prev_v, prev_vf, next_v, \
-                     next_vf, coef, gverts, g_fv_partial)
+                     next_vf, coef, gverts, g_fv_partial, (const int*)live)
   if (vec) { if (overwrite) FV_LAUNCH(float4, true); else FV_LAUNCH(float4, false); }
   else { if (overwrite) FV_LAUNCH(float, true); else FV_LAUNCH(float, false); }
 #undef FV_LAUNCH
@@ -563,6 +586,15 @@ extern "C" int mh_filtered_verts_term_init(int T, size_t E, const float* verts, 
                                            const float* prev_v, const float* prev_vf, const float* next_v,
                                            const float* next_vf, float coef, float* gverts, float* loss_out, void* ws, void* stream) {
   return filtered_verts_term(T, E, verts, verts_filt, prev_v, prev_vf, next_v, next_vf, coef, gverts, loss_out, true, ws, stream);
+}
+
+extern "C" int mh_filtered_verts_term_init_gated(int T, size_t E, const float* verts, const float* verts_filt,
+                                                 const float* prev_v, const float* prev_vf, const float* next_v,
+                                                 const float* next_vf, float coef, float* gverts, float* loss_out,
+                                                 const int32_t* live_dev, void* ws, void* stream) {
+  MH_CHECK(live_dev, "null argument");
+  return filtered_verts_term(T, E, verts, verts_filt, prev_v, prev_vf, next_v, next_vf, coef, gverts, loss_out, true, ws, stream,
+                             live_dev);
 }
 
 // =============================================================================================

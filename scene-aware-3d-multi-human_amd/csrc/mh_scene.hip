@@ -251,6 +251,7 @@ struct ContactP {
   float* gverts;
   float* batch_contact;   // [nbatches]
   float* batch_foot;      // [nbatches]
+  const int* live;        // device-resident switch (mh_contact_foot_terms_gated) or NULL: 0 = no scene yet, the terms are 0
 };
 
 __global__ __launch_bounds__(256) void k_contact_foot(ContactP p) {
@@ -258,6 +259,10 @@ __global__ __launch_bounds__(256) void k_contact_foot(ContactP p) {
   const int pos0 = bt * p.batch;
   __shared__ float s[256];
   __shared__ float scnt;
+  if (p.live && *p.live == 0) {            // before the first scene exists (optimizer.py:485: `if scene_pcd is not None`)
+    if (threadIdx.x == 0) { p.batch_contact[bt] = 0.f; p.batch_foot[bt] = 0.f; }
+    return;
+  }
   auto frame_at = [&](int k) -> int {      // frame at position k of this batch, -1 = none
     const int t = p.frames ? p.frames[pos0 + k] : pos0 + k;
     return t < p.T ? t : -1;
@@ -332,14 +337,14 @@ __global__ __launch_bounds__(256) void k_contact_foot(ContactP p) {
 static int contact_foot_launch(int T, int N, int V, int batch, int nbatches, const int32_t* frames, const float* verts,
                                const int32_t* low_idx, const float* low_xyz, const float* dy, float coef_contact,
                                float coef_foot, float* gpT, float* gverts, float* batch_contact, float* batch_foot,
-                               void* stream) {
+                               void* stream, const int32_t* live = nullptr) {
   MH_CHECK(verts && low_idx && low_xyz && dy && batch_contact && batch_foot, "null argument");
   MH_CHECK(T > 0 && N > 0 && V > 0 && batch > 0, "empty input");
   ContactP p;
   p.T = T; p.N = N; p.V = V; p.batch = batch; p.frames = frames;
   p.verts = verts; p.low_idx = low_idx; p.low_xyz = low_xyz; p.dy = dy;
   p.cc = coef_contact; p.cf = coef_foot; p.gpT = gpT; p.gverts = gverts;
-  p.batch_contact = batch_contact; p.batch_foot = batch_foot;
+  p.batch_contact = batch_contact; p.batch_foot = batch_foot; p.live = (const int*)live;
   hipLaunchKernelGGL(k_contact_foot, dim3(nbatches), dim3(256), 0, (hipStream_t)stream, p);
   MH_LAUNCH_CHECK();
   return MH_OK;
@@ -352,6 +357,18 @@ extern "C" int mh_contact_foot_terms(int T, int N, int V, int batch, const float
   MH_CHECK(T > 0 && batch > 0, "empty input");
   return contact_foot_launch(T, N, V, batch, (T + batch - 1) / batch, nullptr, verts, low_idx, low_xyz, dy, coef_contact,
                              coef_foot, gpT, gverts, batch_contact, batch_foot, stream);
+}
+
+// batch_frames may be NULL (contiguous batches: nbatches must then be ceil(T / batch)); live_dev: see ContactP::live
+extern "C" int mh_contact_foot_terms_gated(int T, int N, int V, int batch, int nbatches, const int32_t* batch_frames,
+                                           const float* verts, const int32_t* low_idx, const float* low_xyz, const float* dy,
+                                           float coef_contact, float coef_foot, float* gpT, float* gverts,
+                                           float* batch_contact, float* batch_foot, const int32_t* live_dev, void* stream) {
+  MH_CHECK(live_dev, "null argument");
+  MH_CHECK(T > 0 && batch > 0 && nbatches > 0, "empty input");
+  MH_CHECK(batch_frames || nbatches == (T + batch - 1) / batch, "contiguous batches: nbatches must be ceil(T / batch)");
+  return contact_foot_launch(T, N, V, batch, nbatches, batch_frames, verts, low_idx, low_xyz, dy, coef_contact, coef_foot,
+                             gpT, gverts, batch_contact, batch_foot, stream, live_dev);
 }
 
 extern "C" int mh_contact_foot_terms_idx(int T, int N, int V, int batch, int nbatches, const int32_t* batch_frames,
@@ -598,9 +615,17 @@ __device__ __forceinline__ float knn_select(float* sd, float* sy, int lane, int 
 // one wave per query
 // (verts != null: the query is the body's lowest vertex, taken from the key the LBS forward's projection epilogue reported --
 // mh_contact_knn_grid_key -- and written to low_idx / low_xyz_out for the contact / foot-sliding kernel)
+// sel != null (mh_contact_knn_grid_sel): the scene is one of TWO grids, chosen by device-resident words -- sel[0] = 0: no scene
+// yet, nothing is written; sel[1] = which grid -- so that one captured launch serves every phase of a fit (the scene
+// update of cycle c builds the grid the cycle does not read, optimizer.py:578-584; the words are set between cycles)
 __global__ __launch_bounds__(64) void k_contact_knn_grid(const GridHdr* hdr, const int* start, const float* sorted, int M,
                                                          const float* low_xyz, int K, float* dy, const float* verts, int V,
-                                                         unsigned long long* lowkey, int* low_idx, float* low_xyz_out) {
+                                                         unsigned long long* lowkey, int* low_idx, float* low_xyz_out,
+                                                         const int* sel, const GridHdr* hdr1, const int* start1, const float* sorted1) {
+  if (sel) {
+    if (sel[0] == 0) return;
+    if (sel[1] != 0) { hdr = hdr1; start = start1; sorted = sorted1; }
+  }
   __shared__ float sd_s[KNN_CAP];
   __shared__ float sy_s[KNN_CAP];
   __shared__ int s_off[65], s_a0[64], s_la[64], s_b0[64];
@@ -755,7 +780,7 @@ extern "C" int mh_contact_knn_grid(const void* grid_ws, int M, const float* low_
   mh_prof_mark(MH_PROF_CONTACT_KNN, 0, (hipStream_t)stream);
   hipLaunchKernelGGL(k_contact_knn_grid, dim3(B), dim3(64), 0, (hipStream_t)stream, (const GridHdr*)g.hdr, (const int*)g.start,
                      (const float*)g.sorted, M, low_xyz, k, dy, (const float*)nullptr, 0, (unsigned long long*)nullptr, (int*)nullptr,
-                     (float*)nullptr);
+                     (float*)nullptr, (const int*)nullptr, (const GridHdr*)nullptr, (const int*)nullptr, (const float*)nullptr);
   MH_LAUNCH_CHECK();
   mh_prof_mark(MH_PROF_CONTACT_KNN, 1, (hipStream_t)stream);
   return MH_OK;
@@ -769,7 +794,27 @@ extern "C" int mh_contact_knn_grid_key(const void* grid_ws, int M, const float* 
   GridWs g = grid_carve((void*)grid_ws, M);
   mh_prof_mark(MH_PROF_CONTACT_KNN, 0, (hipStream_t)stream);
   hipLaunchKernelGGL(k_contact_knn_grid, dim3(B), dim3(64), 0, (hipStream_t)stream, (const GridHdr*)g.hdr, (const int*)g.start,
-                     (const float*)g.sorted, M, (const float*)nullptr, k, dy, verts, V, lowkey, low_idx, low_xyz);
+                     (const float*)g.sorted, M, (const float*)nullptr, k, dy, verts, V, lowkey, low_idx, low_xyz, (const int*)nullptr,
+                     (const GridHdr*)nullptr, (const int*)nullptr, (const float*)nullptr);
+  MH_LAUNCH_CHECK();
+  mh_prof_mark(MH_PROF_CONTACT_KNN, 1, (hipStream_t)stream);
+  return MH_OK;
+}
+
+// mh_contact_knn_grid_key over one of two grids of the same capacity M, chosen on the device: sel_dev[0] = 0 -> no scene yet
+// (nothing is read or written), else grid_ws0 (sel_dev[1] = 0) or grid_ws1.  lowkey NULL: the queries are low_xyz (an input).
+extern "C" int mh_contact_knn_grid_sel(const void* grid_ws0, const void* grid_ws1, int M, const int32_t* sel_dev, const float* verts,
+                                       int V, unsigned long long* lowkey, int B, int k, int32_t* low_idx, float* low_xyz, float* dy,
+                                       void* stream) {
+  MH_CHECK(grid_ws0 && grid_ws1 && sel_dev && low_xyz && dy, "null argument");
+  MH_CHECK(!lowkey || (verts && low_idx), "null argument");
+  MH_CHECK(B > 0 && M > 0 && (!lowkey || V > 0), "empty input");
+  MH_CHECK(k >= 1 && k <= 32, "k must be in 1..32");
+  GridWs g = grid_carve((void*)grid_ws0, M), h = grid_carve((void*)grid_ws1, M);
+  mh_prof_mark(MH_PROF_CONTACT_KNN, 0, (hipStream_t)stream);
+  hipLaunchKernelGGL(k_contact_knn_grid, dim3(B), dim3(64), 0, (hipStream_t)stream, (const GridHdr*)g.hdr, (const int*)g.start,
+                     (const float*)g.sorted, M, lowkey ? (const float*)nullptr : (const float*)low_xyz, k, dy, lowkey ? verts : (const float*)nullptr,
+                     V, lowkey, low_idx, low_xyz, (const int*)sel_dev, (const GridHdr*)h.hdr, (const int*)h.start, (const float*)h.sorted);
   MH_LAUNCH_CHECK();
   mh_prof_mark(MH_PROF_CONTACT_KNN, 1, (hipStream_t)stream);
   return MH_OK;

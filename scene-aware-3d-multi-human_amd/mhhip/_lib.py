@@ -91,6 +91,8 @@ def lib():
         L.mh_lbs_set_mode.argtypes = [ctypes.c_int]
         L.mh_rmsprop_step.argtypes = [vp, vp, vp, vp, ctypes.c_size_t] + [ctypes.c_float] * 4 + [vp]
         L.mh_rmsprop_step_log.argtypes = [vp, vp, vp, vp, ctypes.c_size_t] + [ctypes.c_float] * 4 + [vp, vp, ctypes.c_int, vp]
+        L.mh_rmsprop_step_log_poke.argtypes = [vp, vp, vp, vp, ctypes.c_size_t] + [ctypes.c_float] * 4 + [vp, vp, ctypes.c_int, vp,
+                                                                                                   ctypes.c_int, ctypes.c_int32, ctypes.c_int32, vp]
         L.mh_rmsprop_step_dev.argtypes = [vp, vp, vp, vp, ctypes.c_size_t, vp] + [ctypes.c_float] * 4 + [vp]
         L.mh_adam_step.argtypes = [vp, vp, vp, vp, ctypes.c_size_t, ctypes.c_int] + [ctypes.c_float] * 4 + [vp]
         L.mh_one_euro_scan.argtypes = [vp, vp, ctypes.c_int, ctypes.c_size_t] + [ctypes.c_float] * 3 + [vp]
@@ -98,6 +100,7 @@ def lib():
         L.mh_velocity_term.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_float, vp, vp, vp]
         L.mh_filtered_verts_term.argtypes = [ctypes.c_int, ctypes.c_size_t] + [vp] * 6 + [ctypes.c_float, vp, vp, vp, vp]
         L.mh_filtered_verts_term_init.argtypes = [ctypes.c_int, ctypes.c_size_t] + [vp] * 6 + [ctypes.c_float, vp, vp, vp, vp]
+        L.mh_filtered_verts_term_init_gated.argtypes = [ctypes.c_int, ctypes.c_size_t] + [vp] * 6 + [ctypes.c_float, vp, vp, vp, vp, vp]
         L.mh_filtered_verts_workspace_bytes.restype = ctypes.c_size_t
         L.mh_filtered_verts_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_size_t]
         u32p = vp
@@ -121,6 +124,12 @@ def lib():
         L.mh_scene_postprocess.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp]
         L.mh_scene_fill.argtypes = [ctypes.c_int] * 4 + [vp] * 4
         L.mh_scene_points.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp]
+        L.mh_stream_create.argtypes = [ctypes.POINTER(vp)]
+        L.mh_stream_destroy.argtypes = [vp]
+        L.mh_stream_shares_any.argtypes = [ctypes.POINTER(vp), ctypes.c_int, vp, ctypes.c_float, ctypes.POINTER(ctypes.c_int)]
+        L.mh_streams_classify.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.POINTER(vp), ctypes.c_int, ctypes.c_float, ctypes.POINTER(ctypes.c_int)]
+        L.mh_stream_spin.argtypes = [vp, ctypes.c_float]
+        L.mh_streams_share_queue.argtypes = [vp, vp, ctypes.c_float, ctypes.POINTER(ctypes.c_int)]
         L.mh_profile_enable.argtypes = [ctypes.c_int]
         L.mh_profile_read.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
         L.mh_scene_grid_bytes.restype = ctypes.c_size_t
@@ -129,6 +138,8 @@ def lib():
         L.mh_scene_grid_build_dev.argtypes = [vp, vp, ctypes.c_int, vp, vp]
         L.mh_contact_knn_grid.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp]
         L.mh_contact_knn_grid_key.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
+        L.mh_contact_knn_grid_sel.argtypes = [vp, vp, ctypes.c_int, vp, vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
+        L.mh_contact_foot_terms_gated.argtypes = [ctypes.c_int] * 5 + [vp] * 5 + [ctypes.c_float] * 2 + [vp] * 6
         L.mh_contact_foot_terms.argtypes = [ctypes.c_int] * 4 + [vp] * 4 + [ctypes.c_float] * 2 + [vp] * 5
         L.mh_contact_foot_terms_idx.argtypes = [ctypes.c_int] * 5 + [vp] * 5 + [ctypes.c_float] * 2 + [vp] * 5
         L.mh_scene_unproject.argtypes = [vp, ctypes.c_int, ctypes.c_int, c_float_p, vp, vp]

@@ -302,10 +302,18 @@ def rmsprop_step(params, grads, sq, buf, lr, alpha=0.5, momentum=0.9, eps=1e-8):
                                      eps, _lib.stream_ptr(params.device)))
 
 
-def rmsprop_step_log(params, grads, sq, buf, lr, log_src, log_dst, alpha=0.5, momentum=0.9, eps=1e-8):
-    """mh_rmsprop_step_log: the update and, in the same launch, the cycle's log entries from their staging row into log_dst"""
-    check(_lib.lib().mh_rmsprop_step_log(ptr(params), ptr(grads), ptr(sq), ptr(buf), params.numel(), lr, alpha, momentum,
-                                         eps, ptr(log_src), ptr(log_dst), log_src.numel(), _lib.stream_ptr(params.device)))
+def rmsprop_step_log(params, grads, sq, buf, lr, log_src, log_dst, alpha=0.5, momentum=0.9, eps=1e-8, poke_dst=None, poke=None):
+    """mh_rmsprop_step_log[_poke]: the update and, in the same launch, the cycle's log entries from their staging row into
+    log_dst (log_src None: no copy) and up to two int32 words ``poke`` into ``poke_dst``"""
+    nlog = 0 if log_src is None else log_src.numel()
+    if poke is None:
+        check(_lib.lib().mh_rmsprop_step_log(ptr(params), ptr(grads), ptr(sq), ptr(buf), params.numel(), lr, alpha, momentum,
+                                             eps, ptr(log_src), ptr(log_dst), nlog, _lib.stream_ptr(params.device)))
+        return
+    poke = [int(v) for v in poke] + [0]
+    check(_lib.lib().mh_rmsprop_step_log_poke(ptr(params), ptr(grads), ptr(sq), ptr(buf), params.numel(), lr, alpha, momentum,
+                                              eps, ptr(log_src), ptr(log_dst), nlog, poke_dst.data_ptr(), min(len(poke) - 1, 2),
+                                              poke[0], poke[1], _lib.stream_ptr(params.device)))
 
 
 def adam_step(params, grads, m, v, step, lr, b1=0.5, b2=0.5, eps=1e-6):

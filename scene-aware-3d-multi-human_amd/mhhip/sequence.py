@@ -16,7 +16,7 @@ import numpy as np
 import os
 import torch
 
-from . import _lib, engine
+from . import _lib, engine, queues
 from ._lib import check, ptr
 
 LOG_KEYS = ['loss_pose24j', 'loss_depth', 'loss_silhouette', 'reg_ref_poses', 'reg_scale', 'reg_contact',
@@ -110,6 +110,15 @@ class SequenceEngine(object):
         self.pT_filt = None
         self.has_images = False
         self.halo = None              # filled by the frame-sharded driver
+        # Device-resident switches of the captured cycle: [0] the one-euro filters have run (optimizer.py:383-392: first at
+        # cycle 50), [1] a device-built scene is live (:578-584: from cycle 31 on), [2] which of the two scene sets the contact
+        # term reads.  The launches that depend on them are gated ON THE DEVICE, so ONE captured graph serves every phase of a
+        # fit (round 5 captured five more graphs of 2.2-2.5 ms at cycles 30 / 31 / 32 / 50 / 51).
+        self.phase = torch.zeros(4, dtype=torch.int32, device=self.dev)
+        self._phase_const = [torch.tensor([1, k], dtype=torch.int32, device=self.dev) for k in (0, 1)]
+        self._phase_host = [0, 0, 0]
+        self._phase_poke = None       # (live, set) the next step() writes in its own launch (scene_device_swap)
+        self._filt_gate = False
         self.batch_frames = None      # batch table of the current cycle (set_batch_table); None = contiguous batches
         self.timing = None            # {name: [(start_event, end_event), ...]} when enabled by bench.py
 
@@ -193,6 +202,7 @@ class SequenceEngine(object):
         if getattr(self, '_graphs', None):
             torch.cuda.current_stream(self.dev).synchronize()
             self._graphs = {}
+            self._lane_tests = {}
         self._scene_dev = None
         self.pose2d = _dev(pose2d, self.dev).view(self.B, 17, 3)
         self.poses_ref = _dev(poses_ref, self.dev).view(self.B, 72)
@@ -258,7 +268,11 @@ class SequenceEngine(object):
         T, H, W = self.T, self.H, self.W
         P = H * W
         d = {}
-        d['back'] = torch.as_tensor(np.ascontiguousarray((np.asarray(backmasks) != 0).astype(np.uint8))).to(self.dev)
+        bm = np.asarray(backmasks)
+        if bm.dtype != np.uint8 and bm.dtype != np.bool_:
+            bm = bm != 0
+        bm = np.ascontiguousarray(bm).view(np.uint8)          # (the staging pass of the optimiser already hands over bytes)
+        d['back'] = (torch.as_tensor(bm).to(self.dev) != 0).to(torch.uint8)
         d['ws'] = torch.empty(L.mh_scene_workspace_bytes(T, H, W), dtype=torch.uint8, device=self.dev)
         if T <= 512:      # pixel-major copies of the constant inputs for the register form of the median
             d['depths_t'] = self.depths.view(T, P).t().contiguous()
@@ -266,7 +280,11 @@ class SequenceEngine(object):
         d['ma_depth'] = torch.zeros(H, W, device=self.dev)
         d['ma_mask'] = torch.zeros(H, W, device=self.dev)
         d['depth'] = torch.zeros(H, W, device=self.dev)
-        d['stream'] = _shared_stream(self.dev, 'scene')
+        # the update's own stream: one that does NOT drain through the launch stream's hardware queue (mhhip/queues.py)
+        if queues.enabled():
+            d['stream'] = queues.plan(self.dev).scene_stream(torch.cuda.current_stream(self.dev).cuda_stream)
+        else:
+            d['stream'] = _shared_stream(self.dev, 'scene')
         d['ev_main'] = torch.cuda.Event()
         d['ev_snap'] = torch.cuda.Event()
         with torch.cuda.stream(d['stream']):      # first submission now: the stream gets its hardware queue before any
@@ -279,6 +297,19 @@ class SequenceEngine(object):
         d['ready'] = None             # set written by the last update, not yet swapped in
         d['front'] = None
         self._scene_dev = d
+        self._phase_poke = None       # new sets: none of them is live yet
+        if self._phase_host[1]:
+            self.phase[1:3].zero_()
+            self._phase_host[1] = self._phase_host[2] = 0
+
+    def _scene_move(self, stream):
+        """the scene update continues on another stream (the updates share one workspace: the new stream first waits for
+        whatever the old one still has to do)"""
+        d = self._scene_dev
+        if d is None or d['stream'] is stream:
+            return
+        stream.wait_stream(d['stream'])
+        d['stream'] = stream
 
     def scene_device_update(self):
         """Launch one scene update from the current depth-range leaves into the back set (own stream)."""
@@ -342,13 +373,50 @@ class SequenceEngine(object):
         d = self._scene_dev
         if d['ready'] is None:
             return
-        s = d['sets'][d['ready']]
+        k = d['ready']
+        s = d['sets'][k]
         d['front'], d['ready'] = s, None
+        self._phase_poke = (1, k)                 # the device-side words follow in the next step()'s launch (or _flush_phase)
         self.scene_pts = s['pts']                 # capacity buffer; the live count is s['count'] (device)
         self.scene_grid = s['grid']
         self.scene_M = self.H * self.W
         self._scene_event = s['ev']
         self._scene_pending = True
+
+    def _scene_sel(self):
+        """The two device-built scene sets when the captured cycle can read the scene through the device-resident selector
+        (no scene yet, or the live one IS one of the sets); None: a scene handed in from outside (``set_scene_points``,
+        ``update_scene_pointcloud``) is read through its own pointers, as before."""
+        d = self._scene_dev
+        if d is None or os.environ.get('MHHIP_UNIFORM') == '0':
+            return None
+        if self.scene_pts is None or any(self.scene_pts is x['pts'] for x in d['sets']):
+            return d['sets']
+        return None
+
+    def _flush_phase(self):
+        """scene words scheduled by ``scene_device_swap`` that no ``step`` has taken along: one 8-byte copy on the stream"""
+        if self._phase_poke is not None:
+            (live, k), self._phase_poke = self._phase_poke, None
+            self.phase[1:3].copy_(self._phase_const[k])
+            self._phase_host[1], self._phase_host[2] = live, k
+
+    def enable_filter_gate(self):
+        """Allocate the filtered trajectories NOW (zeros) and run the filtered-vertex term behind the device-resident switch
+        ``phase[0]`` from the first cycle on: the same captured launches before and after the first filter update
+        (optimizer.py:383-392, 571-573).  No-op when filters already exist (a second fit keeps them, like the reference's
+        ``self.verts_filtered``)."""
+        if self.verts_filt is not None or self.pT_filt is not None:
+            return self._filt_gate
+        self.pT_filt = torch.zeros(self.T, self.N, 3, dtype=torch.float32, device=self.dev)
+        self.verts_filt = torch.zeros(self.T, self.N, self.V, 3, dtype=torch.float32, device=self.dev)
+        self._filt_gate = True
+        return True
+
+    def _filters_live(self):
+        if self._filt_gate and not self._phase_host[0]:
+            self.phase[0:1].fill_(1)
+            self._phase_host[0] = 1
 
     # -- hooks of the frame-sharded driver (mhhip/sharded.py; the CPU stand-in of the tests implements the same) -----
     def main_stream(self):
@@ -471,6 +539,7 @@ class SequenceEngine(object):
         follows the all-reduce, ``step_shared``)"""
         self._wait_scene_snapshot()
         self._flush_log()
+        self._flush_phase()
         lo = self.shared_lo
         engine.rmsprop_step(self.params[:lo], self.grads[:lo], self.sq[:lo], self.buf[:lo], float(lr), alpha, momentum, eps)
 
@@ -514,6 +583,8 @@ class SequenceEngine(object):
         g = self.grads
         log = self.tmp_log
         self._flush_log()                # (never inside a capture: cycle_graphed has flushed before it replays)
+        if not torch.cuda.is_current_stream_capturing():
+            self._flush_phase()
         # the gradient buffer (+ the staging row of the log) is cleared by the forward's first kernel when the projection form
         # runs (mh_fwd_proj.clear): the captured cycle starts with k_pose_fwd instead of a fill and a 5-us gap
         # (only in the single-join form: with join=True the leaf-only terms start beside the forward and add into the buffer)
@@ -578,7 +649,10 @@ class SequenceEngine(object):
         Kp = self.K.ctypes.data_as(_lib.c_float_p)
         Kdp = None if self.Kd is None else self.Kd.ctypes.data_as(_lib.c_float_p)
         h = self.halo or {}
-        scene = self.scene_pts is not None
+        # sel: the device-built scene sets, read through the device-resident selector (gated launches: they run -- and do
+        # nothing -- while there is no scene yet, so that the captured sequence is the same before and after cycle 30)
+        sel = self._scene_sel() if scene_ready else None
+        scene = self.scene_pts is not None or sel is not None
         filt = self.verts_filt is not None and self.pT_filt is not None
         images = use_images and self.has_images
         need_gv = scene or filt or (images and raster is not None) or not self.kp_fused
@@ -642,9 +716,15 @@ class SequenceEngine(object):
                     if filt:
                         E = N * self.V * 3
                         ev = self._tic('filtered_verts')
-                        check(L.mh_filtered_verts_term_init(T, E, ptr(self.verts), ptr(self.verts_filt), ptr(h.get('v_prev')),
-                                                            ptr(h.get('vf_prev')), ptr(h.get('v_next')), ptr(h.get('vf_next')),
-                                                            float(c['reg_verts_filter']), ptr(gv), ptr(log[8:9]), ptr(self.fv_ws), s2))
+                        if self._filt_gate:
+                            check(L.mh_filtered_verts_term_init_gated(T, E, ptr(self.verts), ptr(self.verts_filt), ptr(h.get('v_prev')),
+                                                                      ptr(h.get('vf_prev')), ptr(h.get('v_next')), ptr(h.get('vf_next')),
+                                                                      float(c['reg_verts_filter']), ptr(gv), ptr(log[8:9]),
+                                                                      self.phase.data_ptr(), ptr(self.fv_ws), s2))
+                        else:
+                            check(L.mh_filtered_verts_term_init(T, E, ptr(self.verts), ptr(self.verts_filt), ptr(h.get('v_prev')),
+                                                                ptr(h.get('vf_prev')), ptr(h.get('v_next')), ptr(h.get('vf_next')),
+                                                                float(c['reg_verts_filter']), ptr(gv), ptr(log[8:9]), ptr(self.fv_ws), s2))
                         self._toc(ev)
                     else:
                         gv.zero_()
@@ -661,7 +741,7 @@ class SequenceEngine(object):
             self._scene_done = False
             sums = [] if split else [(self.loss2d, log[0:1]), (self.prior_body, log[3:4])]
             if scene and (self._scene_dev is None or scene_ready):     # static scene, or its event already waited for
-                self._scene_terms(s2, reduce=False)
+                self._scene_terms(s2, reduce=False, sel=sel)
                 sums += [(self.batch_contact, log[5:6]), (self.batch_foot, log[6:7])]
                 self._scene_done = True
             if later is not None and not split:
@@ -732,14 +812,30 @@ class SequenceEngine(object):
         if not joined:
             main.wait_stream(side)
 
-    def _scene_terms(self, st, reduce=True):
-        """contact + in-batch foot sliding (optimizer.py:485-518) on stream st; gradients by atomics / disjoint writes"""
+    def _scene_terms(self, st, reduce=True, sel=None):
+        """contact + in-batch foot sliding (optimizer.py:485-518) on stream st; gradients by atomics / disjoint writes.
+        sel: the two device-built scene sets (``_scene_sel``) -- the launches read the live one through ``phase[1:3]`` and do
+        nothing while there is none."""
         L = _lib.lib()
         c = self.c
         T, N, B = self.T, self.N, self.B
         gpT = self.leaf('poses_T', self.grads)
         gv, log = self._gv_cur, self.tmp_log
         fresh, self._lowkey_fresh = getattr(self, '_lowkey_fresh', False), False
+        if sel is not None:
+            words = self.phase.data_ptr() + 4                       # [scene live, which set]
+            if not fresh:
+                check(L.mh_lowest_vertex(ptr(self.verts), B, self.V, ptr(self.low_idx), ptr(self.low_xyz), st))
+            check(L.mh_contact_knn_grid_sel(ptr(sel[0]['grid']), ptr(sel[1]['grid']), self.H * self.W, words,
+                                            ptr(self.verts) if fresh else None, self.V, self._lowkey if fresh else None, B, 32,
+                                            ptr(self.low_idx), ptr(self.low_xyz), ptr(self.dy), st))
+            check(L.mh_contact_foot_terms_gated(T, N, self.V, self.batch, self.nbatches, ptr(getattr(self, 'batch_frames', None)),
+                                                ptr(self.verts), ptr(self.low_idx), ptr(self.low_xyz), ptr(self.dy),
+                                                float(c['reg_contact']), float(c['reg_foot_sliding']), ptr(gpT), ptr(gv),
+                                                ptr(self.batch_contact), ptr(self.batch_foot), words, st))
+            if reduce:
+                _lib.reduce_sum_multi([(self.batch_contact, log[5:6]), (self.batch_foot, log[6:7])], st)
+            return
         if fresh:                                                   # the forward's epilogue has reported the lowest vertices
             check(L.mh_contact_knn_grid_key(ptr(self.scene_grid), self.scene_M, ptr(self.verts), self.V, self._lowkey, B, 32,
                                             ptr(self.low_idx), ptr(self.low_xyz), ptr(self.dy), st))
@@ -804,11 +900,16 @@ class SequenceEngine(object):
 
     def step(self, lr, alpha=0.5, momentum=0.9, eps=1e-8):
         self._wait_scene_snapshot()
-        if self._log_pending is not None:
-            # the log entries of the graph that was just replayed travel to their row in the update's launch
+        poke, self._phase_poke = self._phase_poke, None
+        if self._log_pending is not None or poke is not None:
+            # the log entries of the graph that was just replayed travel to their row in the update's launch -- and so do
+            # the scene words of the next cycle (which of the two device-built scene sets is live)
             row, self._log_pending = self._log_pending, None
-            engine.rmsprop_step_log(self.params, self.grads, self.sq, self.buf, float(lr), self.tmp_log, self.log[row],
-                                    alpha, momentum, eps)
+            engine.rmsprop_step_log(self.params, self.grads, self.sq, self.buf, float(lr), self.tmp_log if row is not None else None,
+                                    self.log[row] if row is not None else None, alpha, momentum, eps,
+                                    poke_dst=self.phase[1:3] if poke is not None else None, poke=poke)
+            if poke is not None:
+                self._phase_host[1], self._phase_host[2] = poke
         else:
             engine.rmsprop_step(self.params, self.grads, self.sq, self.buf, float(lr), alpha, momentum, eps)
 
@@ -827,7 +928,10 @@ class SequenceEngine(object):
         # device addresses and the by-value sizes a capture bakes in (an address recycled by the allocator with the same
         # sizes replays correctly: the kernels read whatever is there now)
         scene = None
-        if self.scene_pts is not None:
+        sel = self._scene_sel()
+        if sel is not None:               # the scene is read through the device-resident selector: one key for the whole fit
+            scene = ('sel', sel[0]['grid'].data_ptr(), sel[1]['grid'].data_ptr())
+        elif self.scene_pts is not None:
             scene = (self.scene_pts.data_ptr(), self.scene_grid.data_ptr(), self.scene_M)
         rast = None if raster is None else (raster.ws.data_ptr(), raster.faces.data_ptr())
         bt = None if getattr(self, 'batch_frames', None) is None else self.batch_frames.data_ptr()
@@ -837,7 +941,7 @@ class SequenceEngine(object):
         glob = (L.mh_raster_get_deterministic(), L.mh_raster_get_sort_margin(), L.mh_lbs_get_mode(), L.mh_raster_get_path(),
                 L.mh_raster_get_winners()) if raster is not None else None
         hk = None if self.halo is None else (bool(self.halo.get('has_prev')), bool(self.halo.get('has_next')), self.halo.get('poses') is not None)
-        return (rast, scene, self.verts_filt is not None and self.pT_filt is not None, hk, bt, glob)
+        return (rast, scene, self.verts_filt is not None and self.pT_filt is not None, self._filt_gate, hk, bt, glob)
 
     def raster_terms(self, znear=1.0, zfar=100.0):
         """The engine's rasteriser binding (workspace + face table), created once and kept alive with the engine:
@@ -855,6 +959,8 @@ class SequenceEngine(object):
             self._scene_pending = False
         if not hasattr(self, '_graphs'):
             self._graphs = {}
+        if not hasattr(self, '_lane_tests'):
+            self._lane_tests = {}
         g = self._graphs.get(key)
         if g is None:
             fn()
@@ -864,7 +970,21 @@ class SequenceEngine(object):
                 fn()
             self._graphs[key] = g
         else:
-            g.replay()
+            # a new graph that runs beside the device-side scene update: its first replays also find out which hardware queues
+            # it keeps busy, and the scene update moves to one it does not (mhhip/queues.py)
+            want = self._scene_dev is not None and queues.enabled() and str(key[0]).startswith('full')      # (the cycle's graphs only)
+            lt = self._lane_tests.get(key) if want else None
+            if lt is None and want and key not in self._lane_tests:
+                lt = self._lane_tests[key] = queues.LaneTest(queues.plan(self.dev), torch.cuda.current_stream(self.dev).cuda_stream)
+            if lt is not None and not lt.done and not getattr(lt, 'recorded', False):
+                main = torch.cuda.current_stream(self.dev)
+                lt.before(main)
+                g.replay()
+                lt.after(main)
+            else:
+                if lt is not None and not lt.done and lt.poll() and lt.choice is not None:
+                    self._scene_move(queues.plan(self.dev).view(lt.choice))
+                g.replay()
 
     def cycle_graphed(self, row, raster=None, scene_update=False):
         """``cycle`` through a captured graph (single-process form; the sharded driver replays
@@ -872,6 +992,7 @@ class SequenceEngine(object):
         device-side scene update (``scene_device_update``), after the first replay has been enqueued."""
         key = self._graph_key(raster)
         self._flush_log()
+        self._flush_phase()
         if scene_update:
             self.scene_device_mark()
         if self._scene_dev is not None:
@@ -904,6 +1025,7 @@ class SequenceEngine(object):
         if not hasattr(self, 'lr_dev'):
             self.lr_dev = torch.full((1,), lr0, dtype=torch.float32, device=self.dev)
         self._flush_log()
+        self._flush_phase()
         self._wait_scene_snapshot()
         check(_lib.lib().mh_rmsprop_step_dev(ptr(self.params), ptr(self.grads), ptr(self.sq), ptr(self.buf),
                                              self.params.numel(), ptr(self.lr_dev), gamma, alpha, momentum, eps,
@@ -922,6 +1044,7 @@ class SequenceEngine(object):
             self.verts_filt = verts_filt.clone()
         else:
             self.verts_filt.copy_(verts_filt)
+        self._filters_live()
 
     def update_filters(self, c1=0.01, b1=0.02, c2=0.001, b2=0.5):
         """optimizer.py:383-392: the translations and the vertices of the current leaves through the one-euro filters.  From
@@ -932,6 +1055,7 @@ class SequenceEngine(object):
             engine.one_euro_scan(pT, c1, b1, out=self.pT_filt)
             self.forward(regress=False)
             engine.one_euro_scan(self.verts.view(self.T, -1), c2, b2, out=self.verts_filt)
+            self._filters_live()
             return
         pf = engine.one_euro_scan(pT, c1, b1)
         self.forward(regress=False)

@@ -408,13 +408,17 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
                     if not own[0] <= idx < own[1]:
                         continue
                     a = data[k].numpy() if isinstance(data[k], torch.Tensor) else np.asarray(data[k])
+                    if k == 'backmasks' and a.dtype != np.uint8:
+                        a = a != 0
                     if k not in store:
-                        alloc(k, a.shape[lead:], a.dtype)
+                        alloc(k, a.shape[lead:], np.uint8 if k == 'backmasks' else a.dtype)
                     store[k][idx - own[0]] = a
                     continue
                 a = data[k].numpy() if isinstance(data[k], torch.Tensor) else np.asarray(data[k])
+                if k == 'backmasks' and a.dtype != np.uint8:
+                    a = a != 0          # only "background or not" is ever read (fhsog.py:190-197): one byte per pixel from here on
                 if k not in store:
-                    alloc(k, a.shape[lead:], a.dtype)
+                    alloc(k, a.shape[lead:], np.uint8 if k == 'backmasks' else a.dtype)
                 store[k][idx] = a
 
         # this extra pass must not advance the shuffle of cycle 0: the global generator AND the loader's / sampler's own
@@ -458,7 +462,7 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
         # own frames only (scene update set-up, colour median of the scene image once per fit); copied out of the staging
         # buffers so that no page-locked memory outlives this call
         self._images = None if 'images' not in store else np.array(loc('images'))
-        self._backmasks = None if 'backmasks' not in store else np.array(loc('backmasks'))
+        self._backmasks = None if 'backmasks' not in store else np.ascontiguousarray(loc('backmasks'))   # uint8, never pinned: no copy
         keep.clear()
         self._staged = True
         try:
@@ -546,6 +550,14 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
         e.buf.zero_()                                                         # start at zero in EVERY call
         sh.leaves_changed()                                                   # (sharded: the neighbours' boundary leaves are gathered
         sh.refresh_halo()                                                     #  here, by every rank: the cycles issue no hidden collective)
+        # ONE captured graph for the whole fit (single process): what changes between the phases of a fit -- no scene before
+        # cycle 30 (:578-584), no filtered trajectories before the first filter update (:383-392, 571-573) -- is switched by
+        # device-resident words the captured launches read, so the buffers those launches touch must exist from cycle 0 on
+        if (self.use_graphs and world == 1 and os.environ.get('MHHIP_UNIFORM') != '0' and hasattr(e, 'enable_filter_gate')):
+            if (num_iter > 30 and scene_mode == 'device' and e.has_images and self._backmasks is not None and e._scene_dev is None):
+                sh.scene_setup(self._backmasks)
+            if any(c % update_filters_every == 0 for c in range(30, num_iter)):
+                e.enable_filter_gate()
         cycles = range(num_iter)
         if verbose and tqdm is not None and rank == 0:
             cycles = tqdm(cycles)

@@ -10,6 +10,17 @@ from mhhip import synthetic, synthetic_seq
 T = 200
 struct = synthetic.make_smpl_struct(1); regs = synthetic.make_extra_regressors(1, struct)
 K = synthetic.default_cam_K(bench.IMG, 60.0)
+def shares(a, b, spin=int(1.0e6)):
+    torch.cuda.synchronize()
+    e0, ea1, eb1 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    with torch.cuda.stream(a):
+        e0.record(a); torch.cuda._sleep(spin); ea1.record(a)
+    with torch.cuda.stream(b):
+        torch.cuda._sleep(1000); eb1.record(b)
+    torch.cuda.synchronize()
+    return int(e0.elapsed_time(eb1) >= 0.8 * e0.elapsed_time(ea1))
+
+
 def one(n):
     opt = bench.build_optimizer(struct, regs, tempfile.mkdtemp(), T, 'cuda:0', K)
     opt.scene_update = 'device'
@@ -36,5 +47,12 @@ def one(n):
     big = np.argsort(-d)[:12]
     print('  longest gaps (cycle: ms [host ms of the launch call]):', ', '.join('%d: %.2f [%.2f]' % (i, d[i], h[i]) for i in sorted(big)))
     print('  host time inside cycle_graphed: sum %.1f ms, median %.3f ms' % (h.sum(), np.median(h)))
+    from mhhip import sequence, queues
+    main = torch.cuda.current_stream()
+    st = dict(sequence._SHARED_STREAMS)
+    scene = e._scene_dev['stream']
+    print('  hardware-queue sharing: scene~main %d, ' % shares(main, scene) + ', '.join('%s~main %d' % (k[1], shares(main, v)) for k, v in st.items())
+          + ', side~scene %d' % shares(st[(0, 'side')], scene) + '; plan: %s' % queues.plan('cuda:0').stats
+          + ' lane test ms: %s' % [[round(x, 2) for x in lt.ms] for lt in getattr(e, '_lane_tests', {}).values() if getattr(lt, 'ms', None)])
 one(250)
 one(250)

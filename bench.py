@@ -370,17 +370,18 @@ def main():
     organic = None
     if world == 1 and not args.strong:
         e.scene_device_setup(seq['backmasks'])
-        for c in range(12):       # two captures (the injected scene, then the device-built sets) + the lane test of mhhip/queues.py
+        for c in range(40):       # two captures (the injected scene, then the device-built sets) + lane test and lane picker of mhhip/queues.py
             one_cycle(args.warmup + args.steps + c, use_graphs, scene=True)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for c in range(nsteps_org):
-            one_cycle(args.warmup + args.steps + 12 + c, use_graphs, scene=True)
+            one_cycle(args.warmup + args.steps + 40 + c, use_graphs, scene=True)
         torch.cuda.synchronize()
         dt1 = time.perf_counter() - t1
         organic = {'value': round(nsteps_org / dt1, 3), 'ms_per_step': round(1e3 * dt1 / nsteps_org, 4), 'steps': nsteps_org,
                    'lane_test': [{'replay_ms': [round(x, 3) for x in getattr(lt, 'ms', [])], 'busy_lanes': len(getattr(lt, 'busy', [])),
                                   'candidates': len(lt.cand)} for lt in getattr(e, '_lane_tests', {}).values()],
+                   'lane_pick': [{'cycle_ms': [round(x, 4) for x in (pk.ms or [])], 'best': pk.best} for pk in getattr(e, '_pickers', {}).values()],
                    'what': 'per-cycle masked median over the 200 frames + bilateral/Sobel/erode/median-fill + un-projection '
                            '+ grid rebuild on a second stream, overlapped with the next cycle'}
         opt.scene_depth = ground_scene(K, W, H)
@@ -652,7 +653,8 @@ def fit_block(struct, regs, tmp, device, K, seq):
               'cycles_30_59_ms': round(float(gaps[30:60].mean()), 4), 'cycles_60_248_ms': round(float(gaps[60:].mean()), 4),
               'graphs_captured': len(getattr(e, '_graphs', {})),
               'lane_test': [{'replay_ms': [round(x, 3) for x in getattr(lt, 'ms', [])], 'busy_lanes': len(getattr(lt, 'busy', [])),
-                             'candidates': len(lt.cand)} for lt in getattr(e, '_lane_tests', {}).values()],
+                             'candidates': len(lt.cand), 'clean': bool(getattr(lt, 'clean', False)), 'done': bool(lt.done)} for lt in getattr(e, '_lane_tests', {}).values()],
+              'lane_pick': [{'cycle_ms': [round(x, 4) for x in (pk.ms or [])], 'best': pk.best} for pk in getattr(e, '_pickers', {}).values()],
               'what': 'GPU time between consecutive cycle launches of this fit (events): cycle 0 holds the eager run + the one capture'}
     ov = opt.get_optimized_variables()
     early = early_fit_block(opt, dl, params0)

@@ -144,6 +144,9 @@ typedef struct mh_fwd_proj {
   float s, w1, h1;             /* x_ndc = s * (-x) / z + w1, y_ndc = s * (-y) / z + h1                      */
   float ra, rk, thr;           /* pixel row = fma(-y_ndc, rk, ra); a vertex has moved when |row - rowb| >= thr */
   float slack_ndc, slack_y;    /* report when beyond (previous extreme -/+ slack): NDC units / metres        */
+  float thr_soft;              /* from |row - rowb| >= thr_soft on the body's face lists are sorted again OFF the chain, beside
+                                  this cycle's gradient kernel, for the next launch; from thr on: now.  thr_soft = thr: no
+                                  deferred sorts                                                                 */
   float* ndc;                  /* (B,V,3) out: x_ndc, y_ndc, z                                              */
   const float* rowb;           /* (B,V)   in : pixel row of every vertex at the body's last face sort        */
   int32_t* bbox;               /* (B,4)   out: order-preserving int of min x, min y, max x, max y (z > 1e-8 only);
@@ -151,7 +154,8 @@ typedef struct mh_fwd_proj {
   int32_t* bbox_prev;          /* (B,4)   the previous launch's bbox (copied, then bbox reset, by the launch itself) */
   unsigned long long* lowkey;  /* (B)     out: order-preserving bits of y << 32 | ~vertex, 0 = nobody reported */
   unsigned long long* lowkey_prev; /* (B) */
-  int32_t* moved;              /* (B)     out: 1 = some vertex left its band                                 */
+  int32_t* moved;              /* (2B)    out: [b] = 1: some vertex left its band (thr); [B + b] = 1: some vertex is on its way
+                                                out (thr_soft).  Plain stores: thousands of vertices of a body report the same */
   float* clear;                /* or NULL: clear_n floats zeroed by the launch's first kernel -- the cycle's gradient buffer,
                                   so that a captured cycle starts with the pose kernel instead of a fill + a gap        */
   unsigned long long clear_n;
@@ -588,11 +592,20 @@ int mh_raster_workspace_offsets(int T, int N, int V, int F, int H, int W, size_t
 int mh_raster_pair_counters(int T, int N, int V, int F, int H, int W, void* ws, unsigned long long* out_host /*[3]*/, void* stream);
 int mh_raster_set_sort_margin(int rows);
 int mh_raster_get_sort_margin(void);
+/* Deferred sorts (round 6): from `fraction` of the margin on, a body's lists are sorted again BESIDE the gradient kernel of the
+ * launch that notices it, for the next launch -- off the chain of the cycle; only a jump of the whole margin inside one launch
+ * still sorts in the preparation.  The keys do not depend on it (every face is decided from the current coordinates).
+ * 0 or 1: no deferred sorts.  Default 0.6; MHHIP_RASTER_SORT_DEFER in the environment.  Process-wide.  At most 64
+ * bodies per launch (the rest stay flagged for a later one, or reach the margin and sort in the preparation).       */
+int mh_raster_set_sort_defer(float fraction);
+float mh_raster_get_sort_defer(void);
 /* test aid: all_even != 0 sends every round of the selection kernel down its even-split path (no depth cull, no pair list);
  * the selection keys must not depend on the path a round takes.  Process-wide; part of the cycle graphs' key. */
 int mh_raster_set_path(int all_even);
 int mh_raster_get_path(void);
 int mh_raster_sort_counters(int T, int N, int V, int F, int H, int W, void* ws, unsigned long long* out_host /*[2]*/, void* stream);
+/* {bodies seen, bodies re-sorted, of which beside the gradient kernel (deferred sorts)}, cumulative */
+int mh_raster_sort_counters3(int T, int N, int V, int F, int H, int W, void* ws, unsigned long long* out_host /*[3]*/, void* stream);
 /* Winners first (round 5): on != 0 (default; MHHIP_RASTER_WINNERS=0 switches it off) = when a body's face lists are sorted, the
  * faces that held one of the five keys of some pixel in the previous launch on this workspace go into a list of their own
  * that every tile of the selection kernel rasterises FIRST, so that the depth cull meets nearly final 4th keys for all other

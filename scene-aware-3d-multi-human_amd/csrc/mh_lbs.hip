@@ -218,6 +218,7 @@ __global__ __launch_bounds__(256) void k_pose_fwd(PoseFwdP p) {
     if (lk) p.lowkey_prev[b] = lk;
     p.lowkey[b] = 0ull;
     p.moved[b] = 0;
+    p.moved[p.B + b] = 0;
   }
 }
 
@@ -631,7 +632,8 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, FWD16_MINB) void k_skin_fwd16(Ski
 #if !(FWD_ABL & 1)
         *(f32x3*)(ng + (size_t)off_r) = nd;
 #endif
-        const bool mv = !(fabsf(fmaf(-yn, p.P.rk, p.P.ra) - rbv[r]) < p.P.thr);    // NaN-safe: anything odd rebuilds
+        const float drow = fabsf(fmaf(-yn, p.P.rk, p.P.ra) - rbv[r]);
+        const bool mv = !(drow < p.P.thr_soft);                                    // NaN-safe: anything odd rebuilds
         const f32x4 th = *(const f32x4*)(sB + 512 + row0 * 16);
         const float ly = *(const float*)(sB + 1024 + row0 * 16);
         const bool zok = Zc > 1e-8f;
@@ -653,7 +655,10 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, FWD16_MINB) void k_skin_fwd16(Ski
           if (c2) atomicMax(bb + 2, mh_ord(xn));
           if (c3) atomicMax(bb + 3, mh_ord(yn));
           if (c4) atomicMax(p.P.lowkey + b, ((unsigned long long)mh_ordu(o[1] + 0.0f) << 32) | (unsigned)~(unsigned)v);
-          if (mv) p.P.moved[b] = 1;
+          // 2: out of the band the kept lists cover -- sorted on the chain, now; 1: on its way out -- sorted beside this cycle's
+          // gradient kernel, for the next launch (k_raster_prepare / r_deferred_sorts)
+          // (plain stores of a constant: every vertex of a moving body reports, same-address atomics would queue up in L2)
+          if (mv) p.P.moved[(drow < p.P.thr ? p.B : 0) + b] = 1;
         }
       }
     }

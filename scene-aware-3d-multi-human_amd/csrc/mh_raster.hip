@@ -468,7 +468,9 @@ __device__ __forceinline__ void r_face_sort(const RasterP& p, int b, int* hist /
       if (f < (unsigned)p.F) atomicOr(&wbits[f >> 5], 1u << (f & 31u));
     }
   }
-  if (tid == 0) p.wstate[b] = have_prev ? 1 : 0;
+  // "sorted with the winners ATTEMPTED", not "found": a body that had keys once and has left the image since (empty previous
+  // window) must not be taken for one that was sorted before it had any -- it would sort again on every launch
+  if (tid == 0) p.wstate[b] = (use_win && p.kvalid[b] != 0) ? 1 : 0;
   int mh = 0, n0 = 0, n1 = 0;
   float z0 = 0.f, z1 = 0.f, ra, rk;
   r_row_affine(p, &ra, &rk);
@@ -583,6 +585,51 @@ __device__ __forceinline__ void r_face_sort(const RasterP& p, int b, int* hist /
   P_MARK(4);
 }
 
+// The deferred sorts of a launch (RasterP::resort), carried by the FIRST workgroups of its gradient kernel before they take
+// their units: the flagged bodies are ranked (every carrier scans the B flags itself: 3 KB, no counter to reset) and carrier w
+// sorts the bodies of rank w, w + carriers, ...  At the head of the kernel a sort costs its 25 us of one CU among 256; at the
+// tail (round 6, first version: workgroup w looked at body w AFTER its units) it cost the kernel those 25 us whenever one of
+// the last workgroups had one to do -- what the sort had cost on the chain.  At most R_DEFER_MAX bodies per launch, the
+// flagged ones of lowest index (~6 us of the kernel): a body that is not served stays flagged and is served by a later
+// launch, or sorted by the preparation once it has used up its whole margin -- where a crowd (RMSprop's first, largest
+// steps: a third of the bodies every cycle) sorts all at once, in parallel, for the price of one.
+#define R_DEFER_WGS 256
+#define R_DEFER_MAX 64
+template <int NT>
+__device__ __forceinline__ void r_deferred_sorts(const RasterP& p, int* lds /* >= r_prepare_lds(p) bytes */) {
+  if (p.resort == nullptr) return;                     // (host: the launch's dynamic LDS does not hold the sort's tables)
+  const int carriers = min((int)gridDim.x, R_DEFER_WGS);
+  if ((int)blockIdx.x >= carriers) return;
+  __shared__ int sd_cnt[NT / 64], sd_pick[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int total = 0;
+  for (int base = 0; base < p.B; base += NT) {
+    const int b = base + tid;
+    const bool f = b < p.B && p.resort[b] != 0;
+    const unsigned long long m = __ballot(f);
+    if (lane == 0) sd_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = total, all = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) { off += w < wave ? sd_cnt[w] : 0; all += sd_cnt[w]; }
+    if (f) {
+      const int rank = off + __popcll(m & ((1ull << lane) - 1ull));
+      if (rank % carriers == (int)blockIdx.x && rank / carriers < 8) sd_pick[rank / carriers] = b;
+    }
+    total += all;
+    __syncthreads();
+  }
+  total = min(total, R_DEFER_MAX);
+  unsigned pacc[8];
+  unsigned long long plast = 0ull;
+  for (int k = 0; k < 8 && (int)blockIdx.x + k * carriers < total; ++k) {
+    const int b = sd_pick[k];
+    r_face_sort<NT>(p, b, lds, p.win[b * 4 + 2], p.win[b * 4 + 3], pacc, plast);      // (ends with a barrier)
+    if (tid == 0) p.stale[b] = 2;
+  }
+  __syncthreads();
+}
+
 // One workgroup per body: NDC projection of the vertices (kept in HBM, 12 B per vertex) + screen window, how far the
 // vertices have moved since the body's face lists were sorted, the sort itself when they moved too far (temporal
 // coherence: the optimiser moves a body by a small fraction of a pixel per cycle; the lists stay a SUPERSET of every
@@ -618,13 +665,14 @@ __global__ __launch_bounds__(RPREP) void k_raster_prepare(RasterP p) {
   // projected: mh_lbs_forward_proj has written the NDC vertices, the motion flag and -- unless nobody reported one of the
   // four extremes -- the box: nothing to read per vertex.  An incomplete box is scanned from the projected vertices and
   // written back, so that the next forward has a complete previous box to filter with.
-  bool scan = true, have_box = false;
+  bool scan = true, have_box = false, soft = false;
   int4 fb = {0, 0, 0, 0};
   if (p.projected) {
     fb = *(const int4*)(p.fbbox + (size_t)b * 4);
     have_box = fb.x != 0x7fffffff && fb.y != 0x7fffffff && fb.z != (int)0x80000000 && fb.w != (int)0x80000000;
     scan = !have_box;
     moved = moved || p.fmoved[b] != 0;
+    soft = p.fmoved[p.B + b] != 0;
   }
   if (scan) {
   const float* vb = (p.projected ? p.ndc : p.verts) + (size_t)b * p.V * 3;
@@ -713,6 +761,7 @@ __global__ __launch_bounds__(RPREP) void k_raster_prepare(RasterP p) {
   const int cap = r_cap(p), ns = min(ncol * nrow, cap), first = b * cap;
   if (tid == 0) {
     p.body_first[b] = first; p.body_ns[b] = ns; p.stale[b] = any_moved;
+    p.resort[b] = (soft && !any_moved && p.margin > 0) ? 1 : 0;      // (r_deferred_sorts, beside this launch's gradient kernel)
     // a body's keys live in a region of its own (the key array has room for a full image per body): where they are does not
     // depend on the other bodies' windows, so the work lists -- which may be a launch old -- carry no addresses
     p.body_koff[b] = (long long)b * p.H * p.W;
@@ -1538,6 +1587,9 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
 #else
 #define RG_TMARK(c) do { } while (0)
 #endif
+  // ---- deferred face sorts (RasterP::resort): the flagged bodies' lists, from this launch's coordinates and the keys the
+  // selection has just written, for the NEXT launch.  Nothing in this kernel reads what a sort writes.
+  r_deferred_sorts<RGB>(p, (int*)gtab);
   // Work items as in k_raster_strip: the listed units (the lists may be a launch old: a listed piece beyond the body's
   // current window is skipped), then per body the pieces its window has gained since (none in a steady sequence).
   int xb = -1, xk = 0, xend = 0;
@@ -1740,6 +1792,8 @@ __global__ __launch_bounds__(RGB) void k_raster_grads_det(RasterP p) {
     }
     if (tid == 0 && lcorr != 0.f) p.sil_corr[b] += lcorr;
   }
+  __syncthreads();
+  r_deferred_sorts<RGB>(p, (int*)rg_tab);
 }
 
 __global__ void k_fill(float* x, size_t n, float v) {
@@ -1778,6 +1832,27 @@ extern "C" int mh_raster_set_sort_margin(int rows) {
   return MH_OK;
 }
 extern "C" int mh_raster_get_sort_margin(void) { return raster_sort_margin(); }
+// deferred sorts: the fraction of the margin from which a body's lists are sorted again beside the gradient kernel (for the
+// next launch) instead of on the chain once the whole margin is used up.  0 (or >= 1): no deferred sorts.
+static float g_raster_defer = -1.f;
+static float raster_sort_defer() {
+  if (g_raster_defer < 0.f) {
+    const char* e = getenv("MHHIP_RASTER_SORT_DEFER");
+    g_raster_defer = e ? (float)atof(e) : 0.6f;
+    if (!(g_raster_defer >= 0.f && g_raster_defer <= 1.f)) g_raster_defer = 0.6f;
+  }
+  return g_raster_defer;
+}
+static float raster_sort_soft(int margin) {
+  const float hard = (float)margin - 0.02f, f = raster_sort_defer();
+  return (f > 0.f && f < 1.f && margin > 0) ? fminf(f * (float)margin, hard) : hard;
+}
+extern "C" int mh_raster_set_sort_defer(float fraction) {
+  MH_CHECK(fraction >= 0.f && fraction <= 1.f, "fraction of the margin: 0..1 (0 or 1: no deferred sorts)");
+  g_raster_defer = fraction;
+  return MH_OK;
+}
+extern "C" float mh_raster_get_sort_defer(void) { return raster_sort_defer(); }
 // test aid: 1 sends every round of the selection kernel down the even-split path (no depth cull, no pair list).  The keys
 // must not depend on the path a round takes (tests/test_raster_paths_gpu.py): the pair arithmetic is spelled out for that.
 static int g_raster_all_even = 0;
@@ -1854,19 +1929,21 @@ static size_t r_carve(RasterP& p, void* ws) {
   p.gunit_total = (int*)c; c += r_align(4);
   p.ns_listed = (int*)c; c += r_align(B * 4);
   p.nu_listed = (int*)c; c += r_align(B * 4);
-  p.sort_count = (unsigned long long*)c; c += r_align(16);
+  p.sort_count = (unsigned long long*)c; c += r_align(24);
   p.pairs = (unsigned long long*)c; c += r_align((2 + 2 * (size_t)R_STRIP_GRID) * 8);
   p.sort_tag = (unsigned long long*)c; c += r_align(B * 8);
   p.sil_corr = (float*)c; c += r_align(B * 4);
   p.kvalid = (int*)c; c += r_align(B * 4);
   p.wstate = (int*)c; c += r_align(B * 4);
+  p.resort = (int*)c; c += r_align(B * 4);
   p.winners_on = raster_winners();
+  p.soft = raster_sort_soft(p.margin);
   p.ctl_end = c;
   p.fbbox = (int*)c; c += r_align(B * 4 * 4);
   p.fbbox_prev = (int*)c; c += r_align(B * 4 * 4);
   p.flowkey = (unsigned long long*)c; c += r_align(B * 8);
   p.flowkey_prev = (unsigned long long*)c; c += r_align(B * 8);
-  p.fmoved = (int*)c; c += r_align(B * 4);
+  p.fmoved = (int*)c; c += r_align(2 * B * 4);
   p.projected = 0;
   p.gkeys = (unsigned long long*)c; c += r_align(B * (size_t)H * W * 5 * 8);
   return (size_t)(c - (char*)ws);
@@ -1992,8 +2069,20 @@ extern "C" int mh_raster_sort_counters(int T, int N, int V, int F, int H, int W,
     MH_HIP(hipMemcpyAsync(out_host, p.sort_count, 16, hipMemcpyDeviceToHost, (hipStream_t)stream));
     MH_HIP(hipStreamSynchronize((hipStream_t)stream));
   } else {            // out_host NULL: reset (a workspace holds anything when it is handed over)
-    MH_HIP(hipMemsetAsync(p.sort_count, 0, 16, (hipStream_t)stream));
+    MH_HIP(hipMemsetAsync(p.sort_count, 0, 24, (hipStream_t)stream));
   }
+  return MH_OK;
+}
+
+// {bodies seen, bodies re-sorted, of which beside the gradient kernel (deferred)}
+extern "C" int mh_raster_sort_counters3(int T, int N, int V, int F, int H, int W, void* ws, unsigned long long* out_host, void* stream) {
+  MH_CHECK(ws && out_host, "null argument");
+  MH_CHECK(T > 0 && N > 0 && V > 0 && F > 0 && H > 0 && W > 0, "empty input");
+  RasterP p;
+  p.B = T * N; p.N = N; p.V = V; p.F = F; p.H = H; p.W = W;
+  r_carve(p, ws);
+  MH_HIP(hipMemcpyAsync(out_host, p.sort_count, 24, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  MH_HIP(hipStreamSynchronize((hipStream_t)stream));
   return MH_OK;
 }
 
@@ -2095,14 +2184,19 @@ static int raster_terms_impl(int T, int N, int V, int F, int H, int W, const flo
     mh_prof_mark(MH_PROF_RASTER_GRADS, 0, st);
     // one workgroup per CU is resident (LDS table); the work-unit count is only known on the device
     const int ggrid = 256 * 6;
+    RasterP pg = p;            // the deferred sorts ride in this launch when its dynamic LDS holds their tables
     if (raster_deterministic()) {
       MH_CHECK(V <= RG_MAXV, "deterministic gradient scatter: model too large for the LDS table");
       static unsigned char attr_det[MH_MAX_DEVICES];
       if (mh_first_on_device(attr_det))
         MH_HIP(hipFuncSetAttribute((const void*)k_raster_grads_det, hipFuncAttributeMaxDynamicSharedMemorySize, ((RG_MAXV + 1) / 2) * 3 * 8));
-      hipLaunchKernelGGL(k_raster_grads_det, dim3(p.B < 4096 ? p.B : 4096), dim3(RGB), (size_t)((V + 1) / 2) * 3 * 8, st, p);
-    } else if (use_tab) hipLaunchKernelGGL(k_raster_grads<true>, dim3(ggrid), dim3(RGB), tab, st, p);
-    else hipLaunchKernelGGL(k_raster_grads<false>, dim3(ggrid), dim3(RGB), tab, st, p);
+      if (r_prepare_lds(p) > (size_t)((V + 1) / 2) * 3 * 8) pg.resort = nullptr;
+      hipLaunchKernelGGL(k_raster_grads_det, dim3(p.B < 4096 ? p.B : 4096), dim3(RGB), (size_t)((V + 1) / 2) * 3 * 8, st, pg);
+    } else {
+      if (r_prepare_lds(p) > tab) pg.resort = nullptr;
+      if (use_tab) hipLaunchKernelGGL(k_raster_grads<true>, dim3(ggrid), dim3(RGB), tab, st, pg);
+      else hipLaunchKernelGGL(k_raster_grads<false>, dim3(ggrid), dim3(RGB), tab, st, pg);
+    }
     MH_LAUNCH_CHECK();
     mh_prof_mark(MH_PROF_RASTER_GRADS, 1, st);
   }
@@ -2214,6 +2308,7 @@ extern "C" int mh_raster_forward_targets(int T, int N, int V, int F, int H, int 
   out->rk = (float)H / range;
   out->ra = (float)H - 0.5f - 0.5f * (float)H;
   out->thr = (float)p.margin - 0.02f;
+  out->thr_soft = p.soft;
   // half a pixel: the optimiser moves a body by a small fraction of a pixel per cycle; a faster body is scanned
   out->slack_ndc = 0.5f * 2.0f / (float)(H < W ? H : W);
   out->slack_y = 0.005f;

@@ -69,7 +69,7 @@ struct RasterP {
   float* rowb;               // [B][V] continuous pixel-row coordinate of every vertex at the body's last sort
   unsigned long long* sort_tag;   // [B] validity tag of the body's lists (a fresh workspace holds anything)
   char* ctl_end;             // (host) end of the control words
-  unsigned long long* sort_count;  // [2] launches x bodies seen, bodies rebuilt (cumulative)
+  unsigned long long* sort_count;  // [3] launches x bodies seen, bodies rebuilt, of which deferred (cumulative)
   unsigned long long* pairs;       // [2 + 2 x R_STRIP_GRID]: launches, -, then per workgroup: candidate (face, pixel-centre) pairs,
                                    // pairs evaluated after the depth cull (cumulative); NULL unless mh_profile_enable(1)
   // what mh_lbs_forward_proj leaves here (include/mhmocap_hip.h, mh_fwd_proj): with projected != 0 the preparation reads
@@ -79,11 +79,17 @@ struct RasterP {
   int* fbbox_prev;           // [B][4]
   unsigned long long* flowkey;       // [B]
   unsigned long long* flowkey_prev;  // [B]
-  int* fmoved;               // [B]
+  int* fmoved;               // [2][B]: left the band / on the way out (mh_fwd_proj.moved)
   // winners' list of the face sort (round 5, r_face_sort)
   int winners_on;            // mh_raster_set_winners / MHHIP_RASTER_WINNERS (default 1)
   int* kvalid;               // [B] 1 = the body's key region holds the keys of a launch on this workspace
   int* wstate;               // [B] 1 = the body's lists were sorted with a winners' list
+  // deferred sorts (round 6): a body whose vertices are on their way out of the band its kept lists cover (mh_fwd_proj.thr_soft
+  // <= motion < thr) is still served by those lists THIS launch; k_raster_prepare only flags it, and its lists are sorted
+  // again beside this launch's gradient kernel (r_deferred_sorts), from the same coordinates and the keys the selection has
+  // just written -- off the chain.  Only a jump of a whole margin inside one cycle sorts on the chain.
+  int* resort;               // [B] 1 = sort this body's lists beside the gradient kernel
+  float soft;                // rows (mh_raster_set_sort_defer; >= margin - 0.02: no deferred sorts)
 };
 
 #define R_SHORT 2            // faces of up to R_SHORT + 1 rows go to the two short lists, taller ones to the third
@@ -102,9 +108,9 @@ __device__ __forceinline__ int r_cap(const RasterP& p) { return p.max_strips / p
 template <int NT>
 __device__ __forceinline__ void r_finalize_lists(const RasterP& p) {
   __shared__ int f_hist[R_NCLS], f_cur[R_NCLS], f_ghist[64], f_gcur[64];
-  __shared__ int f_stale;
+  __shared__ int f_stale, f_defer;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cap = r_cap(p);
-  if (tid == 0) f_stale = 0;
+  if (tid == 0) { f_stale = 0; f_defer = 0; }
   if (tid < R_NCLS) { f_hist[tid] = 0; f_ghist[tid] = 0; }
   __syncthreads();
   auto unit_class = [&](int rem) { return 1 + (31 - min(31, rem * 32 / RG_UNIT)); };
@@ -134,6 +140,7 @@ __device__ __forceinline__ void r_finalize_lists(const RasterP& p) {
     if (nfull) atomicAdd(&f_ghist[0], (int)min(nfull, (long long)p.max_units));
     if (rem) atomicAdd(&f_ghist[unit_class(rem)], 1);
     if (st) atomicAdd(&f_stale, 1);
+    if (st == 2) atomicAdd(&f_defer, 1);
     if (b < p.B) { p.ns_listed[b] = ns; p.nu_listed[b] = (int)min(nfull, (long long)p.max_units) + (rem ? 1 : 0); }
   }
   __syncthreads();
@@ -149,6 +156,7 @@ __device__ __forceinline__ void r_finalize_lists(const RasterP& p) {
         p.total[0] = min(incl, p.max_strips);
         p.sort_count[0] += (unsigned long long)p.B;
         p.sort_count[1] += (unsigned long long)f_stale;
+        p.sort_count[2] += (unsigned long long)f_defer;     // ... of which beside the gradient kernel (r_deferred_sorts)
       } else {
         p.gunit_total[0] = min(incl, p.max_units);
       }

@@ -31,7 +31,7 @@ class FwdProj(ctypes.Structure):
     """mh_fwd_proj of include/mhmocap_hip.h: where the LBS forward's projection epilogue writes for one raster workspace"""
     _fields_ = [('s', ctypes.c_float), ('w1', ctypes.c_float), ('h1', ctypes.c_float),
                 ('ra', ctypes.c_float), ('rk', ctypes.c_float), ('thr', ctypes.c_float),
-                ('slack_ndc', ctypes.c_float), ('slack_y', ctypes.c_float),
+                ('slack_ndc', ctypes.c_float), ('slack_y', ctypes.c_float), ('thr_soft', ctypes.c_float),
                 ('ndc', vp), ('rowb', vp), ('bbox', vp), ('bbox_prev', vp), ('lowkey', vp), ('lowkey_prev', vp),
                 ('moved', vp), ('clear', vp), ('clear_n', ctypes.c_ulonglong)]
 
@@ -149,10 +149,13 @@ def lib():
         L.mh_raster_terms_phase.argtypes = [ctypes.c_int] * 6 + [c_float_p] + [vp] * 12 + [ctypes.c_float] * 3 + [vp] * 8 + [ctypes.c_int, vp]
         L.mh_raster_set_deterministic.argtypes = [ctypes.c_int]
         L.mh_raster_set_sort_margin.argtypes = [ctypes.c_int]
+        L.mh_raster_set_sort_defer.argtypes = [ctypes.c_float]
+        L.mh_raster_get_sort_defer.restype = ctypes.c_float
         L.mh_raster_set_path.argtypes = [ctypes.c_int]
         L.mh_raster_set_winners.argtypes = [ctypes.c_int]
         L.mh_raster_pair_counters.argtypes = [ctypes.c_int] * 6 + [vp, ctypes.POINTER(ctypes.c_ulonglong), vp]
         L.mh_raster_sort_counters.argtypes = [ctypes.c_int] * 6 + [vp, ctypes.POINTER(ctypes.c_ulonglong), vp]
+        L.mh_raster_sort_counters3.argtypes = [ctypes.c_int] * 6 + [vp, ctypes.POINTER(ctypes.c_ulonglong), vp]
         L.mh_raster_terms_phase_log.argtypes = [ctypes.c_int] * 6 + [c_float_p] + [vp] * 12 + [ctypes.c_float] * 3 + [vp] * 8 + [ctypes.c_int, vp, vp, vp]
         L.mh_raster_terms_projected.argtypes = [ctypes.c_int] * 6 + [c_float_p] + [vp] * 12 + [ctypes.c_float] * 3 + [vp] * 8 + [ctypes.c_int, vp, vp, ctypes.c_int, vp]
         L.mh_raster_forward_targets.argtypes = [ctypes.c_int] * 6 + [c_float_p, vp, ctypes.POINTER(FwdProj)]

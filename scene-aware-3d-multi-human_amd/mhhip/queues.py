@@ -19,7 +19,9 @@ So the queue is CHOSEN, per graph, by looking:
   cycle: the side branch has ~0.35 ms of slack under the selection kernel, a short spin hides in it): a replay that takes
   0.5 ms longer than the unspun ones has its chain or its side branch on that queue.  The scene update gets the first lane
   that neither stretches a replay nor shares the launch stream's queue.  Cost: one or two stretched cycles per graph
-  (1-2 ms of a 200-ms fit), no stream created or destroyed, nothing that touches the arithmetic.
+  (1-2 ms of a 200-ms fit), no stream created or destroyed, nothing that touches the arithmetic;
+* ``LanePicker``: once the scene update runs, it spends four cycles on each lane the test left (and on the pooled torch
+  stream of rounds 2-5) and keeps the one with the shortest cycles.
 
 MHHIP_QUEUE_PLAN=0 switches it off (the scene update then runs on a pooled torch stream, as in rounds 2-5).
 """
@@ -151,6 +153,44 @@ class LaneTest(object):
         self.plan.stats['tests'] += 1
         self.plan.stats['busy'].append([self.cand.index(l) for l in self.busy])
         return True
+
+
+class LanePicker(object):
+    """Closed loop behind the lane test: the scene update runs ``per`` cycles on each candidate stream, the candidate with the
+    shortest cycles (median, the first cycle after a switch left out) keeps it.  The lane test says which queues the graph
+    occupies; what a cycle costs beside the update is only known by running it -- at C3 the candidates that pass the test
+    still differ by 0.07 ms per cycle (which other streams of the process share their queues, and with what, cannot be seen).
+    ``tick(main)`` is called at the start of every cycle that launches a scene update; it returns the stream that update
+    should use, or None for "stay".  Nothing waits on the host: the marks are read once the device has passed them."""
+
+    def __init__(self, cands, per=4):
+        self.cands = list(cands)
+        self.per = int(per)
+        self.marks = []
+        self.done = len(self.cands) <= 1
+        self.best = None
+        self.ms = None
+
+    def tick(self, stream):
+        if self.done:
+            return None
+        total = self.per * len(self.cands)
+        n = len(self.marks)
+        if n <= total:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(stream)
+            self.marks.append(ev)
+        if n < total:
+            return self.cands[n // self.per] if n % self.per == 0 else None
+        if not self.marks[-1].query():
+            return None
+        self.ms = []
+        for i in range(len(self.cands)):
+            d = [self.marks[j].elapsed_time(self.marks[j + 1]) for j in range(i * self.per + 1, (i + 1) * self.per)]
+            self.ms.append(float(np.median(d)))
+        self.best = int(np.argmin(self.ms))
+        self.done = True
+        return self.cands[self.best]
 
 
 def plan(device):

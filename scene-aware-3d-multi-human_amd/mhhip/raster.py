@@ -70,6 +70,13 @@ class RasterTerms(object):
         check(_lib.lib().mh_raster_sort_counters(*self.dims, ptr(self.ws), out, _lib.stream_ptr(e.dev)))
         return int(out[0]), int(out[1])
 
+    def sort_counters3(self, e):
+        """(bodies seen, bodies re-sorted, of which beside the gradient kernel: off the chain), cumulative"""
+        import ctypes
+        out = (ctypes.c_ulonglong * 3)()
+        check(_lib.lib().mh_raster_sort_counters3(*self.dims, ptr(self.ws), out, _lib.stream_ptr(e.dev)))
+        return int(out[0]), int(out[1]), int(out[2])
+
     def pair_counters(self, e):
         """(launches, candidate pairs, evaluated pairs) of the selection kernel, counted while mh_profile_enable(1)"""
         import ctypes
@@ -104,6 +111,15 @@ def set_sort_margin(rows):
     old = L.mh_raster_get_sort_margin()
     check(L.mh_raster_set_sort_margin(int(rows)))
     return int(old)
+
+
+def set_sort_defer(fraction):
+    """mh_raster_set_sort_defer (fraction of the margin from which a body is re-sorted beside the gradient kernel; 0 = never);
+    returns the previous setting"""
+    L = _lib.lib()
+    old = float(L.mh_raster_get_sort_defer())
+    check(L.mh_raster_set_sort_defer(float(fraction)))
+    return old
 
 
 def set_winners(on):

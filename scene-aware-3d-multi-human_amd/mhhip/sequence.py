@@ -203,6 +203,7 @@ class SequenceEngine(object):
             torch.cuda.current_stream(self.dev).synchronize()
             self._graphs = {}
             self._lane_tests = {}
+            self._pickers = {}
         self._scene_dev = None
         self.pose2d = _dev(pose2d, self.dev).view(self.B, 17, 3)
         self.poses_ref = _dev(poses_ref, self.dev).view(self.B, 72)
@@ -310,6 +311,27 @@ class SequenceEngine(object):
             return
         stream.wait_stream(d['stream'])
         d['stream'] = stream
+
+    def _scene_pick(self, key):
+        """which stream the scene update runs on is settled by trying (mhhip/queues.py LanePicker): the candidates are the lanes
+        the lane test of this graph found idle (all lanes off the launch stream's queue when the test ran beside a live scene
+        update, or not at all) and the pooled stream of rounds 2-5"""
+        if not hasattr(self, '_pickers'):
+            self._pickers = {}
+        pk = self._pickers.get(key)
+        main = torch.cuda.current_stream(self.dev)
+        if pk is None:
+            if key not in getattr(self, '_graphs', {}) and ('full+scene',) + key not in getattr(self, '_graphs', {}):
+                return                                   # (the capturing cycle: not a replay yet)
+            pl = queues.plan(self.dev)
+            lt = getattr(self, '_lane_tests', {}).get(('full+scene',) + key)
+            clean = lt is not None and lt.done and getattr(lt, 'clean', False)
+            raws = [l for l in lt.cand if l not in lt.busy] if clean else pl.free_lanes(main.cuda_stream)
+            cands = [pl.view(r) for r in raws] + [_shared_stream(self.dev, 'scene')]
+            pk = self._pickers[key] = queues.LanePicker(cands)
+        st = pk.tick(main)
+        if st is not None:
+            self._scene_move(st)
 
     def scene_device_update(self):
         """Launch one scene update from the current depth-range leaves into the back set (own stream)."""
@@ -939,7 +961,7 @@ class SequenceEngine(object):
         # time), the sort margin (a kernel argument by value) and the LBS arithmetic mode
         L = _lib.lib()
         glob = (L.mh_raster_get_deterministic(), L.mh_raster_get_sort_margin(), L.mh_lbs_get_mode(), L.mh_raster_get_path(),
-                L.mh_raster_get_winners()) if raster is not None else None
+                L.mh_raster_get_winners(), float(L.mh_raster_get_sort_defer())) if raster is not None else None
         hk = None if self.halo is None else (bool(self.halo.get('has_prev')), bool(self.halo.get('has_next')), self.halo.get('poses') is not None)
         return (rast, scene, self.verts_filt is not None and self.pT_filt is not None, self._filt_gate, hk, bt, glob)
 
@@ -972,11 +994,14 @@ class SequenceEngine(object):
         else:
             # a new graph that runs beside the device-side scene update: its first replays also find out which hardware queues
             # it keeps busy, and the scene update moves to one it does not (mhhip/queues.py)
-            want = self._scene_dev is not None and queues.enabled() and str(key[0]).startswith('full')      # (the cycle's graphs only)
+            want = self._scene_dev is not None and queues.enabled() and str(key[0]).startswith('full') and os.environ.get('MHHIP_LANE_TEST') != '0'      # (the cycle's graphs only)
             lt = self._lane_tests.get(key) if want else None
             if lt is None and want and key not in self._lane_tests:
                 lt = self._lane_tests[key] = queues.LaneTest(queues.plan(self.dev), torch.cuda.current_stream(self.dev).cuda_stream)
+                lt.clean = True
             if lt is not None and not lt.done and not getattr(lt, 'recorded', False):
+                if self._scene_dev.get('snap_pending') or self._scene_pending:
+                    lt.clean = False              # a scene update in flight: a spun lane may stall IT, not the graph
                 main = torch.cuda.current_stream(self.dev)
                 lt.before(main)
                 g.replay()
@@ -993,6 +1018,8 @@ class SequenceEngine(object):
         key = self._graph_key(raster)
         self._flush_log()
         self._flush_phase()
+        if scene_update and queues.enabled() and os.environ.get('MHHIP_LANE_PICK') != '0':
+            self._scene_pick(key)
         if scene_update:
             self.scene_device_mark()
         if self._scene_dev is not None:

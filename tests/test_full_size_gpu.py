@@ -259,9 +259,11 @@ def test_kept_face_lists_give_the_same_selection_as_a_fresh_sort(smpl_struct, sm
             lr *= 0.99
             if c == 19:                                          # a jump of a few pixels for every fourth frame
                 e.leaf('poses_T')[::4, :, 1] += 0.08
-        seen, rebuilt = kept.sort_counters(e)
+        seen, rebuilt, deferred = kept.sort_counters3(e)
     finally:
         set_sort_margin(old)
     assert seen == 40 * e.B
-    print('face lists rebuilt for %d of %d (body, cycle) pairs' % (rebuilt, seen))
-    assert e.B <= rebuilt < (0.6 if H >= 100 else 0.9) * seen     # everything once, the jump, the early large steps -- not every cycle
+    print('face lists rebuilt for %d of %d (body, cycle) pairs, %d of them beside the gradient kernel' % (rebuilt, seen, deferred))
+    # everything once, the jump, the early large steps -- not every cycle (round 6: the sorts that ride beside the gradient kernel,
+    # tests/test_deferred_sort_gpu.py, are not the chain's)
+    assert e.B <= rebuilt - deferred < (0.6 if H >= 100 else 0.9) * seen

@@ -14,36 +14,18 @@
 //   k_pose_bwd   per body: adjoint of the chain and of rodrigues, priors-free
 #include <algorithm>
 #include <mutex>
+#include <unordered_map>
 
 #include "mh_common.h"
 #include "mh_raster_p.h"
+#include "mh_experiment.h"
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 // =============================================================================================
 // forward
 // =============================================================================================
-// timing builds (tools/mkvariant.sh x mh_lbs.hip -DLBS_TIMING; tools/time_lbs_phases.py): wave-elapsed shader cycles of the two
-// skinning kernels by phase, summed over the waves.  forward: 0 staging, 1 constants + matrix phase, 2 epilogue, 3 everything,
-// 4 waves; backward: 8 staging, 9 stage, 10 wait A, 11 blend, 12 wait B, 13 matrix phase, 14 everything, 15 waves
-#ifdef LBS_TIMING
-__device__ unsigned long long g_lbs_t[16];
-#define L_T0() unsigned long long lt_ = __builtin_readcyclecounter(); const unsigned long long lt_begin = lt_; unsigned lacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define L_MARK(c) do { const unsigned long long t1_ = __builtin_readcyclecounter(); lacc[c] += (unsigned)(t1_ - lt_); lt_ = t1_; } while (0)
-#define L_OUT(base, n) do { if ((threadIdx.x & 63) == 0) { for (int c_ = 0; c_ < (n); ++c_) atomicAdd(&g_lbs_t[(base) + c_], (unsigned long long)lacc[c_]); \
-    atomicAdd(&g_lbs_t[(base) + (n)], __builtin_readcyclecounter() - lt_begin); atomicAdd(&g_lbs_t[(base) + (n) + 1], 1ull); } } while (0)
-extern "C" int mh_lbs_debug_timing(unsigned long long* out16) {
-  MH_HIP(hipDeviceSynchronize());
-  MH_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_lbs_t), sizeof(g_lbs_t)));
-  unsigned long long z[16] = {0};
-  MH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_lbs_t), z, sizeof(z)));
-  return MH_OK;
-}
-#else
-#define L_T0() do { } while (0)
-#define L_MARK(c) do { } while (0)
-#define L_OUT(base, n) do { } while (0)
-#endif
+// (phase probes L_T0 / L_MARK / L_OUT: csrc/mh_experiment.h -- empty in the product build)
 
 struct PoseFwdP {
   int B, NB, G;
@@ -366,10 +348,8 @@ __global__ __launch_bounds__(256, 2) void k_skin_fwd(SkinFwdP p) {
 // transforms (36 KB) are staged in LDS once.  Per 16-k step a wave issues 2 ds_read_b128 (A operand: both terms),
 // six 16-byte global loads (B operand: three components x two terms, double buffered) and nine MFMAs.
 // ---------------------------------------------------------------------------------------------------------------
-#ifndef FWD_ABL
-#define FWD_ABL 0        // timing experiments only (tools/ab_fwd_proj.sh, with MHHIP_LBS_SELFCHECK=0): 1 no NDC store, 2 no row loads, 4 no reports, 8 v_rcp instead of
-                         // the IEEE division, 32 one bone transform per row instead of four, 64 no vertex store, 256 one k-step instead of fourteen
-#endif
+// (round 5's timing-only ablation builds of this kernel -- no NDC store, no row loads, one k-step, ... : DESIGN App. A has the
+// numbers -- lived here as FWD_ABL bits; they are gone from the product kernel)
 #define MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
 struct SkinFwd16P {
@@ -506,7 +486,7 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, FWD16_MINB) void k_skin_fwd16(Ski
 #pragma unroll
     for (int i = 0; i < 6; ++i) bq[st][i] = Dw[(st * 6 + i) * 64];
 #pragma unroll
-  for (int s16 = 0; s16 < ((FWD_ABL & 256) ? 1 : MH_KD / 16); ++s16) {      // (FWD_ABL & 256, timing only: one k-step instead of fourteen)
+  for (int s16 = 0; s16 < MH_KD / 16; ++s16) {
     const int cur = s16 % FWD16_STAGES, nxt = (s16 + FWD16_STAGES - 1) % FWD16_STAGES;
     if (s16 + FWD16_STAGES - 1 < MH_KD / 16) {
 #pragma unroll
@@ -514,15 +494,6 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, FWD16_MINB) void k_skin_fwd16(Ski
     }
     __builtin_amdgcn_sched_barrier(0);   // keep the ring: the scheduler otherwise sinks each load next to its first use
     const f16x8 ah = sF[(s16 * 2) * 64 + lane], al = sF[(s16 * 2 + 1) * 64 + lane];
-#if (FWD_ABL & 16)      // experiment build: no matrix instructions in the form WITHOUT the projection epilogue (sums of operand bits keep the loads alive)
-    if (!PROJ) {
-    ax[0] += (float)ah[0] + (float)bq[cur][0][0] + (float)bq[cur][1][0];
-    ay[0] += (float)al[0] + (float)bq[cur][2][0] + (float)bq[cur][3][0];
-    az[0] += (float)bq[cur][4][0] + (float)bq[cur][5][0];
-    } else {
-#else
-    {
-#endif
     ax = MFMA_F16(ah, bq[cur][0], ax);
     ay = MFMA_F16(ah, bq[cur][2], ay);
     az = MFMA_F16(ah, bq[cur][4], az);
@@ -532,7 +503,6 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, FWD16_MINB) void k_skin_fwd16(Ski
     ax = MFMA_F16(al, bq[cur][0], ax);
     ay = MFMA_F16(al, bq[cur][2], ay);
     az = MFMA_F16(al, bq[cur][4], az);
-    }
     __builtin_amdgcn_sched_barrier(0);
   }
   L_MARK(1);
@@ -561,11 +531,7 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, FWD16_MINB) void k_skin_fwd16(Ski
       const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
       const unsigned off4 = FULL ? (unsigned)(4 * lh * p.V + v) * 4u + (unsigned)((r & 3) + 8 * (r >> 2)) * ((unsigned)p.V * 4u)
                                  : (unsigned)(min(row, last_row) * p.V + v) * 4u;
-#if (FWD_ABL & 2)
-      rbv[r] = (float)off4;
-#else
       rbv[r] = *(const float*)(rbg + (size_t)off4);
-#endif
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -579,9 +545,6 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, FWD16_MINB) void k_skin_fwd16(Ski
     for (int e = 0; e < 12; ++e) T[e] = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-#if (FWD_ABL & 32)      // timing only: ONE transform per row instead of four gathers (no blend traffic)
-      if (k > 0) continue;
-#endif
       const f32x4* Aj = (const f32x4*)(aB[k] + row0 * (MH_NJ * 48));
       const f32x4 q0 = Aj[0], q1 = Aj[1], q2 = Aj[2];
 #pragma unroll
@@ -607,31 +570,17 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, FWD16_MINB) void k_skin_fwd16(Ski
     const f32x3 o = {fmaf(st[0], x0, st[1]), fmaf(st[0], x1, st[2]), fmaf(st[0], x2, st[3])};
     if (FULL || g * 32 + row0 + 4 * lh < p.B) {
       const unsigned off_r = lane_off + (unsigned)row0 * row_b32;
-#if (FWD_ABL & 64)      // timing only: no vertex store (kept alive by an impossible condition)
-      if (o[0] == 12345.f)
-#endif
       *(f32x3*)(vg + (size_t)off_r) = o;
-#ifdef ABL_NOQ_STORE
-      if (qg && vp0 == 12345.f) {
-#else
       if (qg) {
-#endif
         const f32x3 q = {vp0, vp1, vp2};
         *(f32x3*)(qg + (size_t)off_r) = q;
       }
       if (PROJ) {
         // the same three roundings per coordinate as k_raster_prepare's own projection (multiply, IEEE divide, add)
         const float Zc = o[2];
-#if (FWD_ABL & 8)
-        const float rz_ = __builtin_amdgcn_rcpf(Zc);
-        const float xn = p.P.s * (-o[0]) * rz_ + p.P.w1, yn = p.P.s * (-o[1]) * rz_ + p.P.h1;
-#else
         const float xn = p.P.s * (-o[0]) / Zc + p.P.w1, yn = p.P.s * (-o[1]) / Zc + p.P.h1;
-#endif
         const f32x3 nd = {xn, yn, Zc};
-#if !(FWD_ABL & 1)
         *(f32x3*)(ng + (size_t)off_r) = nd;
-#endif
         const float drow = fabsf(fmaf(-yn, p.P.rk, p.P.ra) - rbv[r]);
         const bool mv = !(drow < p.P.thr_soft);                                    // NaN-safe: anything odd rebuilds
         const f32x4 th = *(const f32x4*)(sB + 512 + row0 * 16);
@@ -641,11 +590,7 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, FWD16_MINB) void k_skin_fwd16(Ski
         const bool c4 = o[1] > ly;
         // ONE wave-uniform branch per row (a scalar test of the combined lane mask): nothing below it is on the path of a row
         // in which no vertex reports -- most rows
-#if (FWD_ABL & 4)
-        if (__builtin_amdgcn_ballot_w64((c0 || c1 || c2 || c3 || c4 || mv) && xn == 12345.f) != 0ull) {
-#else
         if (__builtin_amdgcn_ballot_w64(c0 || c1 || c2 || c3 || c4 || mv) != 0ull) {
-#endif
           // (the asm keeps the sixteen rows' slot addresses from being computed ahead of the matrix phase and spilled)
           int b = g * 32 + row0 + 4 * lh;
           asm volatile("" : "+v"(b));
@@ -692,27 +637,26 @@ static FwdWs carve_fwd(void* ws, int G) {
 // What other translation units may read of a forward workspace (mh_keypoints.hip: the key-point term is computed from the pose
 // features and bone transforms the LAST forward on that workspace left): ONE definition of the layout, and a record of which
 // workspaces hold a forward of how many bodies (the layout was re-derived by hand over there).
+// (A map that only grows -- ADVICE r05: the 64-slot table of round 5 evicted by address bits, and every 2-MiB-aligned allocator
+// block hashed to slot 0: a forward on a second workspace between a forward and its key-point term made the check fail on a
+// correct call.  An address the allocator hands out again is noted again by the forward that uses it.)
 static std::mutex g_fwd_seen_mu;
-static struct { const void* ws; int B; } g_fwd_seen[64];
+static std::unordered_map<const void*, int>& fwd_seen() {
+  static std::unordered_map<const void*, int> m;
+  return m;
+}
 static void fwd_note(const void* ws, int B) {
   std::lock_guard<std::mutex> lk(g_fwd_seen_mu);
-  int slot = -1;
-  for (int i = 0; i < 64; ++i) {
-    if (g_fwd_seen[i].ws == ws) { slot = i; break; }
-    if (slot < 0 && !g_fwd_seen[i].ws) slot = i;
-  }
-  if (slot < 0) slot = (int)(((uintptr_t)ws >> 8) & 63);          // (table full: overwrite)
-  g_fwd_seen[slot].ws = ws; g_fwd_seen[slot].B = B;
+  fwd_seen()[ws] = B;
 }
 int mh_lbs_forward_views(int B, const void* ws, const float** featT, const float** A, const float** scale) {
   MH_CHECK(ws && B > 0 && featT && A && scale, "null argument");
   {
     std::lock_guard<std::mutex> lk(g_fwd_seen_mu);
-    int found = 0;
-    for (int i = 0; i < 64; ++i)
-      if (g_fwd_seen[i].ws == ws) found = g_fwd_seen[i].B;
-    MH_CHECK(found == B, "this workspace does not hold an LBS forward of this many bodies: the key-point term reads the pose features "
-                         "and bone transforms of the forward that immediately preceded it on the same workspace");
+    const auto it = fwd_seen().find(ws);
+    MH_CHECK(it != fwd_seen().end() && it->second == B,
+             "this workspace does not hold an LBS forward of this many bodies: the key-point term reads the pose features "
+             "and bone transforms of the forward that immediately preceded it on the same workspace");
   }
   FwdWs w = carve_fwd(const_cast<void*>(ws), mh_groups(B));
   *featT = w.featT; *A = w.A; *scale = w.scale;
@@ -1317,14 +1261,9 @@ __global__ __launch_bounds__(256, SB_OCC) void k_skinbwd16(Bwd16P p) {
       // vertex has zero rows in Dt16 / W16; only the plain sum of g (the translation gradient) masks them, below.
       const int b = g * 32 + fr + 16 * k;
       const size_t o = ((size_t)(b < p.B ? b : p.B - 1) * p.V + (v < p.V ? v : p.V - 1)) * 3;
-#ifndef ABL_NOQ_LOAD
       rq[k] = *(const f32x3*)(p.vposed + o);
-#endif
       rg[k] = (f32x3){0.f, 0.f, 0.f};
       if (p.gverts) rg[k] = *(const f32x3*)(p.gverts + o);
-#ifdef ABL_NOQ_LOAD
-      rq[k] = rg[k] + 1.f;
-#endif
     }
   };
   // skinning rows and key-point head rows of the thread's vertex pair: requested AHEAD of the block's B operands
@@ -1909,11 +1848,6 @@ extern "C" int mh_lbs_backward_ex(const mh_model* m, int B, int NB, const float*
                            gxscale, ws, ws2, stream);
 }
 
-// (developer aid for scheduling experiments, not in the public header) 0 = the whole backward, 1 = the skinning adjoint only,
-// 2 = the pose adjoint + per-person reduction only: lets a caller put a stream join between the two halves
-static int g_bwd_phase = 0;
-extern "C" int mh_lbs_debug_backward_phase(int phase) { g_bwd_phase = phase; return MH_OK; }
-
 static int lbs_backward_impl(const mh_model* m, int B, int NB, const float* betas, const float* poses, const float* rotmats,
                              const float* vposed, const float* gverts, const float* gjoints, const float* gposed,
                              float* gposes, float* grotmats, float* gtransl, float* gbetas, float* gxscale,
@@ -1927,8 +1861,7 @@ static int lbs_backward_impl(const mh_model* m, int B, int NB, const float* beta
   const int G = mh_groups(B), G16 = 2 * G, CH = split16 ? bwd16_chunks(G) : bwd_chunks(G16);
   FwdWs fw = carve_fwd(ws, G);
   BwdWs bw = carve_bwd(ws2, G, CH + 1);      // (+ 1: the chunk slot of mh_keypoint_terms, always laid out)
-  if (g_bwd_phase == 2) {
-  } else if (split16) {
+  if (split16) {
     Bwd16P sp;
     sp.B = B; sp.G = G; sp.V = m->V; sp.VP = m->VP; sp.nw = m->nw; sp.CH = CH;
     sp.PB = (m->VP / 16 + CH - 1) / CH;
@@ -1967,7 +1900,6 @@ static int lbs_backward_impl(const mh_model* m, int B, int NB, const float* beta
   MH_LAUNCH_CHECK();
   mh_prof_mark(MH_PROF_SKIN_BWD, 1, st);
   }
-  if (g_bwd_phase == 1) return MH_OK;
   PoseBwdP pp;
   pp.B = B; pp.NB = NB; pp.G = G; pp.CH = CH + (kp_chunk ? 1 : 0);
   pp.betas = betas; pp.poses = poses; pp.gjoints = gjoints;

@@ -30,6 +30,7 @@
 // two of them per batch).
 #include "mh_common.h"
 #include "mh_raster_p.h"
+#include "mh_experiment.h"
 
 #define RS_EMPTY 0xffffffffffffffffull
 #define R_KEPS 1e-8f
@@ -418,15 +419,6 @@ __device__ __forceinline__ int r_tile_class(const RasterP& p, const int* rs, int
 // Two classes per row: the faces whose class (sign of the screen-space area) is nearer to the camera on average (for a
 // closed mesh: the ones looking at it) come first in fsort, so that a tile rasterises them first and the depth cull of
 // k_raster_strip then removes most of the far-side candidates.  row_start: [2][H+1] (+ total), class-major in that order.
-// timing builds 6 / 7 (-DR_TIMING=6|7, tools/pair_stats.py): elapsed shader cycles of k_raster_prepare's workgroups that SORT,
-// by phase: 0 window + motion test, 1 histogram clear + row coordinates, 2 first pass (gathers, row ranges, histogram),
-// 3 reductions + scan, 4 second pass (placement), 5 tiles, 6 everything, 7 number of sorting workgroups
-#if defined(R_TIMING) && R_TIMING >= 6
-__device__ unsigned long long g_prep_t[8];
-#define P_MARK(c) do { const unsigned long long t1_ = __builtin_readcyclecounter(); pacc[c] += (unsigned)(t1_ - plast); plast = t1_; } while (0)
-#else
-#define P_MARK(c) do { } while (0)
-#endif
 // WINNERS FIRST (round 5).  The depth cull of k_raster_strip only bites once a pixel's own K=4 list has filled, and the
 // faces that fill it are nearly the same from launch to launch: the faces that ended the PREVIOUS launch in some pixel's
 // five keys ("winners", ~18 % of a body's faces) go into a list of their own that every tile rasterises first -- after a
@@ -776,18 +768,7 @@ __global__ __launch_bounds__(RPREP) void k_raster_prepare(RasterP p) {
     p.strip_col0[s] = c0; p.strip_cols[s] = nc;
     p.strip_cls[s] = r_tile_class(p, rs, mh, r0, nr, nc);
   }
-#if defined(R_TIMING) && R_TIMING >= 6
-  if (p.pairs && tid == 0 && (p.margin == 0 || any_moved)) {
-    P_MARK(5);
-    pacc[6] = (unsigned)(__builtin_readcyclecounter() - pbegin);
-    pacc[7] = 1;
-    unsigned long long* slot = p.pairs + 2 + 2 * (size_t)(blockIdx.x % R_STRIP_GRID);
-    const int c = (R_TIMING - 6) * 4;
-    atomicAdd(slot, (unsigned long long)pacc[c] | ((unsigned long long)pacc[c + 1] << 32));
-    atomicAdd(slot + 1, (unsigned long long)pacc[c + 2] | ((unsigned long long)pacc[c + 3] << 32));
-    if (blockIdx.x == 0) p.pairs[0] += 1ull;
-  }
-#endif
+  P_TIMING_FLUSH();
 }
 
 __global__ __launch_bounds__(RLISTS) void k_raster_lists(RasterP p) { r_finalize_lists<RLISTS>(p); }
@@ -843,15 +824,6 @@ __device__ __forceinline__ void r_tile_depth_sums(const RasterP& p, int s, int b
 }
 
 #define RW (RB / 64)         // waves per tile workgroup
-// timing builds (tools/mkvariant.sh ... -DR_TIMING=1|2): wave-elapsed shader cycles per phase of k_raster_strip, summed over
-// the waves into the pair-counter slots (units of 1024 cycles; four phases per build, two 32-bit halves per counter):
-// 0 tile prologue, 1 round head (gathers issued, box, staging, scan), 2 cull walk + pair list, 3 pair evaluation,
-// 4 even-split path, 5 wait for the tile's other waves, 6 tile epilogue, 7 everything
-#ifdef R_TIMING
-#define R_TMARK(c) do { const unsigned long long t1_ = __builtin_readcyclecounter(); tacc[c] += (unsigned)(t1_ - tlast); tlast = t1_; } while (0)
-#else
-#define R_TMARK(c) do { } while (0)
-#endif
 #ifndef R_KEYS_NT
 #define R_KEYS_NT 1
 #endif
@@ -898,12 +870,7 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
   int* pre = (int*)wPl[wave];               // [65]
   int* mark = pre + 65;                     // [64]
   unsigned long long n_cand = 0ull, n_eval = 0ull;        // wave-uniform
-#ifdef R_TIMING
-  unsigned tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long tlast = __builtin_readcyclecounter();
-  const unsigned long long tbegin = tlast;
-  const unsigned long long twall = wall_clock64();
-#endif
+  R_TIMING_DECL();
   // Work items: the listed tiles first (most expensive class first), then, per body, the tiles its window has gained since
   // the lists were put together -- the lists may be a launch old (mh_raster_fin): a listed tile that no longer exists is
   // skipped, a new one is picked up by the workgroup that looks at its body (none in a steady sequence).
@@ -1197,24 +1164,8 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
     r_tile_depth_sums(p, s, b, keys, tw, x0, sy0, npx, s_sums);
     R_TMARK(6);
   }
-#if defined(R_TIMING) && R_TIMING == 3
-  if (p.pairs && tid == 0 && (int)blockIdx.x < total) {      // life span of the workgroup on the 100 MHz clock (last launch wins)
-    unsigned long long* slot = p.pairs + 2 + 2 * (size_t)blockIdx.x;
-    slot[0] = twall; slot[1] = wall_clock64();
-    if (blockIdx.x == 0) p.pairs[0] += 1ull;
-  }
-#elif defined(R_TIMING) && R_TIMING >= 4
-#elif defined(R_TIMING)
-  if (p.pairs) {
-    tacc[7] = (unsigned)(__builtin_readcyclecounter() - tbegin);
-    if (lane == 0) {
-      unsigned long long* slot = p.pairs + 2 + 2 * (size_t)blockIdx.x;
-      const int c = (R_TIMING - 1) * 4;
-      atomicAdd(slot, (unsigned long long)(tacc[c] >> 10) | ((unsigned long long)(tacc[c + 1] >> 10) << 32));
-      atomicAdd(slot + 1, (unsigned long long)(tacc[c + 2] >> 10) | ((unsigned long long)(tacc[c + 3] >> 10) << 32));
-      if (blockIdx.x == 0 && wave == 0) p.pairs[0] += 1ull;
-    }
-  }
+#ifdef MH_EXPERIMENT_TIMING
+  R_TIMING_FLUSH();
 #else
   if (p.pairs) {
     // per-workgroup slots, plain adds (49 000 same-address atomics at the end of the kernel doubled its duration)
@@ -1577,16 +1528,7 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
   int* plist = (int*)(gtab + (use_tab ? p.V * 3 : 0));
   int* s_n = plist + RG_LIST;
   const int nunits = p.gunit_total[0];
-#if defined(R_TIMING) && R_TIMING >= 4
-  // timing builds 4 / 5: wave-elapsed cycles of the gradient kernel by phase: 0 unit header + body sums, 1 classification
-  // loads + table clear, 2 compaction, 3 pixels, 4 reductions + flush, 7 everything
-  unsigned tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long tlast = __builtin_readcyclecounter();
-  const unsigned long long tbegin = tlast;
-#define RG_TMARK(c) R_TMARK(c)
-#else
-#define RG_TMARK(c) do { } while (0)
-#endif
+  RG_TIMING_DECL();
   // ---- deferred face sorts (RasterP::resort): the flagged bodies' lists, from this launch's coordinates and the keys the
   // selection has just written, for the NEXT launch.  Nothing in this kernel reads what a sort writes.
   r_deferred_sorts<RGB>(p, (int*)gtab);
@@ -1697,18 +1639,7 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
       }
     RG_TMARK(4);
   }
-#if defined(R_TIMING) && R_TIMING >= 4 && R_TIMING <= 5
-  if (p.pairs) {
-    tacc[7] = (unsigned)(__builtin_readcyclecounter() - tbegin);
-    if ((tid & 63) == 0) {
-      unsigned long long* slot = p.pairs + 2 + 2 * (size_t)(blockIdx.x % R_STRIP_GRID);
-      const int c = (R_TIMING - 4) * 4;
-      atomicAdd(slot, (unsigned long long)(tacc[c] >> 10) | ((unsigned long long)(tacc[c + 1] >> 10) << 32));
-      atomicAdd(slot + 1, (unsigned long long)(tacc[c + 2] >> 10) | ((unsigned long long)(tacc[c + 3] >> 10) << 32));
-      if (blockIdx.x == 0 && tid == 0) p.pairs[0] += 1ull;
-    }
-  }
-#endif
+  RG_TIMING_FLUSH();
 }
 
 // Deterministic form of the gradient scatter (mh_raster_set_deterministic / MHHIP_DETERMINISTIC=1): one workgroup per
@@ -2018,43 +1949,7 @@ extern "C" int mh_raster_pair_counters(int T, int N, int V, int F, int H, int W,
   MH_HIP(hipMemcpyAsync(host, p.pairs, sizeof(host), hipMemcpyDeviceToHost, (hipStream_t)stream));
   MH_HIP(hipStreamSynchronize((hipStream_t)stream));
   out_host[0] = host[0]; out_host[1] = 0ull; out_host[2] = 0ull;
-#if defined(R_TIMING) && R_TIMING == 3
-  {   // timing build 3: {launches, span of the last launch, sum of the workgroups' life spans} in 10 ns ticks
-    unsigned long long t0 = ~0ull, t1 = 0ull;
-    for (int i = 0; i < R_STRIP_GRID; ++i) {
-      const unsigned long long a = host[2 + 2 * i], b = host[3 + 2 * i];
-      if (!a || b < a) continue;
-      t0 = a < t0 ? a : t0; t1 = b > t1 ? b : t1;
-      out_host[2] += b - a;
-    }
-    out_host[1] = t1 > t0 ? t1 - t0 : 0ull;
-    if (getenv("MHHIP_SPANS")) {      // who ends last?  (workgroup index = position in the cost-sorted tile list)
-      fprintf(stderr, "spans of the last launch (us): kernel %.1f\n", (double)(t1 - t0) / 100.);
-      for (int d = 0; d < 12; ++d) {
-        const int i0 = d * (R_STRIP_GRID / 12), i1 = (d + 1) * (R_STRIP_GRID / 12);
-        double sd = 0, me = 0, ms = 0; int n = 0;
-        for (int i = i0; i < i1; ++i) {
-          const unsigned long long a = host[2 + 2 * i], b = host[3 + 2 * i];
-          if (!a || b < a) continue;
-          sd += (double)(b - a) / 100.; ++n;
-          if ((double)(b - t0) / 100. > me) me = (double)(b - t0) / 100.;
-          ms += (double)(a - t0) / 100.;
-        }
-        fprintf(stderr, "  workgroups %4d..%4d: %4d ran, mean start %6.1f, mean life %5.1f, latest end %6.1f\n", i0, i1 - 1, n, n ? ms / n : 0., n ? sd / n : 0., me);
-      }
-      for (int k = 0; k < 8; ++k) {          // the eight workgroups that end last
-        int best = -1;
-        for (int i = 0; i < R_STRIP_GRID; ++i)
-          if (host[2 + 2 * i] && host[3 + 2 * i] > host[2 + 2 * i] && (best < 0 || host[3 + 2 * i] > host[3 + 2 * best])) best = i;
-        if (best < 0) break;
-        fprintf(stderr, "  ends at %6.1f: workgroup %4d, started %6.1f, life %5.1f\n", (double)(host[3 + 2 * best] - t0) / 100., best,
-                (double)(host[2 + 2 * best] - t0) / 100., (double)(host[3 + 2 * best] - host[2 + 2 * best]) / 100.);
-        host[3 + 2 * best] = host[2 + 2 * best];      // (consumed: the buffer is a copy)
-      }
-    }
-    return MH_OK;
-  }
-#endif
+  R_TIMING_HOST_SPANS();
   for (int i = 0; i < R_STRIP_GRID; ++i) { out_host[1] += host[2 + 2 * i]; out_host[2] += host[3 + 2 * i]; }
   return MH_OK;
 }

@@ -717,20 +717,13 @@ class SequenceEngine(object):
             fv_first = self.kp_fused and order_old
             later = getattr(self, '_leaf_terms_later', None)
             self._leaf_terms_later = None
-            # MHHIP_SIDE_SPLIT=1 (scheduling experiment): the key-point launches, the priors and the velocity
-            # term leave this branch and run in a second one beside the rasteriser's gradient half and the skinning adjoint,
-            # joined in front of the pose adjoint (which adds the key-point chunk); the mask statistics, the vertex-gradient
-            # initialisation and the contact chain must stay ahead of the gradient half
-            split = os.environ.get('MHHIP_SIDE_SPLIT') == '1' and self.kp_fused and later is not None and not order_old \
-                and os.environ.get('MHHIP_NO_KPALG') != '1'
-            self._side_b = None
+            # (a second side branch under the gradient half and the skinning adjoint -- key-point launches, priors, velocity --
+            # was tried in round 5, MHHIP_SIDE_SPLIT: +45 us; DESIGN App. A)
             if not fv_first:
-                if not split:
-                    regress_project()
+                regress_project()
                 if later is not None and not order_old:
-                    later(1 if split else 3)
-                    if not split:
-                        later = None
+                    later(3)
+                    later = None
             with torch.cuda.stream(side):
                 if need_gv and filt and h.get('poses') is not None:
                     self._halo_forward(h, s2)
@@ -761,21 +754,14 @@ class SequenceEngine(object):
             if fv_first:
                 regress_project()
             self._scene_done = False
-            sums = [] if split else [(self.loss2d, log[0:1]), (self.prior_body, log[3:4])]
+            sums = [(self.loss2d, log[0:1]), (self.prior_body, log[3:4])]
             if scene and (self._scene_dev is None or scene_ready):     # static scene, or its event already waited for
                 self._scene_terms(s2, reduce=False, sel=sel)
                 sums += [(self.batch_contact, log[5:6]), (self.batch_foot, log[6:7])]
                 self._scene_done = True
-            if later is not None and not split:
+            if later is not None:
                 later()
-            if sums:
-                _lib.reduce_sum_multi(sums, s2)                        # the small log sums of the side branch: one launch
-            if split:
-                def part_b():
-                    regress_project()
-                    later(2)
-                    _lib.reduce_sum_multi([(self.loss2d, log[0:1]), (self.prior_body, log[3:4])], s2)
-                self._side_b = part_b
+            _lib.reduce_sum_multi(sums, s2)                            # the small log sums of the side branch: one launch
         # ---- main branch: rasterised depth / silhouette terms ----------------------------------------------------------
         joined = False
         # capture order: the chain's kernels BEFORE the side branch's -- the replayed graph keeps the branch whose nodes
@@ -816,12 +802,6 @@ class SequenceEngine(object):
                 # signalled: +0.5 % same-box)
                 main.wait_stream(side)
                 joined = True
-                self._side_b_open = False
-                if getattr(self, '_side_b', None) is not None:
-                    side.wait_stream(main)                 # second side branch: opens here, joined in _finish_b
-                    self._side_b()
-                    self._side_b = None
-                    self._side_b_open = True
                 # the closing kernel's job rides in the LBS backward's pose kernel when that is the fused form
                 # (_finish_b): one launch and one dependent kernel less on the chain
                 defer = bool(getattr(self, '_kp_chunk', False)) and os.environ.get('MHHIP_NO_DEFER') != '1'
@@ -901,17 +881,7 @@ class SequenceEngine(object):
             args = (self.m.handle, B, N, ptr(self.leaf('betas')), ptr(self.leaf('poses_smpl')), ptr(self.vposed),
                     ptr(gv), ptr(gposes), ptr(gpT), ptr(gbetas), ptr(gxs), ptr(self.ws), ptr(self.ws2),
                     ctypes.byref(fin) if fin is not None else None, st)
-            if getattr(self, '_side_b_open', False):
-                # (MHHIP_SIDE_SPLIT) the second side branch joins between the skinning adjoint and the pose adjoint
-                self._side_b_open = False
-                L.mh_lbs_debug_backward_phase(1)
-                check(L.mh_lbs_backward_kp_fin(*args))
-                torch.cuda.current_stream(self.dev).wait_stream(self._side_stream())
-                L.mh_lbs_debug_backward_phase(2)
-                check(L.mh_lbs_backward_kp_fin(*args))
-                L.mh_lbs_debug_backward_phase(0)
-            else:
-                check(L.mh_lbs_backward_kp_fin(*args))
+            check(L.mh_lbs_backward_kp_fin(*args))
         else:
             check(L.mh_lbs_backward(self.m.handle, B, N, ptr(self.leaf('betas')), ptr(self.leaf('poses_smpl')),
                                     ptr(self.leaf('xscale')), ptr(pT), ptr(self.vposed), ptr(gv), ptr(self.gj) if self.kp_fused else None, ptr(gposes),

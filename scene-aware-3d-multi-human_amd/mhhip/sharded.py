@@ -188,7 +188,7 @@ class ShardedSequence(object):
         if not self._halo_ok:
             # no hidden collective: a cycle issued on some ranks only must not deadlock the others inside an all-reduce
             raise RuntimeError('frame-sharded cycle with stale halos: the per-frame leaves were set from outside a cycle -- call '
-                               'refresh_halo() on EVERY rank first (fit() and init_optimized_variables() do)')
+                               'refresh_halo() on EVERY rank first (a collective; fit() and refresh_global_leaves() do)')
         h = self._halo
         h['vf_prev'], h['vf_next'] = self._vf_halo if self._vf_halo is not None else (None, None)
         e.halo = h

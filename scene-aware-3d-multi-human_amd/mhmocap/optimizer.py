@@ -189,6 +189,7 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
         """collective: re-gather the whole-sequence leaves get_optimized_variables() serves (frame-sharded run only)"""
         self._global_cache = None
         self.sh.leaves_changed()
+        self.sh.refresh_halo()            # (every rank is here: the neighbours' boundary leaves are stale too -- ADVICE r05)
         return self._global_leaves()
 
     def check_replicas(self):

@@ -111,7 +111,8 @@ def test_c3_selection_against_brute_force_on_every_body(smpl_struct, smpl_regs, 
         not_ties += [(b0 + t[0],) + tuple(t[1:]) for t in nt]
     print('C3, all %d bodies: selection differs on %d of %d live (pixel, pass) entries; not explained as near-ties: %d'
           % (e.B, ndiff, live, len(not_ties)))
-    assert live > 400000 and ndiff <= 3e-2 * live + 3, (ndiff, live)
+    # measured (round 6, this launch): 15 481 of 1 668 098 = 0.93 %; the gate is 1.5x that -- a regression from 1 % to 3 % used to pass
+    assert live > 400000 and ndiff <= 1.4e-2 * live, (ndiff, live)
     assert not not_ties, not_ties[:5]
 
 

@@ -317,7 +317,9 @@ def test_deterministic_scatter_and_where_the_gradient_errors_come_from(smpl_stru
     # (b) the selections
     ndiff, live, not_ties = _selection_differences(r)
     print('selection differs on %d of %d live (pixel, pass) entries; not explained as near-ties: %d' % (ndiff, live, len(not_ties)))
-    assert live > 300 and ndiff <= 3e-2 * live + 3, (ndiff, live)
+    # measured (round 6): 5 of 344 and 45 of 3111 = 1.45 % at these close-up sizes (0.93 % at C3, tests/test_full_size_gpu.py);
+    # the gate is 1.5x that
+    assert live > 300 and ndiff <= 2.2e-2 * live + 3, (ndiff, live)
     assert not not_ties, not_ties[:5]
 
 

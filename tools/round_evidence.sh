@@ -1,7 +1,7 @@
 #!/bin/bash
 # developer tool (GPU box, through gpurun): the measured evidence of a round beyond the rocprofv3 passes of profile_round.sh --
 # the gfx950 issue-cost micro-benchmarks and the phase timings of the four large kernels (timing builds under variants/:
-# tools/mkvariant.sh t1..t5 mh_raster.hip -DR_TIMING=1..5, lt mh_lbs.hip -DLBS_TIMING) -- into gpurun_out/evidence_<tag>/
+# tools/mkvariant.sh t1..t5 mh_raster.hip -DMH_EXPERIMENT -DR_TIMING=1..5, lt mh_lbs.hip -DMH_EXPERIMENT -DLBS_TIMING) -- into gpurun_out/evidence_<tag>/
 TAG=${1:-rXX}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/evidence_$TAG
@@ -21,7 +21,7 @@ export PYTHONPATH=$R/scene-aware-3d-multi-human_amd
   for t in 1 2 3; do MHHIP_LIB=$R/variants/lib_t$t.so R_TIMING=$t python tools/pair_stats.py 2>&1 | grep "timing build"; done
   echo "# k_raster_grads (builds 4, 5): [unit header + body sums, classification loads + table clear, compaction, pixels], [reductions + flush, -, -, everything]"
   for t in 4 5; do MHHIP_LIB=$R/variants/lib_t$t.so R_TIMING=$t python tools/pair_stats.py 2>&1 | grep "timing build"; done
-  echo "# k_skin_fwd16 / k_skinbwd16 inside the replayed cycle (tools/time_lbs_phases.py, -DLBS_TIMING)"
+  echo "# k_skin_fwd16 / k_skinbwd16 inside the replayed cycle (tools/time_lbs_phases.py, -DMH_EXPERIMENT -DLBS_TIMING)"
   MHHIP_LIB=$R/variants/lib_lt.so python tools/time_lbs_phases.py 2>&1 | grep "per wave"
 } > $O/${TAG}_phase_timings.txt 2>&1
 ls -la $O

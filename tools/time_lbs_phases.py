@@ -1,4 +1,4 @@
-"""developer tool: phase timings of the two skinning kernels from a timing build (tools/mkvariant.sh lt mh_lbs.hip -DLBS_TIMING;
+"""developer tool: phase timings of the two skinning kernels from a timing build (tools/mkvariant.sh lt mh_lbs.hip -DMH_EXPERIMENT -DLBS_TIMING;
 MHHIP_LIB=variants/lib_lt.so python tools/time_lbs_phases.py): wave-elapsed cycles by phase, inside the replayed C3 cycle"""
 import ctypes, os, sys, tempfile
 import numpy as np, torch

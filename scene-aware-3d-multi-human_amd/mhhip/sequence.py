@@ -325,6 +325,11 @@ class SequenceEngine(object):
                 return                                   # (the capturing cycle: not a replay yet)
             pl = queues.plan(self.dev)
             lt = getattr(self, '_lane_tests', {}).get(('full+scene',) + key)
+            if lt is not None and not lt.done and getattr(lt, 'recorded', False):
+                # the host runs tens of cycles ahead of the device: the test's last replay has been launched long ago but
+                # may not have run yet.  Waiting for it costs nothing -- the device has the cycles in between to work on
+                lt.evs[-1][1].synchronize()
+                lt.poll()
             clean = lt is not None and lt.done and getattr(lt, 'clean', False)
             raws = [l for l in lt.cand if l not in lt.busy] if clean else pl.free_lanes(main.cuda_stream)
             cands = [pl.view(r) for r in raws] + [_shared_stream(self.dev, 'scene')]

@@ -244,21 +244,50 @@ class ShardedSequence(object):
         return self._ar_graph
 
     # -- one-euro filters with the state handed down the ranks (optimizer.py:383-392) ----------------
-    def _scan(self, x, c, b):
+    def _scan(self, x, c, b, chunks=None):
+        """one-euro filter of this rank's frames of x (T_local, ...), the recurrence's state handed rank k -> k + 1.
+        The hand-off is a serial chain of world - 1 hops -- so the elements go in CHUNKS (round 6): rank k scans chunk j as soon
+        as its state has arrived and sends the result on before it touches chunk j + 1, i.e. rank k + 1 works on chunk j
+        while rank k works on chunk j + 1: the chain costs (world - 1 + chunks - 1) chunk steps instead of (world - 1) x chunks.
+        Elements are independent of each other: the same bits as the one-piece form (tests/test_sharded_world_cpu.py).
+        MHHIP_SHARD_SCAN_CHUNKS (default 4; 1 = the one-piece hand-off of rounds 3-5)."""
+        import os
         e = self.e
-        state = None
-        if not self.is_first:
-            E = x.numel() // x.shape[0]
-            xp = torch.empty(E, dtype=torch.float32, device=x.device)
-            dxp = torch.empty(E, dtype=torch.float32, device=x.device)
-            dist.recv(xp, src=self._peer(self.rank - 1), group=self.group)
-            dist.recv(dxp, src=self._peer(self.rank - 1), group=self.group)
-            state = (xp, dxp)
-        y, out = e.one_euro_shard(x, c, b, self.first_frame, state)
-        if not self.is_last:
-            dist.send(out[0], dst=self._peer(self.rank + 1), group=self.group)
-            dist.send(out[1], dst=self._peer(self.rank + 1), group=self.group)
-        return y
+        T = x.shape[0]
+        x2 = x.reshape(T, -1)
+        E = x2.shape[1]
+        if chunks is None:
+            chunks = int(os.environ.get('MHHIP_SHARD_SCAN_CHUNKS', '4'))
+        chunks = max(1, min(int(chunks), E))
+        if self.world == 1 or chunks == 1:
+            state = None
+            if not self.is_first:
+                xp = torch.empty(E, dtype=torch.float32, device=x.device)
+                dxp = torch.empty(E, dtype=torch.float32, device=x.device)
+                dist.recv(xp, src=self._peer(self.rank - 1), group=self.group)
+                dist.recv(dxp, src=self._peer(self.rank - 1), group=self.group)
+                state = (xp, dxp)
+            y, out = e.one_euro_shard(x, c, b, self.first_frame, state)
+            if not self.is_last:
+                dist.send(out[0], dst=self._peer(self.rank + 1), group=self.group)
+                dist.send(out[1], dst=self._peer(self.rank + 1), group=self.group)
+            return y
+        bounds = [(j * E) // chunks for j in range(chunks + 1)]
+        y = torch.empty_like(x2)
+        for j in range(chunks):
+            lo, hi = bounds[j], bounds[j + 1]
+            state = None
+            if not self.is_first:
+                st2 = torch.empty(2, hi - lo, dtype=torch.float32, device=x.device)
+                dist.recv(st2, src=self._peer(self.rank - 1), group=self.group)
+                state = (st2[0].contiguous(), st2[1].contiguous())
+            yj, out = e.one_euro_shard(x2[:, lo:hi].contiguous(), c, b, self.first_frame, state)
+            y[:, lo:hi] = yj.reshape(T, hi - lo)
+            if not self.is_last:
+                # (plain send / recv: stream-ordered on nccl, host-blocking on gloo -- either way rank k + 1 has chunk j while
+                # this rank goes on to chunk j + 1)
+                dist.send(torch.stack([out[0].reshape(-1), out[1].reshape(-1)]).contiguous(), dst=self._peer(self.rank + 1), group=self.group)
+        return y.view(x.shape)
 
     def update_filters(self, c1=0.01, b1=0.02, c2=0.001, b2=0.5):
         e = self.e

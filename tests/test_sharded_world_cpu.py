@@ -62,7 +62,11 @@ def _run_shard(group, grank, world):
     sh.scene_swap()
     depth, mask, pts = e.scene_device_result()
     img, imask = sh.scene_image(images[f0:f1])
-    return dict(params=e.params.clone(), log=log, f0=f0, f1=f1, pT_filt=e.pT_filt, vf=e.verts_filt[:, :, ::97],
+    # the one-euro hand-off in chunks (round 6: rank k + 1 starts on chunk j while rank k scans chunk j + 1) against the
+    # one-piece hand-off: the same bits
+    xs = torch.from_numpy(np.random.RandomState(77).randn(T, 37).astype(np.float32))[f0:f1].contiguous()
+    scan_same = all(torch.equal(sh._scan(xs, 0.01, 0.5, chunks=1), sh._scan(xs, 0.01, 0.5, chunks=ch)) for ch in (2, 5, 37, 64))
+    return dict(scan_same=scan_same, params=e.params.clone(), log=log, f0=f0, f1=f1, pT_filt=e.pT_filt, vf=e.verts_filt[:, :, ::97],
                 scene_depth=depth, scene_mask=mask, npts=pts.shape[0], img=img, imask=imask)
 
 
@@ -85,6 +89,7 @@ def _check(tmp_path, world, want_bounds):
     one = _run_shard(None, 0, 1)
     r = [torch.load(os.path.join(str(tmp_path), 'rank%d.pt' % k), weights_only=False) for k in range(world)]
     assert [(x['f0'], x['f1']) for x in r] == want_bounds
+    assert all(x['scan_same'] for x in r) and one['scan_same']
     base = sys.modules['test_sharded_cpu']
     _, model, sp, K, pose2d, _, _, _ = _inputs()
     ref = base._make_engine(model, sp, K, pose2d, 0, T)

@@ -174,6 +174,11 @@ int mh_lowest_resolve(const float* verts /*(B,V,3)*/, int B, int V, unsigned lon
  * Process-wide; also selectable with MHHIP_LBS_FP32=1 in the environment before the first call.             */
 int mh_lbs_set_mode(int split16);
 int mh_lbs_get_mode(void);
+/* mh_lbs_forward_proj as a kernel that is software-pipelined over a wave's vertex tiles (tile i's skinning / projection
+ * epilogue issued between the matrix instructions of tile i + 1; default) or tile after tile: the same bits either way.
+ * MHHIP_FWD_PIPE=0|1 in the environment before the first call.  Process-wide.                                      */
+int mh_lbs_set_forward_pipeline(int on);
+int mh_lbs_get_forward_pipeline(void);
 
 /* sparse joint regression from vertices (smpl.py:603-620, 367-386):
  * joints[b][j] = sum_v R[j][v] * verts[b][v]  (+ (1 - rowsum_j) * corr[b] when corr != NULL,
@@ -395,6 +400,11 @@ int mh_scene_grid_build(const float* points /*(M,3)*/, int M, void* grid_ws, voi
 /* the same with the point count in device memory (written by mh_scene_points): grid_ws sized for M_cap, which is also
  * the M to pass to mh_contact_knn_grid */
 int mh_scene_grid_build_dev(const float* points, const int* M_dev, int M_cap, void* grid_ws, void* stream);
+/* mh_scene_points followed by mh_scene_grid_build_dev(points, count_dev, H*W, grid_ws) as ONE launch (one workgroup: the five
+ * dependent launches of the pair end the per-cycle scene update of optimizer.py:578-584; the same points, count and grid
+ * header bit for bit).  grid_ws: mh_scene_grid_bytes(H*W) bytes.                                                      */
+int mh_scene_points_grid(int H, int W, const float* K_host, const float* scene_depth /*(H,W)*/, const float* mask /*(H,W)*/,
+                         float* points /*(H*W,3)*/, int* count_dev, void* grid_ws, void* stream);
 int mh_contact_knn_grid(const void* grid_ws, int M, const float* low_xyz, int B, int k,
                         float* dy /*(B)*/, void* stream);
 /* the same with the query = the lowest vertex of each body, taken from the keys mh_lbs_forward_proj reported (as

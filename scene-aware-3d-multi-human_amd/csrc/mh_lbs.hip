@@ -613,6 +613,235 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, FWD16_MINB) void k_skin_fwd16(Ski
   L_OUT(0, 3);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same kernel, SOFTWARE-PIPELINED over a wave's tiles (round 6, VERDICT r05 item 2 / DESIGN 10).  The kernel above runs a
+// tile's matrix phase (L2 -> matrix pipe) and then its epilogue (LDS gathers, fp32 FMAs, three row stores); all waves of a CU
+// start behind the same barrier and walk through the same phases in step, so at any moment ONE pipe of the CU works: its time
+// is the sum of the pipes' busy times (round 5: matrix 17 + blend 9 + stores 33 + arithmetic 21 us = 80 against 72 measured).
+// Here a wave carries TWO accumulator sets: while the 9 MFMAs of k-step s of tile i + 1 run, the wave issues row s of tile i's
+// epilogue (16 rows over the 14 k-steps + 2 slots), so the matrix pipe, the VALU, the LDS and the store path work at the
+// same time within every wave.  256 registers (two waves per SIMD, one workgroup per CU): 22 tiles per workgroup, three per
+// wave, i.e. per wave  M0 | M1+E0 | M2+E1 | E2  instead of  M0 E0 M1 E1 M2 E2.
+// Order inside a slot (the vmcnt caution of DESIGN 10): the NEXT k-step's basis loads are issued FIRST, then the MFMAs of this
+// step, then the row's stores -- a load queued behind stores would be waited for together with them.
+// Same arithmetic, operand for operand, as k_skin_fwd16: the two must agree bit for bit (tests/test_fwd_proj_gpu.py).
+// What it gives (measured, C3, with k_pose_fwd's 12 us): 80.0 us against 82.4 -- not the 47 us the sum-of-pipes picture promised.
+// The k-step's wait for its operands is s_waitcnt vmcnt(6), "everything but the six loads just issued": with the previous
+// slot's row stores in flight that is a wait for those stores to be acknowledged.  A hand-counted vmcnt(9) (operands issued
+// through inline assembly: "the six loads and the three stores behind them may stay in flight") ran in 72 us -- and returned
+// NaN vertices: on gfx950 stores retire OUT OF ORDER with respect to older loads, so a count that lets three younger
+// operations stay in flight does not say the loads have landed.  One counter for loads and stores: a wave cannot wait for a
+// load without waiting for the stores it has issued since.  (DESIGN 3.2 / App. A.)
+template <bool FULL, bool NW4, bool PROJ>
+__global__ __launch_bounds__(FWD16_WAVES * 64, 2) void k_skin_fwd16p(SkinFwd16P p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
+  f16x8* sF = (f16x8*)smem16;                                           // [14][2][64]
+  float* sA = (float*)(smem16 + FWD16_SF_BYTES);                        // [32][24][12]
+  f32x4* sS = (f32x4*)(smem16 + FWD16_SF_BYTES + FWD16_SA_BYTES);       // [32] (scale, tx, ty, tz)
+  f32x4* sTH = sS + 32;                                                 // [32] report thresholds: min x, min y, max x, max y (NDC)
+  f32x4* sLY = sTH + 32;                                                // [32] [0] = report threshold of the lowest vertex (camera y)
+                                                                        // (three arrays of one stride: one per-lane base serves all)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int g = blockIdx.y;
+  const int ntiles = p.VP / 32;
+  if ((int)blockIdx.x * p.tpb >= ntiles) return;
+  L_T0();
+  {
+    const f32x4* srcF = (const f32x4*)(p.F16 + (size_t)g * (MH_FS / 16) * 2 * 64 * 8);
+    for (int i = threadIdx.x; i < FWD16_SF_BYTES / 16; i += FWD16_WAVES * 64) ((f32x4*)sF)[i] = srcF[i];
+    const f32x4* srcA = (const f32x4*)(p.A + (size_t)g * 32 * MH_NJ * 12);
+    for (int i = threadIdx.x; i < FWD16_SA_BYTES / 16; i += FWD16_WAVES * 64) ((f32x4*)sA)[i] = srcA[i];
+    if (threadIdx.x < 32) {
+      const int b = g * 32 + threadIdx.x;
+      f32x4 q = {1.f, 0.f, 0.f, 0.f};
+      if (b < p.B) {
+        q[0] = p.scale[b];
+        if (p.transl) { q[1] = p.transl[(size_t)b * 3]; q[2] = p.transl[(size_t)b * 3 + 1]; q[3] = p.transl[(size_t)b * 3 + 2]; }
+      }
+      sS[threadIdx.x] = q;
+      if (PROJ) {
+        // nothing reports for a padding body; an unset / garbage previous extreme gives a NaN or arbitrary threshold:
+        // whatever then reports is still exact per slot (a slot is either the true extreme or stays unset)
+        f32x4 th = {-3e38f, -3e38f, 3e38f, 3e38f};
+        float ly = 3e38f;
+        if (b < p.B) {
+          const int4 pb = *(const int4*)(p.P.bbox_prev + (size_t)b * 4);
+          th[0] = mh_unord(pb.x) + p.P.slack_ndc; th[1] = mh_unord(pb.y) + p.P.slack_ndc;
+          th[2] = mh_unord(pb.z) - p.P.slack_ndc; th[3] = mh_unord(pb.w) - p.P.slack_ndc;
+          ly = mh_unordu((unsigned)(p.P.lowkey_prev[b] >> 32)) - p.P.slack_y;
+        }
+        sTH[threadIdx.x] = th;
+        sLY[threadIdx.x] = (f32x4){ly, 0.f, 0.f, 0.f};
+      }
+    }
+  }
+  __syncthreads();
+  L_MARK(0);
+  const float us = p.unscale;
+  const unsigned char* const sB = (const unsigned char*)sS + (4 * lh) * 16;
+  const size_t row_bytes = (size_t)p.V * 12;
+  const unsigned row_b32 = (unsigned)p.V * 12u;
+  unsigned char* const vg = (unsigned char*)p.verts + (size_t)g * 32 * row_bytes;
+  unsigned char* const qg = p.vposed ? (unsigned char*)p.vposed + (size_t)g * 32 * row_bytes : nullptr;
+  unsigned char* const ng = PROJ ? (unsigned char*)p.P.ndc + (size_t)g * 32 * row_bytes : nullptr;
+  const unsigned char* const rbg = PROJ ? (const unsigned char*)p.P.rowb + (size_t)g * 32 * p.V * 4 : nullptr;
+  // tiles of this wave: wave, wave + WAVES, ... below tpb (and below the model's tile count)
+  int nt = 0;
+  for (int k = wave; k < p.tpb && (int)blockIdx.x * p.tpb + k < ntiles; k += FWD16_WAVES) ++nt;
+  // the tile whose EPILOGUE runs in this pass (accumulators of the previous pass) ...
+  f32x16 ax = {0}, ay = {0}, az = {0};
+  int v_c = 0;
+  bool vok_c = false;
+  f32x3 tv_c = {0.f, 0.f, 0.f};
+  int sj_c[4] = {0, 0, 0, 0};
+  float sw_c[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it <= nt; ++it) {
+    const bool dm = it < nt, de = it > 0;                   // wave-uniform: a matrix phase / an epilogue in this pass
+    // ... and the tile whose MATRIX PHASE runs in this pass
+    const int tile = blockIdx.x * p.tpb + wave + it * FWD16_WAVES;
+    const int v_n = tile * 32 + li;
+    const bool vok_n = dm && v_n < p.V;
+    const int vc = vok_n ? v_n : p.V - 1;
+    f32x3 tv_n = {0.f, 0.f, 0.f};
+    int sj_n[4] = {0, 0, 0, 0};
+    float sw_n[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x16 nx = {0}, ny = {0}, nz = {0};
+    f16x8 bq[2][6];
+    const f16x8* Dw = (const f16x8*)p.D16 + (size_t)(dm ? tile : 0) * (MH_KD / 16) * 6 * 64 + lane;
+    if (dm) {
+      tv_n = *(const f32x3*)(p.vt + (size_t)vc * 3);
+      if (NW4 && p.nw == 4) {
+        const int4 j4 = *(const int4*)(p.skidx + (size_t)vc * 4);
+        const f32x4 w4 = *(const f32x4*)(p.skw + (size_t)vc * 4);
+        sj_n[0] = j4.x; sj_n[1] = j4.y; sj_n[2] = j4.z; sj_n[3] = j4.w;
+        sw_n[0] = w4[0]; sw_n[1] = w4[1]; sw_n[2] = w4[2]; sw_n[3] = w4[3];
+      } else {
+        const int nwl = p.nw < 4 ? p.nw : 4;
+        for (int k = 0; k < nwl; ++k) {
+          const int jj = p.skidx[(size_t)vc * p.nw + k];
+          const float ww = p.skw[(size_t)vc * p.nw + k];
+          if (k == 0) { sj_n[0] = jj; sw_n[0] = ww; }
+          if (k == 1) { sj_n[1] = jj; sw_n[1] = ww; }
+          if (k == 2) { sj_n[2] = jj; sw_n[2] = ww; }
+          if (k == 3) { sj_n[3] = jj; sw_n[3] = ww; }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) bq[0][i] = Dw[i * 64];
+    }
+    // epilogue tile: per-lane LDS bases, the sixteen rows' pixel rows at the last face sort (requested ahead of every store)
+    const unsigned char* aB[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) aB[k] = (const unsigned char*)sA + (4 * lh) * (MH_NJ * 48) + sj_c[k] * 48;
+    const unsigned lane_off = (unsigned)(4 * lh * p.V + v_c) * 12u;
+    const bool epi = de && vok_c;                           // (lanes beyond V in the model's last tile: no epilogue)
+    float rbv[16];
+    if (PROJ && epi) {
+      const int last_row = FULL ? 31 : min(31, p.B - 1 - g * 32);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const unsigned off4 = FULL ? (unsigned)(4 * lh * p.V + v_c) * 4u + (unsigned)((r & 3) + 8 * (r >> 2)) * ((unsigned)p.V * 4u)
+                                   : (unsigned)(min(row, last_row) * p.V + v_c) * 4u;
+        rbv[r] = *(const float*)(rbg + (size_t)off4);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {                          // slot r: k-step r of the matrix tile (r < 14) + row r of the epilogue tile
+      if (r < MH_KD / 16 && dm) {
+        const int cur = r & 1, nxt = cur ^ 1;
+        if (r + 1 < MH_KD / 16) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) bq[nxt][i] = Dw[((r + 1) * 6 + i) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);                  // (the next step's loads stay ahead of this slot's stores)
+        const f16x8 ah = sF[(r * 2) * 64 + lane], al = sF[(r * 2 + 1) * 64 + lane];
+        nx = MFMA_F16(ah, bq[cur][0], nx);
+        ny = MFMA_F16(ah, bq[cur][2], ny);
+        nz = MFMA_F16(ah, bq[cur][4], nz);
+        nx = MFMA_F16(ah, bq[cur][1], nx);
+        ny = MFMA_F16(ah, bq[cur][3], ny);
+        nz = MFMA_F16(ah, bq[cur][5], nz);
+        nx = MFMA_F16(al, bq[cur][0], nx);
+        ny = MFMA_F16(al, bq[cur][2], ny);
+        nz = MFMA_F16(al, bq[cur][4], nz);
+      }
+      if (epi) {
+        const int row0 = (r & 3) + 8 * (r >> 2);                              // + 4*lh = accumulator row = body in group
+        const float vp0 = fmaf(ax[r], us, tv_c[0]), vp1 = fmaf(ay[r], us, tv_c[1]), vp2 = fmaf(az[r], us, tv_c[2]);
+        float T[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) T[e] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const f32x4* Aj = (const f32x4*)(aB[k] + row0 * (MH_NJ * 48));
+          const f32x4 q0 = Aj[0], q1 = Aj[1], q2 = Aj[2];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            T[e] = fmaf(sw_c[k], q0[e], T[e]);
+            T[4 + e] = fmaf(sw_c[k], q1[e], T[4 + e]);
+            T[8 + e] = fmaf(sw_c[k], q2[e], T[8 + e]);
+          }
+        }
+        if (!NW4) {
+          const float* Ab = sA + (row0 + 4 * lh) * MH_NJ * 12;
+          for (int k = 4; k < p.nw; ++k) {   // models with more than 4 bones per vertex
+            const float w = p.skw[(size_t)v_c * p.nw + k];
+            const float* Aj = Ab + p.skidx[(size_t)v_c * p.nw + k] * 12;
+#pragma unroll
+            for (int e = 0; e < 12; ++e) T[e] = fmaf(w, Aj[e], T[e]);
+          }
+        }
+        const f32x4 st = *(const f32x4*)(sB + row0 * 16);                    // (scale, translation) of this body
+        const float x0 = fmaf(T[2], vp2, fmaf(T[1], vp1, T[0] * vp0)) + T[3];
+        const float x1 = fmaf(T[6], vp2, fmaf(T[5], vp1, T[4] * vp0)) + T[7];
+        const float x2 = fmaf(T[10], vp2, fmaf(T[9], vp1, T[8] * vp0)) + T[11];
+        const f32x3 o = {fmaf(st[0], x0, st[1]), fmaf(st[0], x1, st[2]), fmaf(st[0], x2, st[3])};
+        if (FULL || g * 32 + row0 + 4 * lh < p.B) {
+          const unsigned off_r = lane_off + (unsigned)row0 * row_b32;
+          *(f32x3*)(vg + (size_t)off_r) = o;
+          if (qg) {
+            const f32x3 q = {vp0, vp1, vp2};
+            *(f32x3*)(qg + (size_t)off_r) = q;
+          }
+          if (PROJ) {
+            const float Zc = o[2];
+            const float xn = p.P.s * (-o[0]) / Zc + p.P.w1, yn = p.P.s * (-o[1]) / Zc + p.P.h1;
+            const f32x3 nd = {xn, yn, Zc};
+            *(f32x3*)(ng + (size_t)off_r) = nd;
+            const float drow = fabsf(fmaf(-yn, p.P.rk, p.P.ra) - rbv[r]);
+            const bool mv = !(drow < p.P.thr_soft);
+            const f32x4 th = *(const f32x4*)(sB + 512 + row0 * 16);
+            const float ly = *(const float*)(sB + 1024 + row0 * 16);
+            const bool zok = Zc > 1e-8f;
+            const bool c0 = zok && xn < th[0], c1 = zok && yn < th[1], c2 = zok && xn > th[2], c3 = zok && yn > th[3];
+            const bool c4 = o[1] > ly;
+            if (__builtin_amdgcn_ballot_w64(c0 || c1 || c2 || c3 || c4 || mv) != 0ull) {
+              int b = g * 32 + row0 + 4 * lh;
+              asm volatile("" : "+v"(b));
+              int* bb = p.P.bbox + (size_t)b * 4;
+              if (c0) atomicMin(bb, mh_ord(xn));
+              if (c1) atomicMin(bb + 1, mh_ord(yn));
+              if (c2) atomicMax(bb + 2, mh_ord(xn));
+              if (c3) atomicMax(bb + 3, mh_ord(yn));
+              if (c4) atomicMax(p.P.lowkey + b, ((unsigned long long)mh_ordu(o[1] + 0.0f) << 32) | (unsigned)~(unsigned)v_c);
+              if (mv) p.P.moved[(drow < p.P.thr ? p.B : 0) + b] = 1;
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // the matrix tile of this pass is the epilogue tile of the next
+    ax = nx; ay = ny; az = nz;
+    v_c = v_n; vok_c = vok_n; tv_c = tv_n;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sj_c[k] = sj_n[k]; sw_c[k] = sw_n[k]; }
+  }
+}
+
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct FwdWs {
@@ -677,6 +906,21 @@ extern "C" int mh_lbs_set_mode(int split16) {
   return MH_OK;
 }
 extern "C" int mh_lbs_get_mode(void) { return lbs_mode(); }
+// the "LBS + projection" forward software-pipelined over a wave's tiles (k_skin_fwd16p) or tile after tile (k_skin_fwd16):
+// the same bits either way.  MHHIP_FWD_PIPE=0|1 at first use; process-wide, part of the cycle graphs' key.
+static int g_fwd_pipe = -1;
+static int fwd_pipe() {
+  if (g_fwd_pipe < 0) {
+    const char* e = getenv("MHHIP_FWD_PIPE");
+    g_fwd_pipe = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_fwd_pipe;
+}
+extern "C" int mh_lbs_set_forward_pipeline(int on) {
+  g_fwd_pipe = on ? 1 : 0;
+  return MH_OK;
+}
+extern "C" int mh_lbs_get_forward_pipeline(void) { return fwd_pipe(); }
 
 extern "C" size_t mh_lbs_workspace_bytes(int B) {
   int G = mh_groups(B < 1 ? 1 : B);
@@ -772,6 +1016,23 @@ static int lbs_forward_impl(const mh_model* m, int B, int NB, const float* betas
     // number of vertex tiles.  (Rounds 1-2 gave every workgroup 16 tiles: 350 workgroups at C3, so 94 CUs carried two of
     // them and 162 one -- the kernel took as long as the CUs with 32 tiles; with 11 tiles per workgroup every CU has ~22.)
     const int ntiles = m->VP / 32;
+    if (proj && fwd_pipe()) {
+      // the software-pipelined form (k_skin_fwd16p): one workgroup per CU at 256 registers, three tiles per wave
+      auto kp = full ? (nw4 ? k_skin_fwd16p<true, true, true> : k_skin_fwd16p<true, false, true>)
+                     : (nw4 ? k_skin_fwd16p<false, true, true> : k_skin_fwd16p<false, false, true>);
+      static unsigned char attrp[4][MH_MAX_DEVICES];
+      if (mh_first_on_device(attrp[(full ? 2 : 0) + (nw4 ? 1 : 0)]))
+        MH_HIP(hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      int bpg = std::max(1, 256 / G);
+      int tpb = std::min(FWD16_WAVES * 3, (ntiles + bpg - 1) / bpg);
+      if (const char* e = getenv("MHHIP_FWD_TPB")) tpb = std::max(1, std::min(FWD16_WAVES * 4, atoi(e)));
+      sp.tpb = tpb;
+      bpg = (ntiles + tpb - 1) / tpb;
+      hipLaunchKernelGGL(kp, dim3(bpg, G), dim3(FWD16_WAVES * 64), lds, st, sp);
+      MH_LAUNCH_CHECK();
+      mh_prof_mark(MH_PROF_SKIN_FWD, 1, st);
+      return MH_OK;
+    }
     int bpg = std::max(1, (2 * 256) / G);
     int tpb = std::min(FWD16_WAVES * FWD16_TPW, (ntiles + bpg - 1) / bpg);
     if (const char* e = getenv("MHHIP_FWD_TPB")) tpb = std::max(1, std::min(FWD16_WAVES * FWD16_TPW, atoi(e)));

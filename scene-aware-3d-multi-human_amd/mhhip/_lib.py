@@ -89,6 +89,7 @@ def lib():
         L.mh_warmup_project_w.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, c_float_p, c_float_p, c_float_p, vp,
                                           ctypes.c_float, ctypes.c_float, vp, vp, vp]
         L.mh_lbs_set_mode.argtypes = [ctypes.c_int]
+        L.mh_lbs_set_forward_pipeline.argtypes = [ctypes.c_int]
         L.mh_rmsprop_step.argtypes = [vp, vp, vp, vp, ctypes.c_size_t] + [ctypes.c_float] * 4 + [vp]
         L.mh_rmsprop_step_log.argtypes = [vp, vp, vp, vp, ctypes.c_size_t] + [ctypes.c_float] * 4 + [vp, vp, ctypes.c_int, vp]
         L.mh_rmsprop_step_log_poke.argtypes = [vp, vp, vp, vp, ctypes.c_size_t] + [ctypes.c_float] * 4 + [vp, vp, ctypes.c_int, vp,
@@ -124,6 +125,7 @@ def lib():
         L.mh_scene_postprocess.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp]
         L.mh_scene_fill.argtypes = [ctypes.c_int] * 4 + [vp] * 4
         L.mh_scene_points.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp]
+        L.mh_scene_points_grid.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp, vp]
         L.mh_stream_create.argtypes = [ctypes.POINTER(vp)]
         L.mh_stream_destroy.argtypes = [vp]
         L.mh_stream_shares_any.argtypes = [ctypes.POINTER(vp), ctypes.c_int, vp, ctypes.c_float, ctypes.POINTER(ctypes.c_int)]

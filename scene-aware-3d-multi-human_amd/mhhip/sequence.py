@@ -390,9 +390,13 @@ class SequenceEngine(object):
         d, L = self._scene_dev, _lib.lib()
         H, W = self.H, self.W
         check(L.mh_scene_postprocess(H, W, ptr(d['ma_depth']), ptr(d['ma_mask']), 1, 7, ptr(d['depth']), ptr(d['ws']), st))
-        check(L.mh_scene_points(H, W, self.K.ctypes.data_as(_lib.c_float_p), ptr(d['depth']), ptr(d['ma_mask']), ptr(s['pts']),
-                                ptr(s['count']), st))
-        check(L.mh_scene_grid_build_dev(ptr(s['pts']), ptr(s['count']), H * W, ptr(s['grid']), st))
+        if os.environ.get('MHHIP_SCENE_FUSED', '1') == '1':
+            check(L.mh_scene_points_grid(H, W, self.K.ctypes.data_as(_lib.c_float_p), ptr(d['depth']), ptr(d['ma_mask']), ptr(s['pts']),
+                                         ptr(s['count']), ptr(s['grid']), st))
+        else:
+            check(L.mh_scene_points(H, W, self.K.ctypes.data_as(_lib.c_float_p), ptr(d['depth']), ptr(d['ma_mask']), ptr(s['pts']),
+                                    ptr(s['count']), st))
+            check(L.mh_scene_grid_build_dev(ptr(s['pts']), ptr(s['count']), H * W, ptr(s['grid']), st))
 
     def scene_device_swap(self):
         """Make the last update the scene the contact term reads from now on (pointer swap; its consumer waits on the
@@ -936,7 +940,7 @@ class SequenceEngine(object):
         # time), the sort margin (a kernel argument by value) and the LBS arithmetic mode
         L = _lib.lib()
         glob = (L.mh_raster_get_deterministic(), L.mh_raster_get_sort_margin(), L.mh_lbs_get_mode(), L.mh_raster_get_path(),
-                L.mh_raster_get_winners(), float(L.mh_raster_get_sort_defer())) if raster is not None else None
+                L.mh_raster_get_winners(), float(L.mh_raster_get_sort_defer()), L.mh_lbs_get_forward_pipeline()) if raster is not None else None
         hk = None if self.halo is None else (bool(self.halo.get('has_prev')), bool(self.halo.get('has_next')), self.halo.get('poses') is not None)
         return (rast, scene, self.verts_filt is not None and self.pT_filt is not None, self._filt_gate, hk, bt, glob)
 

@@ -127,3 +127,39 @@ def test_halo_forward_gives_the_owners_bits(smpl_struct, smpl_regs, oracle_model
         got = [h['v_prev']] + ([h['v_next']] if len(frames) == 2 else [])
         for f, v in zip(frames, got):
             assert torch.equal(v.view(torch.int32), owner[f].view(torch.int32)), 'halo of frame %d differs from the owner\'s vertices' % f
+
+
+@pytest.mark.parametrize('T,N,W,H,batch', [(50, 4, 240, 135, 10), (16, 4, 96, 54, 4), (7, 5, 64, 64, 7), (3, 1, 96, 54, 3)])
+def test_pipelined_forward_gives_the_same_bits(smpl_struct, smpl_regs, oracle_model, tmp_path, T, N, W, H, batch):
+    """k_skin_fwd16p (round 6: a wave issues tile i's epilogue between the matrix instructions of tile i + 1) against
+    k_skin_fwd16 (tile after tile): vertices, rest-pose vertices, projected vertices, the bodies' report slots and motion flags
+    -- the same bits, on full groups of 32 bodies, a ragged last group and a single small group."""
+    from mhhip import _lib
+    from mhhip.raster import RasterTerms
+    L = _lib.lib()
+    opt, dl, o, batches, seq = _setup(smpl_struct, smpl_regs, oracle_model, tmp_path, T, N, W, H, batch, 59, True)
+    opt._stage_from_dataloader(dl)
+    e = opt.engine
+    raster = RasterTerms(e)
+    e.cycle(0, raster=raster)                 # face lists sorted, previous-launch report slots filled
+    e.step(0.01)
+    off = (ctypes.c_size_t * 6)()
+    L.mh_raster_debug_offsets.argtypes = [ctypes.c_int] * 6 + [ctypes.POINTER(ctypes.c_size_t)]
+    _lib.check(L.mh_raster_debug_offsets(*raster.dims, off))
+    ws0 = raster.ws.clone()
+    old = L.mh_lbs_get_forward_pipeline()
+    outs = []
+    try:
+        for pipe in (0, 1, 0):
+            _lib.check(L.mh_lbs_set_forward_pipeline(pipe))
+            raster.ws.copy_(ws0)              # the same previous-launch slots for both
+            e.verts.fill_(7.0); e.vposed.fill_(7.0)
+            e.forward(regress=False, raster=raster)
+            torch.cuda.synchronize()
+            outs.append((e.verts.clone(), e.vposed.clone(), raster.ws[off[0]:].clone()))
+    finally:
+        L.mh_lbs_set_forward_pipeline(old)
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a.view(torch.uint8).view(-1), b.view(torch.uint8).view(-1))
+    for a, b in zip(outs[0], outs[2]):
+        assert torch.equal(a.view(torch.uint8).view(-1), b.view(torch.uint8).view(-1))

@@ -400,11 +400,6 @@ int mh_scene_grid_build(const float* points /*(M,3)*/, int M, void* grid_ws, voi
 /* the same with the point count in device memory (written by mh_scene_points): grid_ws sized for M_cap, which is also
  * the M to pass to mh_contact_knn_grid */
 int mh_scene_grid_build_dev(const float* points, const int* M_dev, int M_cap, void* grid_ws, void* stream);
-/* mh_scene_points followed by mh_scene_grid_build_dev(points, count_dev, H*W, grid_ws) as ONE launch (one workgroup: the five
- * dependent launches of the pair end the per-cycle scene update of optimizer.py:578-584; the same points, count and grid
- * header bit for bit).  grid_ws: mh_scene_grid_bytes(H*W) bytes.                                                      */
-int mh_scene_points_grid(int H, int W, const float* K_host, const float* scene_depth /*(H,W)*/, const float* mask /*(H,W)*/,
-                         float* points /*(H*W,3)*/, int* count_dev, void* grid_ws, void* stream);
 int mh_contact_knn_grid(const void* grid_ws, int M, const float* low_xyz, int B, int k,
                         float* dy /*(B)*/, void* stream);
 /* the same with the query = the lowest vertex of each body, taken from the keys mh_lbs_forward_proj reported (as

@@ -578,147 +578,10 @@ extern "C" int mh_scene_grid_build_dev(const float* points, const int* M_dev, in
   return grid_build(points, M_cap, M_dev, grid_ws, (hipStream_t)stream);
 }
 
-// ---- un-projection + grid in ONE launch (round 6) ------------------------------------------------------------------------
-// The device-side scene update (reference optimizer.py:578-584) ends with five dependent launches -- compaction of the valid
-// pixels into camera-space points (mh_scene_points), bbox + header, cell counts, scan, scatter (mh_scene_grid_build_dev) --
-// two of them single workgroups anyway and none longer than 45 us: 190 us of kernels + 25 us of launch gaps on the update's
-// stream, at the END of the update, i.e. beside the cycle's gradient half and the skinning adjoint (whose grid fills the device
-// exactly once: a foreign workgroup on one CU costs it a second round).  Here the five are the phases of one 1024-thread
-// workgroup: the same arithmetic per point and per cell (the header bit for bit; the order of the points inside a cell is
-// whatever the atomics make it, as before), ~100 us, one launch.
-__global__ __launch_bounds__(1024) void k_scene_cloud(int H, int W, const float* depth, const float* mask, float i00, float i01, float i10,
-                                                      float i11, float cx, float cy, float* pts, int* count, GridHdr* hdr, int* counts,
-                                                      int* cursor, int* pcell, float* sorted, int max_cells) {
-  __shared__ int swave[16];
-  __shared__ int s_base, s_carry;
-  __shared__ float smn[3][16], smx[3][16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, P = H * W;
-  if (tid == 0) { s_base = 0; s_carry = 0; }
-  __syncthreads();
-  // phase A: the valid pixels, compacted in row-major order (k_scene_points), and the bbox of what this thread wrote
-  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (int base = 0; base < P; base += 1024) {
-    const int p = base + tid;
-    const bool keep = p < P && mask[p] > 0.5f;
-    const unsigned long long m = __ballot(keep);
-    if (lane == 0) swave[wave] = __popcll(m);
-    __syncthreads();
-    int off = s_base;
-    for (int w = 0; w < wave; ++w) off += swave[w];
-    if (keep) {
-      const int o = off + __popcll(m & ((1ull << lane) - 1ull));
-      const float u = (float)(p % W) + 0.5f - cx, v = (float)(p / W) + 0.5f - cy;
-      const float d = depth[p];
-      const float q[3] = {d * (u * i00 + v * i10), d * (u * i01 + v * i11), d};
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        pts[(size_t)o * 3 + c] = q[c];
-        mn[c] = fminf(mn[c], q[c]);
-        mx[c] = fmaxf(mx[c], q[c]);
-      }
-    }
-    __syncthreads();
-    if (tid == 0) {
-      int s2 = 0;
-      for (int w = 0; w < 16; ++w) s2 += swave[w];
-      s_base += s2;
-    }
-    __syncthreads();
-  }
-  const int M = s_base;
-  if (tid == 0) *count = M;
-  // phase B: bbox -> header (k_grid_setup's arithmetic)
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      mn[c] = fminf(mn[c], __shfl_xor(mn[c], o, 64));
-      mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o, 64));
-    }
-    if (lane == 0) { smn[c][wave] = mn[c]; smx[c][wave] = mx[c]; }
-  }
-  __syncthreads();
-  if (tid == 0) {
-    float ext[3];
-    for (int c = 0; c < 3; ++c) {
-      for (int w = 1; w < 16; ++w) { mn[c] = fminf(mn[c], smn[c][w]); mx[c] = fmaxf(mx[c], smx[c][w]); }
-      ext[c] = fmaxf(mx[c] - mn[c], 1e-3f);
-    }
-    const float area = fmaxf(ext[0] * ext[1], fmaxf(ext[1] * ext[2], ext[0] * ext[2]));
-    float cell = fminf(fmaxf(sqrtf(area * 16.f / (float)max(M, 1)), 0.02f), 4.f);
-    if (M == 0) { for (int c = 0; c < 3; ++c) { mn[c] = 0.f; ext[c] = 1e-3f; } cell = 1.f; }
-    int d[3];
-    for (;;) {
-      long long n = 1;
-      for (int c = 0; c < 3; ++c) { d[c] = (int)(ext[c] / cell) + 1; n *= d[c]; }
-      if (n <= max_cells) break;
-      cell *= 1.26f;
-    }
-    hdr->cell = cell;
-    for (int c = 0; c < 3; ++c) { hdr->mn[c] = mn[c]; hdr->dim[c] = d[c]; }
-    hdr->ncells = d[0] * d[1] * d[2];
-    hdr->npts = M;
-  }
-  __threadfence();               // the points and the header: written by other threads of this workgroup, read below
-  __syncthreads();
-  // phase C + D: clear the counts, then one atomic per point
-  const int nc = hdr->ncells;
-  for (int i = tid; i <= nc; i += 1024) counts[i] = 0;
-  __threadfence();
-  __syncthreads();
-  for (int i = tid; i < M; i += 1024) {
-    const int c = grid_cell(hdr, pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2]);
-    pcell[i] = c;
-    atomicAdd(&counts[c], 1);
-  }
-  __threadfence();
-  __syncthreads();
-  // phase E: exclusive scan of the counts in place (k_grid_scan), fill cursors
-  for (int base = 0; base < nc; base += 1024) {
-    const int i = base + tid;
-    const int v = i < nc ? counts[i] : 0;
-    const int incl = mh_wave_scan_add(v);
-    if (lane == 63) swave[wave] = incl;
-    __syncthreads();
-    int woff = s_carry;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) woff += (w < wave) ? swave[w] : 0;
-    if (i < nc) {
-      const int start = woff + incl - v;
-      counts[i] = start;
-      cursor[i] = start;
-    }
-    __syncthreads();
-    if (tid == 1023) s_carry = woff + incl;
-    __syncthreads();
-  }
-  if (tid == 0) counts[nc] = s_carry;
-  __threadfence();
-  __syncthreads();
-  // phase F: scatter
-  for (int i = tid; i < M; i += 1024) {
-    const int pos = atomicAdd(&cursor[pcell[i]], 1);
-    sorted[(size_t)pos * 3] = pts[(size_t)i * 3];
-    sorted[(size_t)pos * 3 + 1] = pts[(size_t)i * 3 + 1];
-    sorted[(size_t)pos * 3 + 2] = pts[(size_t)i * 3 + 2];
-  }
-}
-
-extern "C" int mh_scene_points_grid(int H, int W, const float* K_host, const float* scene_depth, const float* mask, float* points,
-                                    int* count_dev, void* grid_ws, void* stream) {
-  MH_CHECK(K_host && scene_depth && mask && points && count_dev && grid_ws, "null argument");
-  MH_CHECK(H > 0 && W > 0, "empty image");
-  const double a = K_host[0], b = K_host[3], c = K_host[1], d = K_host[4];   // M = K[:2,:2]^T = [[a,b],[c,d]]
-  const double det = a * d - b * c;
-  MH_CHECK(det != 0.0, "singular intrinsics");
-  const float i00 = (float)(d / det), i01 = (float)(-b / det), i10 = (float)(-c / det), i11 = (float)(a / det);
-  GridWs g = grid_carve(grid_ws, H * W);
-  hipLaunchKernelGGL(k_scene_cloud, dim3(1), dim3(1024), 0, (hipStream_t)stream, H, W, scene_depth, mask, i00, i01, i10, i11, K_host[2],
-                     K_host[5], points, count_dev, g.hdr, g.start, g.cursor, g.pcell, g.sorted, GRID_MAX_CELLS);
-  MH_LAUNCH_CHECK();
-  return MH_OK;
-}
-
+// (Round 6 tried the end of the per-cycle scene update -- un-projection / compaction, bbox + header, cell counts, scan, scatter:
+// five dependent launches, ~190 us + gaps -- as the phases of ONE 1024-thread workgroup.  Same results; the cycle with the
+// device-built scene went from 0.74 to 0.90 ms: 32 000 counting and 32 000 returning atomics from a single CU, with
+// device-scope fences between the phases, take far longer than the 127-workgroup launches they replace.  Removed.)
 // Keep the K smallest of the 128 buffered (distance^2, y) candidates of a wave in slots [0, K), unsorted, and return
 // the K-th smallest distance: the two entries of a lane live in registers, the K-th value comes from a bitwise
 // descent with ballots (non-negative floats order like unsigned integers), ties at the bound are kept in lane order.

@@ -125,7 +125,6 @@ def lib():
         L.mh_scene_postprocess.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp]
         L.mh_scene_fill.argtypes = [ctypes.c_int] * 4 + [vp] * 4
         L.mh_scene_points.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp]
-        L.mh_scene_points_grid.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp, vp]
         L.mh_stream_create.argtypes = [ctypes.POINTER(vp)]
         L.mh_stream_destroy.argtypes = [vp]
         L.mh_stream_shares_any.argtypes = [ctypes.POINTER(vp), ctypes.c_int, vp, ctypes.c_float, ctypes.POINTER(ctypes.c_int)]

@@ -390,13 +390,9 @@ class SequenceEngine(object):
         d, L = self._scene_dev, _lib.lib()
         H, W = self.H, self.W
         check(L.mh_scene_postprocess(H, W, ptr(d['ma_depth']), ptr(d['ma_mask']), 1, 7, ptr(d['depth']), ptr(d['ws']), st))
-        if os.environ.get('MHHIP_SCENE_FUSED', '1') == '1':
-            check(L.mh_scene_points_grid(H, W, self.K.ctypes.data_as(_lib.c_float_p), ptr(d['depth']), ptr(d['ma_mask']), ptr(s['pts']),
-                                         ptr(s['count']), ptr(s['grid']), st))
-        else:
-            check(L.mh_scene_points(H, W, self.K.ctypes.data_as(_lib.c_float_p), ptr(d['depth']), ptr(d['ma_mask']), ptr(s['pts']),
-                                    ptr(s['count']), st))
-            check(L.mh_scene_grid_build_dev(ptr(s['pts']), ptr(s['count']), H * W, ptr(s['grid']), st))
+        check(L.mh_scene_points(H, W, self.K.ctypes.data_as(_lib.c_float_p), ptr(d['depth']), ptr(d['ma_mask']), ptr(s['pts']),
+                                ptr(s['count']), st))
+        check(L.mh_scene_grid_build_dev(ptr(s['pts']), ptr(s['count']), H * W, ptr(s['grid']), st))
 
     def scene_device_swap(self):
         """Make the last update the scene the contact term reads from now on (pointer swap; its consumer waits on the

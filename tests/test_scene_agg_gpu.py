@@ -250,56 +250,3 @@ def test_raw_value_median_frame_major_equals_pixel_major():
     np.testing.assert_allclose(a.cpu().numpy()[seen], want.data[seen], rtol=1e-6)
     assert not seen[0, 0] and float(am[0, 0]) == 0.0
 
-
-def test_points_and_grid_in_one_launch_equal_the_five():
-    """mh_scene_points_grid (round 6: the end of the per-cycle scene update as ONE launch of one workgroup) against
-    mh_scene_points + mh_scene_grid_build_dev: the same points, count, grid header and cell starts bit for bit; inside a cell the
-    points are the same SET (their order is whatever the atomics of the counting sort make it, in either form)."""
-    import ctypes
-    from mhhip import _lib, synthetic
-    from mhhip._lib import check, ptr
-    L = _lib.lib()
-    dev = torch.device('cuda:0')
-    st = _lib.stream_ptr(dev)
-    for (H, W, seed) in [(135, 240, 1), (54, 96, 2), (33, 47, 3)]:
-        rng = np.random.RandomState(seed)
-        K = synthetic.default_cam_K((W, H), 60.0)
-        depth = torch.tensor((2.0 + 6.0 * rng.rand(H, W)).astype(np.float32), device=dev)
-        mask = torch.tensor((rng.rand(H, W) > 0.3).astype(np.float32), device=dev)
-        if seed == 3:
-            mask.zero_()                     # an empty cloud
-        P = H * W
-        Kp = np.ascontiguousarray(K.reshape(9).astype(np.float32)).ctypes.data_as(_lib.c_float_p)
-        outs = []
-        for fused in (False, True):
-            pts = torch.full((P, 3), -7.0, device=dev)
-            cnt = torch.zeros(1, dtype=torch.int32, device=dev)
-            grid = torch.zeros(L.mh_scene_grid_bytes(P), dtype=torch.uint8, device=dev)
-            if fused:
-                check(L.mh_scene_points_grid(H, W, Kp, ptr(depth), ptr(mask), ptr(pts), ptr(cnt), ptr(grid), st))
-            else:
-                check(L.mh_scene_points(H, W, Kp, ptr(depth), ptr(mask), ptr(pts), ptr(cnt), st))
-                check(L.mh_scene_grid_build_dev(ptr(pts), ptr(cnt), P, ptr(grid), st))
-            torch.cuda.synchronize()
-            outs.append((pts.cpu().numpy(), int(cnt.item()), grid.cpu().numpy()))
-        (p0, n0, g0), (p1, n1, g1) = outs
-        assert n0 == n1 == int((mask > 0.5).sum())
-        np.testing.assert_array_equal(p0.view(np.int32), p1.view(np.int32))
-        hdr0, hdr1 = g0[:36], g1[:36]                                   # GridHdr: mn[3], cell, dim[3], ncells, npts
-        np.testing.assert_array_equal(hdr0, hdr1)
-        ncells = int(hdr0[28:32].view(np.int32)[0])
-        a256 = lambda x: (x + 255) & ~255
-        o_start = a256(36)
-        s0 = g0[o_start:o_start + 4 * (ncells + 1)].view(np.int32)
-        s1 = g1[o_start:o_start + 4 * (ncells + 1)].view(np.int32)
-        np.testing.assert_array_equal(s0, s1)
-        assert s0[-1] == n0
-        o_sorted = o_start + a256(4 * ((1 << 20) + 1)) + a256(4 * (1 << 20)) + a256(4 * P)
-        q0 = g0[o_sorted:o_sorted + 12 * n0].view(np.float32).reshape(-1, 3)
-        q1 = g1[o_sorted:o_sorted + 12 * n0].view(np.float32).reshape(-1, 3)
-        for c in np.flatnonzero(np.diff(s0) > 1)[:200]:                  # cells with several points: the same set
-            a, b = s0[c], s0[c + 1]
-            assert sorted(map(tuple, q0[a:b])) == sorted(map(tuple, q1[a:b]))
-        one = np.flatnonzero(np.diff(s0) == 1)
-        if len(one):
-            np.testing.assert_array_equal(q0[s0[one]], q1[s0[one]])

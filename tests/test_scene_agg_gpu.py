@@ -249,4 +249,3 @@ def test_raw_value_median_frame_major_equals_pixel_major():
     seen = back.max(axis=0) > 0
     np.testing.assert_allclose(a.cpu().numpy()[seen], want.data[seen], rtol=1e-6)
     assert not seen[0, 0] and float(am[0, 0]) == 0.0
-

@@ -528,7 +528,7 @@ def main():
                     t_al = sum(standalone.values()) * 1e-6
                     full['standalone_us'] = {k: round(v, 1) for k, v in standalone.items()}
                     full['frac_standalone'] = round(by / t_al / 1e9 / PEAK_HBM_GBS, 4)
-            lbs = {'kernels': 'k_skin_fwd16 (projection epilogue) | k_skinbwd16 (split-fp16 / split-bf16 contractions)',
+            lbs = {'kernels': 'k_skin_fwd16p (projection epilogue, software-pipelined over a wave\'s tiles) | k_skinbwd16 (split-fp16 / split-bf16 contractions)',
                    'forward_us': round(kernel_us['lbs_skin_forward'], 1), 'backward_us': round(kernel_us['lbs_skin_backward'], 1),
                    'bound': 'hbm', 'algorithmic_bytes': by, 'achieved': round(by / t_pair / 1e9, 1), 'peak': PEAK_HBM_GBS,
                    'unit': 'GB/s', 'frac': round(by / t_pair / 1e9 / PEAK_HBM_GBS, 4),
@@ -537,7 +537,7 @@ def main():
                    'mfma_16bit': {'issued_tflops': round(fl16 / t_pair / 1e12, 1), 'peak': 2500.0, 'frac': round(fl16 / t_pair / 2.5e15, 4)},
                    'tolerance': 'vertices within 2.4e-7 m and gradients within 6e-6 (relative to the largest entry) of the '
                                 'exact-fp32 MFMA kernels of round 1 (tools/time_lbs.py); fixtures: 1e-5 m / 2e-4',
-                   'traffic': ({k: traffic.get(k) for k in ('k_skin_fwd16', 'k_skinbwd16') if traffic.get(k)}
+                   'traffic': ({k: traffic.get(k) for k in ('k_skin_fwd16p', 'k_skin_fwd16', 'k_skinbwd16') if traffic.get(k)}
                                if counters_fresh(stamp, 'mh_lbs.hip') else None)}
         unit_frames = T_TOTAL if args.strong else T_LOCAL
         out = {

@@ -32,7 +32,7 @@ for k in sorted(set(fetch) | set(write)):
                               'wide (16 B/lane) streaming reads are under-counted by 2x, other widths uncalibrated '
                               '(MI355X_MICROARCH.md, HBM)'}
 json.dump(traffic, open(os.path.join(out, 'pmc_traffic.json'), 'w'), indent=1, sort_keys=True)
-print(json.dumps({k: v for k, v in traffic.items() if k in ('k_raster_strip', 'k_skin_fwd16', 'k_skinbwd16', 'k_raster_grads')}, indent=1))
+print(json.dumps({k: v for k, v in traffic.items() if k in ('k_raster_strip', 'k_skin_fwd16p', 'k_skin_fwd16', 'k_skinbwd16', 'k_raster_grads')}, indent=1))
 
 # stamp: what these passes were taken on (bench.py prints counter-derived numbers only for sources that still match)
 import hashlib, subprocess

@@ -652,10 +652,13 @@ def fit_block(struct, regs, tmp, device, K, seq):
     e = opt.engine
     evs, orig = [], e.cycle_graphed
 
+    host_t = []
+
     def traced(*a, **k):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         evs.append(ev)
+        host_t.append(time.perf_counter())
         return orig(*a, **k)
     e.cycle_graphed = traced
     t0 = time.perf_counter()
@@ -666,6 +669,8 @@ def fit_block(struct, regs, tmp, device, K, seq):
     gaps = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1)])
     phases = {'cycle_0_ms': round(float(gaps[0]), 3), 'cycles_1_29_ms': round(float(gaps[1:30].mean()), 4),
               'cycles_30_59_ms': round(float(gaps[30:60].mean()), 4), 'cycles_60_248_ms': round(float(gaps[60:].mean()), 4),
+              'host_ms_before_first_cycle': round(1e3 * (host_t[0] - t0), 2), 'host_ms_first_to_last_launch': round(1e3 * (host_t[-1] - host_t[0]), 2),
+              'host_ms_after_last_launch': round(1e3 * (t0 + t_fit - host_t[-1]), 2),
               'graphs_captured': len(getattr(e, '_graphs', {})),
               'lane_test': [{'replay_ms': [round(x, 3) for x in getattr(lt, 'ms', [])], 'busy_lanes': len(getattr(lt, 'busy', [])),
                              'candidates': len(lt.cand), 'clean': bool(getattr(lt, 'clean', False)), 'done': bool(lt.done)} for lt in getattr(e, '_lane_tests', {}).values()],

@@ -15,7 +15,7 @@ cd $R
   python tools/trace_cycle.py $W/t 250
   echo
   echo "# one replayed C3 cycle of the organic-scene path (scene rebuilt on the device every cycle, own stream)"
-  python tools/trace_cycle_with.py $W/t k_scene_median 10
+  python tools/trace_cycle_with.py $W/t k_scene_median 50
 } > $O/${TAG}_cycle_timeline.txt 2>&1
 tail -3 $W/t.log > $O/${TAG}_bench_under_trace.txt
 rm -rf $W

@@ -300,6 +300,8 @@ def main():
         nstep[0] += 1
 
     use_graphs = not args.eager
+    if world == 1 and use_graphs:
+        e.defer_person = True         # as fit does: the per-person gradient sums ride in the update's launch
     grad0 = None
     if args.dump_leaves:
         # (parity tests) the gradient of one UNSTEPPED cycle at the initial variables, whole sequence: identical inputs in a

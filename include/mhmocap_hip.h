@@ -212,6 +212,14 @@ int mh_lbs_backward_kp_fin(const mh_model* m, int B, int NB, const float* betas,
                        const float* vposed, const float* gverts, float* gposes, float* gtransl,
                        float* gbetas, float* gxscale, void* ws, void* ws2, const mh_raster_fin* fin, void* stream);
 
+/* With gbetas == gxscale == NULL the backward entries leave the shape / log-scale gradients per BODY in ws2 and skip
+ * the launch that sums them over a person's frames; these two entries are the other half: where those rows are (for
+ * mh_rmsprop_step_person, which sums them inside the update's launch), and the sum as a launch of its own (+= into gbetas
+ * (NB,10) and gxscale (NB), NULL = skip; same order and bits as the undeferred backward).  B and the LBS arithmetic mode
+ * must be those of the backward call.                                                                                  */
+int mh_lbs_backward_person_partials(const mh_model* m, int B, void* ws2, float** gbeta_b, float** gxs_b);
+int mh_lbs_person_reduce(const mh_model* m, int B, int NB, void* ws2, float* gbetas, float* gxscale, void* stream);
+
 /* ---- LBS backward (hand-written adjoint of the above) ---------------------------------------
  * In : gverts (B,V,3) = dL/dverts, gjoints (B,17,3) = dL/d(alphapose joints of the translated,
  *      scaled body) or NULL, vposed from the forward, the same parameters, ws from the forward.
@@ -287,6 +295,24 @@ int mh_rmsprop_step_log_poke(float* params, const float* grads, float* square_av
                              size_t n, float lr, float alpha, float momentum, float eps,
                              const float* log_src, float* log_dst, int nlog, int32_t* poke_dst, int npoke,
                              int32_t poke0, int32_t poke1, void* stream);
+/* The update that also closes the LBS backward (round 6).  mh_lbs_backward* called with gbetas == gxscale == NULL
+ * leaves the shape / scale gradients as per-body rows in its workspace (mh_lbs_backward_person_partials) and skips
+ * the launch that sums them over the frames of a person; this entry does those sums -- same order, same bits --
+ * in NB * (nbeta + 1) extra workgroups of the update's launch, adds each to its element of grads (which is
+ * therefore written: not const) and updates the element.  One launch and one launch gap less at the end of every
+ * optimisation cycle (optimizer.py:343-356, 586-587).  off_xscale < 0: the scale sums are dropped (the reference
+ * zeroes that gradient when optim_scale_factor is off).  Everything else: mh_rmsprop_step_log_poke.             */
+typedef struct mh_person_sums {
+  const float* gbeta_b;   /* [>= B][nbeta] per-body shape gradients (device) */
+  const float* gxs_b;     /* [>= B]        per-body log-scale gradients      */
+  int B, NB, nbeta;       /* bodies (frame-major: body b belongs to person b % NB), people, shape components */
+  long long off_betas;    /* element offset of the (NB, nbeta) shape leaf in params / grads */
+  long long off_xscale;   /* of the (NB) scale leaf; < 0: leave it alone */
+} mh_person_sums;
+int mh_rmsprop_step_person(float* params, float* grads, float* square_avg, float* momentum_buf, size_t n,
+                           float lr, float alpha, float momentum, float eps, const float* log_src,
+                           float* log_dst, int nlog, int32_t* poke_dst, int npoke, int32_t poke0,
+                           int32_t poke1, const mh_person_sums* person, void* stream);
 /* the same update with the learning rate resident on the device (lr_dev[0]); afterwards
  * lr_dev[0] *= gamma (ExponentialLR).  No host scalar changes between calls, so the whole cycle can
  * be captured in a hipGraph and replayed.                                                      */

@@ -2089,6 +2089,28 @@ int mh_lbs_backward_extra_slot(const mh_model* m, int B, void* ws2, float** pF, 
   return MH_OK;
 }
 
+extern "C" int mh_lbs_backward_person_partials(const mh_model* m, int B, void* ws2, float** gbeta_b, float** gxs_b) {
+  MH_CHECK(m && ws2 && gbeta_b && gxs_b, "null argument");
+  MH_CHECK(B > 0, "B must be positive");
+  const bool split16 = lbs_mode() != 0;
+  const int G = mh_groups(B), CH = split16 ? bwd16_chunks(G) : bwd_chunks(2 * G);
+  BwdWs bw = carve_bwd(ws2, G, CH + 1);
+  *gbeta_b = bw.gbeta_b;
+  *gxs_b = bw.gxs_b;
+  return MH_OK;
+}
+
+extern "C" int mh_lbs_person_reduce(const mh_model* m, int B, int NB, void* ws2, float* gbetas, float* gxscale, void* stream) {
+  float *gb = nullptr, *gx = nullptr;
+  const int rc = mh_lbs_backward_person_partials(m, B, ws2, &gb, &gx);
+  if (rc != MH_OK) return rc;
+  MH_CHECK(NB > 0, "NB must be positive");
+  if (!gbetas && !gxscale) return MH_OK;
+  hipLaunchKernelGGL(k_person_reduce, dim3(NB, 11), dim3(256), 0, (hipStream_t)stream, B, NB, (const float*)gb, (const float*)gx, gbetas, gxscale);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
 extern "C" int mh_lbs_backward(const mh_model* m, int B, int NB, const float* betas, const float* poses,
                                const float* xscale, const float* transl, const float* vposed, const float* gverts,
                                const float* gjoints, float* gposes, float* gtransl, float* gbetas, float* gxscale,

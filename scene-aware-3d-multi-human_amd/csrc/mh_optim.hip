@@ -168,16 +168,53 @@ __global__ void k_rmsprop(float* p, const float* g, float* sq, float* buf, size_
 }
 
 // the same update and, riding along in its first workgroup, the cycle's log entries copied from the staging row the captured
-// graph wrote them to into their row of the log (one small launch less behind every graph replay)
-__global__ void k_rmsprop_log(float* p, const float* g, float* sq, float* buf, size_t n, float lr, float alpha,
+// graph wrote them to into their row of the log (one small launch less behind every graph replay).
+// Round 6 (mh_rmsprop_step_person): the launch also carries the per-person reduction of the LBS backward -- the sums over the
+// frames of the per-body shape / scale gradients, k_person_reduce's job, 4 us + a 5-us gap at the end of the cycle's chain --
+// in NB * (nbeta + 1) extra workgroups, one per shared element: the same strided sum and tree as k_person_reduce (same bits),
+// added to the element's gradient, then the element's update.  The element-wise workgroups leave those elements alone.
+struct PersonP {
+  const float* gbeta_b;
+  const float* gxs_b;
+  int B, NB, nbeta, on;
+  long long off_betas, off_xscale;
+};
+__global__ __launch_bounds__(256) void k_rmsprop_log(float* p, float* g, float* sq, float* buf, size_t n, float lr, float alpha,
                               float mom, float eps, const float* log_src, float* log_dst, int nlog, int* poke_dst, int npoke,
-                              int poke0, int poke1) {
+                              int poke0, int poke1, int nmain, PersonP ps) {
+  if ((int)blockIdx.x >= nmain) {
+    __shared__ float s[256];
+    const int e = (int)blockIdx.x - nmain, pn = e % ps.NB, q = e / ps.NB;     // q < nbeta: shape component, == nbeta: scale
+    float a = 0;
+    for (int b = pn + threadIdx.x * ps.NB; b < ps.B; b += 256 * ps.NB) a += (q < ps.nbeta) ? ps.gbeta_b[(size_t)b * ps.nbeta + q] : ps.gxs_b[b];
+    s[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      const size_t i = (size_t)(q < ps.nbeta ? ps.off_betas + (long long)pn * ps.nbeta + q : ps.off_xscale + pn);
+      const float gi = g[i] + s[0];
+      g[i] = gi;
+      const float sv = alpha * sq[i] + (1.f - alpha) * gi * gi;
+      sq[i] = sv;
+      const float bv = mom * buf[i] + gi / (sqrtf(sv) + eps);
+      buf[i] = bv;
+      p[i] = p[i] - lr * bv;
+    }
+    return;
+  }
   if (blockIdx.x == 0) {
     for (int i = threadIdx.x; i < nlog; i += blockDim.x) log_dst[i] = log_src[i];
     // (mh_rmsprop_step_log_poke) up to two device-resident switch words of the NEXT captured cycle, set in this launch
     if (threadIdx.x == 0 && npoke > 0) { poke_dst[0] = poke0; if (npoke > 1) poke_dst[1] = poke1; }
   }
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+  const long long b0 = ps.on ? ps.off_betas : -1, b1 = ps.on ? b0 + (long long)ps.NB * ps.nbeta : -1;
+  const bool xs = ps.on && ps.off_xscale >= 0;
+  const long long x0 = xs ? ps.off_xscale : -1, x1 = xs ? x0 + ps.NB : -1;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)nmain * blockDim.x) {
+    if (ps.on && (((long long)i >= b0 && (long long)i < b1) || ((long long)i >= x0 && (long long)i < x1))) continue;
     const float gi = g[i];
     const float s = alpha * sq[i] + (1.f - alpha) * gi * gi;
     sq[i] = s;
@@ -187,18 +224,48 @@ __global__ void k_rmsprop_log(float* p, const float* g, float* sq, float* buf, s
   }
 }
 
-extern "C" int mh_rmsprop_step_log_poke(float* params, const float* grads, float* square_avg, float* momentum_buf, size_t n,
-                                        float lr, float alpha, float momentum, float eps, const float* log_src, float* log_dst,
-                                        int nlog, int32_t* poke_dst, int npoke, int32_t poke0, int32_t poke1, void* stream) {
+static int rmsprop_log_launch(float* params, float* grads, float* square_avg, float* momentum_buf, size_t n,
+                              float lr, float alpha, float momentum, float eps, const float* log_src, float* log_dst,
+                              int nlog, int32_t* poke_dst, int npoke, int32_t poke0, int32_t poke1, const mh_person_sums* person,
+                              void* stream) {
   MH_CHECK(params && grads && square_avg && momentum_buf, "null argument");
   MH_CHECK(nlog == 0 || (log_src && log_dst && nlog > 0), "log_src / log_dst / nlog");
   MH_CHECK(npoke >= 0 && npoke <= 2 && (npoke == 0 || poke_dst), "poke_dst / npoke");
+  PersonP ps;
+  memset(&ps, 0, sizeof(ps));
+  int extra = 0;
+  if (person) {
+    MH_CHECK(person->gbeta_b && person->gxs_b, "null per-body sums");
+    MH_CHECK(person->B > 0 && person->NB > 0 && person->nbeta > 0, "B, NB and nbeta must be positive");
+    MH_CHECK(person->off_betas >= 0 && (size_t)person->off_betas + (size_t)person->NB * person->nbeta <= n, "betas outside the parameter vector");
+    MH_CHECK(person->off_xscale < 0 || (size_t)person->off_xscale + (size_t)person->NB <= n, "xscale outside the parameter vector");
+    ps.gbeta_b = person->gbeta_b; ps.gxs_b = person->gxs_b; ps.B = person->B; ps.NB = person->NB; ps.nbeta = person->nbeta;
+    ps.on = 1; ps.off_betas = person->off_betas; ps.off_xscale = person->off_xscale;
+    extra = person->NB * (person->nbeta + (person->off_xscale >= 0 ? 1 : 0));
+  }
   if (n == 0 && nlog == 0 && npoke == 0) return MH_OK;
   const int blocks = n == 0 ? 1 : (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-  hipLaunchKernelGGL(k_rmsprop_log, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, square_avg,
-                     momentum_buf, n, lr, alpha, momentum, eps, log_src, log_dst, nlog, (int*)poke_dst, npoke, (int)poke0, (int)poke1);
+  hipLaunchKernelGGL(k_rmsprop_log, dim3(blocks + extra), dim3(256), 0, (hipStream_t)stream, params, grads, square_avg,
+                     momentum_buf, n, lr, alpha, momentum, eps, log_src, log_dst, nlog, (int*)poke_dst, npoke, (int)poke0, (int)poke1,
+                     blocks, ps);
   MH_LAUNCH_CHECK();
   return MH_OK;
+}
+
+extern "C" int mh_rmsprop_step_person(float* params, float* grads, float* square_avg, float* momentum_buf, size_t n,
+                                      float lr, float alpha, float momentum, float eps, const float* log_src, float* log_dst,
+                                      int nlog, int32_t* poke_dst, int npoke, int32_t poke0, int32_t poke1,
+                                      const mh_person_sums* person, void* stream) {
+  MH_CHECK(person, "null argument");
+  return rmsprop_log_launch(params, grads, square_avg, momentum_buf, n, lr, alpha, momentum, eps, log_src, log_dst, nlog, poke_dst,
+                            npoke, poke0, poke1, person, stream);
+}
+
+extern "C" int mh_rmsprop_step_log_poke(float* params, const float* grads, float* square_avg, float* momentum_buf, size_t n,
+                                        float lr, float alpha, float momentum, float eps, const float* log_src, float* log_dst,
+                                        int nlog, int32_t* poke_dst, int npoke, int32_t poke0, int32_t poke1, void* stream) {
+  return rmsprop_log_launch(params, (float*)grads, square_avg, momentum_buf, n, lr, alpha, momentum, eps, log_src, log_dst, nlog,
+                            poke_dst, npoke, poke0, poke1, nullptr, stream);
 }
 
 extern "C" int mh_rmsprop_step_log(float* params, const float* grads, float* square_avg, float* momentum_buf, size_t n,

@@ -46,6 +46,13 @@ class RasterFin(ctypes.Structure):
                     ('has_lists', ctypes.c_int), ('lists', ctypes.c_ulonglong * 80)]
 
 
+class PersonSums(ctypes.Structure):
+    """mh_person_sums of include/mhmocap_hip.h: the per-body shape / scale gradients a backward with gbetas = gxscale = NULL
+    left in its workspace, for the update that sums them (mh_rmsprop_step_person)"""
+    _fields_ = [('gbeta_b', vp), ('gxs_b', vp), ('B', ctypes.c_int), ('NB', ctypes.c_int), ('nbeta', ctypes.c_int),
+                ('off_betas', ctypes.c_longlong), ('off_xscale', ctypes.c_longlong)]
+
+
 _lib = None
 
 
@@ -94,6 +101,11 @@ def lib():
         L.mh_rmsprop_step_log.argtypes = [vp, vp, vp, vp, ctypes.c_size_t] + [ctypes.c_float] * 4 + [vp, vp, ctypes.c_int, vp]
         L.mh_rmsprop_step_log_poke.argtypes = [vp, vp, vp, vp, ctypes.c_size_t] + [ctypes.c_float] * 4 + [vp, vp, ctypes.c_int, vp,
                                                                                                    ctypes.c_int, ctypes.c_int32, ctypes.c_int32, vp]
+        L.mh_rmsprop_step_person.argtypes = [vp, vp, vp, vp, ctypes.c_size_t] + [ctypes.c_float] * 4 + [vp, vp, ctypes.c_int, vp,
+                                                                                                 ctypes.c_int, ctypes.c_int32, ctypes.c_int32,
+                                                                                                 ctypes.POINTER(PersonSums), vp]
+        L.mh_lbs_backward_person_partials.argtypes = [vp, ctypes.c_int, vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
+        L.mh_lbs_person_reduce.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
         L.mh_rmsprop_step_dev.argtypes = [vp, vp, vp, vp, ctypes.c_size_t, vp] + [ctypes.c_float] * 4 + [vp]
         L.mh_adam_step.argtypes = [vp, vp, vp, vp, ctypes.c_size_t, ctypes.c_int] + [ctypes.c_float] * 4 + [vp]
         L.mh_one_euro_scan.argtypes = [vp, vp, ctypes.c_int, ctypes.c_size_t] + [ctypes.c_float] * 3 + [vp]

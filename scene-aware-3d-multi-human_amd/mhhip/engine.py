@@ -302,10 +302,19 @@ def rmsprop_step(params, grads, sq, buf, lr, alpha=0.5, momentum=0.9, eps=1e-8):
                                      eps, _lib.stream_ptr(params.device)))
 
 
-def rmsprop_step_log(params, grads, sq, buf, lr, log_src, log_dst, alpha=0.5, momentum=0.9, eps=1e-8, poke_dst=None, poke=None):
+def rmsprop_step_log(params, grads, sq, buf, lr, log_src, log_dst, alpha=0.5, momentum=0.9, eps=1e-8, poke_dst=None, poke=None,
+                     person=None):
     """mh_rmsprop_step_log[_poke]: the update and, in the same launch, the cycle's log entries from their staging row into
-    log_dst (log_src None: no copy) and up to two int32 words ``poke`` into ``poke_dst``"""
+    log_dst (log_src None: no copy) and up to two int32 words ``poke`` into ``poke_dst``.  person (a ``_lib.PersonSums``):
+    mh_rmsprop_step_person -- the launch also sums the per-body shape / scale gradients of a backward that left them per body"""
     nlog = 0 if log_src is None else log_src.numel()
+    if person is not None:
+        pk = [int(v) for v in (poke or [])] + [0, 0]
+        check(_lib.lib().mh_rmsprop_step_person(ptr(params), ptr(grads), ptr(sq), ptr(buf), params.numel(), lr, alpha, momentum,
+                                                eps, ptr(log_src), ptr(log_dst), nlog, poke_dst.data_ptr() if poke is not None else None,
+                                                0 if poke is None else min(len(poke), 2), pk[0], pk[1], ctypes.byref(person),
+                                                _lib.stream_ptr(params.device)))
+        return
     if poke is None:
         check(_lib.lib().mh_rmsprop_step_log(ptr(params), ptr(grads), ptr(sq), ptr(buf), params.numel(), lr, alpha, momentum,
                                              eps, ptr(log_src), ptr(log_dst), nlog, _lib.stream_ptr(params.device)))

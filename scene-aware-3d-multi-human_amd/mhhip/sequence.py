@@ -83,6 +83,12 @@ class SequenceEngine(object):
         self._grads_log = z(n + 16)      # gradients | staging row of the loss log: cleared by one fill per cycle
         self.grads = self._grads_log[:n]
         self.shared_lo = int(self.offs[4])          # betas | xscale: the all-reduced tail
+        # round 6: a captured cycle whose caller steps right behind it (``fit``) leaves the per-person sums of the shape /
+        # scale gradients to the update's launch (mh_rmsprop_step_person): one launch and one gap less on the chain
+        self.defer_person = False       # set by the caller (mhmocap.optimizer.fit, bench.py); MHHIP_DEFER_PERSON=0 overrides
+        self.freeze_xscale = False      # the deferred scale sums are dropped (optim_scale_factor off: the reference zeroes that gradient)
+        self._person_now = False
+        self._person_pending = False
         self.ws = model.workspace(B)
         self.ws2 = model.backward_workspace(B)
         self.kp_ws = torch.empty(max(1, _lib.lib().mh_keypoint_workspace_bytes(model.handle, B)), dtype=torch.uint8, device=self.dev)
@@ -565,6 +571,7 @@ class SequenceEngine(object):
         """RMSprop on the per-frame leaves only (frame-sharded run: they need no other rank's gradients; the shared tail
         follows the all-reduce, ``step_shared``)"""
         self._wait_scene_snapshot()
+        self._flush_person()
         self._flush_log()
         self._flush_phase()
         lo = self.shared_lo
@@ -595,6 +602,7 @@ class SequenceEngine(object):
     def cycle(self, row, use_images=True, raster=None):
         # the same launch order as the captured form (cycle_graphed): the sums of a cycle are then added in the same order
         # either way, and eager and replayed fits stay bit-identical (deterministic mode) until something else differs
+        self._flush_person()
         nj = raster is not None and use_images and self.has_images
         self.cycle_begin(join=not nj, raster=raster if (use_images and self.has_images) else None)
         self.cycle_finish(row, use_images, raster)
@@ -883,14 +891,16 @@ class SequenceEngine(object):
         ev = self._tic('lbs_backward')
         fin, self._raster_fin = getattr(self, '_raster_fin', None), None
         if getattr(self, '_kp_chunk', False):
+            pb, px = (None, None) if self._person_now else (ptr(gbetas), ptr(gxs))      # (deferred: summed by the update's launch)
             args = (self.m.handle, B, N, ptr(self.leaf('betas')), ptr(self.leaf('poses_smpl')), ptr(self.vposed),
-                    ptr(gv), ptr(gposes), ptr(gpT), ptr(gbetas), ptr(gxs), ptr(self.ws), ptr(self.ws2),
+                    ptr(gv), ptr(gposes), ptr(gpT), pb, px, ptr(self.ws), ptr(self.ws2),
                     ctypes.byref(fin) if fin is not None else None, st)
             check(L.mh_lbs_backward_kp_fin(*args))
         else:
             check(L.mh_lbs_backward(self.m.handle, B, N, ptr(self.leaf('betas')), ptr(self.leaf('poses_smpl')),
                                     ptr(self.leaf('xscale')), ptr(pT), ptr(self.vposed), ptr(gv), ptr(self.gj) if self.kp_fused else None, ptr(gposes),
-                                    ptr(gpT), ptr(gbetas), ptr(gxs), ptr(self.ws), ptr(self.ws2), st))
+                                    ptr(gpT), None if self._person_now else ptr(gbetas), None if self._person_now else ptr(gxs),
+                                    ptr(self.ws), ptr(self.ws2), st))
         self._toc(ev)
         if row is not None:
             self.log[row].copy_(log)
@@ -898,17 +908,36 @@ class SequenceEngine(object):
     def step(self, lr, alpha=0.5, momentum=0.9, eps=1e-8):
         self._wait_scene_snapshot()
         poke, self._phase_poke = self._phase_poke, None
-        if self._log_pending is not None or poke is not None:
+        person = None
+        if self._person_pending:
+            self._person_pending = False
+            person = self._person_sums()
+        if self._log_pending is not None or poke is not None or person is not None:
             # the log entries of the graph that was just replayed travel to their row in the update's launch -- and so do
             # the scene words of the next cycle (which of the two device-built scene sets is live)
             row, self._log_pending = self._log_pending, None
             engine.rmsprop_step_log(self.params, self.grads, self.sq, self.buf, float(lr), self.tmp_log if row is not None else None,
                                     self.log[row] if row is not None else None, alpha, momentum, eps,
-                                    poke_dst=self.phase[1:3] if poke is not None else None, poke=poke)
+                                    poke_dst=self.phase[1:3] if poke is not None else None, poke=poke, person=person)
             if poke is not None:
                 self._phase_host[1], self._phase_host[2] = poke
         else:
             engine.rmsprop_step(self.params, self.grads, self.sq, self.buf, float(lr), alpha, momentum, eps)
+
+    def _person_sums(self):
+        """where the last backward left the per-body shape / scale gradients (``_lib.PersonSums``)"""
+        gb, gx = ctypes.c_void_p(), ctypes.c_void_p()
+        check(_lib.lib().mh_lbs_backward_person_partials(self.m.handle, self.B, ptr(self.ws2), ctypes.byref(gb), ctypes.byref(gx)))
+        return _lib.PersonSums(gb.value, gx.value, self.B, self.N, 10, int(self.offs[4]), -1 if self.freeze_xscale else int(self.offs[5]))
+
+    def _flush_person(self):
+        """the per-person sums a deferring cycle left undone, when no ``step`` has taken them along (somebody else is about to
+        read the gradients): the launch the cycle skipped, now"""
+        if self._person_pending:
+            self._person_pending = False
+            g = self.grads
+            check(_lib.lib().mh_lbs_person_reduce(self.m.handle, self.B, self.N, ptr(self.ws2), ptr(self.leaf('betas', g)),
+                                                  ptr(self.leaf('xscale', g)), _lib.stream_ptr(self.dev)))
 
     def _flush_log(self):
         """the staging row of the last replayed cycle into its row of the log, when no ``step`` has taken it along"""
@@ -990,7 +1019,9 @@ class SequenceEngine(object):
         """``cycle`` through a captured graph (single-process form; the sharded driver replays
         ``cycle_begin`` / ``cycle_finish`` separately around its exchanges).  scene_update: also launch this cycle's
         device-side scene update (``scene_device_update``), after the first replay has been enqueued."""
-        key = self._graph_key(raster)
+        self._flush_person()
+        self._person_now = bool(self.defer_person) and os.environ.get('MHHIP_DEFER_PERSON') != '0'
+        key = self._graph_key(raster) + (self._person_now,)
         self._flush_log()
         self._flush_phase()
         if scene_update and queues.enabled() and os.environ.get('MHHIP_LANE_PICK') != '0':
@@ -1022,10 +1053,12 @@ class SequenceEngine(object):
             if scene_update:
                 self.scene_device_launch()
         self._log_pending = row            # copied by the next step() (same launch) or by whoever reads the log first
+        self._person_pending, self._person_now = self._person_now, False
 
     def step_dev(self, alpha=0.5, momentum=0.9, eps=1e-8, gamma=0.99, lr0=0.01):
         if not hasattr(self, 'lr_dev'):
             self.lr_dev = torch.full((1,), lr0, dtype=torch.float32, device=self.dev)
+        self._flush_person()
         self._flush_log()
         self._flush_phase()
         self._wait_scene_snapshot()

@@ -559,6 +559,12 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
                 sh.scene_setup(self._backmasks)
             if any(c % update_filters_every == 0 for c in range(30, num_iter)):
                 e.enable_filter_gate()
+        # the per-person sums of the shape / scale gradients ride in the update's launch (single process, captured cycles: the
+        # step follows every cycle at once and nothing reads the gradients in between)
+        deferring = bool(self.use_graphs and world == 1 and hasattr(e, 'defer_person'))
+        if deferring:
+            defer_before = e.defer_person
+            e.defer_person, e.freeze_xscale = True, not self.optim_scale_factor
         cycles = range(num_iter)
         if verbose and tqdm is not None and rank == 0:
             cycles = tqdm(cycles)
@@ -596,6 +602,9 @@ class SMPLDepthSequenceOptimizer(SMPLOptimizerBase):
             lr *= 0.99                                                        # ExponentialLR(0.99) :356
             if check_every and cycle % check_every == 0:
                 self.check_replicas()
+        if deferring:
+            e._flush_person()
+            e.defer_person = defer_before
         self._finish_scene()
         self._global_cache = None
         self._global_leaves()                     # sharded: the one gather of the result (collective, every rank is here)

@@ -175,8 +175,9 @@ int mh_lowest_resolve(const float* verts /*(B,V,3)*/, int B, int V, unsigned lon
 int mh_lbs_set_mode(int split16);
 int mh_lbs_get_mode(void);
 /* mh_lbs_forward_proj as a kernel that is software-pipelined over a wave's vertex tiles (tile i's skinning / projection
- * epilogue issued between the matrix instructions of tile i + 1; default) or tile after tile: the same bits either way.
- * MHHIP_FWD_PIPE=0|1 in the environment before the first call.  Process-wide.                                      */
+ * epilogue issued between the matrix instructions of tile i + 1; on = 1, default), tile after tile (0), or as producer and
+ * consumer waves (2: loads and matrix instructions in one wave, epilogue and stores in another, tiles handed over through
+ * LDS): the same bits in every form.  MHHIP_FWD_PIPE=0|1|2 in the environment before the first call.  Process-wide.   */
 int mh_lbs_set_forward_pipeline(int on);
 int mh_lbs_get_forward_pipeline(void);
 

@@ -842,6 +842,273 @@ __global__ __launch_bounds__(FWD16_WAVES * 64, 2) void k_skin_fwd16p(SkinFwd16P 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same kernel as PRODUCER and CONSUMER waves (round 6, second half).  What the software pipeline above
+// ran into: a wave has ONE vmcnt for loads and stores and stores retire out of order with loads, so a wave that stores cannot
+// wait for a load without waiting for its stores to be acknowledged -- however its instructions are interleaved.  Here the two
+// never meet in one wave: per SIMD one producer wave (basis loads, feature fragments from LDS, the 126 MFMAs of a tile; nothing
+// stored to memory) and one consumer wave (bone blend from LDS, fp32 epilogue, the three row stores and the reports; nothing
+// loaded from memory).  A tile goes from producer w to consumer w + 4 through one 19-KB LDS slot: the 48 accumulator words per
+// lane, and what the epilogue needs from memory (template vertex, four bones and weights, the sixteen rows' pixel rows at the
+// last face sort), loaded by the PRODUCER while its matrix phase waits for operands.  Hand-off: one flag word per pair in LDS
+// (0 = slot free, k + 1 = tile k of the pair is in it), polled with s_sleep; the consumer copies the slot to registers and
+// frees it at once, so the producer computes tile k + 1 while tile k's epilogue runs.  The waves of a workgroup are resident
+// together, so a wave polling another one of its workgroup always sees it advance; every poll is bounded all the same.
+// Same arithmetic, operand for operand, as k_skin_fwd16: the three forms agree bit for bit (tests/test_fwd_proj_gpu.py).
+//
+// What it gives (C3, stand-alone with k_pose_fwd, eager launches): 109.6 us against 108.5 for the pipelined form -- NOT the
+// default (mh_lbs_set_forward_pipeline(2) / MHHIP_FWD_PIPE=2 selects it).  What its timing-only variants measured (same
+// scale, ~23 us of which are the pose kernel and launch gaps; the variants lived behind -DMH_FWDPC_DBG and are gone):
+//   consumers hand the slot back unread (producers alone)            70    loads + matrix phase, one wave per SIMD
+//   producers skip loads and matrix phase (consumers alone)          97    = 54 without the row stores, 72 with ONLY the stores
+//   ... stores only, as one dense 768-byte run per instruction       69    the addresses do not matter,
+//   ... stores only, 16 bytes per lane (a third more bytes)          67    nor do the bytes: ~110 cycles per wave-store per CU
+// (a plain fill writes the same 198 MB in 31 us with a quarter of the instructions: 16 bytes per lane and one stream).
+// So: (i) the three row stores are bound by their NUMBER -- 1008 wave-stores per CU at ~110 cycles each = 46 us -- not by the
+// 198 MB (4.2 TB/s) and not by their scatter over 96 rows; (ii) the stores of one wave do not overlap the LDS gathers and
+// FMAs of the OTHER consumer waves of the CU: epilogue arithmetic (31) + stores (46) = consumers alone (74), with no load
+// and no vmcnt wait anywhere in a consumer (checked in the ISA) -- the "sum of the pipes" of DESIGN 10 is not the wave's one
+// counter (that was the pipelined form's problem, and this form removes it) but the CU's;
+// (iii) a first cut polled the flags through a volatile pointer: every volatile access is fenced with s_waitcnt vmcnt(0),
+// i.e. each consumer waited for all stores of its last tile to be acknowledged before it looked for the next one (123 us).
+// What is left to take: 16-byte stores of rows repacked through LDS (36 instead of 48 wave-stores per tile: -12 us of
+// stores for +40 % LDS instructions, net ~-6).  tools/fwd_probe.py times the three forms.
+#ifndef FWDPC_STAGES
+#define FWDPC_STAGES 3                 // k-steps of basis fragments in flight per producer (6 KB each)
+#endif
+#define FWDPC_Q 19                     // 16-byte words per lane in a slot: 12 accumulators, 4 pixel rows, 1 template vertex + index, bones, weights
+#define FWDPC_SLOT_BYTES (FWDPC_Q * 64 * 16)
+#define FWDPC_LDS_BYTES (FWD16_LDS_BYTES + 4 * FWDPC_SLOT_BYTES + 64)
+#define FWDPC_SPIN (1 << 22)
+#ifndef FWDPC_NC
+#define FWDPC_NC 2                     // consumer waves per producer wave (tiles of a pair alternate between them)
+#endif
+#define FWDPC_THREADS (256 * (1 + FWDPC_NC))
+template <bool FULL, bool NW4>
+__global__ __launch_bounds__(FWDPC_THREADS) void k_skin_fwd16pc(SkinFwd16P p) {
+  constexpr bool PROJ = true;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
+  f16x8* sF = (f16x8*)smem16;                                           // [14][2][64]
+  float* sA = (float*)(smem16 + FWD16_SF_BYTES);                        // [32][24][12]
+  f32x4* sS = (f32x4*)(smem16 + FWD16_SF_BYTES + FWD16_SA_BYTES);       // [32] (scale, tx, ty, tz)
+  f32x4* sTH = sS + 32;
+  f32x4* sLY = sTH + 32;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int g = blockIdx.y;
+  const int ntiles = p.VP / 32;
+  if ((int)blockIdx.x * p.tpb >= ntiles) return;
+  const int pr = wave & 3;
+  f32x4* const slot = (f32x4*)(smem16 + FWD16_LDS_BYTES + (size_t)pr * FWDPC_SLOT_BYTES) + lane;      // [q][lane]
+  // (relaxed workgroup-scope atomics, NOT volatile: a volatile access is fenced with s_waitcnt vmcnt(0) -- a consumer would wait for
+  // every store of its last tile to be acknowledged before it looks at the flag; the LDS orders its own operations per wave, the
+  // explicit lgkmcnt waits and compiler barriers below are all the hand-off needs)
+  int* const flag = (int*)(smem16 + FWD16_LDS_BYTES + 4 * FWDPC_SLOT_BYTES) + pr;
+#define FWDPC_FLAG() __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define FWDPC_SET(x) __hip_atomic_store(flag, (x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+  {
+    const f32x4* srcF = (const f32x4*)(p.F16 + (size_t)g * (MH_FS / 16) * 2 * 64 * 8);
+    for (int i = threadIdx.x; i < FWD16_SF_BYTES / 16; i += FWDPC_THREADS) ((f32x4*)sF)[i] = srcF[i];
+    const f32x4* srcA = (const f32x4*)(p.A + (size_t)g * 32 * MH_NJ * 12);
+    for (int i = threadIdx.x; i < FWD16_SA_BYTES / 16; i += FWDPC_THREADS) ((f32x4*)sA)[i] = srcA[i];
+    if (threadIdx.x < 32) {
+      const int b = g * 32 + threadIdx.x;
+      f32x4 q = {1.f, 0.f, 0.f, 0.f};
+      if (b < p.B) {
+        q[0] = p.scale[b];
+        if (p.transl) { q[1] = p.transl[(size_t)b * 3]; q[2] = p.transl[(size_t)b * 3 + 1]; q[3] = p.transl[(size_t)b * 3 + 2]; }
+      }
+      sS[threadIdx.x] = q;
+      f32x4 th = {-3e38f, -3e38f, 3e38f, 3e38f};
+      float ly = 3e38f;
+      if (b < p.B) {
+        const int4 pb = *(const int4*)(p.P.bbox_prev + (size_t)b * 4);
+        th[0] = mh_unord(pb.x) + p.P.slack_ndc; th[1] = mh_unord(pb.y) + p.P.slack_ndc;
+        th[2] = mh_unord(pb.z) - p.P.slack_ndc; th[3] = mh_unord(pb.w) - p.P.slack_ndc;
+        ly = mh_unordu((unsigned)(p.P.lowkey_prev[b] >> 32)) - p.P.slack_y;
+      }
+      sTH[threadIdx.x] = th;
+      sLY[threadIdx.x] = (f32x4){ly, 0.f, 0.f, 0.f};
+    }
+    if (threadIdx.x >= 64 && threadIdx.x < 68) ((int*)(smem16 + FWD16_LDS_BYTES + 4 * FWDPC_SLOT_BYTES))[threadIdx.x - 64] = 0;
+  }
+  __syncthreads();
+  // tiles of this pair: first + pr, first + pr + 4, ... below the workgroup's end
+  const int first = blockIdx.x * p.tpb, tend = min(first + p.tpb, ntiles);
+  int nt = 0;
+  for (int t = first + pr; t < tend; t += 4) ++nt;
+  const size_t row_bytes = (size_t)p.V * 12;
+  if (wave < 4) {
+    // ------------------------------------------------ producer ------------------------------------------------
+    const unsigned char* const rbg = (const unsigned char*)p.P.rowb + (size_t)g * 32 * p.V * 4;
+    const int last_row = FULL ? 31 : min(31, p.B - 1 - g * 32);
+    for (int k = 0; k < nt; ++k) {
+      const int tile = first + pr + 4 * k;
+      const int v = tile * 32 + li;
+      const int vc = v < p.V ? v : p.V - 1;
+      const f16x8* Dw = (const f16x8*)p.D16 + (size_t)tile * (MH_KD / 16) * 6 * 64 + lane;
+      f16x8 bq[FWDPC_STAGES][6];
+#pragma unroll
+      for (int st = 0; st < FWDPC_STAGES - 1; ++st)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) bq[st][i] = Dw[(st * 6 + i) * 64];
+      // what the consumer's epilogue needs from memory (behind the first operands in the queue: they are not needed before the slot is written)
+      const f32x3 tv = *(const f32x3*)(p.vt + (size_t)vc * 3);
+      int4 j4 = {0, 0, 0, 0};
+      f32x4 w4 = {0.f, 0.f, 0.f, 0.f};
+      if (NW4 && p.nw == 4) {
+        j4 = *(const int4*)(p.skidx + (size_t)vc * 4);
+        w4 = *(const f32x4*)(p.skw + (size_t)vc * 4);
+      } else {
+        const int nwl = p.nw < 4 ? p.nw : 4;
+        for (int q = 0; q < nwl; ++q) {
+          const int jj = p.skidx[(size_t)vc * p.nw + q];
+          const float ww = p.skw[(size_t)vc * p.nw + q];
+          if (q == 0) { j4.x = jj; w4[0] = ww; }
+          if (q == 1) { j4.y = jj; w4[1] = ww; }
+          if (q == 2) { j4.z = jj; w4[2] = ww; }
+          if (q == 3) { j4.w = jj; w4[3] = ww; }
+        }
+      }
+      float rbv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const unsigned off4 = FULL ? (unsigned)(4 * lh * p.V + vc) * 4u + (unsigned)((r & 3) + 8 * (r >> 2)) * ((unsigned)p.V * 4u)
+                                   : (unsigned)(min(row, last_row) * p.V + vc) * 4u;
+        rbv[r] = *(const float*)(rbg + (size_t)off4);
+      }
+      f32x16 ax = {0}, ay = {0}, az = {0};
+#pragma unroll
+      for (int s16 = 0; s16 < MH_KD / 16; ++s16) {
+        const int cur = s16 % FWDPC_STAGES, nxt = (s16 + FWDPC_STAGES - 1) % FWDPC_STAGES;
+        if (s16 + FWDPC_STAGES - 1 < MH_KD / 16) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) bq[nxt][i] = Dw[((s16 + FWDPC_STAGES - 1) * 6 + i) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const f16x8 ah = sF[(s16 * 2) * 64 + lane], al = sF[(s16 * 2 + 1) * 64 + lane];
+        ax = MFMA_F16(ah, bq[cur][0], ax);
+        ay = MFMA_F16(ah, bq[cur][2], ay);
+        az = MFMA_F16(ah, bq[cur][4], az);
+        ax = MFMA_F16(ah, bq[cur][1], ax);
+        ay = MFMA_F16(ah, bq[cur][3], ay);
+        az = MFMA_F16(ah, bq[cur][5], az);
+        ax = MFMA_F16(al, bq[cur][0], ax);
+        ay = MFMA_F16(al, bq[cur][2], ay);
+        az = MFMA_F16(al, bq[cur][4], az);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // hand the tile over
+      for (int spin = 0; FWDPC_FLAG() != 0 && spin < FWDPC_SPIN; ++spin) __builtin_amdgcn_s_sleep(2);
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        slot[(q) * 64] = (f32x4){ax[4 * q], ax[4 * q + 1], ax[4 * q + 2], ax[4 * q + 3]};
+        slot[(4 + q) * 64] = (f32x4){ay[4 * q], ay[4 * q + 1], ay[4 * q + 2], ay[4 * q + 3]};
+        slot[(8 + q) * 64] = (f32x4){az[4 * q], az[4 * q + 1], az[4 * q + 2], az[4 * q + 3]};
+        slot[(12 + q) * 64] = (f32x4){rbv[4 * q], rbv[4 * q + 1], rbv[4 * q + 2], rbv[4 * q + 3]};
+      }
+      slot[16 * 64] = (f32x4){tv[0], tv[1], tv[2], __int_as_float(v)};
+      slot[17 * 64] = (f32x4){__int_as_float(j4.x), __int_as_float(j4.y), __int_as_float(j4.z), __int_as_float(j4.w)};
+      slot[18 * 64] = w4;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      FWDPC_SET(k + 1);
+    }
+    return;
+  }
+  // -------------------------------------------------- consumer --------------------------------------------------
+  const float us = p.unscale;
+  const unsigned char* const sB = (const unsigned char*)sS + (4 * lh) * 16;
+  const unsigned row_b32 = (unsigned)p.V * 12u;
+  unsigned char* const vg = (unsigned char*)p.verts + (size_t)g * 32 * row_bytes;
+  unsigned char* const qg = p.vposed ? (unsigned char*)p.vposed + (size_t)g * 32 * row_bytes : nullptr;
+  unsigned char* const ng = (unsigned char*)p.P.ndc + (size_t)g * 32 * row_bytes;
+  for (int k = (wave - 4) >> 2; k < nt; k += FWDPC_NC) {
+    for (int spin = 0; FWDPC_FLAG() != k + 1 && spin < FWDPC_SPIN; ++spin) __builtin_amdgcn_s_sleep(2);
+    asm volatile("" ::: "memory");
+    f32x4 qq[FWDPC_Q];
+#pragma unroll
+    for (int q = 0; q < FWDPC_Q; ++q) qq[q] = slot[q * 64];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    FWDPC_SET(0);
+    const int v = __float_as_int(qq[16][3]);
+    if (v >= p.V) continue;                                 // (lanes beyond V in the model's last tile: no epilogue)
+    const float tv0 = qq[16][0], tv1 = qq[16][1], tv2 = qq[16][2];
+    const int sj[4] = {__float_as_int(qq[17][0]), __float_as_int(qq[17][1]), __float_as_int(qq[17][2]), __float_as_int(qq[17][3])};
+    const float sw[4] = {qq[18][0], qq[18][1], qq[18][2], qq[18][3]};
+    const unsigned char* aB[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) aB[q] = (const unsigned char*)sA + (4 * lh) * (MH_NJ * 48) + sj[q] * 48;
+    const unsigned lane_off = (unsigned)(4 * lh * p.V + v) * 12u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row0 = (r & 3) + 8 * (r >> 2);                              // + 4*lh = accumulator row = body in group
+      const float vp0 = fmaf(qq[r >> 2][r & 3], us, tv0), vp1 = fmaf(qq[4 + (r >> 2)][r & 3], us, tv1), vp2 = fmaf(qq[8 + (r >> 2)][r & 3], us, tv2);
+      float T[12];
+#pragma unroll
+      for (int e = 0; e < 12; ++e) T[e] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4* Aj = (const f32x4*)(aB[q] + row0 * (MH_NJ * 48));
+        const f32x4 q0 = Aj[0], q1 = Aj[1], q2 = Aj[2];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          T[e] = fmaf(sw[q], q0[e], T[e]);
+          T[4 + e] = fmaf(sw[q], q1[e], T[4 + e]);
+          T[8 + e] = fmaf(sw[q], q2[e], T[8 + e]);
+        }
+      }
+      if (!NW4) {
+        const float* Ab = sA + (row0 + 4 * lh) * MH_NJ * 12;
+        for (int q = 4; q < p.nw; ++q) {   // models with more than 4 bones per vertex (the one place a consumer loads)
+          const float w = p.skw[(size_t)v * p.nw + q];
+          const float* Aj = Ab + p.skidx[(size_t)v * p.nw + q] * 12;
+#pragma unroll
+          for (int e = 0; e < 12; ++e) T[e] = fmaf(w, Aj[e], T[e]);
+        }
+      }
+      const f32x4 st = *(const f32x4*)(sB + row0 * 16);                    // (scale, translation) of this body
+      const float x0 = fmaf(T[2], vp2, fmaf(T[1], vp1, T[0] * vp0)) + T[3];
+      const float x1 = fmaf(T[6], vp2, fmaf(T[5], vp1, T[4] * vp0)) + T[7];
+      const float x2 = fmaf(T[10], vp2, fmaf(T[9], vp1, T[8] * vp0)) + T[11];
+      const f32x3 o = {fmaf(st[0], x0, st[1]), fmaf(st[0], x1, st[2]), fmaf(st[0], x2, st[3])};
+      if (FULL || g * 32 + row0 + 4 * lh < p.B) {
+        const unsigned off_r = lane_off + (unsigned)row0 * row_b32;
+        *(f32x3*)(vg + (size_t)off_r) = o;
+        if (qg) {
+          const f32x3 q = {vp0, vp1, vp2};
+          *(f32x3*)(qg + (size_t)off_r) = q;
+        }
+        if (PROJ) {
+          const float Zc = o[2];
+          const float xn = p.P.s * (-o[0]) / Zc + p.P.w1, yn = p.P.s * (-o[1]) / Zc + p.P.h1;
+          const f32x3 nd = {xn, yn, Zc};
+          *(f32x3*)(ng + (size_t)off_r) = nd;
+          const float drow = fabsf(fmaf(-yn, p.P.rk, p.P.ra) - qq[12 + (r >> 2)][r & 3]);
+          const bool mv = !(drow < p.P.thr_soft);
+          const f32x4 th = *(const f32x4*)(sB + 512 + row0 * 16);
+          const float ly = *(const float*)(sB + 1024 + row0 * 16);
+          const bool zok = Zc > 1e-8f;
+          const bool c0 = zok && xn < th[0], c1 = zok && yn < th[1], c2 = zok && xn > th[2], c3 = zok && yn > th[3];
+          const bool c4 = o[1] > ly;
+          if (__builtin_amdgcn_ballot_w64(c0 || c1 || c2 || c3 || c4 || mv) != 0ull) {
+            int b = g * 32 + row0 + 4 * lh;
+            asm volatile("" : "+v"(b));
+            int* bb = p.P.bbox + (size_t)b * 4;
+            if (c0) atomicMin(bb, mh_ord(xn));
+            if (c1) atomicMin(bb + 1, mh_ord(yn));
+            if (c2) atomicMax(bb + 2, mh_ord(xn));
+            if (c3) atomicMax(bb + 3, mh_ord(yn));
+            if (c4) atomicMax(p.P.lowkey + b, ((unsigned long long)mh_ordu(o[1] + 0.0f) << 32) | (unsigned)~(unsigned)v);
+            if (mv) p.P.moved[(drow < p.P.thr ? p.B : 0) + b] = 1;
+          }
+        }
+      }
+    }
+  }
+}
+
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct FwdWs {
@@ -912,12 +1179,12 @@ static int g_fwd_pipe = -1;
 static int fwd_pipe() {
   if (g_fwd_pipe < 0) {
     const char* e = getenv("MHHIP_FWD_PIPE");
-    g_fwd_pipe = (e && e[0] == '0') ? 0 : 1;
+    g_fwd_pipe = (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : 1;
   }
   return g_fwd_pipe;
 }
 extern "C" int mh_lbs_set_forward_pipeline(int on) {
-  g_fwd_pipe = on ? 1 : 0;
+  g_fwd_pipe = on == 2 ? 2 : on ? 1 : 0;         // 2: producer and consumer waves (k_skin_fwd16pc)
   return MH_OK;
 }
 extern "C" int mh_lbs_get_forward_pipeline(void) { return fwd_pipe(); }
@@ -1016,6 +1283,23 @@ static int lbs_forward_impl(const mh_model* m, int B, int NB, const float* betas
     // number of vertex tiles.  (Rounds 1-2 gave every workgroup 16 tiles: 350 workgroups at C3, so 94 CUs carried two of
     // them and 162 one -- the kernel took as long as the CUs with 32 tiles; with 11 tiles per workgroup every CU has ~22.)
     const int ntiles = m->VP / 32;
+    if (proj && fwd_pipe() == 2) {
+      // producer and consumer waves (k_skin_fwd16pc): one workgroup per CU, its tiles dealt to four producer / consumer pairs
+      auto kc = full ? (nw4 ? k_skin_fwd16pc<true, true> : k_skin_fwd16pc<true, false>)
+                     : (nw4 ? k_skin_fwd16pc<false, true> : k_skin_fwd16pc<false, false>);
+      static unsigned char attrc[4][MH_MAX_DEVICES];
+      if (mh_first_on_device(attrc[(full ? 2 : 0) + (nw4 ? 1 : 0)]))
+        MH_HIP(hipFuncSetAttribute((const void*)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWDPC_LDS_BYTES));
+      int bpg = std::max(1, 256 / G);
+      int tpb = std::max(1, (ntiles + bpg - 1) / bpg);
+      if (const char* e = getenv("MHHIP_FWD_TPB")) tpb = std::max(1, atoi(e));
+      sp.tpb = tpb;
+      bpg = (ntiles + tpb - 1) / tpb;
+      hipLaunchKernelGGL(kc, dim3(bpg, G), dim3(FWDPC_THREADS), (size_t)FWDPC_LDS_BYTES, st, sp);
+      MH_LAUNCH_CHECK();
+      mh_prof_mark(MH_PROF_SKIN_FWD, 1, st);
+      return MH_OK;
+    }
     if (proj && fwd_pipe()) {
       // the software-pipelined form (k_skin_fwd16p): one workgroup per CU at 256 registers, three tiles per wave
       auto kp = full ? (nw4 ? k_skin_fwd16p<true, true, true> : k_skin_fwd16p<true, false, true>)

@@ -150,7 +150,7 @@ def test_pipelined_forward_gives_the_same_bits(smpl_struct, smpl_regs, oracle_mo
     old = L.mh_lbs_get_forward_pipeline()
     outs = []
     try:
-        for pipe in (0, 1, 0):
+        for pipe in (0, 1, 0, 2):
             _lib.check(L.mh_lbs_set_forward_pipeline(pipe))
             raster.ws.copy_(ws0)              # the same previous-launch slots for both
             e.verts.fill_(7.0); e.vposed.fill_(7.0)
@@ -162,4 +162,7 @@ def test_pipelined_forward_gives_the_same_bits(smpl_struct, smpl_regs, oracle_mo
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a.view(torch.uint8).view(-1), b.view(torch.uint8).view(-1))
     for a, b in zip(outs[0], outs[2]):
+        assert torch.equal(a.view(torch.uint8).view(-1), b.view(torch.uint8).view(-1))
+    # ... and the form with producer and consumer waves (k_skin_fwd16pc: the accumulators travel through an LDS slot)
+    for a, b in zip(outs[0], outs[3]):
         assert torch.equal(a.view(torch.uint8).view(-1), b.view(torch.uint8).view(-1))

@@ -26,6 +26,46 @@
 #define R_TIMING_DECL() do { } while (0)
 #endif
 
+// k_raster_strip, -DMH_EXPERIMENT -DR_NEAR_PROBE: how much work would an exact re-evaluation of the
+// decisions the fast pair evaluation can get wrong be?  Counter A = candidate pairs one of whose insertion decisions lies
+// inside the fast path's error bound (an edge function within R_NEAR_W of zero; a distance within R_NEAR_REL of a blur
+// radius; a depth within R_NEAR_REL of one of the pixel's five keys of another face), counter B = 64-pair batches that hold
+// at least one such pair -- a re-evaluation is a divergent branch: it costs a batch, not a pair.  tools/pair_stats.py prints both.
+#if defined(MH_EXPERIMENT) && defined(R_NEAR_PROBE)
+#define R_NEAR_W 1e-5f
+#define R_NEAR_REL 1e-6f
+#define R_NEAR_ARG , &wmin_
+#define R_NEAR_VARS() unsigned n_near = 0u, n_nbatch = 0u
+#define R_NEAR_FLUSH() \
+  do { \
+    __syncthreads(); \
+    if (lane == 0) { s_cnt[wave][0] = 0ull; s_cnt[wave][1] = 0ull; } \
+    __syncthreads(); \
+    atomicAdd(&s_cnt[wave][0], (unsigned long long)n_near); atomicAdd(&s_cnt[wave][1], (unsigned long long)n_nbatch); \
+  } while (0)
+#define R_NEAR_DECL() float wmin_ = 1.f
+#define R_NEAR_COUNT(q_, pz_, in_, dd_, f_) \
+  do { \
+    const unsigned long long* nq_ = (q_); \
+    bool nr_ = wmin_ < R_NEAR_W; \
+    if (!(in_)) nr_ = nr_ || fabsf((dd_) - BLUR_D) < R_NEAR_REL * BLUR_D || fabsf((dd_) - BLUR_S) < R_NEAR_REL * BLUR_S; \
+    if ((in_) || (dd_) < BLUR_D) \
+      for (int k_ = 0; k_ < 5; ++k_) { \
+        const unsigned long long e_ = nq_[k_]; \
+        if (e_ != RS_EMPTY && (int)(e_ & 0xffffffffu) != (f_)) nr_ = nr_ || fabsf((pz_) - __uint_as_float((unsigned)(e_ >> 32))) <= R_NEAR_REL * fabsf(pz_); \
+      } \
+    const unsigned long long nm_ = __ballot(nr_); \
+    n_near += nr_ ? 1u : 0u; \
+    if (nm_ && (int)(threadIdx.x & 63) == __ffsll((long long)nm_) - 1) n_nbatch += 1u; \
+  } while (0)
+#else
+#define R_NEAR_ARG
+#define R_NEAR_VARS() do { } while (0)
+#define R_NEAR_FLUSH() do { } while (0)
+#define R_NEAR_DECL() do { } while (0)
+#define R_NEAR_COUNT(q_, pz_, in_, dd_, f_) do { } while (0)
+#endif
+
 #if defined(MH_EXPERIMENT) && defined(R_TIMING) && R_TIMING == 3
 #define R_TIMING_FLUSH() \
 do { \

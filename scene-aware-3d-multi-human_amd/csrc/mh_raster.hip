@@ -298,7 +298,7 @@ __device__ __forceinline__ float r_max0(float x) {
 // blur-band membership can differ in the last ulp.
 // (An early exit for candidates provably outside the blur band -- distance to the line of a violated
 // edge -- was measured and does not pay inside a 64-wide divergent loop: some lane always survives.)
-__device__ __forceinline__ bool r_eval_fast(const float* T, float xf, float yf, float* pz, bool* inside, float* dist) {
+__device__ __forceinline__ bool r_eval_fast(const float* T, float xf, float yf, float* pz, bool* inside, float* dist, float* wmin = nullptr) {
   // Every multiply-add of this function is spelled out and the compiler's own contraction is off: the function is inlined
   // into two loops of k_raster_strip (pair list / even split), and left to itself hipcc fused a * b - c * d one way in
   // one copy and the other way in the other -- the same (face, pixel) pair then got a depth one ulp apart depending on
@@ -314,6 +314,7 @@ __device__ __forceinline__ bool r_eval_fast(const float* T, float xf, float yf, 
   const float w0 = e0 * ia, w1 = e1 * ia, w2 = e2 * ia;
   const bool in = w0 > 0.f && w1 > 0.f && w2 > 0.f;
   *inside = in;
+  if (wmin) *wmin = fminf(fminf(fabsf(w0), fabsf(w1)), fabsf(w2));      // (experiment builds only: mh_experiment.h, R_NEAR_PROBE)
   const float c0 = r_max0(w0), c1 = r_max0(w1), c2 = r_max0(w2);
   const float ics = __builtin_amdgcn_rcpf(fmaxf((c0 + c1) + c2, 1e-5f));
   *pz = fmaf(c2 * ics, z2, fmaf(c1 * ics, z1, (c0 * ics) * z0));
@@ -870,6 +871,7 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
   int* pre = (int*)wPl[wave];               // [65]
   int* mark = pre + 65;                     // [64]
   unsigned long long n_cand = 0ull, n_eval = 0ull;        // wave-uniform
+  R_NEAR_VARS();
   R_TIMING_DECL();
   // Work items: the listed tiles first (most expensive class first), then, per body, the tiles its window has gained since
   // the lists were put together -- the lists may be a launch old (mh_raster_fin): a listed tile that no longer exists is
@@ -1071,7 +1073,9 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
             for (int q = 0; q < RT; ++q) T[q] = T_[lo * RT + q];
             float pz, dd;
             bool inside;
-            r_eval_fast(T, sXf[xi], sYf[yi], &pz, &inside, &dd);
+            R_NEAR_DECL();
+            r_eval_fast(T, sXf[xi], sYf[yi], &pz, &inside, &dd R_NEAR_ARG);
+            R_NEAR_COUNT((const unsigned long long*)((const char*)keys + __umul24(__umul24(yi, (unsigned)tw) + xi, 40u)), pz, inside, dd, (int)fw);
             r_insert((unsigned long long*)((char*)keys + __umul24(__umul24(yi, (unsigned)tw) + xi, 40u)), pz, inside, dd, (int)fw);
           }
           R_WAVE_SYNC();
@@ -1113,7 +1117,9 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
               const int xi = xa + kx_, yi = ya + ky_;
               float pz, dd;
               bool inside;
-              r_eval_fast(T, sXf[xi], sYf[yi], &pz, &inside, &dd);
+              R_NEAR_DECL();
+              r_eval_fast(T, sXf[xi], sYf[yi], &pz, &inside, &dd R_NEAR_ARG);
+              R_NEAR_COUNT((const unsigned long long*)((const char*)keys + __umul24(__umul24((unsigned)yi, (unsigned)tw) + (unsigned)xi, 40u)), pz, inside, dd, f);
               r_insert((unsigned long long*)((char*)keys + __umul24(__umul24((unsigned)yi, (unsigned)tw) + (unsigned)xi, 40u)), pz, inside, dd, f);
               if (++j >= j1) break;
               if (++kx_ == nx) { kx_ = 0; ++ky_; }
@@ -1172,6 +1178,7 @@ __global__ __launch_bounds__(RB, RMINW) void k_raster_strip(RasterP p) {       /
     __shared__ unsigned long long s_cnt[RW][2];
     __syncthreads();
     if (lane == 0) { s_cnt[wave][0] = n_cand; s_cnt[wave][1] = n_eval; }
+    R_NEAR_FLUSH();
     __syncthreads();
     if (tid == 0) {
       unsigned long long a = 0ull, b2 = 0ull;

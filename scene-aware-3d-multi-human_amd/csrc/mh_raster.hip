@@ -149,6 +149,12 @@ __device__ __forceinline__ float r_seg_rcp(float px, float py, float ax, float a
 // atomics), then added to dL/dverts with plain coalesced read-modify-writes -- no global atomics.
 // Bodies whose table does not fit in LDS (V > RG_MAXV) scatter with global atomics instead.
 #define RG_MAXV 11500
+#ifndef RG_WAVE_SUMS
+#define RG_WAVE_SUMS 1
+#endif
+#ifndef RG_CAS
+#define RG_CAS 1             // 0: ds_add_f32 (the form of rounds 2-5)
+#endif
 #define RG_LIST RG_UNIT
 // dynamic LDS of the gradient kernel: [V][3] gradient table when it fits, then the live-pixel list.  The scatter
 // goes through this symbol (not through a pointer chosen at run time) so that the compiler emits ds_add_f32 rather
@@ -176,9 +182,27 @@ __device__ __forceinline__ void r_acc_add(float* gvb, int vid, float gx, float g
     atomicAdd(o + 1, (unsigned long long)__double2ll_rn(ldexp((double)gy, dc.shift)));
     atomicAdd(o + 2, (unsigned long long)__double2ll_rn(ldexp((double)gz, dc.shift)));
   } else if (MODE == 1) {
+#if RG_CAS
+    // ds_add_f32 costs ~3 cycles per ACTIVE LANE on gfx950 (192 for a full wave instruction; integer LDS atomics and
+    // compare-and-swaps ~4.5 per instruction whatever the lanes: profiles/r04_ubench_valu_lds.txt): the float add as a
+    // read + compare-and-swap, the three components of a vertex in flight together, repeated for the lanes that lost
+    // (the lanes of a wave are neighbouring pixels and share vertices).  Round 6: 99.3 -> 92.3 us in the cycle.
+    unsigned* u = (unsigned*)&rg_tab[vid * 3];
+    unsigned o0 = u[0], o1 = u[1], o2 = u[2];
+    bool d0 = gx == 0.f, d1 = gy == 0.f, d2 = gz == 0.f;
+    while (!(d0 && d1 && d2)) {
+      unsigned r0 = o0, r1 = o1, r2 = o2;
+      if (!d0) r0 = atomicCAS(u, o0, __float_as_uint(__uint_as_float(o0) + gx));
+      if (!d1) r1 = atomicCAS(u + 1, o1, __float_as_uint(__uint_as_float(o1) + gy));
+      if (!d2) r2 = atomicCAS(u + 2, o2, __float_as_uint(__uint_as_float(o2) + gz));
+      d0 = d0 || r0 == o0; d1 = d1 || r1 == o1; d2 = d2 || r2 == o2;
+      o0 = r0; o1 = r1; o2 = r2;
+    }
+#else
     atomicAdd(&rg_tab[vid * 3], gx);
     atomicAdd(&rg_tab[vid * 3 + 1], gy);
     atomicAdd(&rg_tab[vid * 3 + 2], gz);
+#endif
   } else {
     float* o = gvb + (size_t)vid * 3;
     atomicAdd(o, gx);
@@ -1281,6 +1305,23 @@ __device__ __forceinline__ void r_body_sums(const RasterP& p, int b, float out[6
     for (int k = 0; k < 6; ++k) out[k] += p.partial[(size_t)s * 6 + k];
 }
 
+// The same totals, the same order of additions, for a whole wave at once (b wave-uniform, every lane active): the strips'
+// partial sums come in with ONE load per ten strips (lane = strip x 6 + k) instead of one scalar round trip per strip --
+// the serial form was most of the 2.2 us a gradient unit spent on its header (round 6, timing build: 12 % of the kernel).
+__device__ __forceinline__ void r_body_sums_wave(const RasterP& p, int b, float out[6]) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) out[k] = 0.f;
+  const int lane = threadIdx.x & 63;
+  const int first = p.body_first[b], ns = p.body_ns[b];
+  for (int s0 = 0; s0 < ns; s0 += 10) {
+    const int m = min(10, ns - s0);
+    const float v = lane < m * 6 ? p.partial[(size_t)(first + s0) * 6 + lane] : 0.f;
+    for (int s = 0; s < m; ++s)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) out[k] += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), s * 6 + k));
+  }
+}
+
 // per-body loss values + depth-range partials (also covers bodies that are entirely off screen)
 __global__ void k_raster_body_out(RasterP p) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1499,6 +1540,7 @@ __device__ __forceinline__ void rg_pixel(const RasterP& p, const RgBody& bd, con
           egx[2 * k + 1] = -p.s * rz * ux; egy[2 * k + 1] = -p.s * rz * uy; egz[2 * k + 1] = -((xb - p.w1) * ux + (yb - p.h1) * uy) * rz;
         }
       }
+#ifndef RG_NOMERGE
 #pragma unroll
       for (int i = 1; i < 8; ++i) {
         bool merged = false;
@@ -1512,6 +1554,7 @@ __device__ __forceinline__ void rg_pixel(const RasterP& p, const RgBody& bd, con
         }
         if (merged) eid[i] = -1;
       }
+#endif
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         if (eid[i] >= 0) r_acc_add<MODE>(gvb, eid[i], egx[i], egy[i], egz[i], dc);
@@ -1571,7 +1614,11 @@ __global__ __launch_bounds__(RGB) void k_raster_grads(RasterP p) {
     // the strips of a body are consecutive in the work list, so its window is one contiguous key range
     const unsigned long long* gk = p.gkeys + (size_t)p.body_koff[b] * 5;
     float S[6];
+#if RG_WAVE_SUMS
+    r_body_sums_wave(p, b, S);
+#else
     r_body_sums(p, b, S);
+#endif
     const float cnt = S[2] + 1.f;
     const float diff = S[0] / cnt - S[1] / cnt;
     const float gA = p.coef_depth * 2.f * diff / cnt;

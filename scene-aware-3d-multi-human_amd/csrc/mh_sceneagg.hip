@@ -80,9 +80,17 @@ __global__ __launch_bounds__(64) void k_scene_median(int T, int P, const float* 
 // off the CUs) and ~6x less time.  T <= 64 * SMT_NV (8: 512 frames; 32: 2048, the whole sequence of a pixel-sharded
 // multi-GPU run).
 typedef float f32x2s __attribute__((ext_vector_type(2)));
+// The per-frame depth range (k_scene_ranges' arithmetic, the same bits) is evaluated here by the lane that holds the frame:
+// one launch less on the update's stream -- every kernel boundary there costs the optimiser's chain ~1.3 us (round 6).
+__device__ __forceinline__ f32x2s sm_range(const float* zmin_lin, const float* zmax_lin, int t) {
+  const float min_z = logf(1.f + expf(zmin_lin[t]));
+  const float max_z = min_z + 1.f + logf(1.f + expf(zmax_lin[t]));
+  return (f32x2s){1.f / min_z, 1.f / max_z};
+}
 template <int SMT_NV>
 __global__ __launch_bounds__(256) void k_scene_median_t(int T, int P, const float* depths_t, const unsigned char* backmask_t,
-                                                        const float* invz, float* ma_depth, float* ma_mask) {
+                                                        const float* zmin_lin, const float* zmax_lin, float* ma_depth, float* ma_mask) {
+  const bool invz = zmin_lin != nullptr;
   const int lane = threadIdx.x & 63;
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= P) return;
@@ -101,7 +109,7 @@ __global__ __launch_bounds__(256) void k_scene_median_t(int T, int P, const floa
       const int t = min(j * 64 + lane, T - 1);
       bm[j] = bp[t];
       dv[j] = dp[t];
-      iz[j] = invz ? *(const f32x2s*)(invz + 2 * t) : (f32x2s){0.f, 0.f};
+      iz[j] = invz ? sm_range(zmin_lin, zmax_lin, t) : (f32x2s){0.f, 0.f};
     }
 #pragma unroll
     for (int j = 0; j < SMT_NV; ++j) {
@@ -125,7 +133,8 @@ __global__ __launch_bounds__(256) void k_scene_median_t(int T, int P, const floa
       v[j] = SM_INVALID;
       if (t < T && bp[t] != 0) {
         if (invz) {
-          const float inv_min = invz[2 * t], inv_max = invz[2 * t + 1];
+          const f32x2s iz = sm_range(zmin_lin, zmax_lin, t);
+          const float inv_min = iz[0], inv_max = iz[1];
           const float disp = dp[t] * (inv_min - inv_max) + inv_max;      // optimizer.py:425
           v[j] = __float_as_uint(1.0f / disp);                           // :426
         } else {
@@ -233,7 +242,10 @@ __device__ __forceinline__ double blk_sum(double v, double* sh) {
   return s;
 }
 
-__global__ __launch_bounds__(256) void k_scene_sobel(int H, int W, const float* depth, float* g_disp, float* g_depth, double* stats) {
+// Sobel magnitudes of disparity and depth (utils.py:174-190) and, per workgroup, their sums and sums of squares -- plain
+// stores into part[workgroup][4] (rounds 3-5 added them to four global doubles with atomics: a memset before, an order of
+// additions that changed from run to run).
+__global__ __launch_bounds__(256) void k_scene_sobel(int H, int W, const float* depth, float* g_disp, float* g_depth, double* part) {
   __shared__ double sh[4];
   const int p = blockIdx.x * 256 + threadIdx.x;
   double a = 0.0, a2 = 0.0, b = 0.0, b2 = 0.0;
@@ -253,38 +265,39 @@ __global__ __launch_bounds__(256) void k_scene_sobel(int H, int W, const float* 
     a = gd; a2 = (double)gd * gd; b = gz; b2 = (double)gz * gz;
   }
   a = blk_sum(a, sh); a2 = blk_sum(a2, sh); b = blk_sum(b, sh); b2 = blk_sum(b2, sh);
-  if (threadIdx.x == 0) { atomicAdd(&stats[0], a); atomicAdd(&stats[1], a2); atomicAdd(&stats[2], b); atomicAdd(&stats[3], b2); }
+  if (threadIdx.x == 0) { double* o = part + 4 * (size_t)blockIdx.x; o[0] = a; o[1] = a2; o[2] = b; o[3] = b2; }
 }
 
-// grad = g_disp / std(g_disp) + g_depth / std(g_depth), and its global sum
-__global__ __launch_bounds__(256) void k_scene_grad(int P, const float* g_disp, const float* g_depth, double* stats, float* grad) {
-  __shared__ double sh[4];
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  const double n = (double)P;
-  const double ma = stats[0] / n, mb = stats[2] / n;
-  const float sa = (float)sqrt(fmax(stats[1] / n - ma * ma, 0.0)), sb = (float)sqrt(fmax(stats[3] / n - mb * mb, 0.0));
-  double g = 0.0;
-  if (p < P) {
-    const float v = g_disp[p] / sa + g_depth[p] / sb;
-    grad[p] = v;
-    g = v;
+// grad = g_disp / std(g_disp) + g_depth / std(g_depth); dmask = erode^2(1 - [grad > 3 mean(grad)]) * mask (two 3x3 erosions
+// with an ignoring border = one 5x5 erosion) -- as ONE launch behind the Sobel kernel (rounds 3-5: two, with a third global
+// sum between them; every kernel boundary on the update's stream costs the optimiser's chain ~1.3 us, round 6).  Every
+// workgroup adds the Sobel workgroups' partial sums itself, in their order; grad is linear in the two magnitudes, so its
+// mean is mean(g_disp) / std(g_disp) + mean(g_depth) / std(g_depth) -- no second global sum; and a neighbour's grad is
+// evaluated where it is compared (the same two IEEE divisions and addition that used to be stored: the same bits).
+__global__ __launch_bounds__(256) void k_scene_edges2(int H, int W, const float* g_disp, const float* g_depth, const float* ma_mask,
+                                                      const double* part, int nparts, float* dmask) {
+  __shared__ double s_tot[4];
+  if (threadIdx.x < 4) {
+    double t = 0.0;
+    for (int w = 0; w < nparts; ++w) t += part[4 * (size_t)w + threadIdx.x];
+    s_tot[threadIdx.x] = t;
   }
-  g = blk_sum(g, sh);
-  if (threadIdx.x == 0) atomicAdd(&stats[4], g);
-}
-
-// dmask = erode^2(1 - [grad > 3 mean]) * mask ; two 3x3 erosions with an ignoring border = one 5x5 erosion
-__global__ void k_scene_edges(int H, int W, const float* grad, const float* ma_mask, const double* stats, float* dmask) {
+  __syncthreads();
+  const int P = H * W;
+  const double n = (double)P;
+  const double ma = s_tot[0] / n, mb = s_tot[2] / n;
+  const float sa = (float)sqrt(fmax(s_tot[1] / n - ma * ma, 0.0)), sb = (float)sqrt(fmax(s_tot[3] / n - mb * mb, 0.0));
+  const float thr = 3.f * (float)(ma / (double)sa + mb / (double)sb);
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= H * W) return;
+  if (p >= P) return;
   const int y = p / W, x = p - y * W;
-  const float thr = 3.f * (float)(stats[4] / (double)(H * W));
   float keep = 1.f;
   for (int dy = -2; dy <= 2; ++dy)
     for (int dx = -2; dx <= 2; ++dx) {
       const int yy = y + dy, xx = x + dx;
       if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-      if (grad[yy * W + xx] > thr) keep = 0.f;
+      const int q = yy * W + xx;
+      if (g_disp[q] / sa + g_depth[q] / sb > thr) keep = 0.f;
     }
   dmask[p] = ma_mask ? keep * ma_mask[p] : keep;
 }
@@ -470,7 +483,7 @@ struct SceneWs {
   float* depth1;    // [P] bilateral-filtered depth, then filled in place
   float* g_disp;    // [P]
   float* g_depth;   // [P]
-  float* grad;      // [P]
+  float* grad;      // [P] (round 6: the Sobel workgroups' partial sums, as doubles)
   float* dmask;     // [P]
   float* upd;       // [P]
   int* list_a;      // [P]
@@ -535,14 +548,10 @@ extern "C" int mh_scene_median_t(int T, int H, int W, const float* depths_t, con
   const int P = H * W;
   SceneWs s = scene_carve(ws, P);
   hipStream_t st = (hipStream_t)stream;
-  if (zmin_lin) {
-    hipLaunchKernelGGL(k_scene_ranges, dim3((T + 127) / 128), dim3(128), 0, st, T, zmin_lin, zmax_lin, s.invz);
-    MH_LAUNCH_CHECK();
-  }
-  const float* invz = zmin_lin ? (const float*)s.invz : (const float*)nullptr;
-  if (T <= 256) hipLaunchKernelGGL(k_scene_median_t<4>, dim3((P + 3) / 4), dim3(256), 0, st, T, P, depths_t, backmask_t, invz, ma_depth, ma_mask);
-  else if (T <= 512) hipLaunchKernelGGL(k_scene_median_t<8>, dim3((P + 3) / 4), dim3(256), 0, st, T, P, depths_t, backmask_t, invz, ma_depth, ma_mask);
-  else hipLaunchKernelGGL(k_scene_median_t<32>, dim3((P + 3) / 4), dim3(256), 0, st, T, P, depths_t, backmask_t, invz, ma_depth, ma_mask);
+  (void)s;
+  if (T <= 256) hipLaunchKernelGGL(k_scene_median_t<4>, dim3((P + 3) / 4), dim3(256), 0, st, T, P, depths_t, backmask_t, zmin_lin, zmax_lin, ma_depth, ma_mask);
+  else if (T <= 512) hipLaunchKernelGGL(k_scene_median_t<8>, dim3((P + 3) / 4), dim3(256), 0, st, T, P, depths_t, backmask_t, zmin_lin, zmax_lin, ma_depth, ma_mask);
+  else hipLaunchKernelGGL(k_scene_median_t<32>, dim3((P + 3) / 4), dim3(256), 0, st, T, P, depths_t, backmask_t, zmin_lin, zmax_lin, ma_depth, ma_mask);
   MH_LAUNCH_CHECK();
   return MH_OK;
 }
@@ -557,22 +566,22 @@ extern "C" int mh_scene_postprocess(int H, int W, const float* ma_depth, const f
   SceneWs s = scene_carve(ws, P);
   hipStream_t st = (hipStream_t)stream;
   const dim3 g256((P + 255) / 256), b256(256);
+  // the filtered depth is built in the caller's output buffer and filled there in place (no copy at the end)
+  MH_CHECK(scene_depth != ma_depth, "scene_depth must not alias ma_depth");
   if (use_bilateral) {
-    hipLaunchKernelGGL(k_scene_bilateral, g256, b256, 0, st, H, W, ma_depth, s.depth1);
+    hipLaunchKernelGGL(k_scene_bilateral, g256, b256, 0, st, H, W, ma_depth, scene_depth);
     MH_LAUNCH_CHECK();
   } else {
-    MH_HIP(hipMemcpyAsync(s.depth1, ma_depth, (size_t)P * 4, hipMemcpyDeviceToDevice, st));
+    MH_HIP(hipMemcpyAsync(scene_depth, ma_depth, (size_t)P * 4, hipMemcpyDeviceToDevice, st));
   }
-  MH_HIP(hipMemsetAsync(s.stats, 0, 64, st));
-  hipLaunchKernelGGL(k_scene_sobel, g256, b256, 0, st, H, W, (const float*)s.depth1, s.g_disp, s.g_depth, s.stats);
+  double* part = (double*)s.grad;          // [workgroups of the Sobel kernel][4] (32 bytes per 256 pixels of a 4 P-byte array)
+  hipLaunchKernelGGL(k_scene_sobel, g256, b256, 0, st, H, W, (const float*)scene_depth, s.g_disp, s.g_depth, part);
   MH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_scene_grad, g256, b256, 0, st, P, (const float*)s.g_disp, (const float*)s.g_depth, s.stats, s.grad);
+  hipLaunchKernelGGL(k_scene_edges2, g256, b256, 0, st, H, W, (const float*)s.g_disp, (const float*)s.g_depth, ma_mask, (const double*)part,
+                     (int)g256.x, s.dmask);
   MH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_scene_edges, g256, b256, 0, st, H, W, (const float*)s.grad, ma_mask, (const double*)s.stats, s.dmask);
+  MH_CHECK(scene_fill_launch(H, W, fillin_ksize, 0, scene_depth, s.dmask, s.list_a, s.list_b, s.upd, st) == 0, "fill-in window must be 2..11");
   MH_LAUNCH_CHECK();
-  MH_CHECK(scene_fill_launch(H, W, fillin_ksize, 0, s.depth1, s.dmask, s.list_a, s.list_b, s.upd, st) == 0, "fill-in window must be 2..11");
-  MH_LAUNCH_CHECK();
-  MH_HIP(hipMemcpyAsync(scene_depth, s.depth1, (size_t)P * 4, hipMemcpyDeviceToDevice, st));
   return MH_OK;
 }
 

@@ -386,6 +386,9 @@ def main():
                    'lane_pick': [{'cycle_ms': [round(x, 4) for x in (pk.ms or [])], 'best': pk.best} for pk in getattr(e, '_pickers', {}).values()],
                    'what': 'per-cycle masked median over the 200 frames + bilateral/Sobel/erode/median-fill + un-projection '
                            '+ grid rebuild on a second stream, overlapped with the next cycle'}
+        gp = getattr(e, '_gate_probe', None)
+        if gp:      # MHHIP_GATE_PROBE=1: what the main stream waited for the previous cycle's scene update, per cycle of the timed region
+            organic['gate_wait_ms'] = round(sum(a.elapsed_time(b) for a, b in gp[-nsteps_org:]) / min(len(gp), nsteps_org), 4)
         opt.scene_depth = ground_scene(K, W, H)
         opt.update_scene_pointcloud(opt.scene_depth, scene_mask)   # back to the static scene
     # per-kernel durations: HIP events cannot be read back from inside a replayed graph, so the same

@@ -990,7 +990,15 @@ class SequenceEngine(object):
         """Run ``fn`` (a fixed launch sequence on static buffers) through a captured graph; the first
         call runs it eagerly (lazy allocations, one-time attribute calls) and captures it."""
         if wait_scene and self._scene_pending:   # cross-stream dependency stays outside the captured sequence
-            torch.cuda.current_stream(self.dev).wait_event(self._scene_event)
+            main = torch.cuda.current_stream(self.dev)
+            if os.environ.get('MHHIP_GATE_PROBE') == '1':      # (probe: how long does the cycle wait for the previous scene update?)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(main)
+                main.wait_event(self._scene_event)
+                e1.record(main)
+                self.__dict__.setdefault('_gate_probe', []).append((e0, e1))
+            else:
+                main.wait_event(self._scene_event)
             self._scene_pending = False
         if not hasattr(self, '_graphs'):
             self._graphs = {}

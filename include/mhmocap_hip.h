@@ -486,6 +486,7 @@ int mh_scene_median(int T, int H, int W, const float* depths /*(T,H,W)*/, const 
  * per pixel, no LDS.  Any (H, W) with H*W = number of pixel rows works: a pixel-sharded caller passes its slice. */
 int mh_scene_median_t(int T, int H, int W, const float* depths_t /*(H*W,T)*/, const uint8_t* backmask_t /*(H*W,T)*/,
                       const float* zmin_lin, const float* zmax_lin, float* ma_depth, float* ma_mask, void* ws, void* stream);
+/* scene_depth must not alias ma_depth: the filtered map is built and filled in scene_depth itself (round 6: no copy at the end) */
 int mh_scene_postprocess(int H, int W, const float* ma_depth, const float* ma_mask, int use_bilateral, int fillin_ksize,
                          float* scene_depth /*(H,W)*/, void* ws, void* stream);
 /* utils.py:91-135 looped until no masked pixel is left (optimizer.py:595-600 uses it with ksize 11 on the colour median):

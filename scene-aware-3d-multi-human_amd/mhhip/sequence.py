@@ -380,6 +380,8 @@ class SequenceEngine(object):
                 s['zsnap'][T:].copy_(zh)
         d['ev_snap'].record(side)
         d['snap_pending'] = True
+        if os.environ.get('MHHIP_SCENE_DELAY_US'):      # (probe: the update's wide kernels later in the cycle, DESIGN App. A)
+            check(L.mh_stream_spin(st, float(os.environ['MHHIP_SCENE_DELAY_US'])))
         if 'depths_t' in d:
             check(L.mh_scene_median_t(T, H, W, ptr(d['depths_t']), ptr(d['back_t']), ptr(s['zsnap'][:T]), ptr(s['zsnap'][T:]),
                                       ptr(d['ma_depth']), ptr(d['ma_mask']), ptr(d['ws']), st))

@@ -1306,8 +1306,10 @@ __device__ __forceinline__ void r_body_sums(const RasterP& p, int b, float out[6
 }
 
 // The same totals, the same order of additions, for a whole wave at once (b wave-uniform, every lane active): the strips'
-// partial sums come in with ONE load per ten strips (lane = strip x 6 + k) instead of one scalar round trip per strip --
-// the serial form was most of the 2.2 us a gradient unit spent on its header (round 6, timing build: 12 % of the kernel).
+// partial sums come in with ONE load per ten strips (lane = strip x 6 + k) instead of one scalar round trip per strip.
+// (Round 6: a gradient unit spends 2.2 us -- 12 % of the kernel by the timing build -- on its header's chain of dependent
+// loads; this link of it is worth 0.4 us of the kernel's 92: the chain's other links are the unit list, the body's window
+// and the per-body coefficients.)
 __device__ __forceinline__ void r_body_sums_wave(const RasterP& p, int b, float out[6]) {
 #pragma unroll
   for (int k = 0; k < 6; ++k) out[k] = 0.f;
@@ -1511,7 +1513,8 @@ __device__ __forceinline__ void rg_pixel(const RasterP& p, const RgBody& bd, con
       // LDS float atomic costs ~4 cycles per active LANE on gfx950 whatever the addresses (SQ_LDS_IDX_ACTIVE:
       // 26 M cycles for the 7 M lane-atomics this scatter issued unmerged -- a third of the kernel; unique
       // addresses, fewer instructions under the same masks or de-correlated lanes changed nothing), while the vector
-      // instructions of the merge are nearly free here (VALU 23 % busy).  113 -> 90 us.  (Merging the three
+      // instructions of the merge are nearly free here (VALU 23 % busy).  113 -> 90 us.  (Round 6, with the adds as
+      // compare-and-swaps -- r_acc_add -- the merge is still worth 1.2 us: -DRG_NOMERGE 93.5 against 92.3.)  (Merging the three
       // vertices of the depth term's face as well costs 45 spilled registers at 1024 threads: 139 us.)
       int eid[8];
       float egx[8], egy[8], egz[8];
